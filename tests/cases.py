@@ -1,0 +1,129 @@
+"""Numeric inputs of the reference's example cases (the constants of their params.py files),
+shared by the oracle tests and the HIP parity tests.  Sources are relative to
+/root/reference/numerical_examples."""
+import numpy as np
+
+
+class Rijke:
+    """Longitudinal/NetworkCode/RijkeTube{1D,2D,3D}/params.py."""
+    r_gas = 287.0
+    gamma = 1.4
+    p_amb = 1e5
+    rho_amb = 1.22
+    rho_u = rho_amb
+    rho_d = 0.85
+    c_u = np.sqrt(gamma * p_amb / rho_u)
+    c_d = np.sqrt(gamma * p_amb / rho_d)
+    T_u = c_u ** 2 / (gamma * r_gas)
+    T_d = c_d ** 2 / (gamma * r_gas)
+    q_0 = -27.008910380099735
+    u_b = 0.10066660027273297
+    tau = 0.0015
+    d_tube = 0.047
+    a_f = 0.025
+    a_r = 0.025
+    target = 200 * 2 * np.pi
+
+    @staticmethod
+    def n(dim):
+        if dim == 1:
+            return 0.1 / (np.pi * Rijke.d_tube ** 2 / 4)
+        if dim == 2:
+            return 0.1 / (np.pi * Rijke.d_tube / 4)
+        return 0.1
+
+    @staticmethod
+    def x_f(dim):
+        return np.array([[0.0, 0.0, 0.25]]) if dim == 3 else np.array([[0.25, 0.0, 0.0]])
+
+    @staticmethod
+    def x_r(dim):
+        return np.array([[0.0, 0.0, 0.20]]) if dim == 3 else np.array([[0.20, 0.0, 0.0]])
+
+
+class PRF:
+    """Longitudinal/PRF/RijkeTube1D/params.py (non-dimensional)."""
+    r_gas = 287.0
+    gamma = 1.4
+    p_amb = 1e5
+    rho_amb = 1.22
+    c_amb = 339
+    rho_in_dim = rho_amb
+    rho_out_dim = 0.85
+    c_in_dim = np.sqrt(gamma * p_amb / rho_in_dim)
+    c_out_dim = np.sqrt(gamma * p_amb / rho_out_dim)
+    T_in_dim = p_amb / (r_gas * rho_in_dim)
+    T_out_dim = p_amb / (r_gas * rho_out_dim)
+    R_in = -0.975 - 0.05j
+    R_out = -0.975 - 0.05j
+    q_0 = 200.0
+    u_b = 0.1
+    U_ref = c_amb
+    p_ref = p_amb
+    rho_u = rho_in_dim * U_ref ** 2 / p_ref
+    rho_d = rho_out_dim * U_ref ** 2 / p_ref
+    c_u = c_in_dim / U_ref
+    c_d = c_out_dim / U_ref
+    T_u = T_in_dim * r_gas / U_ref ** 2
+    T_d = T_out_dim * r_gas / U_ref ** 2
+    n = 0.014 / (np.pi * 0.047 ** 2 / 4) / p_ref
+    tau = 0.0015 * U_ref
+    x_f = np.array([[0.25, 0.0, 0.0]])
+    x_r = np.array([[0.20, 0.0, 0.0]])
+    a_f = 0.025
+    a_r = 0.025
+    target = np.pi
+
+
+class Micca:
+    """AnnularCombustor/Micca/fullAnnulus/params.py."""
+    l_cc = 0.2
+    r_p = 0.14
+    d_2 = 0.035
+    r_f = r_p + d_2
+    theta = np.deg2rad(22.5)
+    z_f = 0.0
+    r_r = r_f
+    z_r = -0.02
+    r = 287.0
+    gamma = 1.4
+    p_amb = 101325.0
+    T_amb = 300.0
+    rho_amb = p_amb / (r * T_amb)
+    T_a = 1521.0
+    T_b = 1200.0
+    q_0 = 2080.0
+    u_b = 0.66
+    N_sector = 16
+    R_outlet = -0.875 - 0.2j
+    target = 3225.120 + 481.0j
+
+    @staticmethod
+    def x_f():
+        return np.array([[Micca.r_f * np.cos(i * Micca.theta), Micca.r_f * np.sin(i * Micca.theta), Micca.z_f]
+                         for i in range(Micca.N_sector)])
+
+    @staticmethod
+    def x_r():
+        return np.array([[Micca.r_r * np.cos(i * Micca.theta), Micca.r_r * np.sin(i * Micca.theta), Micca.z_r]
+                         for i in range(Micca.N_sector)])
+
+    @staticmethod
+    def c_of_z(z):
+        """params.py:53-70 (cell-midpoint rule; note the strict inequalities)."""
+        g, r = Micca.gamma, Micca.r
+        mid = np.sqrt(g * r * ((Micca.T_b - Micca.T_a) * (z / Micca.l_cc) ** 2 + Micca.T_a))
+        return np.where(z < 0, np.sqrt(g * r * Micca.T_amb),
+                        np.where((z > 0) & (z < Micca.l_cc), mid, np.sqrt(g * r * Micca.T_b)))
+
+
+def dispersion_root(k0, Z, L=0.4, h=0.1):
+    """Root of manufacturedSolution/matlab_data/dispersion2d.m:1-3 by Newton from k0."""
+    def f(k):
+        ky = np.sqrt(k ** 2 - (np.pi / L) ** 2 + 0j)
+        return np.exp(2j * ky * h) * (ky - k / Z) - (ky + k / Z)
+    k = complex(k0)
+    for _ in range(60):
+        d = (f(k + 1e-7) - f(k - 1e-7)) / 2e-7
+        k = k - f(k) / d
+    return k

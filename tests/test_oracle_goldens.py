@@ -1,0 +1,134 @@
+"""Pin the CPU oracle to the reference's committed result logs.
+
+CPU-only.  Every expected number below comes from tests/golden/reference_logs.json, which cites
+the reference log file and lines it was transcribed from."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import PRF, Rijke, dispersion_root
+from oracle import eigen, fem, meshes
+
+
+def _close(z, ref, digits=8):
+    # logs print 8 decimals; allow the reference's own serial/parallel spread (2e-10 relative)
+    ref = complex(*ref)
+    assert abs(z - ref) <= 0.6 * 10 ** (-digits) + 3e-10 * abs(ref), (z, ref)
+
+
+def _rijke_distributed(m, dim, A_from_T):
+    R = Rijke
+    T = fem.step_field(m.x, dim, R.x_f(dim), R.T_u, R.T_d)
+    c = fem.sound_speed_variable_gamma(T) if A_from_T else fem.step_field(m.x, dim, R.x_f(dim), R.c_u, R.c_d)
+    A = fem.assemble_A(m.x, m.cells, c)
+    C = fem.assemble_C(m.x, m.cells)
+    axis = 2 if dim == 3 else 0
+    rho = fem.density_step(m.x[:, axis], 0.25, R.a_f, R.rho_d, R.rho_u)
+    w = fem.gaussian_function(m.x, m.cells, R.x_r(dim), R.a_r)
+    h = fem.gaussian_function(m.x, m.cells, R.x_f(dim), R.a_f)
+    a = fem.distributed_left(m.x, m.cells, fem.gamma_of_T(T), h, R.q_0, R.u_b)
+    b = fem.distributed_right(m.x, m.cells, rho, w)
+    left = fem.threshold_pack(a, 1e-5)
+    right = fem.threshold_pack(b, 1e-5)
+    n = m.x.shape[0]
+    flame = eigen.OracleFlame(fem.flame_outer(n, left, right), eigen.NTau(R.n(dim), R.tau),
+                              fem.flame_outer(n, left, right, 'adjoint'))
+    return A, C, flame, left, right
+
+
+def test_rijke1d_passive(ref_logs):
+    g = ref_logs["rijke1d_passive"]
+    m = meshes.interval(g["n_elem"])
+    c = fem.step_field(m.x, 1, Rijke.x_f(1), Rijke.c_u, Rijke.c_u)
+    E = eigen.eps_solve(fem.assemble_A(m.x, m.cells, c), fem.assemble_C(m.x, m.cells), g["target"], 4)
+    for lam, ref in zip(E.eigs, g["lambda"]):
+        assert abs(lam - ref) < 2e-6 * max(1.0, abs(ref)) * 1e-3 + 2e-6
+    assert abs(np.sqrt(E.eigs[0]) - g["omega0"]) < 1e-6
+
+
+def test_rijke1d_active_direct_and_adjoint(ref_logs):
+    g = ref_logs["rijke1d_active"]
+    m = meshes.interval(g["n_elem"])
+    A, C, flame, left, right = _rijke_distributed(m, 1, True)
+    assert len(left[0]) == g["nnz_left"] and len(right[0]) == g["nnz_right"]
+    assert flame.D_ij.nnz == g["nnz_D"]
+    _, hist = eigen.fixed_point_iteration(A, None, C, flame, Rijke.target, nev=2, i=0)
+    assert len(hist) == len(g["trajectory"])
+    for z, ref in zip(hist, g["trajectory"]):
+        _close(z, ref)
+    _, hist = eigen.fixed_point_iteration(A, None, C, flame, Rijke.target, nev=2, i=0, problem_type='adjoint')
+    _close(hist[-1], ref_logs["rijke1d_active_adjoint"]["omega"])
+
+
+def test_prf1d_pep_direct_and_adjoint(ref_logs):
+    g = ref_logs["prf1d_active"]
+    P = PRF
+    m = meshes.interval(g["n_elem"])
+    c = fem.step_field(m.x, 1, P.x_f, P.c_u, P.c_d)
+    n = m.x.shape[0]
+    A = fem.assemble_A(m.x, m.cells, c)
+    C = fem.assemble_C(m.x, m.cells)
+    terms = [(m.facets[m.facet_tags == t], fem.robin_Z(R), c, None) for t, R in ((1, P.R_in), (2, P.R_out))]
+    B = fem.assemble_B(m.x, n, terms)
+    rho = fem.density_step(m.x[:, 0], 0.25, P.a_f, P.rho_d, P.rho_u)
+    w = fem.gaussian_function(m.x, m.cells, P.x_r, P.a_r)
+    h = fem.gaussian_function(m.x, m.cells, P.x_f, P.a_f)
+    left = fem.threshold_pack(fem.distributed_left(m.x, m.cells, P.gamma, h, P.q_0, P.u_b), 1e-5)
+    right = fem.threshold_pack(fem.distributed_right(m.x, m.cells, rho, w), 1e-5)
+    flame = eigen.OracleFlame(fem.flame_outer(n, left, right), eigen.NTau(P.n, P.tau),
+                              fem.flame_outer(n, left, right, 'adjoint'))
+    _, hist = eigen.fixed_point_iteration(A, B, C, flame, P.target, nev=2, i=0)
+    for z, ref in zip(hist[1:], g["trajectory"]):
+        _close(z, ref)
+    _, hist = eigen.fixed_point_iteration(A, B, C, flame, P.target, nev=2, i=0, problem_type='adjoint',
+                                          B_adj=B.conj().T.tocsr())
+    _close(hist[-1], g["adjoint_omega"])
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_rijke_gmsh_cases(ref_logs, golden_dir, dim):
+    g = ref_logs["rijke%dd" % dim]
+    m = meshes.read_gmsh41(os.path.join(golden_dir, "meshes", "rijke%dd.msh" % dim), dim)
+    c = fem.step_field(m.x, dim, Rijke.x_f(dim), Rijke.c_u, Rijke.c_u)
+    E = eigen.eps_solve(fem.assemble_A(m.x, m.cells, c), fem.assemble_C(m.x, m.cells), Rijke.target, 2)
+    assert abs(E.eigs[0] - g["passive_lambda0"]) < 2e-6
+    A, C, flame, _, _ = _rijke_distributed(m, dim, A_from_T=(dim == 2))
+    _, hist = eigen.fixed_point_iteration(A, None, C, flame, Rijke.target, nev=2, i=0)
+    assert len(hist) == len(g["trajectory"])
+    for z, ref in zip(hist, g["trajectory"]):
+        _close(z, ref)
+
+
+def test_manufactured_2d_against_dispersion_relation(ref_logs):
+    g = ref_logs["manufactured2d"]
+    m = meshes.rectangle(g["nx"], g["ny"], g["L"], g["h"])
+    c = np.full(m.x.shape[0], g["c0"])
+    A = fem.assemble_A(m.x, m.cells, c)
+    C = fem.assemble_C(m.x, m.cells)
+    top = m.facets[m.facet_tags == 4]
+    omega = 600 * 2 * np.pi
+    for Z in np.linspace(-10, 10, 10)[:5]:         # manufacturedHelmholtz.py:46-53 continuation
+        R = (Z - 1) / (Z + 1)
+        B = fem.assemble_B(m.x, m.x.shape[0], [(top, fem.robin_Z(R), c, None)])
+        omega = eigen.pep_solve(A, B, C, omega, 2).eigs[0]
+        k = dispersion_root(omega / g["c0"], Z)
+        f_num, f_ana = omega / (2 * np.pi), g["c0"] * k / (2 * np.pi)
+        assert abs(f_num - f_ana) < 2e-4 * abs(f_ana)      # P1 discretisation error on 160x40
+        if Z == -10:
+            assert abs(f_ana - complex(*g["analytical_f_Z_minus10"])) < 0.06   # analytical.txt (0.1 Hz)
+
+
+def test_flame_transfer_functions(golden_dir):
+    from scipy.io import loadmat
+    mat = loadmat(os.path.join(golden_dir, "micca_ftf.mat"))
+    ss = eigen.StateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+    w = 3000.0 + 400.0j
+    d = 1e-3
+    assert abs((ss(w + d) - ss(w - d)) / (2 * d) - ss.derivative(w)) < 1e-6 * abs(ss.derivative(w))
+    # the fit reproduces the measured FTF it was made from (params.py __main__ plot)
+    freq, f = mat['freq'][0], mat['f'][0]
+    z = np.array([ss(2 * np.pi * fr) for fr in freq])
+    assert np.max(np.abs(np.abs(z) - np.abs(f))) < 0.15
+    nt = eigen.NTau(2.0, 1e-3)
+    assert abs((nt(w + d) - nt(w - d)) / (2 * d) - nt.derivative(w)) < 1e-6

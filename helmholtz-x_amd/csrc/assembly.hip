@@ -1,0 +1,427 @@
+// P1 (Lagrange degree 1) operator and load-vector assembly on simplices, vertex-centric.
+//
+// One thread owns one CSR row (= one mesh vertex) and gathers the element contributions of the cells
+// incident to that vertex in ascending cell order.  Consequences: no atomics, bitwise reproducible
+// values, integer maps (adjacency, rowptr, col) that are a pure function of the mesh, and an
+// "owner computes" formulation that needs no inter-GPU exchange when rows are sharded (each GPU keeps
+// one ghost layer of cells).  Element integrals are the closed forms of the reference's UFL forms
+// (acoustic_matrices.py:101,108,121; flame_matrices.py:141,199,200); the small per-simplex tables
+// (mass / triple-product templates, degree-2 quadrature points) are compile-time constants.
+#include <hipcub/hipcub.hpp>
+
+#include "hx_common.h"
+
+// ------------------------------------------------------------------------------------------------ adjacency
+__global__ void k_count_incidence(int64_t total, const int32_t* __restrict__ ents, int32_t* __restrict__ cnt) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&cnt[ents[t]], 1);
+}
+__global__ void k_fill_incidence(int64_t total, int k, const int32_t* __restrict__ ents,
+                                 const int32_t* __restrict__ ptr, int32_t* __restrict__ cursor,
+                                 int32_t* __restrict__ idx) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int32_t v = ents[t];
+    int32_t pos = atomicAdd(&cursor[v], 1);
+    idx[ptr[v] + pos] = (int32_t)(t / k);
+  }
+}
+__global__ void k_sort_lists(int32_t n, const int32_t* __restrict__ ptr, int32_t* __restrict__ idx) {
+  for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    int32_t s = ptr[v], e = ptr[v + 1];
+    for (int32_t a = s + 1; a < e; ++a) {          // insertion sort: lists are short (vertex degree)
+      int32_t key = idx[a], b = a - 1;
+      while (b >= s && idx[b] > key) { idx[b + 1] = idx[b]; --b; }
+      idx[b + 1] = key;
+    }
+  }
+}
+
+static int exclusive_scan_i32(int32_t* d_inout, int64_t count, hipStream_t s) {
+  size_t bytes = 0;
+  HX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_inout, d_inout, (int)count, s));
+  void* tmp = nullptr;
+  HX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, d_inout, d_inout, (int)count, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return hx_fail(HX_ERR_HIP, "ExclusiveSum", hipGetErrorString(e));
+  if (e2 != hipSuccess) return hx_fail(HX_ERR_HIP, "hipStreamSynchronize", hipGetErrorString(e2));
+  return HX_OK;
+}
+
+extern "C" int hx_build_v2e(int32_t n_vert, int32_t n_ent, int k, const int32_t* ents, int32_t* v2e_ptr,
+                            int32_t* v2e_idx, hx_stream s_) {
+  HX_REQUIRE(n_vert > 0 && n_ent >= 0 && k >= 1 && k <= 4 && v2e_ptr && (n_ent == 0 || (ents && v2e_idx)),
+             "bad argument");
+  hipStream_t s = hx_s(s_);
+  const int64_t total = (int64_t)n_ent * k;
+  HX_REQUIRE(total < (int64_t)INT32_MAX, "adjacency exceeds int32 range");
+  HX_HIP(hipMemsetAsync(v2e_ptr, 0, sizeof(int32_t) * ((size_t)n_vert + 1), s));
+  if (total > 0) {
+    k_count_incidence<<<hx_grid(total, 256), 256, 0, s>>>(total, ents, v2e_ptr);
+    HX_LAUNCH_CHECK("k_count_incidence");
+  }
+  int rc = exclusive_scan_i32(v2e_ptr, (int64_t)n_vert + 1, s);
+  if (rc) return rc;
+  if (total == 0) return HX_OK;
+  int32_t* cursor = nullptr;
+  HX_HIP(hipMalloc((void**)&cursor, sizeof(int32_t) * (size_t)n_vert));
+  (void)hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_vert, s);
+  k_fill_incidence<<<hx_grid(total, 256), 256, 0, s>>>(total, k, ents, v2e_ptr, cursor, v2e_idx);
+  k_sort_lists<<<hx_grid(n_vert, 256), 256, 0, s>>>(n_vert, v2e_ptr, v2e_idx);
+  hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(cursor);
+  if (e != hipSuccess) return hx_fail(HX_ERR_HIP, "hx_build_v2e", hipGetErrorString(e));
+  HX_LAUNCH_CHECK("hx_build_v2e");
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pattern
+// Row v = sorted unique union of the vertices of the entities incident to v, built by
+// insert-if-absent into the row's scratch region [k*ptr[v], k*ptr[v+1]).
+__global__ void k_pattern_rows(int32_t n, int k, const int32_t* __restrict__ ents, const int32_t* __restrict__ ptr,
+                               const int32_t* __restrict__ idx, int32_t* __restrict__ scratch,
+                               int32_t* __restrict__ rowlen) {
+  for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    int32_t* list = scratch + (int64_t)k * ptr[v];
+    int32_t len = 0;
+    for (int32_t p = ptr[v]; p < ptr[v + 1]; ++p) {
+      const int32_t* ev = ents + (int64_t)idx[p] * k;
+      for (int j = 0; j < k; ++j) {
+        int32_t c = ev[j];
+        int32_t lo = 0, hi = len;                   // lower bound
+        while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (list[mid] < c) lo = mid + 1; else hi = mid; }
+        if (lo < len && list[lo] == c) continue;
+        for (int32_t t = len; t > lo; --t) list[t] = list[t - 1];
+        list[lo] = c;
+        ++len;
+      }
+    }
+    rowlen[v] = len;
+  }
+}
+__global__ void k_pattern_fill(int32_t n, int k, const int32_t* __restrict__ ptr, const int32_t* __restrict__ rowptr,
+                               const int32_t* __restrict__ scratch, int32_t* __restrict__ col) {
+  for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const int32_t* list = scratch + (int64_t)k * ptr[v];
+    int32_t s = rowptr[v], e = rowptr[v + 1];
+    for (int32_t t = s; t < e; ++t) col[t] = list[t - s];
+  }
+}
+extern "C" int hx_p1_pattern_count(int32_t n_vert, int32_t n_ent, int k, const int32_t* ents,
+                                   const int32_t* v2e_ptr, const int32_t* v2e_idx, int32_t* rowptr,
+                                   int32_t* scratch, int64_t* h_nnz, hx_stream s_) {
+  HX_REQUIRE(n_vert > 0 && n_ent >= 0 && k >= 1 && k <= 4 && v2e_ptr && rowptr && h_nnz, "bad argument");
+  hipStream_t s = hx_s(s_);
+  HX_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * ((size_t)n_vert + 1), s));
+  if (n_ent > 0) {
+    HX_REQUIRE(ents && v2e_idx && scratch, "null argument");
+    k_pattern_rows<<<hx_grid(n_vert, 128), 128, 0, s>>>(n_vert, k, ents, v2e_ptr, v2e_idx, scratch, rowptr);
+    HX_LAUNCH_CHECK("k_pattern_rows");
+  }
+  int rc = exclusive_scan_i32(rowptr, (int64_t)n_vert + 1, s);
+  if (rc) return rc;
+  int32_t last = 0;
+  HX_HIP(hipMemcpy(&last, rowptr + n_vert, sizeof(int32_t), hipMemcpyDeviceToHost));
+  *h_nnz = last;
+  return HX_OK;
+}
+extern "C" int hx_p1_pattern_fill(int32_t n_vert, int k, const int32_t* v2e_ptr, const int32_t* rowptr,
+                                  const int32_t* scratch, int32_t* col, hx_stream s) {
+  HX_REQUIRE(n_vert > 0 && v2e_ptr && rowptr && scratch && col, "bad argument");
+  k_pattern_fill<<<hx_grid(n_vert, 128), 128, 0, hx_s(s)>>>(n_vert, k, v2e_ptr, rowptr, scratch, col);
+  HX_LAUNCH_CHECK("k_pattern_fill");
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ geometry
+template <int D>
+__device__ __forceinline__ void p1_geometry(const double* __restrict__ x, const int32_t* v, double G[D + 1][D],
+                                            double& vol) {
+  double X[D + 1][D];
+#pragma unroll
+  for (int a = 0; a <= D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) X[a][c] = x[(int64_t)v[a] * 3 + c];
+  if (D == 1) {
+    double h = X[1][0] - X[0][0];
+    G[1][0] = 1.0 / h;
+    G[0][0] = -G[1][0];
+    vol = fabs(h);
+  } else if (D == 2) {
+    // J[:,i] = v_{i+1} - v_0 ; rows of J^{-1} are grad(phi_1), grad(phi_2)
+    double a = X[1][0] - X[0][0], b = X[2][0] - X[0][0];
+    double c = X[1][1] - X[0][1], d = X[2][1] - X[0][1];
+    double det = a * d - b * c, id = 1.0 / det;
+    G[1][0] = d * id;  G[1][1] = -b * id;
+    G[2][0] = -c * id; G[2][1] = a * id;
+    G[0][0] = -(G[1][0] + G[2][0]);
+    G[0][1] = -(G[1][1] + G[2][1]);
+    vol = 0.5 * fabs(det);
+  } else {
+    double J[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) J[c][i] = X[i + 1][c] - X[0][c];
+    double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = 1.0 / det;
+    // inverse = adj/det ; row i of the inverse = grad(phi_{i+1})
+    G[1][0] = c00 * id;
+    G[1][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+    G[1][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    G[2][0] = c01 * id;
+    G[2][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+    G[2][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    G[3][0] = c02 * id;
+    G[3][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+    G[3][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G[0][c] = -(G[1][c] + G[2][c] + G[3][c]);
+    vol = fabs(det) / 6.0;
+  }
+}
+
+__device__ __forceinline__ int32_t find_slot(const int32_t* __restrict__ col, int32_t s, int32_t e, int32_t c) {
+  int32_t lo = s, hi = e;
+  while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (col[mid] < c) lo = mid + 1; else hi = mid; }
+  return lo;  // pattern contains c by construction
+}
+
+// ------------------------------------------------------------------------------------------------ A and C
+template <int D>
+__global__ void __launch_bounds__(128)
+k_stiff_mass(int32_t n, const double* __restrict__ x, const int32_t* __restrict__ cells,
+             const int32_t* __restrict__ v2c_ptr, const int32_t* __restrict__ v2c_idx,
+             const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ cf,
+             int cellwise, zc* __restrict__ A, zc* __restrict__ C) {
+  constexpr int K = D + 1;
+  constexpr double MT = 1.0 / ((D + 1) * (D + 2));
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int32_t rs = rowptr[i], re = rowptr[i + 1];
+    for (int32_t t = rs; t < re; ++t) {
+      if (A) A[t] = make_double2(0.0, 0.0);
+      if (C) C[t] = make_double2(0.0, 0.0);
+    }
+    for (int32_t p = v2c_ptr[i]; p < v2c_ptr[i + 1]; ++p) {
+      const int32_t c = v2c_idx[p];
+      int32_t v[K];
+      int j = 0;
+#pragma unroll
+      for (int a = 0; a < K; ++a) { v[a] = cells[(int64_t)c * K + a]; if (v[a] == i) j = a; }
+      double G[K][D], vol;
+      p1_geometry<D>(x, v, G, vol);
+      zc w;  // int_K c^2 dx  (complex square, acoustic_matrices.py:101)
+      if (cellwise) {
+        zc cc = cf[c];
+        w = zscale(vol, zmul(cc, cc));
+      } else {
+        zc sum = make_double2(0.0, 0.0), sq = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int a = 0; a < K; ++a) { zc ca = cf[v[a]]; sum = zadd(sum, ca); sq = zadd(sq, zmul(ca, ca)); }
+        w = zscale(vol * MT, zadd(zmul(sum, sum), sq));
+      }
+#pragma unroll
+      for (int m = 0; m < K; ++m) {
+        double gg = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) gg += G[j][d] * G[m][d];
+        const int32_t slot = find_slot(col, rs, re, v[m]);
+        if (A) { zc a = A[slot]; a.x -= w.x * gg; a.y -= w.y * gg; A[slot] = a; }
+        if (C) { zc cm = C[slot]; cm.x += vol * MT * (m == j ? 2.0 : 1.0); C[slot] = cm; }
+      }
+    }
+  }
+}
+
+extern "C" int hx_assemble_p1_stiff_mass(int dim, int32_t n_vert, const double* x, const int32_t* cells,
+                                         const int32_t* v2c_ptr, const int32_t* v2c_idx, const int32_t* rowptr,
+                                         const int32_t* col, const hx_c128* c, int c_is_cellwise,
+                                         hx_c128* A_val, hx_c128* C_val, hx_stream s) {
+  HX_REQUIRE(dim >= 1 && dim <= 3 && n_vert > 0 && x && cells && v2c_ptr && v2c_idx && rowptr && col, "bad argument");
+  HX_REQUIRE(A_val || C_val, "nothing to assemble");
+  HX_REQUIRE(!A_val || c, "A needs the sound-speed field");
+  const int grid = hx_grid(n_vert, 128, 256 * 16);
+#define HX_GO(D) k_stiff_mass<D><<<grid, 128, 0, hx_s(s)>>>(n_vert, x, cells, v2c_ptr, v2c_idx, rowptr, col, \
+                                                              (const zc*)c, c_is_cellwise, (zc*)A_val, (zc*)C_val)
+  if (dim == 1) HX_GO(1); else if (dim == 2) HX_GO(2); else HX_GO(3);
+#undef HX_GO
+  HX_LAUNCH_CHECK("k_stiff_mass");
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Robin B
+// triple-product template on a unit-measure simplex of dimension DS: DS! a!b!c!/(DS+3)!
+__device__ __forceinline__ double triple_T(int DS, int a, int b, int c) {
+  const double base = DS == 0 ? 1.0 / 6.0 : DS == 1 ? 1.0 / 24.0 : DS == 2 ? 1.0 / 60.0 : 1.0 / 120.0;
+  const int mult = (a == b && b == c) ? 6 : (a == b || b == c || a == c) ? 2 : 1;
+  return base * mult;
+}
+
+template <int KF>  // facet vertex count = cell dim
+__global__ void __launch_bounds__(128)
+k_robin(int32_t n, const double* __restrict__ x, const int32_t* __restrict__ facets,
+        const int32_t* __restrict__ v2f_ptr, const int32_t* __restrict__ v2f_idx, const int32_t* __restrict__ rowptr,
+        const int32_t* __restrict__ col, const zc* __restrict__ cf, int cellwise,
+        const int32_t* __restrict__ facet_cell, const zc* __restrict__ coef, zc* __restrict__ B) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int32_t rs = rowptr[i], re = rowptr[i + 1];
+    for (int32_t t = rs; t < re; ++t) B[t] = make_double2(0.0, 0.0);
+    for (int32_t p = v2f_ptr[i]; p < v2f_ptr[i + 1]; ++p) {
+      const int32_t f = v2f_idx[p];
+      int32_t v[KF];
+      int j = 0;
+#pragma unroll
+      for (int a = 0; a < KF; ++a) { v[a] = facets[(int64_t)f * KF + a]; if (v[a] == i) j = a; }
+      double meas = 1.0;
+      if (KF == 2) {
+        double dx = x[(int64_t)v[1] * 3] - x[(int64_t)v[0] * 3], dy = x[(int64_t)v[1] * 3 + 1] - x[(int64_t)v[0] * 3 + 1];
+        meas = sqrt(dx * dx + dy * dy);
+      } else if (KF == 3) {
+        double e1[3], e2[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          e1[d] = x[(int64_t)v[1] * 3 + d] - x[(int64_t)v[0] * 3 + d];
+          e2[d] = x[(int64_t)v[2] * 3 + d] - x[(int64_t)v[0] * 3 + d];
+        }
+        double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        meas = 0.5 * sqrt(cx * cx + cy * cy + cz * cz);
+      }
+      const zc kf = zscale(meas, coef[f]);
+#pragma unroll
+      for (int m = 0; m < KF; ++m) {
+        zc e;
+        if (cellwise) {
+          e = zscale((m == j ? 2.0 : 1.0) / (KF * (KF + 1)), cf[facet_cell[f]]);
+        } else {
+          e = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int q = 0; q < KF; ++q) e = zadd(e, zscale(triple_T(KF - 1, q, j, m), cf[v[q]]));
+        }
+        const int32_t slot = find_slot(col, rs, re, v[m]);
+        zc b = B[slot];
+        zfma(b, kf, e);
+        B[slot] = b;
+      }
+    }
+  }
+}
+
+extern "C" int hx_assemble_p1_robin(int dim, int32_t n_vert, const double* x, const int32_t* facets,
+                                    const int32_t* v2f_ptr, const int32_t* v2f_idx, const int32_t* rowptr,
+                                    const int32_t* col, const hx_c128* c, int c_is_cellwise,
+                                    const int32_t* facet_cell, const hx_c128* coef_per_facet, hx_c128* B_val,
+                                    hx_stream s) {
+  HX_REQUIRE(dim >= 1 && dim <= 3 && n_vert > 0 && x && facets && v2f_ptr && v2f_idx && rowptr && col && c &&
+                 coef_per_facet && B_val, "bad argument");
+  HX_REQUIRE(!c_is_cellwise || facet_cell, "cellwise c needs facet_cell");
+  const int grid = hx_grid(n_vert, 128, 256 * 16);
+#define HX_GO(KF) k_robin<KF><<<grid, 128, 0, hx_s(s)>>>(n_vert, x, facets, v2f_ptr, v2f_idx, rowptr, col, (const zc*)c, \
+                                                          c_is_cellwise, facet_cell, (const zc*)coef_per_facet, (zc*)B_val)
+  if (dim == 1) HX_GO(1); else if (dim == 2) HX_GO(2); else HX_GO(3);
+#undef HX_GO
+  HX_LAUNCH_CHECK("k_robin");
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Dirichlet
+__global__ void k_dirichlet(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                            zc* __restrict__ val, const uint8_t* __restrict__ is_bc, double diag) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const bool rbc = is_bc[i] != 0;
+    for (int32_t t = rowptr[i]; t < rowptr[i + 1]; ++t) {
+      const int32_t c = col[t];
+      if (rbc) val[t] = make_double2(c == i ? diag : 0.0, 0.0);
+      else if (is_bc[c]) val[t] = make_double2(0.0, 0.0);
+    }
+  }
+}
+extern "C" int hx_csr_apply_dirichlet(int32_t n, const int32_t* rowptr, const int32_t* col, hx_c128* val,
+                                      const uint8_t* is_bc, double diag, hx_stream s) {
+  HX_REQUIRE(n > 0 && rowptr && col && val && is_bc, "bad argument");
+  k_dirichlet<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, rowptr, col, (zc*)val, is_bc, diag);
+  HX_LAUNCH_CHECK("k_dirichlet");
+  return HX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ load vectors
+template <int D>
+struct Quad2;  // degree-2 simplex rule in barycentric coordinates (the rule FFCx selects for kind 2)
+template <> struct Quad2<1> { static constexpr int NQ = 2; };
+template <> struct Quad2<2> { static constexpr int NQ = 3; };
+template <> struct Quad2<3> { static constexpr int NQ = 4; };
+
+template <int D>
+__device__ __forceinline__ double quad2_bary(int q, int a) {
+  if (D == 1) { const double g = 0.28867513459481287; return (q == a) ? 0.5 + g : 0.5 - g; }
+  if (D == 2) return (q == a) ? 2.0 / 3.0 : 1.0 / 6.0;
+  return (q == a) ? 0.5854101966249685 : 0.1381966011250105;
+}
+
+template <int D, int KIND>
+__global__ void __launch_bounds__(128)
+k_load(int32_t n, const double* __restrict__ x, const int32_t* __restrict__ cells, const int32_t* __restrict__ v2c_ptr,
+       const int32_t* __restrict__ v2c_idx, const zc* __restrict__ fa, const zc* __restrict__ fb, zc scale,
+       zc* __restrict__ out) {
+  constexpr int K = D + 1;
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    zc acc = make_double2(0.0, 0.0);
+    for (int32_t p = v2c_ptr[i]; p < v2c_ptr[i + 1]; ++p) {
+      const int32_t c = v2c_idx[p];
+      int32_t v[K];
+      int j = 0;
+#pragma unroll
+      for (int a = 0; a < K; ++a) { v[a] = cells[(int64_t)c * K + a]; if (v[a] == i) j = a; }
+      double G[K][D], vol;
+      p1_geometry<D>(x, v, G, vol);
+      if (KIND == 0) {
+        acc = zadd(acc, zscale(vol / K, fa[c]));
+      } else if (KIND == 1) {
+        zc e = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+          zc am = fa[v[m]];
+#pragma unroll
+          for (int l = 0; l < K; ++l) zfma(e, zscale(triple_T(D, j, m, l), am), fb[v[l]]);
+        }
+        acc = zadd(acc, zscale(vol, e));
+      } else {
+        zc sq = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < Quad2<D>::NQ; ++q) {
+          zc rq = make_double2(0.0, 0.0), wq = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int a = 0; a < K; ++a) {
+            const double l = quad2_bary<D>(q, a);
+            rq = zadd(rq, zscale(l, fa[v[a]]));
+            wq = zadd(wq, zscale(l, fb[v[a]]));
+          }
+          sq = zadd(sq, zscale(1.0 / Quad2<D>::NQ, zdiv(wq, rq)));
+        }
+        const double gn = G[j][D == 3 ? 2 : 0];   // n_r = e_x (1D/2D), e_z (3D): flame_matrices.py:35-40
+        acc = zadd(acc, zscale(vol * gn, sq));
+      }
+    }
+    out[i] = zmul(scale, acc);
+  }
+}
+
+extern "C" int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const double* x, const int32_t* cells,
+                                   const int32_t* v2c_ptr, const int32_t* v2c_idx, const hx_c128* fa,
+                                   const hx_c128* fb, const double scale[2], hx_c128* out, hx_stream s) {
+  HX_REQUIRE(kind >= 0 && kind <= 2 && dim >= 1 && dim <= 3 && n_vert > 0 && x && cells && v2c_ptr && v2c_idx && fa &&
+                 scale && out, "bad argument");
+  HX_REQUIRE(kind == 0 || fb, "kind 1/2 need both fields");
+  const int grid = hx_grid(n_vert, 128, 256 * 16);
+  const zc sc = hx_z(scale);
+#define HX_GO(D, KD) k_load<D, KD><<<grid, 128, 0, hx_s(s)>>>(n_vert, x, cells, v2c_ptr, v2c_idx, (const zc*)fa, \
+                                                               (const zc*)fb, sc, (zc*)out)
+#define HX_DIM(KD) do { if (dim == 1) HX_GO(1, KD); else if (dim == 2) HX_GO(2, KD); else HX_GO(3, KD); } while (0)
+  if (kind == 0) HX_DIM(0); else if (kind == 1) HX_DIM(1); else HX_DIM(2);
+#undef HX_DIM
+#undef HX_GO
+  HX_LAUNCH_CHECK("k_load");
+  return HX_OK;
+}

@@ -1,0 +1,70 @@
+// Shared device/host helpers for libhx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hx.h"
+
+#define HX_WAVE 64
+
+extern thread_local char hx_errbuf[512];
+
+static inline int hx_fail(int code, const char* what, const char* detail) {
+  snprintf(hx_errbuf, sizeof(hx_errbuf), "%s: %s", what, detail ? detail : "");
+  return code;
+}
+
+#define HX_HIP(call)                                                        \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess) return hx_fail(HX_ERR_HIP, #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define HX_LAUNCH_CHECK(name)                                               \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) return hx_fail(HX_ERR_HIP, name, hipGetErrorString(e_)); \
+  } while (0)
+
+#define HX_REQUIRE(cond, msg) \
+  do { if (!(cond)) return hx_fail(HX_ERR_ARG, __func__, msg); } while (0)
+
+typedef double2 zc;  // complex128 as {re, im}: one 16-byte (dwordx4) access per element
+
+__device__ __forceinline__ zc zmul(zc a, zc b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ zc zcmul(zc a, zc b) { /* conj(a)*b */ return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ zc zadd(zc a, zc b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ zc zsub(zc a, zc b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ zc zscale(double s, zc a) { return make_double2(s * a.x, s * a.y); }
+__device__ __forceinline__ void zfma(zc& acc, zc a, zc b) {
+  acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
+}
+__device__ __forceinline__ void zcfma(zc& acc, zc a, zc b) {  // acc += conj(a)*b
+  acc.x = fma(a.x, b.x, acc.x); acc.x = fma(a.y, b.y, acc.x);
+  acc.y = fma(a.x, b.y, acc.y); acc.y = fma(-a.y, b.x, acc.y);
+}
+__device__ __forceinline__ zc zdiv(zc a, zc b) {
+  double d = b.x * b.x + b.y * b.y;
+  return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+template <int W>
+__device__ __forceinline__ zc zreduce_sub(zc v) {  // sum over aligned groups of W lanes
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    v.x += __shfl_down(v.x, o, W);
+    v.y += __shfl_down(v.y, o, W);
+  }
+  return v;
+}
+
+static inline int hx_grid(int64_t work_items, int block, int max_blocks = 256 * 8) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+static inline hipStream_t hx_s(hx_stream s) { return (hipStream_t)s; }
+static inline zc hx_z(const double a[2]) { return make_double2(a[0], a[1]); }

@@ -1,0 +1,71 @@
+// Complex128 CSR SpMV, y = alpha*A*x + beta*y  (PETSc MatMult on the shift-invert Arnoldi path).
+//
+// HBM-bound: algorithmic traffic = nnz*(16 B value + 4 B column) + n*(4 B rowptr + 16 B x + 16 B y)
+// (SURVEY.md section 8d).  Layout: LPR consecutive lanes cooperate on one row, so a 64-lane wave
+// streams 64/LPR adjacent rows = one contiguous span of val/col (P1 rows are short and nearly
+// uniform: 3 / 7 / ~15 nonzeros in 1D / 2D / 3D).  Values are read as one dwordx4 per lane; the x
+// gather is served by L2 / Infinity Cache because FEM columns are local.  Grid-stride over rows with a
+// capped grid (>> 256 workgroups) so every XCD's L2 sees a contiguous band of rows per workgroup.
+#include "hx_common.h"
+
+template <int LPR>
+__global__ void __launch_bounds__(256)
+k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ val,
+       const zc* __restrict__ x, zc* __restrict__ y, zc alpha, zc beta, int beta_is_zero) {
+  constexpr int RPB = 256 / LPR;                       // rows per block per sweep
+  const int sub = threadIdx.x % LPR;
+  const int64_t stride = (int64_t)gridDim.x * RPB;
+  // every lane of a wave runs the same number of sweeps => the sub-wave shuffles below are convergent
+  const int64_t sweeps = ((int64_t)n + stride - 1) / stride;
+  int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  for (int64_t it = 0; it < sweeps; ++it, row += stride) {
+    zc acc = make_double2(0.0, 0.0);
+    if (row < n) {
+      const int32_t s = rowptr[row], e = rowptr[row + 1];
+      for (int32_t p = s + sub; p < e; p += LPR) zfma(acc, val[p], x[col[p]]);
+    }
+    if (LPR > 1) acc = zreduce_sub<LPR>(acc);
+    if (row < n && sub == 0) {
+      zc r = zmul(alpha, acc);
+      if (!beta_is_zero) zfma(r, beta, y[row]);
+      y[row] = r;
+    }
+  }
+}
+
+template <int LPR>
+static int launch(int32_t n, const int32_t* rowptr, const int32_t* col, const zc* val, const zc* x, zc* y,
+                  zc alpha, zc beta, hipStream_t s) {
+  int64_t rows_per_block = 256 / LPR;
+  int grid = hx_grid((int64_t)n, (int)rows_per_block, 256 * 16);
+  k_spmv<LPR><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, alpha, beta, (beta.x == 0.0 && beta.y == 0.0));
+  HX_LAUNCH_CHECK("k_spmv");
+  return HX_OK;
+}
+
+extern "C" int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                             const hx_c128* val, const hx_c128* x, hx_c128* y, const double alpha[2],
+                             const double beta[2], int lanes_per_row, hx_stream s) {
+  HX_REQUIRE(n_rows >= 0 && nnz >= 0 && rowptr && x && y && alpha && beta && (nnz == 0 || (col && val)),
+             "bad argument");
+  if (n_rows == 0) return HX_OK;
+  int lpr = lanes_per_row;
+  if (lpr == 0) {
+    double avg = (double)nnz / (double)n_rows;
+    lpr = avg <= 2.0 ? 1 : avg <= 4.5 ? 2 : avg <= 9.0 ? 4 : avg <= 24.0 ? 8 : avg <= 64.0 ? 16 : avg <= 160 ? 32 : 64;
+  }
+  const zc a = hx_z(alpha), b = hx_z(beta);
+  const zc* v = (const zc*)val;
+  const zc* xx = (const zc*)x;
+  zc* yy = (zc*)y;
+  switch (lpr) {
+    case 1: return launch<1>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 2: return launch<2>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 4: return launch<4>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 8: return launch<8>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 16: return launch<16>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 32: return launch<32>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 64: return launch<64>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    default: return hx_fail(HX_ERR_ARG, __func__, "lanes_per_row must be 0,1,2,4,8,16,32,64");
+  }
+}

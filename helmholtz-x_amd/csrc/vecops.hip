@@ -1,0 +1,247 @@
+// Complex128 vector / tall-skinny panel kernels (PETSc Vec + SLEPc BV equivalents).
+// All are HBM-bound streaming kernels: 16-byte (dwordx4) accesses, grid-stride, 256-thread blocks.
+#include "hx_common.h"
+
+thread_local char hx_errbuf[512] = "";
+
+extern "C" int hx_version(void) { return 100; }
+extern "C" const char* hx_last_error(void) { return hx_errbuf; }
+
+extern "C" int hx_device_info(char* name, int name_len, int* cu_count, size_t* hbm_bytes) {
+  int dev = 0;
+  HX_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  HX_HIP(hipGetDeviceProperties(&p, dev));
+  if (name && name_len > 0) { strncpy(name, p.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  return HX_OK;
+}
+
+__global__ void k_zaxpy(int64_t n, zc a, const zc* __restrict__ x, zc* __restrict__ y) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    zc xv = x[i], yv = y[i];
+    zfma(yv, a, xv);
+    y[i] = yv;
+  }
+}
+extern "C" int hx_zaxpy(int64_t n, const double alpha[2], const hx_c128* x, hx_c128* y, hx_stream s) {
+  HX_REQUIRE(n >= 0 && x && y && alpha, "null/negative argument");
+  if (n == 0) return HX_OK;
+  k_zaxpy<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, hx_z(alpha), (const zc*)x, (zc*)y);
+  HX_LAUNCH_CHECK("k_zaxpy");
+  return HX_OK;
+}
+
+__global__ void k_zscal(int64_t n, zc a, zc* __restrict__ x) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = zmul(a, x[i]);
+}
+extern "C" int hx_zscal(int64_t n, const double alpha[2], hx_c128* x, hx_stream s) {
+  HX_REQUIRE(n >= 0 && x && alpha, "null/negative argument");
+  if (n == 0) return HX_OK;
+  k_zscal<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, hx_z(alpha), (zc*)x);
+  HX_LAUNCH_CHECK("k_zscal");
+  return HX_OK;
+}
+
+struct LinComb4 { const zc* x[4]; zc c[4]; int nt; };
+__global__ void k_zlincomb(int64_t n, LinComb4 p, zc* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    zc acc = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < p.nt) zfma(acc, p.c[t], p.x[t][i]);
+    out[i] = acc;
+  }
+}
+extern "C" int hx_zlincomb(int64_t n, int nterms, const double* h_coefs, const hx_c128* const* h_xs,
+                           hx_c128* out, hx_stream s) {
+  HX_REQUIRE(n >= 0 && nterms >= 1 && nterms <= 4 && h_coefs && h_xs && out, "bad argument");
+  if (n == 0) return HX_OK;
+  LinComb4 p;
+  p.nt = nterms;
+  for (int t = 0; t < 4; ++t) {
+    p.x[t] = t < nterms ? (const zc*)h_xs[t] : nullptr;
+    p.c[t] = t < nterms ? make_double2(h_coefs[2 * t], h_coefs[2 * t + 1]) : make_double2(0, 0);
+    if (t < nterms && !p.x[t]) return hx_fail(HX_ERR_ARG, __func__, "null term");
+  }
+  k_zlincomb<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, p, (zc*)out);
+  HX_LAUNCH_CHECK("k_zlincomb");
+  return HX_OK;
+}
+
+__global__ void k_zscatter_axpy(int64_t m, zc a, const zc* __restrict__ src, const int32_t* __restrict__ slot,
+                                zc* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t k = slot[i];
+    zc d = dst[k];
+    zfma(d, a, src[i]);
+    dst[k] = d;
+  }
+}
+extern "C" int hx_zscatter_axpy(int64_t m, const double alpha[2], const hx_c128* src, const int32_t* slot,
+                                hx_c128* dst, hx_stream s) {
+  HX_REQUIRE(m >= 0 && alpha && src && slot && dst, "bad argument");
+  if (m == 0) return HX_OK;
+  k_zscatter_axpy<<<hx_grid(m, 256), 256, 0, hx_s(s)>>>(m, hx_z(alpha), (const zc*)src, slot, (zc*)dst);
+  HX_LAUNCH_CHECK("k_zscatter_axpy");
+  return HX_OK;
+}
+
+__global__ void k_zgather(int64_t m, const zc* __restrict__ x, const int32_t* __restrict__ idx, zc* __restrict__ y) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = x[idx[i]];
+}
+extern "C" int hx_zgather(int64_t m, const hx_c128* x, const int32_t* idx, hx_c128* y, hx_stream s) {
+  HX_REQUIRE(m >= 0 && x && idx && y, "bad argument");
+  if (m == 0) return HX_OK;
+  k_zgather<<<hx_grid(m, 256), 256, 0, hx_s(s)>>>(m, (const zc*)x, idx, (zc*)y);
+  HX_LAUNCH_CHECK("k_zgather");
+  return HX_OK;
+}
+
+// ---------------------------------------------------------------- CGS panel: out[j] = V_j^H w, out[k] = w^H w
+// Stage 1: each block owns a contiguous slab of rows and produces k+1 partial sums; columns are
+// processed in register tiles of JT so V is streamed exactly once (w is re-read per tile from L2/MALL).
+// Stage 2: one block sums the per-block partials in a fixed order => bitwise reproducible.
+#define PD_BLOCK 256
+#define PD_JT 8
+#define PD_MAXBLOCKS 1024
+
+extern "C" size_t hx_panel_dot_ws(int k) { return (size_t)PD_MAXBLOCKS * (size_t)(k + 1); }
+
+__global__ void __launch_bounds__(PD_BLOCK)
+k_panel_dot_stage1(int64_t n, int k, const zc* __restrict__ V, int64_t ldv, const zc* __restrict__ w,
+                   zc* __restrict__ partials, int64_t rows_per_block) {
+  __shared__ zc red[PD_BLOCK / HX_WAVE][PD_JT];
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  const int lane = threadIdx.x & (HX_WAVE - 1), wv = threadIdx.x / HX_WAVE;
+  for (int j0 = 0; j0 <= k; j0 += PD_JT) {           // column k is w itself (w^H w)
+    zc acc[PD_JT];
+#pragma unroll
+    for (int t = 0; t < PD_JT; ++t) acc[t] = make_double2(0.0, 0.0);
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += PD_BLOCK) {
+      const zc wi = w[i];
+#pragma unroll
+      for (int t = 0; t < PD_JT; ++t) {
+        const int j = j0 + t;
+        if (j < k) zcfma(acc[t], V[(int64_t)j * ldv + i], wi);
+        else if (j == k) zcfma(acc[t], wi, wi);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < PD_JT; ++t) {
+      zc v = zreduce_sub<HX_WAVE>(acc[t]);
+      if (lane == 0) red[wv][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PD_JT && j0 + (int)threadIdx.x <= k) {
+      zc v = red[0][threadIdx.x];
+      for (int q = 1; q < PD_BLOCK / HX_WAVE; ++q) v = zadd(v, red[q][threadIdx.x]);
+      partials[(int64_t)blockIdx.x * (k + 1) + j0 + threadIdx.x] = v;
+    }
+    __syncthreads();
+  }
+}
+__global__ void k_panel_dot_stage2(int nblocks, int k, const zc* __restrict__ partials, zc* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > k) return;
+  zc v = make_double2(0.0, 0.0);
+  for (int b = 0; b < nblocks; ++b) v = zadd(v, partials[(int64_t)b * (k + 1) + j]);
+  out[j] = v;
+}
+extern "C" int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, hx_c128* out,
+                             hx_c128* partials, hx_stream s) {
+  HX_REQUIRE(n > 0 && k >= 0 && w && out && partials && (k == 0 || V) && ldv >= n, "bad argument");
+  int64_t rpb = (n + PD_MAXBLOCKS - 1) / PD_MAXBLOCKS;
+  if (rpb < PD_BLOCK * 4) rpb = PD_BLOCK * 4;
+  int nblocks = (int)((n + rpb - 1) / rpb);
+  k_panel_dot_stage1<<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, (const zc*)V, ldv, (const zc*)w, (zc*)partials, rpb);
+  HX_LAUNCH_CHECK("k_panel_dot_stage1");
+  k_panel_dot_stage2<<<(k + 1 + 63) / 64, 64, 0, hx_s(s)>>>(nblocks, k, (const zc*)partials, (zc*)out);
+  HX_LAUNCH_CHECK("k_panel_dot_stage2");
+  return HX_OK;
+}
+
+// ---------------------------------------------------------------- w -= V h
+#define PS_MAXK 128
+__global__ void __launch_bounds__(256)
+k_panel_sub(int64_t n, int k, const zc* __restrict__ V, int64_t ldv, const zc* __restrict__ h, zc* __restrict__ w) {
+  __shared__ zc hs[PS_MAXK];
+  for (int j = threadIdx.x; j < k; j += blockDim.x) hs[j] = h[j];
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    zc acc = w[i];
+    for (int j = 0; j < k; ++j) {
+      zc v = V[(int64_t)j * ldv + i], hj = hs[j];
+      acc.x = fma(-v.x, hj.x, acc.x); acc.x = fma(v.y, hj.y, acc.x);
+      acc.y = fma(-v.x, hj.y, acc.y); acc.y = fma(-v.y, hj.x, acc.y);
+    }
+    w[i] = acc;
+  }
+}
+extern "C" int hx_zpanel_sub(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* h, hx_c128* w,
+                             hx_stream s) {
+  HX_REQUIRE(n > 0 && k >= 0 && k <= PS_MAXK && w && (k == 0 || (V && h)) && ldv >= n, "bad argument");
+  if (k == 0) return HX_OK;
+  k_panel_sub<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const zc*)V, ldv, (const zc*)h, (zc*)w);
+  HX_LAUNCH_CHECK("k_panel_sub");
+  return HX_OK;
+}
+
+// ---------------------------------------------------------------- Vout = V Q (restart update)
+#define PM_CT 4
+__global__ void __launch_bounds__(256)
+k_panel_mul(int64_t n, int m, int kout, const zc* __restrict__ V, int64_t ldv, const zc* __restrict__ Q,
+            zc* __restrict__ Vout, int64_t ldvout) {
+  extern __shared__ zc qs[];  // m x kout, column-major
+  for (int t = threadIdx.x; t < m * kout; t += blockDim.x) qs[t] = Q[t];
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int c0 = 0; c0 < kout; c0 += PM_CT) {
+      zc acc[PM_CT];
+#pragma unroll
+      for (int t = 0; t < PM_CT; ++t) acc[t] = make_double2(0.0, 0.0);
+      for (int j = 0; j < m; ++j) {
+        const zc v = V[(int64_t)j * ldv + i];
+#pragma unroll
+        for (int t = 0; t < PM_CT; ++t)
+          if (c0 + t < kout) zfma(acc[t], v, qs[(c0 + t) * m + j]);
+      }
+#pragma unroll
+      for (int t = 0; t < PM_CT; ++t)
+        if (c0 + t < kout) Vout[(int64_t)(c0 + t) * ldvout + i] = acc[t];
+    }
+  }
+}
+extern "C" int hx_zpanel_mul(int64_t n, int m, int kout, const hx_c128* V, int64_t ldv, const hx_c128* Q,
+                             hx_c128* Vout, int64_t ldvout, hx_stream s) {
+  HX_REQUIRE(n > 0 && m > 0 && kout > 0 && V && Q && Vout && ldv >= n && ldvout >= n, "bad argument");
+  size_t lds = (size_t)m * kout * sizeof(zc);
+  HX_REQUIRE(lds <= 64 * 1024, "Q too large for LDS staging");
+  k_panel_mul<<<hx_grid(n, 256), 256, lds, hx_s(s)>>>(n, m, kout, (const zc*)V, ldv, (const zc*)Q, (zc*)Vout, ldvout);
+  HX_LAUNCH_CHECK("k_panel_mul");
+  return HX_OK;
+}
+
+// ---------------------------------------------------------------- sparse dots (b_f^T y), one wave per vector
+__global__ void k_sparse_dots(int nvec, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                              const zc* __restrict__ vals, const zc* __restrict__ y, zc* __restrict__ out) {
+  int f = blockIdx.x;
+  if (f >= nvec) return;
+  zc acc = make_double2(0.0, 0.0);
+  for (int p = ptr[f] + threadIdx.x; p < ptr[f + 1]; p += HX_WAVE) zfma(acc, vals[p], y[idx[p]]);
+  acc = zreduce_sub<HX_WAVE>(acc);
+  if (threadIdx.x == 0) out[f] = acc;
+}
+extern "C" int hx_zsparse_dots(int nvec, const int32_t* ptr, const int32_t* idx, const hx_c128* vals,
+                               const hx_c128* y, hx_c128* out, hx_stream s) {
+  HX_REQUIRE(nvec >= 0 && ptr && y && out, "bad argument");
+  if (nvec == 0) return HX_OK;
+  k_sparse_dots<<<nvec, HX_WAVE, 0, hx_s(s)>>>(nvec, ptr, idx, (const zc*)vals, (const zc*)y, (zc*)out);
+  HX_LAUNCH_CHECK("k_sparse_dots");
+  return HX_OK;
+}

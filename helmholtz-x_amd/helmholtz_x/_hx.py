@@ -1,0 +1,88 @@
+"""ctypes binding of libhx.so (include/hx.h).  There is NO fallback: if the library is missing, or a
+call fails, an exception is raised -- the product path never routes through a CPU implementation."""
+import ctypes as C
+import os
+
+import torch  # first: libhx.so then binds to the HIP runtime torch already loaded (same SONAME)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhx.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libhx.so not found at %s -- build it with `make -C helmholtz-x_amd/csrc` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i32, _i64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_int
+_dp = C.POINTER(C.c_double)
+
+SIGNATURES = {
+    "hx_version": (C.c_int, []),
+    "hx_last_error": (C.c_char_p, []),
+    "hx_device_info": (C.c_int, [C.c_char_p, _int, C.POINTER(_int), C.POINTER(C.c_size_t)]),
+    "hx_zaxpy": (C.c_int, [_i64, _dp, _vp, _vp, _vp]),
+    "hx_zscal": (C.c_int, [_i64, _dp, _vp, _vp]),
+    "hx_zlincomb": (C.c_int, [_i64, _int, _dp, C.POINTER(_vp), _vp, _vp]),
+    "hx_zscatter_axpy": (C.c_int, [_i64, _dp, _vp, _vp, _vp, _vp]),
+    "hx_zgather": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "hx_panel_dot_ws": (C.c_size_t, [_int]),
+    "hx_zpanel_dot": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "hx_zpanel_sub": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp]),
+    "hx_zpanel_mul": (C.c_int, [_i64, _int, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "hx_zsparse_dots": (C.c_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hx_csr_spmv_z": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _dp, _dp, _int, _vp]),
+    "hx_build_v2e": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp]),
+    "hx_p1_pattern_count": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    "hx_p1_pattern_fill": (C.c_int, [_i32, _int, _vp, _vp, _vp, _vp, _vp]),
+    "hx_assemble_p1_stiff_mass": (C.c_int, [_int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
+    "hx_assemble_p1_robin": (C.c_int, [_int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
+    "hx_csr_apply_dirichlet": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.c_double, _vp]),
+    "hx_assemble_p1_load": (C.c_int, [_int, _int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _dp, _vp, _vp]),
+    "hx_sptrsv_create": (C.c_int, [C.POINTER(_vp), _i32, _int, _vp, _vp, _vp, _vp]),
+    "hx_sptrsv_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
+    "hx_sptrsv_solve": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "hx_sptrsv_destroy": (C.c_int, [_vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)      # AttributeError here = the library does not export what hx.h declares
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class HxError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise HxError("libhx error %d: %s" % (rc, lib.hx_last_error().decode(errors="replace")))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HxError("no MI355X visible: the helmholtz_x hot path runs on the GPU only (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def z2(z):
+    z = complex(z)
+    return (C.c_double * 2)(z.real, z.imag)
+
+
+def nptr(a):
+    """Host address of a contiguous numpy array."""
+    return a.ctypes.data_as(C.c_void_p)

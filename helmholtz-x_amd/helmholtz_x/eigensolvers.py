@@ -1,0 +1,181 @@
+"""Eigen-solvers with the reference's signatures, running on the GPU.
+
+Drop-in for ``helmholtz_x.eigensolvers`` (reference: eigensolvers.py:8-276): ``results``, ``eps_solver``,
+``pep_solver``, ``fixed_point_iteration_eps``, ``fixed_point_iteration_pep``, ``fixed_point_iteration``.
+Same update rule (relaxed secant fixed point, alpha_0 = 0.5), same printed log lines, same returned
+solver object ``E``.
+
+Because the shift-invert target never changes during a fixed-point iteration (:53-54, :105), the sparse
+part K of the shifted operator is omega-independent: it is factorised ONCE per call and reused, while
+the omega-dependent rank-r flame term enters through a Woodbury update (slepc.py).  The reference instead
+re-assembles and re-factorises A - D(omega_k), with D explicit, every iteration (:165-178, :232-242).
+
+Deliberate fixes of reference quirks (last paragraph): ``maxiter`` is enforced
+(the reference only sizes arrays with it and raises IndexError beyond); the adjoint/direct ValueError is
+actually raised.
+"""
+import numpy as np
+
+from .slepc import DECIDE, EPS, PEP
+from .solver_utils import info
+
+
+def results(E):
+    print()
+    print("******************************")
+    print("*** SLEPc Solution Results ***")
+    print("******************************")
+    print()
+    print("Number of iterations of the method: %d" % E.getIterationNumber())
+    print("Solution method: %s" % E.getType())
+    nev, ncv, mpd = E.getDimensions()
+    print("Number of requested eigenvalues: %d" % nev)
+    tol, maxit = E.getTolerances()
+    print("Stopping condition: tol=%.4g, maxit=%d" % (tol, maxit))
+    nconv = E.getConverged()
+    print("Number of converged eigenpairs %d" % nconv)
+    if nconv > 0:
+        print()
+    for i in range(nconv):
+        k = E.getEigenvalue(i)
+        print("%15f, %15f" % (k.real, k.imag))
+    print()
+
+
+def eps_solver(A, C, target, nev, two_sided=False, print_results=False, st_type=None, _caches=None):
+    E = EPS().create()
+    C = -C
+    E.setOperators(A, C)
+    st = E.getST()
+    st.setType('sinvert')
+    E.setTarget(target ** 2)
+    E.setWhichEigenpairs(EPS.Which.TARGET_MAGNITUDE)
+    E.setTwoSided(two_sided)
+    E.setDimensions(nev, DECIDE)
+    E.setTolerances(1e-15)
+    E.setFromOptions()
+    E.st_type = st_type
+    if _caches is not None:
+        E.inner_cache, E.W_cache = _caches
+    info("- EPS solver started.")
+    E.solve()
+    info("- EPS solver converged. Eigenvalue computed.")
+    if print_results:
+        results(E)
+    return E
+
+
+def pep_solver(A, B, C, target, nev, print_results=False, st_type=None, _caches=None):
+    Q = PEP().create()
+    Q.setOperators([A, B, C])
+    st = Q.getST()
+    st.setType('sinvert')
+    Q.setTarget(target)
+    Q.setWhichEigenpairs(PEP.Which.TARGET_MAGNITUDE)
+    Q.setDimensions(nev, DECIDE)
+    Q.setTolerances(1e-15)
+    Q.setFromOptions()
+    Q.st_type = st_type
+    if _caches is not None:
+        Q.inner_cache, Q.W_cache = _caches
+    info("- PEP solver started.")
+    Q.solve()
+    info("- PEP solver converged. Eigenvalue computed.")
+    if print_results:
+        results(Q)
+    return Q
+
+
+def _fmt(tol):
+    digits = int("{:.0e}".format(tol)[-2:])
+    return "{{:+.{}f}}".format(digits)
+
+
+def _flame_matrix(D, omega, problem_type):
+    D.assemble_matrix(omega, problem_type)
+    if problem_type == 'direct':
+        return D.matrix
+    if problem_type == 'adjoint':
+        return D.adjoint_matrix
+    raise ValueError("The problem type should be specified as 'direct' or 'adjoint'.")
+
+
+def _iterate(solve_passive, solve_active, tol, maxiter, s, history):
+    """Relaxed secant fixed-point loop shared by the EPS and PEP variants (eigensolvers.py:143-193, 213-257)."""
+    omega = np.zeros(maxiter + 1, dtype=complex)
+    f = np.zeros(maxiter, dtype=complex)
+    alpha = np.zeros(maxiter, dtype=complex)
+    E, omega[0] = solve_passive()
+    alpha[0] = 0.5
+    if history is not None:
+        history.append(omega[0])
+    domega = 2 * tol
+    k = -1
+    while abs(domega) > tol:
+        k += 1
+        if k >= maxiter:
+            raise RuntimeError("fixed-point iteration did not converge in maxiter=%d iterations" % maxiter)
+        E.destroy()
+        print("* iter = {:2d}".format(k + 1))
+        E, f[k] = solve_active(omega[k])
+        if k != 0:
+            alpha[k] = 1 / (1 - ((f[k] - f[k - 1]) / (omega[k] - omega[k - 1])))
+        omega[k + 1] = alpha[k] * f[k] + (1 - alpha[k]) * omega[k]
+        domega = omega[k + 1] - omega[k]
+        if history is not None:
+            history.append(omega[k + 1])
+        print('+ omega = {}  {}j,  |domega| = {:.2e}\n'.format(
+            s.format(omega[k + 1].real), s.format(omega[k + 1].imag), abs(domega)))
+    return E
+
+
+def fixed_point_iteration_eps(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,
+                              problem_type='direct', two_sided=False, st_type=None, history=None):
+    A, C = operators.A, operators.C
+    B = operators.B_adj if problem_type == 'adjoint' else operators.B
+    caches = ({}, {})
+    s = _fmt(tol)
+    info("--> Fixed point iteration started.\n")
+
+    def passive():
+        E = eps_solver(A, C, target, nev, print_results=print_results, st_type=st_type, _caches=caches)
+        w0 = np.sqrt(E.getEigenvalue(i))
+        print("+ Starting eigenvalue is found: {}  {}j. ".format(s.format(w0.real), s.format(w0.imag)))
+        info("-> Iterations are starting.\n ")
+        return E, w0
+
+    def active(omega_k):
+        D_Mat = _flame_matrix(D, omega_k, problem_type)
+        D_Mat = (A - D_Mat) if not B else (A + (omega_k * B) - D_Mat)
+        E = eps_solver(D_Mat, C, target, nev, two_sided=two_sided, print_results=print_results, st_type=st_type,
+                       _caches=caches)
+        return E, np.sqrt(E.getEigenvalue(i))
+
+    return _iterate(passive, active, tol, maxiter, s, history)
+
+
+def fixed_point_iteration_pep(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,
+                              problem_type='direct', st_type=None, history=None):
+    A, C = operators.A, operators.C
+    B = operators.B_adj if problem_type == 'adjoint' else operators.B
+    caches = ({}, {})
+    s = _fmt(tol)
+
+    def passive():
+        E = pep_solver(A, B, C, target, nev, print_results=print_results, st_type=st_type, _caches=caches)
+        info("-> Fixed point iteration started.\n")
+        return E, E.getEigenvalue(i)
+
+    def active(omega_k):
+        D_Mat = A - _flame_matrix(D, omega_k, problem_type)
+        E = pep_solver(D_Mat, B, C, target, nev, print_results=print_results, st_type=st_type, _caches=caches)
+        return E, E.getEigenvalue(i)
+
+    return _iterate(passive, active, tol, maxiter, s, history)
+
+
+def fixed_point_iteration(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,
+                          problem_type='direct', st_type=None, history=None):
+    solver = fixed_point_iteration_pep if operators.B else fixed_point_iteration_eps
+    return solver(operators, D, target, nev=nev, i=i, tol=tol, maxiter=maxiter, print_results=print_results,
+                  problem_type=problem_type, st_type=st_type, history=history)

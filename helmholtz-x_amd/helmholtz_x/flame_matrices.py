@@ -1,0 +1,170 @@
+"""Active flame operator D(omega), kept factored on the GPU.
+
+Drop-in for ``helmholtz_x.flame_matrices`` (reference: flame_matrices.py:12-244): same classes,
+constructor signatures, methods (``assemble_submatrices / assemble_matrix / get_derivative / blochify``)
+and properties (``matrix, submatrices, adjoint_matrix, adjoint_submatrices``).
+
+D_ij = sum_f a_f (x) b_f is rank-1 per flame.  The reference materialises it as an explicit AIJ with
+|a|*|b| entries (:91-92,176,233); here ``submatrices`` is a ``Mat`` holding the sparse factors (a_f, b_f)
+only, which the shift-invert operator applies through a rank-r Woodbury update.  ``getValuesCSR()`` on
+it still yields the explicit matrix for inspection on small cases.
+
+Load vectors are integrated by hx_assemble_p1_load (HIP); the thresholding rule of
+``indices_and_values`` (:66-72: zero |Re| < tol and |Im| < tol separately, keep the non-zeros) is applied
+to those float64 values on the host, as the vectors are tiny.
+"""
+import numpy as np
+
+from .fem import Function, FunctionSpace
+from .parameters_utils import gamma_function
+from .petsc import LowRank, Mat
+from .solver_utils import info
+
+
+def _locate_cell(x, cells, point, tol=1e-10):
+    """First cell containing ``point`` (determine_point_ownership, flame_matrices.py:144)."""
+    d = cells.shape[1] - 1
+    p = np.asarray(point, dtype=float).reshape(-1)[:d]
+    X = x[cells][:, :, :d]
+    lo, hi = X.min(axis=1) - tol, X.max(axis=1) + tol
+    cand = np.flatnonzero(((p >= lo) & (p <= hi)).all(axis=1))     # bounding-box prefilter
+    J = np.transpose(X[cand, 1:, :] - X[cand, :1, :], (0, 2, 1))
+    lam = np.linalg.solve(J, (p[None, :] - X[cand, 0, :])[:, :, None])[:, :, 0]
+    bary = np.concatenate([1 - lam.sum(axis=1, keepdims=True), lam], axis=1)
+    hit = cand[(bary >= -tol).all(axis=1)]
+    if hit.size == 0:
+        raise ValueError("reference point %s is outside the mesh" % (point,))
+    c = int(hit[0])
+    k = np.flatnonzero(cand == c)[0]
+    grads = np.concatenate([-np.linalg.inv(J[k]).sum(axis=0, keepdims=True), np.linalg.inv(J[k])], axis=0)
+    return c, grads          # grads[i] = grad(phi_i) on that cell
+
+
+class FlameMatrix:
+
+    def __init__(self, mesh, h, q_0, u_b, FTF, degree, bloch_object=None, tol=1e-5):
+        self.mesh = mesh
+        self.h = h
+        self.q_0 = q_0
+        self.u_b = u_b
+        self.FTF = FTF
+        self.degree = degree
+        self.bloch_object = bloch_object
+        self.tol = tol
+        self.V = FunctionSpace(mesh, "Lagrange", degree)
+        self.gdim = mesh.geometry.dim
+        self.global_size = self.local_size = self.V.size
+        self.n_r = np.zeros(self.gdim)
+        self.n_r[2 if self.gdim == 3 else 0] = 1.0       # e_x in 1D/2D, e_z in 3D
+        self._D_ij = self._D_ij_adj = self._D = self._D_adj = None
+
+    @property
+    def matrix(self):
+        return self._D
+
+    @property
+    def submatrices(self):
+        return self._D_ij
+
+    @property
+    def adjoint_matrix(self):
+        return self._D_adj
+
+    @property
+    def adjoint_submatrices(self):
+        return self._D_ij_adj
+
+    def indices_and_values(self, device_vector):
+        packed = device_vector.cpu().numpy().copy()
+        packed.real[np.abs(packed.real) < self.tol] = 0.0
+        packed.imag[np.abs(packed.imag) < self.tol] = 0.0
+        indices = np.flatnonzero(packed).astype(np.int32)
+        return indices, packed[indices]
+
+    def _store(self, pairs, problem_type):
+        n = self.global_size
+        if problem_type == 'direct':
+            self._D_ij = Mat((n, n), lr_terms=[(1.0, LowRank(n, pairs))])
+        elif problem_type == 'adjoint':            # plain transpose, no conjugate (flame_matrices.py:84-89)
+            self._D_ij_adj = Mat((n, n), lr_terms=[(1.0, LowRank(n, [(r, l) for l, r in pairs]))])
+        else:
+            raise ValueError("The problem type should be specified as 'direct' or 'adjoint'.")
+        info("- Submatrix D is Assembled.")
+
+    def assemble_matrix(self, omega, problem_type='direct'):
+        if problem_type == 'direct':
+            self._D = self._D_ij * self.FTF(omega)
+            info("- Direct matrix D is assembling...")
+        elif problem_type == 'adjoint':
+            self._D_adj = self._D_ij_adj * np.conj(self.FTF(np.conj(omega)))
+            info("- Adjoint matrix D is assembling...")
+        else:
+            raise ValueError("The problem type should be specified as 'direct' or 'adjoint'.")
+        info("- Matrix D is assembled.")
+
+    def get_derivative(self, omega):
+        dD_domega = self.FTF.derivative(omega) * self._D_ij
+        info("- Derivative of matrix D is assembled.")
+        return dD_domega
+
+    def blochify(self, problem_type='direct'):
+        if problem_type == 'direct':
+            self._D_ij = self.bloch_object.blochify(self.submatrices)
+        elif problem_type == 'adjoint':
+            self._D_ij_adj = self.bloch_object.blochify(self.adjoint_submatrices)
+        else:
+            raise ValueError("The problem type should be specified as 'direct' or 'adjoint'.")
+
+
+class PointwiseFlameMatrix(FlameMatrix):
+
+    def __init__(self, mesh, subdomains, x_r, h, rho_u, q_0, u_b, FTF, degree=1, bloch_object=None, gamma=1.4,
+                 tol=1e-10):
+        super().__init__(mesh, h, q_0, u_b, FTF, degree, bloch_object, tol)
+        self.subdomains = subdomains
+        self.x_r = x_r
+        self.rho_u = rho_u
+        self.gamma = gamma
+
+    def _assemble_vectors(self, flame, point):
+        asm = self.mesh.assembler()
+        # left: (gamma-1) q0/u_b int_{Omega_flame} h phi_j dx with h DG0  -> kind 0 load with a masked cell weight
+        weight = np.zeros(self.mesh.num_cells, dtype=np.complex128)
+        cells = self.subdomains.find(flame)
+        weight[cells] = self.h.x.array[cells]
+        left = self.indices_and_values(asm.load(0, weight, scale=(self.gamma - 1) * self.q_0 / self.u_b))
+        # right: grad(phi_k).n_r / rho_u at x_r: 4 (d+1) numbers on the cell that holds the point
+        c, grads = _locate_cell(self.mesh.geometry.x, self.mesh.topology.cells, point)
+        right = (self.mesh.topology.cells[c].astype(np.int32), (grads @ self.n_r) / self.rho_u + 0j)
+        return left, right
+
+    def assemble_submatrices(self, problem_type='direct'):
+        info("- Generating matrix D..")
+        pairs = []
+        for flame, point in enumerate(self.x_r):
+            pairs.append(self._assemble_vectors(flame, point))
+            info("- Matrix contribution of flame " + str(flame) + " is computed.")
+        self._store(pairs, problem_type)
+
+
+class DistributedFlameMatrix(FlameMatrix):
+
+    def __init__(self, mesh, w, h, rho, T, q_0, u_b, FTF, degree=1, bloch_object=None, gamma=None, tol=1e-5):
+        super().__init__(mesh, h, q_0, u_b, FTF, degree, bloch_object, tol)
+        if gamma is None:                      # variable gamma depends on temperature
+            gamma = gamma_function(T)
+        self.gamma, self.w, self.rho = gamma, w, rho
+
+    def _assemble_vectors(self, problem_type='direct'):
+        asm = self.mesh.assembler()
+        if isinstance(self.gamma, Function):
+            gm1 = self.gamma.x.array - 1.0
+        else:
+            gm1 = np.full(self.V.size, self.gamma - 1.0, dtype=np.complex128)
+        left = self.indices_and_values(asm.load(1, gm1, self.h.x.array, scale=self.q_0 / self.u_b))
+        right = self.indices_and_values(asm.load(2, self.rho.x.array, self.w.x.array))
+        return left, right
+
+    def assemble_submatrices(self, problem_type='direct'):
+        info("- Generating matrix D..")
+        self._store([self._assemble_vectors(problem_type)], problem_type)

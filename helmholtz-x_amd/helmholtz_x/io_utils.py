@@ -1,0 +1,149 @@
+"""Mesh ingestion and small result writers (reference: helmholtz_x/io_utils.py:10-217).
+
+The reference converts gmsh ``.msh`` files to XDMF/HDF5 with meshio and reads those through DOLFINx; neither
+library is a dependency here.  ``XDMFReader(name)`` therefore reads the ASCII gmsh-4.1 file ``name.msh``
+directly and keeps, like io_utils.py:71-139, the top-dimensional simplices and the (dim-1)-simplices that
+carry a physical tag.  ``dict_writer`` / ``dict_loader`` keep the reference's on-disk format."""
+import ast
+import json
+from itertools import combinations
+
+import numpy as np
+
+from .fem import Mesh, MeshTags
+from .solver_utils import info
+
+_NODES_PER_TYPE = {15: 1, 1: 2, 2: 3, 4: 4}     # gmsh element type -> vertex count (point, line, tri, tet)
+
+
+def dict_writer(filename, dictionary, extension=".txt"):
+    with open(filename + extension, 'w') as file:
+        file.write(json.dumps(str(dictionary)))
+    print(filename + extension, " is saved.")
+
+
+def dict_loader(filename, extension=".txt"):
+    with open(filename + extension) as f:
+        data = ast.literal_eval(json.load(f))
+    print(filename + extension, " is loaded.")
+    return data
+
+
+def _sections(path):
+    with open(path) as fh:
+        lines = fh.read().split("\n")
+    out, name, start = {}, None, 0
+    for i, ln in enumerate(lines):
+        if ln.startswith("$End"):
+            out[name] = lines[start:i]
+            name = None
+        elif ln.startswith("$"):
+            name, start = ln[1:].strip(), i + 1
+    return out
+
+
+def read_gmsh(path, dim=None):
+    """ASCII gmsh 4.1 -> (Mesh, cell MeshTags, facet MeshTags)."""
+    sec = _sections(path)
+    if not sec["MeshFormat"][0].startswith("4.1 0"):
+        raise NotImplementedError("only ASCII gmsh 4.1 files are supported")
+    # entity -> first physical tag
+    ent = sec["Entities"]
+    counts = [int(v) for v in ent[0].split()]
+    phys, row = {}, 1
+    for edim, cnt in enumerate(counts):
+        for _ in range(cnt):
+            p = ent[row].split()
+            row += 1
+            off = 4 if edim == 0 else 7
+            if int(p[off]):
+                phys[(edim, int(p[0]))] = int(p[off + 1])
+    # nodes
+    nd = sec["Nodes"]
+    nblocks, nnodes = (int(v) for v in nd[0].split()[:2])
+    tags, xyz, row = [], [], 1
+    for _ in range(nblocks):
+        nb = int(nd[row].split()[3])
+        row += 1
+        tags.extend(int(t) for t in nd[row:row + nb])
+        xyz.extend([float(v) for v in t.split()] for t in nd[row + nb:row + 2 * nb])
+        row += 2 * nb
+    tags = np.asarray(tags, dtype=np.int64)
+    xyz = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+    lookup = np.full(tags.max() + 1, -1, dtype=np.int64)
+    lookup[tags] = np.arange(tags.size)
+    # elements of tagged entities, grouped by dimension
+    el = sec["Elements"]
+    nblocks = int(el[0].split()[0])
+    conn = {d: [] for d in range(4)}
+    ptag = {d: [] for d in range(4)}
+    row = 1
+    for _ in range(nblocks):
+        edim, etag, etype, nb = (int(v) for v in el[row].split())
+        row += 1
+        k = _NODES_PER_TYPE.get(etype)
+        if k is not None and (edim, etag) in phys:
+            block = np.array([[int(v) for v in t.split()[1:1 + k]] for t in el[row:row + nb]], dtype=np.int64)
+            conn[edim].append(lookup[block])
+            ptag[edim].append(np.full(nb, phys[(edim, etag)], dtype=np.int32))
+        row += nb
+    if dim is None:
+        dim = max(d for d in conn if conn[d])
+    cells = np.concatenate(conn[dim])
+    cell_values = np.concatenate(ptag[dim])
+    used = np.unique(cells)
+    renum = np.full(xyz.shape[0], -1, dtype=np.int64)
+    renum[used] = np.arange(used.size)
+    cells = renum[cells].astype(np.int32)
+    facets = np.sort(renum[np.concatenate(conn[dim - 1])], axis=1).astype(np.int32)
+    facet_values = np.concatenate(ptag[dim - 1])
+    # adjacent cell of each tagged facet
+    combos = list(combinations(range(dim + 1), dim))
+    allf = np.sort(np.concatenate([cells[:, c] for c in combos], axis=0), axis=1)
+    owner = np.tile(np.arange(cells.shape[0]), len(combos))
+    base = int(used.size) + 1
+    key_all = np.zeros(allf.shape[0], dtype=np.int64)
+    key_f = np.zeros(facets.shape[0], dtype=np.int64)
+    for c in range(dim):
+        key_all = key_all * base + allf[:, c]
+        key_f = key_f * base + facets[:, c]
+    order = np.argsort(key_all, kind="stable")
+    pos = np.searchsorted(key_all[order], key_f)
+    facet_cells = owner[order[pos]].astype(np.int32)
+    mesh = Mesh(xyz[used], cells, facets=facets, facet_cells=facet_cells)
+    cell_tags = MeshTags(mesh, dim, np.arange(cells.shape[0]), cell_values)
+    facet_tags = MeshTags(mesh, dim - 1, np.arange(facets.shape[0]), facet_values)
+    return mesh, cell_tags, facet_tags
+
+
+class XDMFReader:
+    """Same accessors as the reference's reader (io_utils.py:160-217); the source is ``name.msh``."""
+
+    def __init__(self, name, dim=None):
+        self.name = name
+        self._mesh, self._cell_tags, self._facet_tags = read_gmsh(name + ".msh", dim)
+        info("\nXDMF Mesh - Cell data loaded.")
+        info("XDMF Mesh - Facet data loaded.")
+
+    @property
+    def mesh(self):
+        return self._mesh
+
+    @property
+    def subdomains(self):
+        return self._cell_tags
+
+    @property
+    def facet_tags(self):
+        return self._facet_tags
+
+    @property
+    def dimension(self):
+        return self._mesh.topology.dim
+
+    def getAll(self):
+        return self.mesh, self.subdomains, self.facet_tags
+
+    def getInfo(self):
+        print("Number of cells:  {:,}".format(self._mesh.num_cells))
+        print("Number of cores: ", 1, "\n")

@@ -1,0 +1,407 @@
+"""petsc4py-shaped ``Vec`` / ``Mat`` wrappers over device memory and libhx kernels.
+
+Only the surface the reference's hot path touches is provided (call sites:
+eigensolvers.py:45,173-176,211,240,309-315; petsc4py_utils.py:4-111; bloch_operator.py:42,68,106-110;
+eigenvectors.py:20-46).  A ``Mat`` is a *lazy* linear combination
+
+    M = sum_i coef_i * CSR_i  +  sum_j coef_j * (U_j V_j^T)
+
+so ``A - D`` or ``A + omega*B - D`` (eigensolvers.py:174-176,240) never materialises the rank-r flame
+block ``a (x) b`` that the reference stores explicitly (flame_matrices.py:91-92,176,233).
+PyTorch is used for device allocation / copies only; all arithmetic is libhx (HIP).
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _hx
+
+
+def _dev():
+    return _hx.require_gpu()
+
+
+def to_device(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(_dev())
+
+
+class Vec:
+    """Device complex128 vector with the petsc4py Vec methods the reference calls."""
+
+    def __init__(self, data):
+        if isinstance(data, torch.Tensor):
+            self.t = data
+        else:
+            self.t = to_device(np.asarray(data, dtype=np.complex128))
+
+    @classmethod
+    def zeros(cls, n):
+        return cls(torch.zeros(int(n), dtype=torch.complex128, device=_dev()))
+
+    # --- petsc4py surface
+    def copy(self):
+        return Vec(self.t.clone())
+
+    def duplicate(self):
+        return Vec.zeros(self.t.numel())
+
+    def getSize(self):
+        return self.t.numel()
+
+    def scale(self, z):
+        _hx.check(_hx.lib.hx_zscal(self.t.numel(), _hx.z2(z), _hx.ptr(self.t), _hx.stream()))
+
+    def conjugate(self):
+        self.t = torch.conj_physical(self.t)
+
+    def axpy(self, alpha, x):
+        _hx.check(_hx.lib.hx_zaxpy(self.t.numel(), _hx.z2(alpha), _hx.ptr(x.t), _hx.ptr(self.t), _hx.stream()))
+
+    def dot(self, other):
+        """PETSc VecDot(x, y) = y^H x  (petsc4py_utils.py:57-61 relies on this)."""
+        return panel_dot(other.t.reshape(1, -1), 1, self.t)[0]
+
+    def norm(self):
+        return float(np.sqrt(panel_dot(None, 0, self.t)[-1].real))
+
+    def sum(self):
+        return complex(self.t.sum().item())
+
+    @property
+    def array(self):
+        return self.t.cpu().numpy()
+
+    def getArray(self):
+        return self.array
+
+    def setArray(self, a):
+        self.t.copy_(torch.from_numpy(np.asarray(a, dtype=np.complex128)))
+
+    def getComm(self):
+        return _SerialComm()
+
+    def __getitem__(self, i):
+        return complex(self.t[i].item())
+
+    def assemble(self):
+        pass
+
+    def destroy(self):
+        self.t = None
+
+
+class _SerialComm:
+    def getRank(self):
+        return 0
+
+    def getSize(self):
+        return 1
+
+
+_ws_cache = {}
+
+
+def panel_dot(V, k, w):
+    """[V_j^H w for j<k] + [w^H w] as a host numpy array (one D2H sync).  V: (m, n) tensor, rows = vectors."""
+    n = w.numel()
+    key = (w.device.index, k)
+    if key not in _ws_cache:
+        _ws_cache[key] = (torch.empty(_hx.lib.hx_panel_dot_ws(k), dtype=torch.complex128, device=w.device),
+                          torch.empty(k + 1, dtype=torch.complex128, device=w.device))
+    ws, out = _ws_cache[key]
+    ldv = V.stride(0) if (V is not None and k > 0) else n
+    _hx.check(_hx.lib.hx_zpanel_dot(n, k, _hx.ptr(V) if k > 0 else None, ldv, _hx.ptr(w), _hx.ptr(out),
+                                    _hx.ptr(ws), _hx.stream()))
+    return out.cpu().numpy()
+
+
+class CSR:
+    """Device CSR (int32 rowptr/col, complex128 val) + a host copy of the integer pattern."""
+
+    def __init__(self, shape, rowptr, col, val, h_rowptr=None, h_col=None, pattern_id=None):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self._h_rowptr, self._h_col = h_rowptr, h_col
+        self.pattern_id = pattern_id if pattern_id is not None else id(self)
+        self.nnz = int(col.numel())
+
+    @classmethod
+    def from_scipy(cls, M):
+        M = sp.csr_matrix(M, dtype=np.complex128)
+        M.sort_indices()
+        rp, ci = M.indptr.astype(np.int32), M.indices.astype(np.int32)
+        return cls(M.shape, to_device(rp), to_device(ci), to_device(M.data), rp, ci)
+
+    def host_pattern(self):
+        if self._h_rowptr is None:
+            self._h_rowptr = self.rowptr.cpu().numpy()
+            self._h_col = self.col.cpu().numpy()
+        return self._h_rowptr, self._h_col
+
+    def to_scipy(self):
+        rp, ci = self.host_pattern()
+        return sp.csr_matrix((self.val.cpu().numpy(), ci.copy(), rp.copy()), shape=self.shape)
+
+    def with_values(self, val):
+        return CSR(self.shape, self.rowptr, self.col, val, self._h_rowptr, self._h_col, self.pattern_id)
+
+    def spmv(self, x, y, alpha=1.0, beta=0.0, lanes=0):
+        _hx.check(_hx.lib.hx_csr_spmv_z(self.shape[0], self.nnz, _hx.ptr(self.rowptr), _hx.ptr(self.col),
+                                        _hx.ptr(self.val), _hx.ptr(x), _hx.ptr(y), _hx.z2(alpha), _hx.z2(beta),
+                                        lanes, _hx.stream()))
+
+
+class LowRank:
+    """sum_f u_f v_f^T with sparse u_f, v_f given as (int32 idx, complex128 val) host pairs."""
+
+    def __init__(self, n, pairs):
+        self.n = int(n)
+        self.pairs = [((np.asarray(ui, np.int32), np.asarray(uv, np.complex128)),
+                       (np.asarray(vi, np.int32), np.asarray(vv, np.complex128))) for (ui, uv), (vi, vv) in pairs]
+
+    @property
+    def rank(self):
+        return len(self.pairs)
+
+    def transposed(self):
+        return LowRank(self.n, [(v, u) for u, v in self.pairs])
+
+    def conjugated(self):
+        return LowRank(self.n, [((ui, uv.conj()), (vi, vv.conj())) for (ui, uv), (vi, vv) in self.pairs])
+
+    def to_scipy(self):
+        M = sp.csr_matrix((self.n, self.n), dtype=np.complex128)
+        for (ui, uv), (vi, vv) in self.pairs:
+            rows = np.repeat(ui, len(vi))
+            cols = np.tile(vi, len(ui))
+            M = M + sp.coo_matrix((np.outer(uv, vv).ravel(), (rows, cols)), shape=(self.n, self.n)).tocsr()
+        return M
+
+    # device views (built on demand)
+    def right_packed(self):
+        if not hasattr(self, "_rp"):
+            ptr = np.zeros(self.rank + 1, np.int32)
+            ptr[1:] = np.cumsum([len(v[0]) for _, v in self.pairs])
+            idx = np.concatenate([v[0] for _, v in self.pairs]) if self.rank else np.zeros(0, np.int32)
+            val = np.concatenate([v[1] for _, v in self.pairs]) if self.rank else np.zeros(0, np.complex128)
+            self._rp = (to_device(ptr), to_device(idx), to_device(val))
+        return self._rp
+
+    def left_dense(self):
+        """(rank, n) device tensor whose rows are the dense u_f."""
+        if not hasattr(self, "_ld"):
+            U = torch.zeros((self.rank, self.n), dtype=torch.complex128, device=_dev())
+            for f, ((ui, uv), _) in enumerate(self.pairs):
+                U[f, torch.from_numpy(ui.astype(np.int64)).to(U.device)] = to_device(uv)
+            self._ld = U
+        return self._ld
+
+
+class Mat:
+    """Lazy linear combination of CSR terms and low-rank terms (see module docstring)."""
+
+    __array_ufunc__ = None        # numpy scalars defer to Mat.__rmul__ (omega * B, eigensolvers.py:176)
+
+    def __init__(self, shape, csr_terms=(), lr_terms=()):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.csr_terms = [(complex(c), m) for c, m in csr_terms]
+        self.lr_terms = [(complex(c), m) for c, m in lr_terms]
+        self._mat = None
+
+    # ---- construction helpers (petsc4py API)
+    @classmethod
+    def from_csr(cls, csr):
+        return cls(csr.shape, [(1.0, csr)])
+
+    def createAIJ(self, size, csr=None, comm=None):
+        if np.isscalar(size):
+            size = (size, size)
+        ai, aj, av = csr
+        M = sp.csr_matrix((np.asarray(av, np.complex128), np.asarray(aj), np.asarray(ai)), shape=tuple(size))
+        m = Mat.from_csr(CSR.from_scipy(M))
+        self.__dict__.update(m.__dict__)
+        return self
+
+    def getSize(self):
+        return self.shape
+
+    def createVecs(self):
+        return Vec.zeros(self.shape[1]), Vec.zeros(self.shape[0])
+
+    getVecs = createVecs
+
+    def assemble(self):
+        return self
+
+    def assemblyBegin(self):
+        pass
+
+    def assemblyEnd(self):
+        pass
+
+    def destroy(self):
+        self.csr_terms, self.lr_terms, self._mat = [], [], None
+
+    def copy(self):
+        return Mat(self.shape, list(self.csr_terms), list(self.lr_terms))
+
+    # ---- algebra (new lazy objects; nothing is computed here)
+    def _scaled(self, z):
+        z = complex(z)
+        return Mat(self.shape, [(c * z, m) for c, m in self.csr_terms], [(c * z, m) for c, m in self.lr_terms])
+
+    def __mul__(self, z):
+        if isinstance(z, Vec):
+            y = Vec.zeros(self.shape[0])
+            self.mult(z, y)
+            return y
+        return self._scaled(z)
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self._scaled(-1.0)
+
+    def __add__(self, other):
+        if other is None:
+            return self.copy()
+        return Mat(self.shape, self.csr_terms + other.csr_terms, self.lr_terms + other.lr_terms)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self + (-other)
+
+    def scale(self, z):
+        m = self._scaled(z)
+        self.csr_terms, self.lr_terms, self._mat = m.csr_terms, m.lr_terms, None
+
+    def transpose(self):
+        """In place, like petsc4py (acoustic_matrices.py:113).  The CSR transpose is integer/structural work done
+        once on the host; values are re-uploaded."""
+        self.csr_terms = [(c, CSR.from_scipy(m.to_scipy().T.tocsr())) for c, m in self.csr_terms]
+        self.lr_terms = [(c, m.transposed()) for c, m in self.lr_terms]
+        self._mat = None
+        return self
+
+    def conjugate(self):
+        self.csr_terms = [(np.conj(c), m.with_values(torch.conj_physical(m.val))) for c, m in self.csr_terms]
+        self.lr_terms = [(np.conj(c), m.conjugated()) for c, m in self.lr_terms]
+        self._mat = None
+        return self
+
+    # ---- evaluation
+    def csr_part(self):
+        """Materialise sum_i coef_i CSR_i as ONE device CSR (cached)."""
+        if self._mat is None:
+            self._mat = combine_csr(self.shape, self.csr_terms)
+        return self._mat
+
+    def lowrank_part(self):
+        """[(coef, LowRank)] as given."""
+        return self.lr_terms
+
+    def mult(self, x, y):
+        K = self.csr_part()
+        if K is None:
+            y.t.zero_()
+        else:
+            K.spmv(x.t, y.t)
+        for coef, lr in self.lr_terms:
+            if lr.rank == 0:
+                continue
+            ptr, idx, val = lr.right_packed()
+            t = torch.empty(lr.rank, dtype=torch.complex128, device=x.t.device)
+            _hx.check(_hx.lib.hx_zsparse_dots(lr.rank, _hx.ptr(ptr), _hx.ptr(idx), _hx.ptr(val), _hx.ptr(x.t),
+                                              _hx.ptr(t), _hx.stream()))
+            h = (-coef) * t                      # y -= U (-(coef) t)
+            U = lr.left_dense()
+            _hx.check(_hx.lib.hx_zpanel_sub(lr.n, lr.rank, _hx.ptr(U), U.stride(0), _hx.ptr(h), _hx.ptr(y.t),
+                                            _hx.stream()))
+
+    def getValuesCSR(self):
+        """Explicit CSR including the outer-product blocks -- what the reference stores (small cases / tests only)."""
+        M = sp.csr_matrix(self.shape, dtype=np.complex128)
+        K = self.csr_part()
+        if K is not None:
+            M = M + K.to_scipy()
+        for coef, lr in self.lr_terms:
+            M = M + coef * lr.to_scipy()
+        M = sp.csr_matrix(M)
+        M.sort_indices()
+        return M.indptr, M.indices, M.data
+
+    def to_scipy(self):
+        ai, aj, av = self.getValuesCSR()
+        return sp.csr_matrix((av, aj, ai), shape=self.shape)
+
+
+def combine_csr(shape, terms):
+    """sum_i coef_i CSR_i on the device.  Same-pattern terms are one fused lincomb kernel; terms on a different
+    pattern are scatter-added through a host-computed slot map (integer work only)."""
+    terms = [(c, m) for c, m in terms if m is not None]
+    if not terms:
+        return None
+    if len(terms) == 1 and terms[0][0] == 1.0:
+        return terms[0][1]
+    # base pattern = the one with most nonzeros; if some term's pattern is not contained in it, use the union
+    base = max(terms, key=lambda cm: cm[1].nnz)[1]
+    others = [m for _, m in terms if m.pattern_id != base.pattern_id]
+    slot_maps = {}
+    if others:
+        brp, bci = base.host_pattern()
+        n = shape[0]
+        P = sp.csr_matrix((np.ones(len(bci), np.int8), bci, brp), shape=shape)
+        need_union = False
+        for m in others:
+            rp, ci = m.host_pattern()
+            Q = sp.csr_matrix((np.ones(len(ci), np.int8), ci, rp), shape=shape)
+            if Q.multiply(P).nnz != Q.nnz:
+                need_union = True
+        if need_union:
+            U = P.copy()
+            for m in others:
+                rp, ci = m.host_pattern()
+                U = U + sp.csr_matrix((np.ones(len(ci), np.int8), ci, rp), shape=shape)
+            U = sp.csr_matrix(U)
+            U.sort_indices()
+            urp, uci = U.indptr.astype(np.int32), U.indices.astype(np.int32)
+            base = CSR(shape, to_device(urp), to_device(uci), None, urp, uci)
+            others = [m for _, m in terms]
+        brp, bci = base.host_pattern()
+        row_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(brp))
+        base_keys = row_of * shape[1] + bci
+        for m in others:
+            if m.pattern_id in slot_maps:
+                continue
+            rp, ci = m.host_pattern()
+            keys = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp)) * shape[1] + ci
+            slot_maps[m.pattern_id] = to_device(np.searchsorted(base_keys, keys).astype(np.int32))
+    same = [(c, m) for c, m in terms if m.pattern_id == base.pattern_id and m.val is not None]
+    out = None
+    i = 0
+    while i < len(same):
+        take = 4 if out is None else 3
+        chunk = same[i:i + take]
+        i += take
+        vals = [m.val for _, m in chunk]
+        coefs = [c for c, _ in chunk]
+        if out is None:
+            out = torch.empty(base.nnz, dtype=torch.complex128, device=_dev())
+        else:
+            vals, coefs = [out] + vals, [1.0] + coefs
+        arr = (C.c_void_p * len(vals))(*[v.data_ptr() for v in vals])
+        cf = (C.c_double * (2 * len(coefs)))(*[p for c in coefs for p in (complex(c).real, complex(c).imag)])
+        _hx.check(_hx.lib.hx_zlincomb(base.nnz, len(vals), cf, arr, _hx.ptr(out), _hx.stream()))
+    if out is None:
+        out = torch.zeros(base.nnz, dtype=torch.complex128, device=_dev())
+    for c, m in terms:
+        if m.pattern_id != base.pattern_id:
+            _hx.check(_hx.lib.hx_zscatter_axpy(m.nnz, _hx.z2(c), _hx.ptr(m.val), _hx.ptr(slot_maps[m.pattern_id]),
+                                               _hx.ptr(out), _hx.stream()))
+    return base.with_values(out)

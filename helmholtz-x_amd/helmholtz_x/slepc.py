@@ -1,0 +1,426 @@
+"""slepc4py-shaped ``EPS`` / ``PEP`` solvers running on the GPU.
+
+Replaces what the reference reaches through SLEPc (eigensolvers.py:43-62, 96-113): ST = sinvert at a fixed
+target, TARGET_MAGNITUDE ordering, ncv = max(2 nev, nev+15), tol = 1e-15.
+
+Per Krylov step on the device (libhx):
+  EPS:  w = K^-1 (-C v),                K = A + sigma C,            lambda = sigma + 1/theta  (= omega^2)
+  PEP:  first companion form z = [x; lambda x],  K = A + sigma B + sigma^2 C,
+        y1 = -K^-1[(B + sigma C) x1 + C x2],  y2 = x1 + sigma y1,   lambda = sigma + 1/theta  (= omega)
+followed by classical Gram-Schmidt with one re-orthogonalisation (hx_zpanel_dot / hx_zpanel_sub).
+
+K^-1 is applied by ``K^-1 + W (I - F V^T W)^-1 F V^T K^-1`` (Woodbury) when the operator carries the
+rank-r flame term ``- sum_f F u_f v_f^T``; K itself never contains the dense outer-product block.
+The inner solver for the sparse K is pluggable (``st_type``):
+  'lu'   host SuperLU factorisation -> device level-scheduled triangular solves (hx_sptrsv_*)
+  'amg'  device AMG-preconditioned GMRES (amg.py) for 3-D problems where a direct factorisation does not fit
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+import torch
+
+from . import _hx
+from .krylov import default_ncv, krylov_schur
+from .petsc import Mat, Vec, combine_csr, panel_dot, to_device
+from .solver_utils import info
+
+DEFAULTS = {"st_type": "auto", "lu_max_dofs_3d": 120_000, "lu_max_dofs": 600_000}
+
+
+# ----------------------------------------------------------------------------- inner solvers for sparse K
+class LUSolver:
+    """Pr K Pc = L U on the host (SuperLU, sequential) + device triangular solves."""
+
+    name = "lu"
+
+    def __init__(self, K_csr):
+        n = K_csr.shape[0]
+        Ks = K_csr.to_scipy().tocsc()
+        lu = spla.splu(Ks, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.1,
+                       options=dict(SymmetricMode=True))
+        self.n = n
+        self.fill = (lu.L.nnz + lu.U.nnz) / max(Ks.nnz, 1)
+        self.handles = []
+        for M, lower in ((lu.L, 1), (lu.U, 0)):
+            M = sp.csr_matrix(M)
+            M.sort_indices()
+            diag = M.diagonal()
+            if np.any(diag == 0):
+                raise ZeroDivisionError("singular factor: the target coincides with an eigenvalue")
+            S = (sp.tril(M, -1) if lower else sp.triu(M, 1)).tocsr()
+            S.sort_indices()
+            rp = np.ascontiguousarray(S.indptr, dtype=np.int32)
+            ci = np.ascontiguousarray(S.indices, dtype=np.int32)
+            va = np.ascontiguousarray(S.data, dtype=np.complex128)
+            inv = np.ascontiguousarray(1.0 / diag, dtype=np.complex128)
+            h = C.c_void_p()
+            _hx.check(_hx.lib.hx_sptrsv_create(C.byref(h), n, lower, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(va),
+                                               _hx.nptr(inv)))
+            self.handles.append(h)
+        # Pr K Pc = L U  =>  x = Pc U^-1 L^-1 Pr b ;  (Pr b)[perm_r[i]] = b[i],  x[i] = y[perm_c[i]]
+        self.gather_in = to_device(np.argsort(lu.perm_r).astype(np.int32))
+        self.gather_out = to_device(lu.perm_c.astype(np.int32))
+        self.tmp = torch.empty(n, dtype=torch.complex128, device=self.gather_in.device)
+
+    def info(self):
+        lv, ln, nz = C.c_int32(), C.c_int32(), C.c_int64()
+        out = []
+        for h in self.handles:
+            _hx.check(_hx.lib.hx_sptrsv_info(h, C.byref(lv), C.byref(ln), C.byref(nz)))
+            out.append((lv.value, ln.value, nz.value))
+        return out
+
+    def solve(self, b, x):
+        """x = K^-1 b (device tensors; b is preserved, may not alias x)."""
+        s = _hx.stream()
+        _hx.check(_hx.lib.hx_zgather(self.n, _hx.ptr(b), _hx.ptr(self.gather_in), _hx.ptr(self.tmp), s))
+        _hx.check(_hx.lib.hx_sptrsv_solve(self.handles[0], _hx.ptr(self.tmp), _hx.ptr(self.tmp), s))
+        _hx.check(_hx.lib.hx_sptrsv_solve(self.handles[1], _hx.ptr(self.tmp), _hx.ptr(self.tmp), s))
+        _hx.check(_hx.lib.hx_zgather(self.n, _hx.ptr(self.tmp), _hx.ptr(self.gather_out), _hx.ptr(x), s))
+
+    def destroy(self):
+        for h in self.handles:
+            _hx.lib.hx_sptrsv_destroy(h)
+        self.handles = []
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None):
+    st = st_type or DEFAULTS["st_type"]
+    n = K_csr.shape[0]
+    if st == "auto":
+        dense_rows = K_csr.nnz / max(n, 1) > 10.5        # 3-D P1 rows have ~15 nonzeros, 2-D ~7, 1-D 3
+        limit = DEFAULTS["lu_max_dofs_3d"] if dense_rows else DEFAULTS["lu_max_dofs"]
+        st = "lu" if n <= limit else "amg"
+    if st == "lu":
+        return LUSolver(K_csr)
+    if st == "amg":
+        from .amg import AMGSolver
+        return AMGSolver(K_csr, hierarchy=hierarchy)
+    raise ValueError("unknown st_type %r" % st)
+
+
+class WoodburySolver:
+    """(K - sum_j c_j U_j V_j^T)^-1 through the inner solver of K.
+
+    Operator:  M = K + sum_j coef_j * (U_j V_j^T)   (coef_j already carries the sign and the FTF value)."""
+
+    def __init__(self, inner, lr_terms, W_cache=None):
+        self.inner = inner
+        self.n = inner.n
+        terms = [(c, lr) for c, lr in lr_terms if lr.rank > 0 and c != 0]
+        self.active = bool(terms)
+        if not self.active:
+            return
+        dev = inner.tmp.device if hasattr(inner, "tmp") else _hx.require_gpu()
+        # stack all rank-1 pieces: U (r x n dense rows), V packed sparse, coefficient per piece
+        self.coefs = np.concatenate([np.full(lr.rank, c, dtype=np.complex128) for c, lr in terms])
+        U = torch.cat([lr.left_dense() for _, lr in terms], dim=0)
+        ptrs, idxs, vals, off = [np.zeros(1, np.int32)], [], [], 0
+        for _, lr in terms:
+            for _, (vi, vv) in lr.pairs:
+                idxs.append(vi)
+                vals.append(vv)
+                off += len(vi)
+                ptrs.append(np.array([off], np.int32))
+        self.r = U.shape[0]
+        self.v_ptr = to_device(np.concatenate(ptrs))
+        self.v_idx = to_device(np.concatenate(idxs).astype(np.int32))
+        self.v_val = to_device(np.concatenate(vals).astype(np.complex128))
+        self.t_dev = torch.empty(self.r, dtype=torch.complex128, device=dev)
+        key = None
+        if W_cache is not None:
+            key = (id(inner), tuple(id(lr) for _, lr in terms))
+        if key is not None and key in W_cache:
+            self.W, self.VtW = W_cache[key]
+        else:
+            self.W = torch.empty_like(U)                         # rows: K^-1 u_f
+            for f in range(self.r):
+                inner.solve(U[f], self.W[f])
+            self.VtW = np.empty((self.r, self.r), dtype=np.complex128)
+            for f in range(self.r):
+                self.VtW[:, f] = self._vt(self.W[f])
+            if key is not None:
+                W_cache[key] = (self.W, self.VtW)
+        # M^-1 = K^-1 - W (I + diag(c) V^T W)^-1 diag(c) V^T K^-1
+        self.small = np.linalg.inv(np.eye(self.r) + self.coefs[:, None] * self.VtW) * self.coefs[None, :]
+
+    def _vt(self, y):
+        """t_f = v_f^T y (bilinear, no conjugate) for all rank-1 pieces; returns a host array."""
+        _hx.check(_hx.lib.hx_zsparse_dots(self.r, _hx.ptr(self.v_ptr), _hx.ptr(self.v_idx), _hx.ptr(self.v_val),
+                                          _hx.ptr(y), _hx.ptr(self.t_dev), _hx.stream()))
+        return self.t_dev.cpu().numpy().copy()
+
+    def solve(self, b, x):
+        self.inner.solve(b, x)
+        if not self.active:
+            return
+        t = self._vt(x)
+        s = self.small @ t                                   # r x r host solve (tiny)
+        h = to_device(s)
+        _hx.check(_hx.lib.hx_zpanel_sub(self.n, self.r, _hx.ptr(self.W), self.W.stride(0), _hx.ptr(h), _hx.ptr(x),
+                                        _hx.stream()))
+
+
+# ----------------------------------------------------------------------------- device Krylov basis
+class DeviceBasis:
+    """(m, n) row-major block of Krylov vectors + the libhx CGS2 / rotation kernels."""
+
+    def __init__(self, n, m, apply_op, seed=0):
+        dev = _hx.require_gpu()
+        self.n, self.m = n, m
+        self.V = torch.zeros((m, n), dtype=torch.complex128, device=dev)
+        self.V2 = torch.zeros((m, n), dtype=torch.complex128, device=dev)
+        self.apply_op = apply_op
+        self.seed = seed
+        self.h_dev = torch.empty(m + 1, dtype=torch.complex128, device=dev)
+        self.ws = torch.empty(_hx.lib.hx_panel_dot_ws(m), dtype=torch.complex128, device=dev)
+        self.n_ops = 0
+
+    def _dots(self, k, w):
+        _hx.check(_hx.lib.hx_zpanel_dot(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(w), _hx.ptr(self.h_dev),
+                                        _hx.ptr(self.ws), _hx.stream()))
+
+    def _sub(self, k, w):
+        _hx.check(_hx.lib.hx_zpanel_sub(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(self.h_dev), _hx.ptr(w),
+                                        _hx.stream()))
+
+    def set_start(self, j):
+        rng = np.random.default_rng(self.seed)
+        v = rng.standard_normal(self.n) + 1j * rng.standard_normal(self.n)
+        self.V[j].copy_(torch.from_numpy(v))
+        self._dots(0, self.V[j])
+        nrm = np.sqrt(self.h_dev[:1].cpu().numpy()[0].real)
+        _hx.check(_hx.lib.hx_zscal(self.n, _hx.z2(1.0 / nrm), _hx.ptr(self.V[j]), _hx.stream()))
+
+    def expand(self, j):
+        w = self.V[j + 1]
+        self.apply_op(self.V[j], w)
+        self.n_ops += 1
+        k = j + 1
+        self._dots(k, w)
+        self._sub(k, w)
+        h1 = self.h_dev[:k].cpu().numpy().copy()
+        self._dots(k, w)
+        self._sub(k, w)
+        out = self.h_dev[:k + 1].cpu().numpy()
+        h2, ww = out[:k], out[k].real
+        beta2 = ww - float(np.sum(np.abs(h2) ** 2))
+        if beta2 <= 1e-8 * ww:                       # cancellation: measure the norm directly
+            self._dots(0, w)
+            beta2 = self.h_dev[:1].cpu().numpy()[0].real
+        beta = np.sqrt(max(beta2, 0.0))
+        if beta == 0.0:
+            raise ArithmeticError("Arnoldi breakdown (invariant subspace found)")
+        _hx.check(_hx.lib.hx_zscal(self.n, _hx.z2(1.0 / beta), _hx.ptr(w), _hx.stream()))
+        return h1 + h2, beta
+
+    def rotate(self, Q, k):
+        mact = Q.shape[0]
+        Qd = to_device(np.ascontiguousarray(np.asarray(Q, dtype=np.complex128).T))   # column-major (mact x k)
+        _hx.check(_hx.lib.hx_zpanel_mul(self.n, mact, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(Qd),
+                                        _hx.ptr(self.V2), self.V2.stride(0), _hx.stream()))
+        if mact < self.m:
+            self.V2[k].copy_(self.V[mact])
+        self.V, self.V2 = self.V2, self.V
+
+
+# ----------------------------------------------------------------------------- EPS / PEP
+class _EigenSolverBase:
+    def __init__(self):
+        self._ops = None
+        self._target = 0.0
+        self._nev = 1
+        self._ncv = None
+        self._tol = 1e-15
+        self._max_it = 100
+        self._two_sided = False
+        self._result = None
+        self._eigs = None
+        self._basis = None
+        self.st_type = None
+        self.W_cache = None
+        self.inner_cache = None
+
+    # --- slepc4py configuration surface (eigensolvers.py:43-60, 96-109)
+    def create(self, comm=None):
+        return self
+
+    def setOperators(self, *ops):
+        self._ops = ops[0] if (len(ops) == 1 and isinstance(ops[0], (list, tuple))) else ops
+
+    def getOperators(self):
+        return tuple(self._ops)
+
+    def getST(self):
+        return self
+
+    def setType(self, t):          # ST type: always shift-and-invert on this path
+        if t not in ("sinvert", "krylovschur", "toar"):
+            raise NotImplementedError("only ST=sinvert / krylovschur / toar are on the hot path")
+
+    def setTarget(self, t):
+        self._target = complex(t)
+
+    def setWhichEigenpairs(self, which):
+        pass                        # TARGET_MAGNITUDE only
+
+    def setTwoSided(self, flag):
+        if flag:
+            raise NotImplementedError("two-sided solves belong to the newtonSolver row (SURVEY.md 8f-2)")
+
+    def setDimensions(self, nev, ncv=None, mpd=None):
+        self._nev = int(nev)
+        self._ncv = None if (ncv is None or ncv < 0) else int(ncv)
+
+    def setTolerances(self, tol=None, max_it=None):
+        if tol is not None:
+            self._tol = tol
+        if max_it is not None:
+            self._max_it = max_it
+
+    def setFromOptions(self):
+        pass
+
+    # --- results
+    def getConverged(self):
+        return self._result.nconv
+
+    def getIterationNumber(self):
+        return self._result.its
+
+    def getDimensions(self):
+        return self._nev, self._ncv_used, self._ncv_used
+
+    def getTolerances(self):
+        return self._tol, self._max_it
+
+    def getEigenvalue(self, i):
+        return complex(self._eigs[i])
+
+    def getEigenvector(self, i, vr, vi=None):
+        vr.t.copy_(self._basis.V[i][:vr.t.numel()])
+
+    def getEigenpair(self, i, vr=None, vi=None):
+        if vr is not None:
+            self.getEigenvector(i, vr, vi)
+        return self.getEigenvalue(i)
+
+    def getErrorEstimate(self, i):
+        return float(self._result.resid[i])
+
+    def destroy(self):
+        self._basis = None
+
+    def _finish(self, basis, sigma):
+        ncv = self._ncv_used
+        res = krylov_schur(basis, self._nev, ncv, tol=self._tol, max_it=self._max_it)
+        self._result = res
+        self._eigs = sigma + 1.0 / res.theta
+        self._basis = basis
+        if res.nconv < self._nev:
+            info("! only %d of %d eigenpairs reached tol=%g (max residual estimate %.2e)"
+                 % (res.nconv, self._nev, self._tol, float(np.max(res.resid))))
+
+    def _ncv_for(self, n):
+        ncv = self._ncv if self._ncv else default_ncv(self._nev)
+        self._ncv_used = max(min(ncv, n - 1), self._nev + 1)
+        return self._ncv_used
+
+    def _inner(self, K, key):
+        """Inner solver for the sparse part of the shifted operator; cached across fixed-point iterations when
+        the caller supplies ``inner_cache`` (K does not depend on omega_k when the target is fixed)."""
+        if self.inner_cache is not None and key in self.inner_cache:
+            return self.inner_cache[key]
+        solver = make_inner_solver(K, st_type=self.st_type)
+        if self.inner_cache is not None:
+            self.inner_cache[key] = solver
+        return solver
+
+
+def _term_key(mat):
+    return tuple((c, m.pattern_id, id(m.val)) for c, m in mat.csr_terms)
+
+
+class EPS(_EigenSolverBase):
+    """Generalised problem  A x = lambda M x  with M = -C (eigensolvers.py:45-46)."""
+
+    def getType(self):
+        return "krylovschur"
+
+    def solve(self):
+        A, M = self._ops
+        n = A.shape[0]
+        sigma = self._target
+        K = combine_csr(A.shape, A.csr_terms + [(-sigma * c, m) for c, m in M.csr_terms])   # A - sigma M
+        if M.lr_terms:
+            raise NotImplementedError("low-rank terms in the mass operator")
+        inner = self._inner(K, ("eps", sigma, _term_key(A), _term_key(M)))
+        solver = WoodburySolver(inner, A.lr_terms, self.W_cache)
+        Mcsr = M.csr_part()
+        tmp = torch.empty(n, dtype=torch.complex128, device=Mcsr.val.device)
+
+        def op(v, w):
+            Mcsr.spmv(v, tmp)
+            solver.solve(tmp, w)
+
+        self._finish(DeviceBasis(n, self._ncv_for(n) + 1, op), sigma)
+
+
+class PEP(_EigenSolverBase):
+    """Quadratic problem (A + lambda B + lambda^2 C) x = 0 (eigensolvers.py:96-99)."""
+
+    def getType(self):
+        return "toar"
+
+    def solve(self):
+        A, B, Cm = self._ops
+        n = A.shape[0]
+        sigma = self._target
+        b_terms = B.csr_terms if B is not None else []
+        K = combine_csr(A.shape, A.csr_terms + [(sigma * c, m) for c, m in b_terms]
+                        + [(sigma ** 2 * c, m) for c, m in Cm.csr_terms])
+        BsC = combine_csr(A.shape, list(b_terms) + [(sigma * c, m) for c, m in Cm.csr_terms])
+        Ccsr = Cm.csr_part()
+        inner = self._inner(K, ("pep", sigma, _term_key(A), _term_key(B) if B is not None else None, _term_key(Cm)))
+        solver = WoodburySolver(inner, A.lr_terms, self.W_cache)
+        tmp = torch.empty(n, dtype=torch.complex128, device=Ccsr.val.device)
+
+        def op(z, y):
+            x1, x2 = z[:n], z[n:]
+            y1, y2 = y[:n], y[n:]
+            BsC.spmv(x1, tmp, alpha=-1.0)
+            Ccsr.spmv(x2, tmp, alpha=-1.0, beta=1.0)
+            solver.solve(tmp, y1)                                # y1 = -K^-1[(B + sigma C) x1 + C x2]
+            arr = (C.c_void_p * 2)(x1.data_ptr(), y1.data_ptr())
+            cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
+            _hx.check(_hx.lib.hx_zlincomb(n, 2, cf, arr, _hx.ptr(y2), _hx.stream()))   # y2 = x1 + sigma y1
+
+        self._finish(DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op), sigma)
+        self._n = n
+
+
+class _Which:
+    TARGET_MAGNITUDE = "target_magnitude"
+    TARGET_REAL = "target_real"
+    TARGET_IMAGINARY = "target_imaginary"
+
+
+EPS.Which = _Which
+PEP.Which = _Which
+DECIDE = -1
+
+
+class SLEPc:
+    """Namespace so that ``isinstance(obj, SLEPc.EPS)`` (eigenvectors.py:23,31) keeps working."""
+    EPS = EPS
+    PEP = PEP
+    DECIDE = DECIDE

@@ -1,0 +1,146 @@
+/* hx.h -- C ABI of libhx.so: the MI355X (gfx950) hot path of helmholtz-x.
+ *
+ * The reference (ekremekc/helmholtz-x) has no C/FFI boundary of its own: every flop of its hot path
+ * runs inside DOLFINx / PETSc / SLEPc, reached from Python.  This header is
+ * therefore the boundary a maintainer would bind in place of those library calls; each entry point
+ * cites the reference line(s) whose delegated arithmetic it replaces (paths relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *  - plain C, no exceptions: every function returns 0 on success, a negative hx_status otherwise;
+ *    hx_last_error() gives a thread-local message.
+ *  - all array arguments are DEVICE pointers unless the name starts with h_ (host).
+ *  - complex128 is interleaved {re, im} doubles (PETSc complex scalar layout); scalars are passed as
+ *    const double[2].
+ *  - indices are int32 (the reference uses np.int32 / PetscInt32, flame_matrices.py:70).
+ *  - `stream` is a hipStream_t passed as void*; NULL = the default stream.  Nothing synchronises
+ *    unless documented ("SYNC").  One calling thread per device, as in the reference
+ *    (single-threaded Python per MPI rank).
+ *  - buffers are caller-owned; opaque handles have explicit create / destroy.
+ */
+#ifndef HX_H
+#define HX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double re, im; } hx_c128;
+typedef void* hx_stream;
+
+enum hx_status {
+  HX_OK = 0,
+  HX_ERR_ARG = -1,      /* bad argument (null pointer, negative size, unsupported dim) */
+  HX_ERR_HIP = -2,      /* a HIP runtime call failed; see hx_last_error() */
+  HX_ERR_NOGPU = -3,    /* no gfx950 device visible */
+  HX_ERR_ALLOC = -4,
+  HX_ERR_BREAKDOWN = -5 /* numerical breakdown (zero pivot / zero norm) */
+};
+
+int hx_version(void);
+const char* hx_last_error(void);
+/* SYNC. Device name, compute-unit count and HBM bytes of the current device. */
+int hx_device_info(char* name, int name_len, int* cu_count, size_t* hbm_bytes);
+
+/* ------------------------------------------------------------------ vectors (PETSc Vec / SLEPc BV)
+ * replaces: VecAXPY / VecScale reached from petsc4py_utils.py:4-34, eigensolvers.py:174-176;
+ *           BVDotVec / BVMultVec / VecNorm inside EPSSolve/PEPSolve (eigensolvers.py:62,113).   */
+int hx_zaxpy(int64_t n, const double alpha[2], const hx_c128* x, hx_c128* y, hx_stream s);
+int hx_zscal(int64_t n, const double alpha[2], hx_c128* x, hx_stream s);
+/* out = sum_t coef[t] * xs[t], nterms <= 4; h_xs is a HOST array of device pointers. */
+int hx_zlincomb(int64_t n, int nterms, const double* h_coefs, const hx_c128* const* h_xs,
+                hx_c128* out, hx_stream s);
+/* dst[slot[i]] += alpha * src[i]; slots must be unique. */
+int hx_zscatter_axpy(int64_t m, const double alpha[2], const hx_c128* src, const int32_t* slot,
+                     hx_c128* dst, hx_stream s);
+/* y[i] = x[idx[i]] (gather) */
+int hx_zgather(int64_t m, const hx_c128* x, const int32_t* idx, hx_c128* y, hx_stream s);
+/* Classical Gram-Schmidt panel: out[j] = V_j^H w (j < k), out[k] = w^H w.  V is column-major with
+ * leading dimension ldv.  `partials` is workspace of hx_panel_dot_ws(k) complex numbers.
+ * Deterministic two-stage reduction (no atomics). */
+size_t hx_panel_dot_ws(int k);
+int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, hx_c128* out,
+                  hx_c128* partials, hx_stream s);
+/* w -= V[:, :k] h   (h: k complex numbers on the device) */
+int hx_zpanel_sub(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* h, hx_c128* w,
+                  hx_stream s);
+/* Vout[:, :kout] = V[:, :m] Q,  Q (m x kout) column-major on the device (Krylov-Schur restart). */
+int hx_zpanel_mul(int64_t n, int m, int kout, const hx_c128* V, int64_t ldv, const hx_c128* Q,
+                  hx_c128* Vout, int64_t ldvout, hx_stream s);
+/* Sparse dots t[f] = sum_i vals[ptr[f]+i] * y[idx[ptr[f]+i]]  (the b_f^T y of the rank-1 flame
+ * operator kept factored; replaces the explicit D of flame_matrices.py:91-92,176,233). */
+int hx_zsparse_dots(int nvec, const int32_t* ptr, const int32_t* idx, const hx_c128* vals,
+                    const hx_c128* y, hx_c128* out, hx_stream s);
+
+/* ------------------------------------------------------------------ CSR SpMV (PETSc MatMult)
+ * replaces: MatMult inside EPSSolve/PEPSolve (eigensolvers.py:62,113), Mat.mult
+ * (petsc4py_utils.py:85,95).  y = alpha*A*x + beta*y.  lanes_per_row: 0 = choose from nnz/n_rows,
+ * else one of 1,2,4,8,16,32,64. */
+int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                  const hx_c128* val, const hx_c128* x, hx_c128* y, const double alpha[2],
+                  const double beta[2], int lanes_per_row, hx_stream s);
+/* y = alpha*A^T*x + beta*y is not provided: the operators of this path are complex symmetric or are
+ * transposed once on the host (B_adj = B^H, acoustic_matrices.py:112-114). */
+
+/* ------------------------------------------------------------------ P1 assembly (DOLFINx assemble_*)
+ * Vertex-centric "owner computes" assembly: one CSR row per vertex, gathered from the cells incident
+ * to that vertex in ascending cell order => deterministic, no atomics, no inter-GPU exchange.
+ * `ents` are simplices as (n_ent x k) int32 vertex ids (k = 2,3,4 for cells; facets use k = dim). */
+
+/* vertex -> incident entity adjacency (CSR, entity ids ascending).  SYNC (uses a device scan). */
+int hx_build_v2e(int32_t n_vert, int32_t n_ent, int k, const int32_t* ents, int32_t* v2e_ptr,
+                 int32_t* v2e_idx, hx_stream s);
+/* CSR pattern of the P1 operator on those entities: sorted unique columns per row.
+ * Step 1 (SYNC): writes rowptr (n_vert+1) and returns nnz in *h_nnz; `scratch` holds k*k*n_ent int32.
+ * Step 2: writes col (nnz). */
+int hx_p1_pattern_count(int32_t n_vert, int32_t n_ent, int k, const int32_t* ents,
+                        const int32_t* v2e_ptr, const int32_t* v2e_idx, int32_t* rowptr,
+                        int32_t* scratch, int64_t* h_nnz, hx_stream s);
+int hx_p1_pattern_fill(int32_t n_vert, int k, const int32_t* v2e_ptr, const int32_t* rowptr,
+                       const int32_t* scratch, int32_t* col, hx_stream s);
+/* A_jk = -int c^2 grad(phi_k).grad(phi_j) dx and C_jk = int phi_k phi_j dx on the same pattern
+ * (acoustic_matrices.py:101-105, 121-125).  c is nodal (P1, n_vert) or cellwise (DG0, n_cells).
+ * Either of A_val / C_val may be NULL. dim = 1,2,3 (cells have dim+1 vertices; x is n_vert x 3). */
+int hx_assemble_p1_stiff_mass(int dim, int32_t n_vert, const double* x, const int32_t* cells,
+                              const int32_t* v2c_ptr, const int32_t* v2c_idx, const int32_t* rowptr,
+                              const int32_t* col, const hx_c128* c, int c_is_cellwise,
+                              hx_c128* A_val, hx_c128* C_val, hx_stream s);
+/* B_jk = sum_facets coef_f int_F c phi_k phi_j ds, coef_f = i/Z_tag (acoustic_matrices.py:71,83,95,
+ * 108-110).  facets are (n_facets x dim) vertex ids; c nodal, or cellwise through facet_cell. */
+int hx_assemble_p1_robin(int dim, int32_t n_vert, const double* x, const int32_t* facets,
+                         const int32_t* v2f_ptr, const int32_t* v2f_idx, const int32_t* rowptr,
+                         const int32_t* col, const hx_c128* c, int c_is_cellwise,
+                         const int32_t* facet_cell, const hx_c128* coef_per_facet, hx_c128* B_val,
+                         hx_stream s);
+/* DOLFINx assemble_matrix(bcs=...) semantics: zero rows+cols flagged in is_bc, diagonal = diag. */
+int hx_csr_apply_dirichlet(int32_t n, const int32_t* rowptr, const int32_t* col, hx_c128* val,
+                           const uint8_t* is_bc, double diag, hx_stream s);
+/* Load vectors (DOLFINx assemble_vector; flame_matrices.py:63,141,199-200):
+ *  kind 0: out_j = scale * int f_cell phi_j dx                 (f DG0: fa = f_cell (n_cells), fb unused)
+ *  kind 1: out_j = scale * int fa fb phi_j dx                  (fa, fb nodal P1; exact cubic rule)
+ *  kind 2: out_k = scale * int (n_r . grad phi_k) fb / fa dx   (fa = rho, fb = w nodal; degree-2 rule)
+ * n_r = e_x (dim 1,2) or e_z (dim 3), flame_matrices.py:35-40. */
+int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const double* x, const int32_t* cells,
+                        const int32_t* v2c_ptr, const int32_t* v2c_idx, const hx_c128* fa,
+                        const hx_c128* fb, const double scale[2], hx_c128* out, hx_stream s);
+
+/* ------------------------------------------------------------------ sparse triangular solves (MatSolve)
+ * replaces: KSP(preonly)+PC(LU) MatSolve inside ST sinvert (eigensolvers.py:49-50,102-103 -> :62,:113).
+ * The factors come from a host factorisation (Pr*A*Pc = L*U); each triangle is passed as strictly
+ * triangular CSR + inverse diagonal.  Level-scheduled on the device. */
+typedef struct hx_sptrsv hx_sptrsv;
+/* h_* are HOST arrays (analysed on the host, then uploaded).  lower != 0 for L. SYNC. */
+int hx_sptrsv_create(hx_sptrsv** out, int32_t n, int lower, const int32_t* h_rowptr,
+                     const int32_t* h_col, const hx_c128* h_val, const hx_c128* h_inv_diag);
+int hx_sptrsv_info(const hx_sptrsv* t, int32_t* n_levels, int32_t* n_launches, int64_t* nnz);
+/* x = T^{-1} b  (b, x device vectors of length n; may alias) */
+int hx_sptrsv_solve(hx_sptrsv* t, const hx_c128* b, hx_c128* x, hx_stream s);
+int hx_sptrsv_destroy(hx_sptrsv* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HX_H */

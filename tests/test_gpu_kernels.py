@@ -1,0 +1,194 @@
+"""GPU parity of the libhx kernels against NumPy/SciPy and the CPU oracle (called through the C-ABI)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hx():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need the MI355X"
+    from helmholtz_x import _hx
+    return _hx
+
+
+def _dev(a):
+    from helmholtz_x.petsc import to_device
+    return to_device(a)
+
+
+def _rand_c(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+@pytest.mark.parametrize("n,density", [(1, 1.0), (257, 0.05), (5000, 0.003), (20000, 0.0008)])
+def test_spmv_random_all_lane_widths(hx, n, density):
+    from helmholtz_x.petsc import CSR
+    import torch
+    rng = np.random.default_rng(n)
+    M = sp.random(n, n, density=density, random_state=rng, format="csr", dtype=np.float64)
+    M = M + 1j * sp.random(n, n, density=density, random_state=rng, format="csr") + sp.eye(n)
+    M = sp.csr_matrix(M)
+    A = CSR.from_scipy(M)
+    x = _rand_c(rng, n)
+    y0 = _rand_c(rng, n)
+    alpha, beta = 0.7 - 0.2j, -1.3 + 0.4j
+    ref = alpha * (M @ x) + beta * y0
+    for lanes in (0, 1, 2, 4, 8, 16, 32, 64):
+        y = _dev(y0.copy())
+        A.spmv(_dev(x), y, alpha, beta, lanes)
+        got = y.cpu().numpy()
+        assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref)), lanes
+    y = _dev(np.full(n, np.nan + 0j))        # beta == 0 must ignore the previous content of y
+    A.spmv(_dev(x), y)
+    assert np.allclose(y.cpu().numpy(), M @ x, rtol=1e-13, atol=1e-13)
+    torch.cuda.synchronize()
+
+
+def test_spmv_empty_rows_and_ragged(hx):
+    from helmholtz_x.petsc import CSR
+    rng = np.random.default_rng(3)
+    n = 1000
+    rows = rng.integers(0, n // 2, 4000) * 2          # odd rows are empty
+    cols = rng.integers(0, n, 4000)
+    M = sp.csr_matrix((_rand_c(rng, 4000), (rows, cols)), shape=(n, n))
+    M[10, :] = _rand_c(rng, n)                          # one very long row
+    M = sp.csr_matrix(M)
+    x = _rand_c(rng, n)
+    for lanes in (0, 1, 8, 64):
+        y = _dev(np.zeros(n, complex))
+        CSR.from_scipy(M).spmv(_dev(x), y, lanes=lanes)
+        assert np.allclose(y.cpu().numpy(), M @ x, rtol=1e-12, atol=1e-12)
+
+
+def test_vector_and_panel_kernels(hx):
+    import torch
+    from helmholtz_x.petsc import panel_dot
+    rng = np.random.default_rng(0)
+    n, m = 70001, 21
+    V = _rand_c(rng, m, n)
+    w = _rand_c(rng, n)
+    Vd, wd = _dev(V), _dev(w)
+    for k in (0, 1, 7, 8, 9, 20, 21):
+        got = panel_dot(Vd, k, wd)
+        ref = np.concatenate([V[:k].conj() @ w, [np.vdot(w, w)]])
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-9), k
+    got2 = panel_dot(Vd, 9, wd)
+    assert np.array_equal(got2, panel_dot(Vd, 9, wd))          # deterministic reduction
+    h = _rand_c(rng, m)
+    w2 = _dev(w.copy())
+    hx.check(hx.lib.hx_zpanel_sub(n, m, hx.ptr(Vd), n, hx.ptr(_dev(h)), hx.ptr(w2), hx.stream()))
+    assert np.allclose(w2.cpu().numpy(), w - V.T @ h, rtol=1e-12, atol=1e-12)
+    Q = _rand_c(rng, m, 6)
+    out = torch.zeros((6, n), dtype=torch.complex128, device=Vd.device)
+    hx.check(hx.lib.hx_zpanel_mul(n, m, 6, hx.ptr(Vd), n, hx.ptr(_dev(np.ascontiguousarray(Q.T))), hx.ptr(out), n,
+                                  hx.stream()))
+    assert np.allclose(out.cpu().numpy(), Q.T @ V, rtol=1e-12, atol=1e-11)
+    # axpy / scal / lincomb / gather / scatter
+    a = 0.3 - 1.1j
+    y = _dev(w.copy())
+    hx.check(hx.lib.hx_zaxpy(n, hx.z2(a), hx.ptr(Vd[3]), hx.ptr(y), hx.stream()))
+    assert np.allclose(y.cpu().numpy(), w + a * V[3])
+    hx.check(hx.lib.hx_zscal(n, hx.z2(a), hx.ptr(y), hx.stream()))
+    assert np.allclose(y.cpu().numpy(), a * (w + a * V[3]))
+    arr = (C.c_void_p * 3)(Vd[0].data_ptr(), Vd[1].data_ptr(), Vd[2].data_ptr())
+    cf = (C.c_double * 6)(1, 0, 0, 2, -1, 0.5)
+    hx.check(hx.lib.hx_zlincomb(n, 3, cf, arr, hx.ptr(y), hx.stream()))
+    assert np.allclose(y.cpu().numpy(), V[0] + 2j * V[1] + (-1 + 0.5j) * V[2])
+    idx = rng.permutation(n).astype(np.int32)
+    hx.check(hx.lib.hx_zgather(n, hx.ptr(wd), hx.ptr(_dev(idx)), hx.ptr(y), hx.stream()))
+    assert np.array_equal(y.cpu().numpy(), w[idx])
+    dst = _dev(V[5].copy())
+    hx.check(hx.lib.hx_zscatter_axpy(n, hx.z2(a), hx.ptr(wd), hx.ptr(_dev(idx)), hx.ptr(dst), hx.stream()))
+    ref = V[5].copy()
+    ref[idx] += a * w
+    assert np.allclose(dst.cpu().numpy(), ref)
+    # sparse dots
+    ptr = np.array([0, 5, 5, 400], np.int32)
+    sidx = rng.integers(0, n, 400).astype(np.int32)
+    sval = _rand_c(rng, 400)
+    out3 = torch.zeros(3, dtype=torch.complex128, device=Vd.device)
+    hx.check(hx.lib.hx_zsparse_dots(3, hx.ptr(_dev(ptr)), hx.ptr(_dev(sidx)), hx.ptr(_dev(sval)), hx.ptr(wd),
+                                    hx.ptr(out3), hx.stream()))
+    ref3 = [np.sum(sval[ptr[f]:ptr[f + 1]] * w[sidx[ptr[f]:ptr[f + 1]]]) for f in range(3)]
+    assert np.allclose(out3.cpu().numpy(), ref3, rtol=1e-12, atol=1e-12)
+
+
+def test_vec_mat_wrappers(hx):
+    from helmholtz_x.petsc import CSR, LowRank, Mat, Vec
+    rng = np.random.default_rng(5)
+    n = 300
+    M1 = sp.random(n, n, 0.05, random_state=rng, format="csr") + sp.eye(n)
+    M2 = sp.random(n, n, 0.02, random_state=rng, format="csr") * 1j
+    A, B = Mat.from_csr(CSR.from_scipy(M1)), Mat.from_csr(CSR.from_scipy(M2))
+    lr = LowRank(n, [((np.array([1, 5, 9], np.int32), _rand_c(rng, 3)), (np.array([0, 2], np.int32), _rand_c(rng, 2))),
+                     ((np.array([7], np.int32), _rand_c(rng, 1)), (np.arange(20, dtype=np.int32), _rand_c(rng, 20)))])
+    D = Mat((n, n), lr_terms=[(1.0, lr)])
+    w = np.complex128(3.0 - 2.0j)
+    T = A + (w * B) - D * (0.5 + 0.1j)
+    ref = M1 + w * M2 - (0.5 + 0.1j) * lr.to_scipy()
+    assert np.allclose(T.to_scipy().toarray(), ref.toarray())
+    x = Vec(_rand_c(rng, n))
+    y = Vec.zeros(n)
+    T.mult(x, y)
+    assert np.allclose(y.array, ref @ x.array, rtol=1e-12, atol=1e-12)
+    Bh = B.copy()
+    Bh.transpose()
+    Bh.conjugate()
+    assert np.allclose(Bh.to_scipy().toarray(), M2.conj().T.toarray())
+    # PETSc VecDot(x, y) = y^H x
+    z = Vec(_rand_c(rng, n))
+    assert np.isclose(x.dot(z), np.vdot(z.array, x.array))
+    assert np.isclose(x.norm(), np.linalg.norm(x.array))
+
+
+@pytest.mark.parametrize("n,lower", [(50, 1), (4000, 1), (4000, 0)])
+def test_sptrsv_against_scipy(hx, n, lower):
+    import torch
+    rng = np.random.default_rng(n + lower)
+    T = sp.random(n, n, density=min(1.0, 8.0 / n), random_state=rng, format="csr")
+    T = T + 1j * sp.random(n, n, density=min(1.0, 8.0 / n), random_state=rng, format="csr")
+    # add a long dependency chain and a dense trailing block, like LU factors have
+    chain = sp.diags([np.ones(n - 1)], [-1]) * 0.3
+    dense = sp.lil_matrix((n, n), dtype=complex)
+    dense[n - 40:, n - 40:] = _rand_c(rng, 40, 40) * 0.1
+    T = sp.tril(T + chain + dense.tocsr(), -1).tocsr()
+    if not lower:
+        T = T.T.tocsr()
+    T.sort_indices()
+    diag = 2.0 + _rand_c(rng, n) * 0.2
+    full = (T + sp.diags(diag)).tocsr()
+    b = _rand_c(rng, n)
+    ref = spla.spsolve_triangular(full, b, lower=bool(lower))
+    h = C.c_void_p()
+    rp, ci = T.indptr.astype(np.int32), T.indices.astype(np.int32)
+    va, inv = T.data.astype(np.complex128), (1.0 / diag).astype(np.complex128)
+    hx.check(hx.lib.hx_sptrsv_create(C.byref(h), n, lower, hx.nptr(rp), hx.nptr(ci), hx.nptr(va), hx.nptr(inv)))
+    xb = _dev(b.copy())
+    hx.check(hx.lib.hx_sptrsv_solve(h, hx.ptr(xb), hx.ptr(xb), hx.stream()))     # in place
+    torch.cuda.synchronize()
+    got = xb.cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-11 * np.max(np.abs(ref))
+    hx.check(hx.lib.hx_sptrsv_destroy(h))
+
+
+def test_lu_solver_matches_splu(hx):
+    from helmholtz_x.petsc import CSR
+    from helmholtz_x.slepc import LUSolver
+    from oracle import fem, meshes
+    m = meshes.rectangle(60, 20, 0.4, 0.1)
+    c = np.full(m.x.shape[0], 450.0)
+    K = (fem.assemble_A(m.x, m.cells, c) + (3000.0 + 200j) ** 2 * fem.assemble_C(m.x, m.cells)).tocsr()
+    rng = np.random.default_rng(1)
+    b = _rand_c(rng, K.shape[0])
+    S = LUSolver(CSR.from_scipy(K))
+    x = _dev(np.zeros_like(b))
+    S.solve(_dev(b), x)
+    ref = spla.splu(K.tocsc()).solve(b)
+    assert np.max(np.abs(x.cpu().numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))

@@ -1,0 +1,298 @@
+"""GPU parity of the drop-in API (AcousticMatrices / FlameMatrix / eps_solver / pep_solver /
+fixed_point_iteration) against the CPU oracle and the reference's logged eigenvalues.
+
+Tolerances: integer maps (CSR rowptr / col, flame supports) bit-exact; matrix / vector values 1e-12 relative
+to the largest entry; eigenvalues |dw|/|w| < 1e-8 (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import PRF, Rijke, dispersion_root
+
+pytestmark = pytest.mark.gpu
+
+os.environ.setdefault("HX_QUIET", "1")
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _csr_equal(mat, ref, tol=1e-12):
+    ai, aj, av = mat.getValuesCSR()
+    ref = ref.tocsr()
+    ref.sort_indices()
+    assert np.array_equal(ai, ref.indptr), "rowptr differs"
+    assert np.array_equal(aj, ref.indices), "col differs"
+    assert _rel(av, ref.data) <= tol
+
+
+def _oracle_mesh(mesh):
+    return mesh.geometry.x, mesh.topology.cells
+
+
+def _mesh_cases(golden_dir):
+    from helmholtz_x.dolfinx_utils import OneDimensionalSetup, RectangleSetup
+    from helmholtz_x.io_utils import read_gmsh
+    yield "interval", OneDimensionalSetup(300)
+    yield "rectangle", RectangleSetup(40, 10, 0.4, 0.1)
+    yield "rijke3d", read_gmsh(os.path.join(golden_dir, "meshes", "rijke3d.msh"))
+
+
+def test_pattern_and_passive_matrices(golden_dir):
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.fem import Function, FunctionSpace
+    from helmholtz_x.parameters_utils import c_step, temperature_step
+    from oracle import fem
+    for name, (mesh, subdomains, facet_tags) in _mesh_cases(golden_dir):
+        x, cells = _oracle_mesh(mesh)
+        d = mesh.topology.dim
+        x_f = Rijke.x_f(d)
+        # nodal sound speed with a jump, then the temperature route (variable gamma)
+        for param, c_ref in ((c_step(mesh, x_f, Rijke.c_u, Rijke.c_d), fem.step_field(x, d, x_f, Rijke.c_u, Rijke.c_d)),
+                             (temperature_step(mesh, x_f, Rijke.T_u, Rijke.T_d),
+                              fem.sound_speed_variable_gamma(fem.step_field(x, d, x_f, Rijke.T_u, Rijke.T_d)))):
+            M = AcousticMatrices(mesh, facet_tags, {1: {'Neumann'}}, param)
+            _csr_equal(M.A, fem.assemble_A(x, cells, c_ref))
+            _csr_equal(M.C, fem.assemble_C(x, cells))
+            assert M.B is None
+        # DG0 (cellwise) complex sound speed
+        cf = Function(FunctionSpace(mesh, "DG", 0), "soundspeed")
+        rng = np.random.default_rng(0)
+        cf.x.array[:] = 300 + 100 * rng.random(mesh.num_cells) + 5j * rng.random(mesh.num_cells)
+        M = AcousticMatrices(mesh, facet_tags, {}, cf)
+        _csr_equal(M.A, fem.assemble_A(x, cells, cf.x.array, c_is_cellwise=True))
+
+
+def test_robin_choked_and_dirichlet(golden_dir):
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.fem import Function, FunctionSpace
+    from helmholtz_x.parameters_utils import c_step, temperature_step
+    from oracle import fem
+    for name, (mesh, subdomains, facet_tags) in _mesh_cases(golden_dir):
+        x, cells = _oracle_mesh(mesh)
+        d = mesh.topology.dim
+        n = x.shape[0]
+        tags = np.unique(facet_tags.values)
+        t_robin, t_choke = int(tags[0]), int(tags[-1])
+        c = c_step(mesh, Rijke.x_f(d), Rijke.c_u, Rijke.c_d)
+        R = -0.975 - 0.05j
+        bcs = {t_robin: {'Robin': R}, t_choke: {'ChokedOutlet': 0.05}}
+        M = AcousticMatrices(mesh, facet_tags, bcs, c)
+        f1 = mesh.facets[facet_tags.find(t_robin)]
+        f2 = mesh.facets[facet_tags.find(t_choke)]
+        g_out = fem.facet_average(x, f2, np.full(n, 1.4))
+        Z2 = fem.robin_Z(fem.choked_outlet_R(g_out, 0.05))
+        ref = fem.assemble_B(x, n, [(f1, fem.robin_Z(R), c.x.array, None), (f2, Z2, c.x.array, None)])
+        _csr_equal(M.B, ref)
+        _csr_equal(M.B_adj, ref.conj().T.tocsr())
+        # temperature route: choked inlet uses the facet-averaged variable gamma
+        T = temperature_step(mesh, Rijke.x_f(d), Rijke.T_u, Rijke.T_d)
+        M = AcousticMatrices(mesh, facet_tags, {t_robin: {'ChokedInlet': 0.03}}, T)
+        Tn = fem.step_field(x, d, Rijke.x_f(d), Rijke.T_u, Rijke.T_d)
+        g_in = fem.facet_average(x, f1, fem.gamma_of_T(Tn).real)
+        ref = fem.assemble_B(x, n, [(f1, fem.robin_Z(fem.choked_inlet_R(g_in, 0.03)),
+                                      fem.sound_speed_variable_gamma(Tn), None)])
+        _csr_equal(M.B, ref)
+        # DG0 sound speed on the boundary + Dirichlet rows/cols
+        cf = Function(FunctionSpace(mesh, "DG", 0), "soundspeed")
+        cf.x.array[:] = 340 + np.arange(mesh.num_cells) % 7
+        M = AcousticMatrices(mesh, facet_tags, {t_robin: {'Robin': R}, t_choke: {'Dirichlet'}}, cf)
+        ref = fem.assemble_B(x, n, [(f1, fem.robin_Z(R), cf.x.array, mesh.facet_cells[facet_tags.find(t_robin)])])
+        _csr_equal(M.B, ref)
+        dofs = np.unique(f2)
+        _csr_equal(M.A, fem.assemble_A(x, cells, cf.x.array, dofs, c_is_cellwise=True))
+        _csr_equal(M.C, fem.assemble_C(x, cells, dofs))
+
+
+def _distributed_flame(mesh, dim, gamma=None):
+    from helmholtz_x.flame_matrices import DistributedFlameMatrix
+    from helmholtz_x.flame_transfer_function import nTau
+    from helmholtz_x.parameters_utils import gaussianFunction, rho_step, temperature_step
+    R = Rijke
+    T = temperature_step(mesh, R.x_f(dim), R.T_u, R.T_d)
+    rho = rho_step(mesh, R.x_f(dim), R.a_f, R.rho_d, R.rho_u)
+    w = gaussianFunction(mesh, R.x_r(dim), R.a_r)
+    h = gaussianFunction(mesh, R.x_f(dim), R.a_f)
+    D = DistributedFlameMatrix(mesh, w, h, rho, T, R.q_0, R.u_b, nTau(R.n(dim), R.tau), gamma=gamma)
+    return D, T, rho, w, h
+
+
+def test_distributed_flame_vectors(ref_logs, golden_dir):
+    from helmholtz_x.dolfinx_utils import OneDimensionalSetup
+    from helmholtz_x.io_utils import read_gmsh
+    from oracle import fem
+    R = Rijke
+    for dim, mesh in ((1, OneDimensionalSetup(3000)[0]),
+                      (2, read_gmsh(os.path.join(golden_dir, "meshes", "rijke2d.msh"))[0]),
+                      (3, read_gmsh(os.path.join(golden_dir, "meshes", "rijke3d.msh"))[0])):
+        x, cells = _oracle_mesh(mesh)
+        D, T, rho, w, h = _distributed_flame(mesh, dim)
+        assert _rel(w.x.array, fem.gaussian_function(x, cells, R.x_r(dim), R.a_r)) < 1e-13
+        D.assemble_submatrices('direct')
+        (li, lv), (ri, rv) = D.submatrices.lr_terms[0][1].pairs[0]
+        a = fem.distributed_left(x, cells, fem.gamma_of_T(T.x.array), h.x.array, R.q_0, R.u_b)
+        b = fem.distributed_right(x, cells, rho.x.array, w.x.array)
+        oli, olv = fem.threshold_pack(a, 1e-5)
+        ori, orv = fem.threshold_pack(b, 1e-5)
+        assert np.array_equal(li, oli) and np.array_equal(ri, ori)          # supports bit-exact
+        assert _rel(lv, olv) < 1e-12 and _rel(rv, orv) < 1e-12
+        if dim == 1:
+            g = ref_logs["rijke1d_active"]
+            assert (len(li), len(ri)) == (g["nnz_left"], g["nnz_right"])
+            ai, aj, av = D.submatrices.getValuesCSR()                        # the reference's explicit D
+            assert len(aj) == g["nnz_D"]
+            D.assemble_submatrices('adjoint')
+            ref = fem.flame_outer(x.shape[0], (oli, olv), (ori, orv), 'adjoint')
+            assert _rel(D.adjoint_submatrices.to_scipy().toarray(), ref.toarray()) < 1e-12
+
+
+def test_pointwise_flame_vectors(golden_dir):
+    from helmholtz_x.fem import Function, FunctionSpace
+    from helmholtz_x.flame_matrices import PointwiseFlameMatrix
+    from helmholtz_x.flame_transfer_function import nTau
+    from helmholtz_x.io_utils import read_gmsh
+    from helmholtz_x.parameters_utils import Q_volumetric
+    from oracle import fem
+    mesh, subdomains, facet_tags = read_gmsh(os.path.join(golden_dir, "meshes", "micca_bloch_sector.msh"))
+    x, cells = _oracle_mesh(mesh)
+    h = Q_volumetric(mesh, subdomains, 1.0, flame_tag=0)
+    x_r = np.array([[0.175, 0.0, -0.02]])
+    D = PointwiseFlameMatrix(mesh, subdomains, x_r, h, 1.17, 2080.0, 0.66, nTau(1.0, 1e-3))
+    D.assemble_submatrices('direct')
+    (li, lv), (ri, rv) = D.submatrices.lr_terms[0][1].pairs[0]
+    q = fem.q_multiple(x, cells, subdomains.values, 1)
+    assert _rel(h.x.array, q) < 1e-13
+    a = fem.pointwise_left(x, cells, subdomains.values, 0, q, 1.4, 2080.0, 0.66)
+    oli, olv = fem.threshold_pack(a, 1e-10)
+    ori, orv = fem.pointwise_right(x, cells, x_r[0], 1.17)
+    assert np.array_equal(li, oli) and _rel(lv, olv) < 1e-12
+    assert np.array_equal(ri, ori) and _rel(rv, orv) < 1e-12
+
+
+def _check_traj(hist, ref, tol=1e-8):
+    assert len(hist) == len(ref), (hist, ref)
+    for z, r in zip(hist, ref):
+        r = complex(*r)
+        assert abs(z - r) / abs(r) < tol, (z, r)
+
+
+def test_rijke1d_passive_eps(ref_logs):
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.dolfinx_utils import OneDimensionalSetup
+    from helmholtz_x.eigensolvers import eps_solver
+    from helmholtz_x.parameters_utils import c_step
+    g = ref_logs["rijke1d_passive"]
+    mesh, subdomains, facet_tags = OneDimensionalSetup(g["n_elem"])
+    c = c_step(mesh, Rijke.x_f(1), Rijke.c_u, Rijke.c_u)
+    M = AcousticMatrices(mesh, facet_tags, {1: {'Neumann'}, 2: {'Neumann'}}, c)
+    E = eps_solver(M.A, M.C, Rijke.target, nev=2, print_results=True)
+    assert E.getConverged() >= 2
+    lam = np.array([E.getEigenvalue(i) for i in range(2)])
+    assert abs(lam[0] - g["lambda"][0]) / g["lambda"][0] < 1e-9
+    assert abs(lam[1] - g["lambda"][1]) < 1e-3                 # the zero (constant) mode
+    assert abs(np.sqrt(lam[0]) - g["omega0"]) < 1e-6
+    # eigenvector really is one: residual of A x + lambda C x
+    vr, vi = M.A.createVecs()
+    E.getEigenvector(0, vr, vi)
+    A, Cm = M.A.to_scipy(), M.C.to_scipy()
+    xv = vr.array
+    assert np.linalg.norm(A @ xv + lam[0] * (Cm @ xv)) <= 1e-9 * np.linalg.norm(lam[0] * (Cm @ xv))
+
+
+def test_rijke1d_active_fixed_point_direct_and_adjoint(ref_logs):
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.dolfinx_utils import OneDimensionalSetup
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.parameters_utils import temperature_step
+    g = ref_logs["rijke1d_active"]
+    mesh, subdomains, facet_tags = OneDimensionalSetup(g["n_elem"])
+    T = temperature_step(mesh, Rijke.x_f(1), Rijke.T_u, Rijke.T_d)
+    M = AcousticMatrices(mesh, facet_tags, {1: {'Neumann'}, 2: {'Neumann'}}, T)
+    D = _distributed_flame(mesh, 1)[0]
+    D.assemble_submatrices()
+    hist = []
+    E = fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, history=hist)
+    _check_traj(hist, g["trajectory"])
+    assert abs(np.sqrt(E.getEigenvalue(0)) - hist[-1]) < 1e-6
+    D.assemble_submatrices('adjoint')
+    hist = []
+    fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, problem_type='adjoint', history=hist)
+    r = complex(*ref_logs["rijke1d_active_adjoint"]["omega"])
+    assert abs(hist[-1] - r) / abs(r) < 1e-8
+
+
+def test_prf1d_pep_fixed_point_direct_and_adjoint(ref_logs):
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.dolfinx_utils import OneDimensionalSetup
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.flame_matrices import DistributedFlameMatrix
+    from helmholtz_x.flame_transfer_function import nTau
+    from helmholtz_x.parameters_utils import c_step, gaussianFunction, rho_step, temperature_step
+    g = ref_logs["prf1d_active"]
+    P = PRF
+    mesh, subdomains, facet_tags = OneDimensionalSetup(g["n_elem"])
+    c = c_step(mesh, P.x_f, P.c_u, P.c_d)
+    M = AcousticMatrices(mesh, facet_tags, {1: {'Robin': P.R_in}, 2: {'Robin': P.R_out}}, c)
+    rho = rho_step(mesh, P.x_f, P.a_f, P.rho_d, P.rho_u)
+    T = temperature_step(mesh, P.x_f, P.T_u, P.T_d)
+    w = gaussianFunction(mesh, P.x_r, P.a_r)
+    h = gaussianFunction(mesh, P.x_f, P.a_f)
+    D = DistributedFlameMatrix(mesh, w, h, rho, T, P.q_0, P.u_b, nTau(P.n, P.tau), gamma=P.gamma)
+    D.assemble_submatrices()
+    hist = []
+    fixed_point_iteration(M, D, P.target, nev=2, i=0, history=hist)
+    _check_traj(hist[1:], g["trajectory"], tol=3e-9)       # log prints 8 decimals of a O(3) number
+    D.assemble_submatrices('adjoint')
+    hist = []
+    fixed_point_iteration(M, D, P.target, nev=2, i=0, problem_type='adjoint', history=hist)
+    r = complex(*g["adjoint_omega"])
+    assert abs(hist[-1] - r) / abs(r) < 3e-9
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_rijke_gmsh_fixed_point(ref_logs, golden_dir, dim):
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import eps_solver, fixed_point_iteration
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.parameters_utils import c_step, temperature_step
+    g = ref_logs["rijke%dd" % dim]
+    mesh, subdomains, facet_tags = XDMFReader(os.path.join(golden_dir, "meshes", "rijke%dd" % dim)).getAll()
+    bcs = {t: {'Neumann'} for t in (1, 2, 3, 4)}
+    c = c_step(mesh, Rijke.x_f(dim), Rijke.c_u, Rijke.c_u)
+    M = AcousticMatrices(mesh, facet_tags, bcs, c)
+    E = eps_solver(M.A, M.C, Rijke.target, nev=2)
+    assert abs(E.getEigenvalue(0) - g["passive_lambda0"]) / g["passive_lambda0"] < 1e-9
+    if dim == 2:
+        param = temperature_step(mesh, Rijke.x_f(dim), Rijke.T_u, Rijke.T_d)
+    else:
+        param = c_step(mesh, Rijke.x_f(dim), Rijke.c_u, Rijke.c_d)
+    M = AcousticMatrices(mesh, facet_tags, bcs, param)
+    D = _distributed_flame(mesh, dim)[0]
+    D.assemble_submatrices()
+    hist = []
+    fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, history=hist)
+    _check_traj(hist, g["trajectory"])
+
+
+def test_manufactured_2d_pep_against_dispersion_relation(ref_logs):
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.dolfinx_utils import RectangleSetup
+    from helmholtz_x.eigensolvers import pep_solver
+    from helmholtz_x.parameters_utils import c_uniform
+    from oracle import eigen, fem
+    g = ref_logs["manufactured2d"]
+    mesh, subdomains, facet_tags = RectangleSetup(g["nx"], g["ny"], g["L"], g["h"])
+    c = c_uniform(mesh, g["c0"])
+    x, cells = _oracle_mesh(mesh)
+    omega = 600 * 2 * np.pi
+    for Z in np.linspace(-10, 10, 10)[:3]:
+        M = AcousticMatrices(mesh, facet_tags, {4: {'Robin': (Z - 1) / (Z + 1)}}, c)
+        E = pep_solver(M.A, M.B, M.C, omega, nev=2)
+        got = E.getEigenvalue(0)
+        ref = eigen.pep_solve(M.A.to_scipy(), M.B.to_scipy(), M.C.to_scipy(), omega, 2).eigs[0]
+        assert abs(got - ref) / abs(ref) < 1e-8
+        k = dispersion_root(got / g["c0"], Z)
+        assert abs(got / (2 * np.pi) - g["c0"] * k / (2 * np.pi)) < 2e-4 * abs(got / (2 * np.pi))
+        omega = got

@@ -1,0 +1,134 @@
+"""Synthetic benchmark meshes: structured hex grids split into 6 Kuhn tetrahedra.
+
+The real MICCA combustor mesh of the reference ships only as compressed HDF5, so the headline workload is a
+synthetic annulus with the same radii / heights / burner layout / material data
+(numerical_examples/AnnularCombustor/Micca/fullAnnulus/params.py:5-70): r in [0.14, 0.21],
+z in [-0.09, 0.2], welded in theta, outlet z = 0.2 (facet tag 11), 16 cylindrical flame volumes of
+radius 0.0175 on r_f = 0.175 for z in [0, 0.02] (cell tags 0..15), reference points at z_r = -0.02.
+
+Node numbering is theta-major: idx = (i_theta*(nr+1) + i_r)*(nz+1) + i_z, so contiguous DOF ranges are
+theta-slabs -- the partition used for multi-GPU row sharding.
+"""
+import numpy as np
+
+from .fem import Function, FunctionSpace, Mesh, MeshTags
+
+_KUHN = np.array([(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)])
+
+
+def _kuhn_tets(v):
+    """v: (nhex, 2, 2, 2) vertex ids indexed [h, a, b, c] along the three grid axes -> (nhex*6, 4) tets.
+
+    Tet p of a hex walks 000 -> +e_p0 -> +e_p1 -> 111; all hexes share the 000-111 diagonal so neighbouring
+    hexes agree on their common face diagonals (conforming mesh)."""
+    nh = v.shape[0]
+    out = np.empty((nh, 6, 4), dtype=np.int32)
+    for p, perm in enumerate(_KUHN):
+        cur = np.zeros(3, dtype=int)
+        out[:, p, 0] = v[:, 0, 0, 0]
+        for s in range(2):
+            cur[perm[s]] = 1
+            out[:, p, s + 1] = v[:, cur[0], cur[1], cur[2]]
+        out[:, p, 3] = v[:, 1, 1, 1]
+    return out.reshape(-1, 4)
+
+
+def annulus(nr, ntheta, nz, r_in=0.14, r_out=0.21, z0=-0.09, z1=0.2, n_flames=16, r_f=0.175, flame_radius=0.0175,
+            flame_z=(0.0, 0.02), sector=None):
+    """Returns (mesh, subdomains, facet_tags).  ``sector=(theta0, theta1)`` builds an un-welded sector with
+    facet tags 12 (theta0 side, 'Master') and 13 (theta1 side, 'Slave') instead of the full ring."""
+    full = sector is None
+    nth_nodes = ntheta if full else ntheta + 1
+    th = (np.arange(nth_nodes) * (2 * np.pi / ntheta) if full
+          else np.linspace(sector[0], sector[1], ntheta + 1))
+    r = np.linspace(r_in, r_out, nr + 1)
+    z = np.linspace(z0, z1, nz + 1)
+    T, R, Z = np.meshgrid(th, r, z, indexing="ij")
+    x = np.stack([R * np.cos(T), R * np.sin(T), Z], axis=-1).reshape(-1, 3)
+
+    def nid(it, ir, iz):
+        return ((it % nth_nodes) * (nr + 1) + ir) * (nz + 1) + iz
+
+    it, ir, iz = np.meshgrid(np.arange(ntheta), np.arange(nr), np.arange(nz), indexing="ij")
+    it, ir, iz = it.ravel(), ir.ravel(), iz.ravel()
+    v = np.empty((it.size, 2, 2, 2), dtype=np.int64)
+    for a in range(2):
+        for b in range(2):
+            for c in range(2):
+                v[:, a, b, c] = nid(it + a, ir + b, iz + c)
+    cells = _kuhn_tets(v)
+
+    # outlet facets (top, c = 1): triangles {001,101,111} in tet perm (2,0,1) and {001,011,111} in perm (2,1,0)
+    top = np.flatnonzero(iz == nz - 1)
+    p201 = int(np.flatnonzero((_KUHN == (2, 0, 1)).all(axis=1))[0])
+    p210 = int(np.flatnonzero((_KUHN == (2, 1, 0)).all(axis=1))[0])
+    f1 = np.stack([v[top, 0, 0, 1], v[top, 1, 0, 1], v[top, 1, 1, 1]], axis=1)
+    f2 = np.stack([v[top, 0, 0, 1], v[top, 0, 1, 1], v[top, 1, 1, 1]], axis=1)
+    facets = [f1, f2]
+    fcells = [top * 6 + p201, top * 6 + p210]
+    ftags = [np.full(top.size, 11), np.full(top.size, 11)]
+    if not full:
+        # theta faces: a = 0 of the first slab (Master, 12) / a = 1 of the last slab (Slave, 13)
+        for side, tag, sel in ((0, 12, it == 0), (1, 13, it == ntheta - 1)):
+            h = np.flatnonzero(sel)
+            pa = int(np.flatnonzero((_KUHN == (1, 2, 0)).all(axis=1))[0]) if side == 0 else \
+                int(np.flatnonzero((_KUHN == (0, 1, 2)).all(axis=1))[0])
+            pb = int(np.flatnonzero((_KUHN == (2, 1, 0)).all(axis=1))[0]) if side == 0 else \
+                int(np.flatnonzero((_KUHN == (0, 2, 1)).all(axis=1))[0])
+            a = side
+            facets += [np.stack([v[h, a, 0, 0], v[h, a, 1, 0], v[h, a, 1, 1]], axis=1),
+                       np.stack([v[h, a, 0, 0], v[h, a, 0, 1], v[h, a, 1, 1]], axis=1)]
+            fcells += [h * 6 + pa, h * 6 + pb]
+            ftags += [np.full(h.size, tag), np.full(h.size, tag)]
+    facets = np.sort(np.concatenate(facets), axis=1)
+    mesh = Mesh(x, cells, facets=facets, facet_cells=np.concatenate(fcells))
+    facet_tags = MeshTags(mesh, 2, np.arange(facets.shape[0]), np.concatenate(ftags))
+
+    # flame volumes: cell centroid inside the burner cylinder
+    cent = x[cells].mean(axis=1)
+    tags = np.full(cells.shape[0], -1, dtype=np.int32)
+    band = (cent[:, 2] >= flame_z[0]) & (cent[:, 2] <= flame_z[1])
+    idx = np.flatnonzero(band)
+    for f in range(n_flames):
+        ang = f * 2 * np.pi / 16
+        cx, cy = r_f * np.cos(ang), r_f * np.sin(ang)
+        hit = idx[(cent[idx, 0] - cx) ** 2 + (cent[idx, 1] - cy) ** 2 <= flame_radius ** 2]
+        tags[hit] = f
+    marked = np.flatnonzero(tags >= 0)
+    subdomains = MeshTags(mesh, 3, marked, tags[marked])
+    mesh._centroids = cent
+    return mesh, subdomains, facet_tags
+
+
+def micca_sound_speed(mesh, gamma=1.4, r=287.0, T_amb=300.0, T_a=1521.0, T_b=1200.0, l_cc=0.2):
+    """DG0 axial sound-speed field of Micca/fullAnnulus/params.py:53-70 (cell-midpoint rule)."""
+    c = Function(FunctionSpace(mesh, "DG", 0), "soundspeed")
+    zc = getattr(mesh, "_centroids", None)
+    zc = (mesh.geometry.x[mesh.topology.cells].mean(axis=1) if zc is None else zc)[:, 2]
+    mid = np.sqrt(gamma * r * ((T_b - T_a) * (zc / l_cc) ** 2 + T_a))
+    c.x.array[:] = np.where(zc < 0, np.sqrt(gamma * r * T_amb),
+                            np.where((zc > 0) & (zc < l_cc), mid, np.sqrt(gamma * r * T_b)))
+    return c
+
+
+def box(nx, ny, nz, lengths=(1.0, 1.0, 1.0)):
+    """[0,Lx]x[0,Ly]x[0,Lz] hex grid -> 6 tets per hex; facet tags 1..6 = x0,x1,y0,y1,z0,z1 (exterior facets found
+    combinatorially, so only use for moderate sizes)."""
+    gx, gy, gz = (np.linspace(0, L, n + 1) for L, n in zip(lengths, (nx, ny, nz)))
+    X, Y, Z = np.meshgrid(gx, gy, gz, indexing="ij")
+    x = np.stack([X, Y, Z], axis=-1).reshape(-1, 3)
+    i, j, k = (a.ravel() for a in np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"))
+    v = np.empty((i.size, 2, 2, 2), dtype=np.int64)
+    for a in range(2):
+        for b in range(2):
+            for c in range(2):
+                v[:, a, b, c] = ((i + a) * (ny + 1) + (j + b)) * (nz + 1) + (k + c)
+    mesh = Mesh(x, _kuhn_tets(v))
+    pts = mesh.geometry.x[mesh.facets]
+    idx, val = [], []
+    for tag, (ax, pos) in enumerate(((0, 0.0), (0, lengths[0]), (1, 0.0), (1, lengths[1]), (2, 0.0), (2, lengths[2])), 1):
+        hit = np.flatnonzero(np.isclose(pts[:, :, ax], pos).all(axis=1))
+        idx.append(hit)
+        val.append(np.full(hit.size, tag))
+    facet_tags = MeshTags(mesh, 2, np.hstack(idx), np.hstack(val))
+    return mesh, MeshTags(mesh, 3, np.zeros(0, np.int32), np.zeros(0, np.int32)), facet_tags

@@ -41,12 +41,13 @@ def test_spmv_random_all_lane_widths(hx, n, density):
     alpha, beta = 0.7 - 0.2j, -1.3 + 0.4j
     ref = alpha * (M @ x) + beta * y0
     for lanes in (0, 1, 2, 4, 8, 16, 32, 64):
-        y = _dev(y0.copy())
-        A.spmv(_dev(x), y, alpha, beta, lanes)
+        y, xd = _dev(y0.copy()), _dev(x)
+        A.spmv(xd, y, alpha, beta, lanes)
         got = y.cpu().numpy()
         assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref)), lanes
     y = _dev(np.full(n, np.nan + 0j))        # beta == 0 must ignore the previous content of y
-    A.spmv(_dev(x), y)
+    xd = _dev(x)
+    A.spmv(xd, y)
     assert np.allclose(y.cpu().numpy(), M @ x, rtol=1e-13, atol=1e-13)
     torch.cuda.synchronize()
 
@@ -62,8 +63,8 @@ def test_spmv_empty_rows_and_ragged(hx):
     M = sp.csr_matrix(M)
     x = _rand_c(rng, n)
     for lanes in (0, 1, 8, 64):
-        y = _dev(np.zeros(n, complex))
-        CSR.from_scipy(M).spmv(_dev(x), y, lanes=lanes)
+        y, xd, Ad = _dev(np.zeros(n, complex)), _dev(x), CSR.from_scipy(M)
+        Ad.spmv(xd, y, lanes=lanes)
         assert np.allclose(y.cpu().numpy(), M @ x, rtol=1e-12, atol=1e-12)
 
 
@@ -83,12 +84,13 @@ def test_vector_and_panel_kernels(hx):
     assert np.array_equal(got2, panel_dot(Vd, 9, wd))          # deterministic reduction
     h = _rand_c(rng, m)
     w2 = _dev(w.copy())
-    hx.check(hx.lib.hx_zpanel_sub(n, m, hx.ptr(Vd), n, hx.ptr(_dev(h)), hx.ptr(w2), hx.stream()))
+    hd = _dev(h)
+    hx.check(hx.lib.hx_zpanel_sub(n, m, hx.ptr(Vd), n, hx.ptr(hd), hx.ptr(w2), hx.stream()))
     assert np.allclose(w2.cpu().numpy(), w - V.T @ h, rtol=1e-12, atol=1e-12)
     Q = _rand_c(rng, m, 6)
     out = torch.zeros((6, n), dtype=torch.complex128, device=Vd.device)
-    hx.check(hx.lib.hx_zpanel_mul(n, m, 6, hx.ptr(Vd), n, hx.ptr(_dev(np.ascontiguousarray(Q.T))), hx.ptr(out), n,
-                                  hx.stream()))
+    Qd = _dev(np.ascontiguousarray(Q.T))
+    hx.check(hx.lib.hx_zpanel_mul(n, m, 6, hx.ptr(Vd), n, hx.ptr(Qd), hx.ptr(out), n, hx.stream()))
     assert np.allclose(out.cpu().numpy(), Q.T @ V, rtol=1e-12, atol=1e-11)
     # axpy / scal / lincomb / gather / scatter
     a = 0.3 - 1.1j
@@ -102,10 +104,11 @@ def test_vector_and_panel_kernels(hx):
     hx.check(hx.lib.hx_zlincomb(n, 3, cf, arr, hx.ptr(y), hx.stream()))
     assert np.allclose(y.cpu().numpy(), V[0] + 2j * V[1] + (-1 + 0.5j) * V[2])
     idx = rng.permutation(n).astype(np.int32)
-    hx.check(hx.lib.hx_zgather(n, hx.ptr(wd), hx.ptr(_dev(idx)), hx.ptr(y), hx.stream()))
+    idx_d = _dev(idx)
+    hx.check(hx.lib.hx_zgather(n, hx.ptr(wd), hx.ptr(idx_d), hx.ptr(y), hx.stream()))
     assert np.array_equal(y.cpu().numpy(), w[idx])
     dst = _dev(V[5].copy())
-    hx.check(hx.lib.hx_zscatter_axpy(n, hx.z2(a), hx.ptr(wd), hx.ptr(_dev(idx)), hx.ptr(dst), hx.stream()))
+    hx.check(hx.lib.hx_zscatter_axpy(n, hx.z2(a), hx.ptr(wd), hx.ptr(idx_d), hx.ptr(dst), hx.stream()))
     ref = V[5].copy()
     ref[idx] += a * w
     assert np.allclose(dst.cpu().numpy(), ref)
@@ -114,8 +117,9 @@ def test_vector_and_panel_kernels(hx):
     sidx = rng.integers(0, n, 400).astype(np.int32)
     sval = _rand_c(rng, 400)
     out3 = torch.zeros(3, dtype=torch.complex128, device=Vd.device)
-    hx.check(hx.lib.hx_zsparse_dots(3, hx.ptr(_dev(ptr)), hx.ptr(_dev(sidx)), hx.ptr(_dev(sval)), hx.ptr(wd),
-                                    hx.ptr(out3), hx.stream()))
+    ptr_d, sidx_d, sval_d = _dev(ptr), _dev(sidx), _dev(sval)     # keep alive: temporaries would be recycled
+    hx.check(hx.lib.hx_zsparse_dots(3, hx.ptr(ptr_d), hx.ptr(sidx_d), hx.ptr(sval_d), hx.ptr(wd), hx.ptr(out3),
+                                    hx.stream()))
     ref3 = [np.sum(sval[ptr[f]:ptr[f + 1]] * w[sidx[ptr[f]:ptr[f + 1]]]) for f in range(3)]
     assert np.allclose(out3.cpu().numpy(), ref3, rtol=1e-12, atol=1e-12)
 
@@ -188,7 +192,7 @@ def test_lu_solver_matches_splu(hx):
     rng = np.random.default_rng(1)
     b = _rand_c(rng, K.shape[0])
     S = LUSolver(CSR.from_scipy(K))
-    x = _dev(np.zeros_like(b))
-    S.solve(_dev(b), x)
+    x, bd = _dev(np.zeros_like(b)), _dev(b)
+    S.solve(bd, x)
     ref = spla.splu(K.tocsc()).solve(b)
     assert np.max(np.abs(x.cpu().numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))

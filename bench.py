@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X hot path (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic annular-combustor case already resident in HBM:
+P1 assembly of A, B, C (+ integer maps), the 16 pointwise flame vectors, and the whole
+``fixed_point_iteration`` call (passive PEP solve + relaxed fixed-point loop, every factorisation / hierarchy
+set-up included).  ``value`` = converged eigenpairs per second = (pairs the final solve returns, capped at
+nev) x steps / wall time, summed over ranks.
+
+Extra objects on the JSON line:
+  roofline      the CSR SpMV of the shifted operator K inside the shift-invert Arnoldi loop, timed live with
+                HIP events on the launch stream; achieved = (nnz*20 + n*36) bytes / average launch time.
+  cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference: explicit D, SuperLU re-factorisation
+                every iteration, ARPACK) timed on this box's host on a bounded sample of the same workload.
+
+Multi-GPU (--gpus N via torch.distributed.run): one process per GPU; see DESIGN.md "Multi-GPU".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "helmholtz-x_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+os.environ.setdefault("HX_QUIET", "1")
+
+WORKLOADS = {
+    # name: (nr, ntheta, nz)  -> DOFs = (nr+1)*ntheta*(nz+1)
+    "annulus-5M": (56, 1792, 48),      # 5,005,056 DOF (BASELINE configs[3], the metric's headline size)
+    "annulus-1M": (32, 1024, 30),      # 1,047,552 DOF (configs[2])
+    "annulus-260k": (20, 640, 18),     # 255,360 DOF
+    "annulus-66k": (12, 384, 12),      # 64,896 DOF
+    "annulus-34k": (10, 256, 11),      # 33,792 DOF ~ the reference's real MICCA mesh (34,787 DOF)
+}
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_case(shape):
+    import numpy as np
+    from scipy.io import loadmat
+    from cases import Micca
+    from helmholtz_x.flame_transfer_function import stateSpace
+    from helmholtz_x.synthetic import annulus, micca_sound_speed
+    mesh, subdomains, facet_tags = annulus(*shape)
+    c = micca_sound_speed(mesh)
+    mat = loadmat(os.path.join(ROOT, "tests", "golden", "micca_ftf.mat"))
+    ftf = stateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+    return dict(mesh=mesh, subdomains=subdomains, facet_tags=facet_tags, c=c, ftf=ftf, P=Micca, np=np)
+
+
+def hot_path(case, st_type=None, nev=4, tol=1e-3, history=None):
+    """One full pass: assembly + flame vectors + fixed-point iteration.  Returns (E, matrices)."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.flame_matrices import PointwiseFlameMatrix
+    from helmholtz_x.parameters_utils import Q_multiple
+    P, mesh = case["P"], case["mesh"]
+    mesh.assembler().rebuild_maps()
+    matrices = AcousticMatrices(mesh, case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    h = case.get("h")
+    if h is None:
+        h = case["h"] = Q_multiple(mesh, case["subdomains"], P.N_sector)
+    D = PointwiseFlameMatrix(mesh, case["subdomains"], P.x_r(), h, P.rho_amb, P.q_0, P.u_b, case["ftf"])
+    D.assemble_submatrices('direct')
+    E = fixed_point_iteration(matrices, D, P.target, i=0, nev=nev, tol=tol, st_type=st_type, history=history)
+    return E, matrices
+
+
+def spmv_roofline(matrices, target, reps=50):
+    """Average launch time of hx_csr_spmv_z on K = A + sigma B + sigma^2 C, HIP events on the launch stream."""
+    import torch
+    from helmholtz_x.petsc import combine_csr
+    A, B, C = matrices.A, matrices.B, matrices.C
+    K = combine_csr(A.shape, A.csr_terms + [(target * c, m) for c, m in B.csr_terms]
+                    + [(target ** 2 * c, m) for c, m in C.csr_terms])
+    n, nnz = K.shape[0], K.nnz
+    x = torch.randn(n, dtype=torch.complex128, device=K.val.device)
+    y = torch.empty_like(x)
+    for _ in range(5):
+        K.spmv(x, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        K.spmv(x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg_bytes = nnz * 20 + n * 36
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="k_spmv (hx_csr_spmv_z)", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, n_rows=n, nnz=nnz, bytes_per_launch=alg_bytes,
+                avg_launch_ms=round(ms, 5))
+
+
+def cpu_baseline(sample="annulus-34k", budget_s=40.0):
+    """Oracle ("port") fixed-point iteration on the host, bounded sample of the same workload."""
+    import numpy as np
+    from oracle import eigen, fem
+    case = build_case(WORKLOADS[sample])
+    P, mesh = case["P"], case["mesh"]
+    x, cells = mesh.geometry.x, mesh.topology.cells
+    n = x.shape[0]
+    t0 = time.perf_counter()
+    c = case["c"].x.array
+    A = fem.assemble_A(x, cells, c, c_is_cellwise=True)
+    C = fem.assemble_C(x, cells)
+    sel = case["facet_tags"].find(11)
+    B = fem.assemble_B(x, n, [(mesh.facets[sel], fem.robin_Z(P.R_outlet), c, mesh.facet_cells[sel])])
+    tags = np.full(cells.shape[0], -1, np.int32)
+    tags[case["subdomains"].indices] = case["subdomains"].values
+    q = fem.q_multiple(x, cells, tags, P.N_sector)
+    D = None
+    for f, pt in enumerate(P.x_r()):
+        left = fem.threshold_pack(fem.pointwise_left(x, cells, tags, f, q, 1.4, P.q_0, P.u_b), 1e-10)
+        Df = fem.flame_outer(n, left, fem.pointwise_right(x, cells, pt, P.rho_amb))
+        D = Df if D is None else D + Df
+    E, hist = eigen.fixed_point_iteration(A, B, C, eigen.OracleFlame(D, case["ftf"]), P.target, nev=4, i=0, tol=1e-3)
+    dt = time.perf_counter() - t0
+    return dict(value=round(4 / dt, 5), unit="eigenpairs/s", cores=1, kind="port",
+                sample="%s (%d DOF, %d tets), 1 full fixed_point_iteration (nev=4, tol=1e-3, %d iterations), "
+                       "SciPy SuperLU + ARPACK, %.1f s" % (sample, n, cells.shape[0], len(hist) - 1, dt),
+                omega=[hist[-1].real, hist[-1].imag])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--workload", default=os.environ.get("HX_BENCH_WORKLOAD", "annulus-66k"))
+    ap.add_argument("--st-type", default=None, help="inner solver for the shifted operator: lu | amg | auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="annulus-34k")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    shape = WORKLOADS[args.workload]
+    case = build_case(shape)
+    mesh = case["mesh"]
+    mesh.assembler()                           # mesh arrays -> HBM (outside the timed region)
+    n_dof, n_cells = mesh.num_vertices, mesh.num_cells
+
+    for _ in range(args.warmup):
+        hot_path(case, args.st_type)
+    barrier()
+    t0 = time.perf_counter()
+    pairs = 0
+    hist = []
+    for _ in range(args.steps):
+        hist = []
+        E, matrices = hot_path(case, args.st_type, history=hist)
+        pairs += min(E.getConverged(), 4)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(pairs)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt, pairs_all = float(tmax.item()), float(tot.item())
+
+    if rank == 0:
+        omegas = [E.getEigenvalue(i) for i in range(min(E.getConverged(), 4))]
+        inner = next(iter(E.inner_cache.values())) if E.inner_cache else None
+        roof = spmv_roofline(matrices, case["P"].target)
+        out = {
+            "metric": "converged eigenpairs/sec + SpMV GB/s (% HBM roofline), AnnularCombustor",
+            "value": round(pairs_all / dt, 5), "unit": "eigenpairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / max(args.steps, 1), 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "c128", "data": "synthetic",
+            "config": {"workload": args.workload, "grid_nr_ntheta_nz": list(shape), "dofs": n_dof, "tets": n_cells,
+                       "nev": 4, "fpi_tol": 1e-3, "fpi_iterations": len(hist) - 1, "flames": 16,
+                       "inner_solver": getattr(inner, "name", None),
+                       "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
+                       "omega": [[round(w.real, 6), round(w.imag, 6)] for w in omegas]},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -364,12 +364,13 @@ template <int D, int KIND>
 __global__ void __launch_bounds__(128)
 k_load(int32_t n, const double* __restrict__ x, const int32_t* __restrict__ cells, const int32_t* __restrict__ v2c_ptr,
        const int32_t* __restrict__ v2c_idx, const zc* __restrict__ fa, const zc* __restrict__ fb, zc scale,
-       zc* __restrict__ out) {
+       const int32_t* __restrict__ cell_tag, int32_t tag, zc* __restrict__ out) {
   constexpr int K = D + 1;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     zc acc = make_double2(0.0, 0.0);
     for (int32_t p = v2c_ptr[i]; p < v2c_ptr[i + 1]; ++p) {
       const int32_t c = v2c_idx[p];
+      if (cell_tag && cell_tag[c] != tag) continue;
       int32_t v[K];
       int j = 0;
 #pragma unroll
@@ -410,14 +411,15 @@ k_load(int32_t n, const double* __restrict__ x, const int32_t* __restrict__ cell
 
 extern "C" int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const double* x, const int32_t* cells,
                                    const int32_t* v2c_ptr, const int32_t* v2c_idx, const hx_c128* fa,
-                                   const hx_c128* fb, const double scale[2], hx_c128* out, hx_stream s) {
+                                   const hx_c128* fb, const double scale[2], const int32_t* cell_tag, int32_t tag,
+                                   hx_c128* out, hx_stream s) {
   HX_REQUIRE(kind >= 0 && kind <= 2 && dim >= 1 && dim <= 3 && n_vert > 0 && x && cells && v2c_ptr && v2c_idx && fa &&
                  scale && out, "bad argument");
   HX_REQUIRE(kind == 0 || fb, "kind 1/2 need both fields");
   const int grid = hx_grid(n_vert, 128, 256 * 16);
   const zc sc = hx_z(scale);
 #define HX_GO(D, KD) k_load<D, KD><<<grid, 128, 0, hx_s(s)>>>(n_vert, x, cells, v2c_ptr, v2c_idx, (const zc*)fa, \
-                                                               (const zc*)fb, sc, (zc*)out)
+                                                               (const zc*)fb, sc, cell_tag, tag, (zc*)out)
 #define HX_DIM(KD) do { if (dim == 1) HX_GO(1, KD); else if (dim == 2) HX_GO(2, KD); else HX_GO(3, KD); } while (0)
   if (kind == 0) HX_DIM(0); else if (kind == 1) HX_DIM(1); else HX_DIM(2);
 #undef HX_DIM

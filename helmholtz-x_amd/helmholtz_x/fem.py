@@ -250,14 +250,32 @@ class P1Assembler:
         return Mat.from_csr(CSR((self.n, self.n), rowptr, col, val))
 
     # ---- load vectors (device tensors of length n)
-    def load(self, kind, fa, fb=None, scale=1.0):
+    def load(self, kind, fa, fb=None, scale=1.0, cell_tag=None, tag=0):
+        """cell_tag: optional int32 device tensor (n_cells); only cells with cell_tag == tag contribute."""
         fa_t = fa if isinstance(fa, torch.Tensor) else to_device(np.asarray(fa, dtype=np.complex128))
         fb_t = None if fb is None else (fb if isinstance(fb, torch.Tensor) else to_device(np.asarray(fb, np.complex128)))
         out = torch.empty(self.n, dtype=torch.complex128, device=self.x.device)
         _hx.check(_hx.lib.hx_assemble_p1_load(kind, self.dim, self.n, _hx.ptr(self.x), _hx.ptr(self.cells),
                                               _hx.ptr(self.v2c_ptr), _hx.ptr(self.v2c_idx), _hx.ptr(fa_t),
-                                              _hx.ptr(fb_t), _hx.z2(scale), _hx.ptr(out), _hx.stream()))
+                                              _hx.ptr(fb_t), _hx.z2(scale), _hx.ptr(cell_tag), int(tag), _hx.ptr(out),
+                                              _hx.stream()))
         return out
+
+    def cell_tag_array(self, tags):
+        """Dense int32 device array of cell tags (-1 = untagged) from a MeshTags, cached per MeshTags object."""
+        cache = self.__dict__.setdefault("_tag_cache", {})
+        if id(tags) not in cache:
+            dense = np.full(self.nc, -1, dtype=np.int32)
+            dense[tags.indices] = tags.values
+            cache[id(tags)] = (tags, to_device(dense))
+        return cache[id(tags)][1]
+
+    def rebuild_maps(self):
+        """Recompute adjacency and CSR pattern from the resident mesh arrays (what a fresh assembly pays)."""
+        self.v2c_ptr, self.v2c_idx = self._adjacency(self.cells, self.nc, self.dim + 1)
+        self.rowptr, self.col = self._pattern(self.cells, self.nc, self.dim + 1, self.v2c_ptr, self.v2c_idx)
+        self.pattern_id = object()
+        self.pattern_id = id(self.rowptr)
 
     def lumped(self):
         """m_j = int phi_j dx, so that int f dx = m . f for nodal P1 f."""

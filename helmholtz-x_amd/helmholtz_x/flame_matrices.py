@@ -21,23 +21,35 @@ from .petsc import LowRank, Mat
 from .solver_utils import info
 
 
-def _locate_cell(x, cells, point, tol=1e-10):
-    """First cell containing ``point`` (determine_point_ownership, flame_matrices.py:144)."""
+def _locate_cell(mesh, point, tol=1e-10, ncand=256):
+    """First (lowest-index) cell containing ``point`` and the P1 gradients on it
+    (determine_point_ownership + Expression.eval of grad(phi), flame_matrices.py:144-152).
+
+    Candidates are the ``ncand`` cells with the nearest centroids (cached on the mesh), so the search is one O(nc)
+    distance pass per point even on 30 M-cell meshes; the candidate set is widened until a hit is found."""
+    x, cells = mesh.geometry.x, mesh.topology.cells
     d = cells.shape[1] - 1
     p = np.asarray(point, dtype=float).reshape(-1)[:d]
-    X = x[cells][:, :, :d]
-    lo, hi = X.min(axis=1) - tol, X.max(axis=1) + tol
-    cand = np.flatnonzero(((p >= lo) & (p <= hi)).all(axis=1))     # bounding-box prefilter
-    J = np.transpose(X[cand, 1:, :] - X[cand, :1, :], (0, 2, 1))
-    lam = np.linalg.solve(J, (p[None, :] - X[cand, 0, :])[:, :, None])[:, :, 0]
-    bary = np.concatenate([1 - lam.sum(axis=1, keepdims=True), lam], axis=1)
-    hit = cand[(bary >= -tol).all(axis=1)]
-    if hit.size == 0:
-        raise ValueError("reference point %s is outside the mesh" % (point,))
-    c = int(hit[0])
-    k = np.flatnonzero(cand == c)[0]
-    grads = np.concatenate([-np.linalg.inv(J[k]).sum(axis=0, keepdims=True), np.linalg.inv(J[k])], axis=0)
-    return c, grads          # grads[i] = grad(phi_i) on that cell
+    cent = getattr(mesh, "_centroids", None)
+    if cent is None:
+        cent = mesh._centroids = x[cells].mean(axis=1)
+    dist2 = ((cent[:, :d] - p[None, :]) ** 2).sum(axis=1)
+    while True:
+        ncand = min(ncand, cells.shape[0])
+        cand = np.sort(np.argpartition(dist2, ncand - 1)[:ncand])
+        X = x[cells[cand]][:, :, :d]
+        J = np.transpose(X[:, 1:, :] - X[:, :1, :], (0, 2, 1))
+        lam = np.linalg.solve(J, (p[None, :] - X[:, 0, :])[:, :, None])[:, :, 0]
+        bary = np.concatenate([1 - lam.sum(axis=1, keepdims=True), lam], axis=1)
+        hit = np.flatnonzero((bary >= -tol).all(axis=1))
+        if hit.size:
+            k = hit[0]
+            Jinv = np.linalg.inv(J[k])
+            grads = np.concatenate([-Jinv.sum(axis=0, keepdims=True), Jinv], axis=0)   # grads[i] = grad(phi_i)
+            return int(cand[k]), grads
+        if ncand == cells.shape[0]:
+            raise ValueError("reference point %s is outside the mesh" % (point,))
+        ncand *= 16
 
 
 class FlameMatrix:
@@ -129,12 +141,13 @@ class PointwiseFlameMatrix(FlameMatrix):
     def _assemble_vectors(self, flame, point):
         asm = self.mesh.assembler()
         # left: (gamma-1) q0/u_b int_{Omega_flame} h phi_j dx with h DG0  -> kind 0 load with a masked cell weight
-        weight = np.zeros(self.mesh.num_cells, dtype=np.complex128)
-        cells = self.subdomains.find(flame)
-        weight[cells] = self.h.x.array[cells]
-        left = self.indices_and_values(asm.load(0, weight, scale=(self.gamma - 1) * self.q_0 / self.u_b))
+        if getattr(self, "_h_dev", None) is None:
+            from .petsc import to_device
+            self._h_dev = to_device(self.h.x.array.astype(np.complex128))
+        left = self.indices_and_values(asm.load(0, self._h_dev, scale=(self.gamma - 1) * self.q_0 / self.u_b,
+                                                cell_tag=asm.cell_tag_array(self.subdomains), tag=flame))
         # right: grad(phi_k).n_r / rho_u at x_r: 4 (d+1) numbers on the cell that holds the point
-        c, grads = _locate_cell(self.mesh.geometry.x, self.mesh.topology.cells, point)
+        c, grads = _locate_cell(self.mesh, point)
         right = (self.mesh.topology.cells[c].astype(np.int32), (grads @ self.n_r) / self.rho_u + 0j)
         return left, right
 

@@ -122,10 +122,13 @@ int hx_csr_apply_dirichlet(int32_t n, const int32_t* rowptr, const int32_t* col,
  *  kind 0: out_j = scale * int f_cell phi_j dx                 (f DG0: fa = f_cell (n_cells), fb unused)
  *  kind 1: out_j = scale * int fa fb phi_j dx                  (fa, fb nodal P1; exact cubic rule)
  *  kind 2: out_k = scale * int (n_r . grad phi_k) fb / fa dx   (fa = rho, fb = w nodal; degree-2 rule)
- * n_r = e_x (dim 1,2) or e_z (dim 3), flame_matrices.py:35-40. */
+ * n_r = e_x (dim 1,2) or e_z (dim 3), flame_matrices.py:35-40.
+ * cell_tag (may be NULL): when given, only cells with cell_tag[c] == tag contribute (the dx(flame) subdomain
+ * measure of flame_matrices.py:137,141). */
 int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const double* x, const int32_t* cells,
                         const int32_t* v2c_ptr, const int32_t* v2c_idx, const hx_c128* fa,
-                        const hx_c128* fb, const double scale[2], hx_c128* out, hx_stream s);
+                        const hx_c128* fb, const double scale[2], const int32_t* cell_tag, int32_t tag,
+                        hx_c128* out, hx_stream s);
 
 /* ------------------------------------------------------------------ sparse triangular solves (MatSolve)
  * replaces: KSP(preonly)+PC(LU) MatSolve inside ST sinvert (eigensolvers.py:49-50,102-103 -> :62,:113).

@@ -44,6 +44,18 @@ SIGNATURES = {
     "hx_sptrsv_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "hx_sptrsv_solve": (C.c_int, [_vp, _vp, _vp, _vp]),
     "hx_sptrsv_destroy": (C.c_int, [_vp]),
+    "hx_csr_jacobi_z": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp]),
+    "hx_zdiag_scale": (C.c_int, [_i64, C.c_double, _vp, _vp, _vp, _vp]),
+    "hx_amg_create": (C.c_int, [C.POINTER(_vp), _int, _int, _int, C.c_double]),
+    "hx_amg_set_level": (C.c_int, [_vp, _int, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
+                                   _vp, _vp]),
+    "hx_amg_set_coarse": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
+    "hx_amg_vcycle": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "hx_amg_destroy": (C.c_int, [_vp]),
+    "hx_gmres_ws": (C.c_size_t, [_i64, _int]),
+    "hx_gmres": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp,
+                           C.POINTER(_int), C.POINTER(C.c_double), _vp]),
+    "hx_host_aggregate": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

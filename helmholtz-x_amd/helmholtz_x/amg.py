@@ -1,0 +1,171 @@
+"""Smoothed-aggregation AMG hierarchy + device GMRES: the iterative "inner solve" of shift-invert Arnoldi.
+
+Role on the path: K^-1 for K = A + sigma B + sigma^2 C when a sparse direct factorisation does not fit (3-D, from
+~1e5 DOF up to the 5 M-DOF headline case); the reference delegates this to PETSc PCLU -> MUMPS (eigensolvers.py:
+49-50, 102-103).  The thermoacoustic problems here are LOW-frequency Helmholtz problems with a complex shift
+(the domain spans 1-2 wavelengths, sigma has a 10-30 % imaginary part), for which a multigrid V-cycle built on the
+Laplacian-like part of K is an effective preconditioner and every coarse grid still resolves the wave.
+
+Split of work
+  host (once per K, integer / graph work + sparse products): strength-of-connection filter, greedy aggregation
+      (hx_host_aggregate, C++), tentative + Jacobi-smoothed prolongator, Galerkin products P^T K P, dense inverse
+      of the coarsest operator;
+  device (every solve): hx_gmres -> hx_amg_vcycle -> fused Jacobi sweeps / residual / P, R products / CGS2 panels.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _hx
+from .petsc import CSR, to_device
+from .solver_utils import info
+
+PARAMS = dict(theta=0.08, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=40,
+              max_it=200)
+
+
+def _aggregate(S):
+    """Greedy aggregation of the (symmetric) strength graph S (CSR, weights = coupling magnitude)."""
+    n = S.shape[0]
+    rp = np.ascontiguousarray(S.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(S.indices, dtype=np.int32)
+    w = np.ascontiguousarray(S.data, dtype=np.float64)
+    agg = np.empty(n, dtype=np.int32)
+    na = C.c_int32(0)
+    _hx.check(_hx.lib.hx_host_aggregate(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(w), _hx.nptr(agg), C.byref(na)))
+    return agg, na.value
+
+
+def _spectral_radius(M, iters=12, seed=0):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(M.shape[0])
+    lam = 1.0
+    for _ in range(iters):
+        w = M @ v
+        lam = np.linalg.norm(w)
+        v = w / lam
+    return lam
+
+
+def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], coarse_size=PARAMS["coarse_size"]):
+    """K: scipy CSR (complex).  Returns a list of dicts {K, dinv, P, R, rho} (host scipy objects), finest first."""
+    levels = []
+    Kl = sp.csr_matrix(K, dtype=np.complex128)
+    th = theta
+    while True:
+        n = Kl.shape[0]
+        diag = Kl.diagonal()
+        # Laplacian-like real part with positive diagonal drives strength / prolongator smoothing
+        sgn = -1.0 if np.median(diag.real) < 0 else 1.0
+        L = sp.csr_matrix((sgn * Kl.data.real, Kl.indices, Kl.indptr), shape=Kl.shape)
+        d = np.abs(L.diagonal())
+        d[d == 0] = 1.0
+        level = dict(K=Kl, n=n)
+        if n <= coarse_size or len(levels) == max_levels - 1:
+            levels.append(level)
+            break
+        # ---- strength filter: |l_ij| >= theta * sqrt(l_ii l_jj), off-diagonal
+        coo = L.tocoo()
+        off = coo.row != coo.col
+        strong = off & (np.abs(coo.data) >= th * np.sqrt(d[coo.row] * d[coo.col]))
+        S = sp.csr_matrix((np.abs(coo.data[strong]), (coo.row[strong], coo.col[strong])), shape=L.shape)
+        agg, na = _aggregate(S)
+        if na >= 0.8 * n:                          # coarsening stalled
+            levels.append(level)
+            break
+        cnt = np.bincount(agg, minlength=na).astype(np.float64)
+        P0 = sp.csr_matrix((1.0 / np.sqrt(cnt[agg]), (np.arange(n), agg)), shape=(n, na))
+        # ---- filtered matrix: weak couplings lumped onto the diagonal, then P = (I - w Df^-1 Lf) P0
+        weak = off & ~strong
+        lump = np.bincount(coo.row[weak], weights=coo.data[weak], minlength=n)
+        keep = ~weak
+        Lf = sp.csr_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=L.shape) + sp.diags(lump)
+        df = Lf.diagonal()
+        df[df == 0] = 1.0
+        DinvLf = sp.diags(1.0 / df) @ Lf
+        rho = _spectral_radius(DinvLf)
+        P = (P0 - (4.0 / (3.0 * rho)) * (DinvLf @ P0)).tocsr()
+        P.sort_indices()
+        R = P.T.tocsr()
+        R.sort_indices()
+        # smoother: damped Jacobi on K itself
+        rhoK = _spectral_radius(sp.diags(1.0 / d) @ L)
+        level.update(P=P, R=R, dinv=1.0 / diag, omega=4.0 / (3.0 * rhoK), n_coarse=na)
+        levels.append(level)
+        Kl = (R @ Kl @ P).tocsr()
+        Kl.sort_indices()
+        th *= 0.5
+    return levels
+
+
+class AMGSolver:
+    """K^-1 b by V-cycle-preconditioned GMRES on the device (hx_gmres)."""
+
+    name = "amg"
+
+    def __init__(self, K_csr, hierarchy=None, **overrides):
+        self.params = dict(PARAMS, **overrides)
+        self.n = K_csr.shape[0]
+        self.K = K_csr
+        dev = K_csr.val.device
+        levels = hierarchy if hierarchy is not None else build_hierarchy(K_csr.to_scipy(), self.params["theta"],
+                                                                           self.params["max_levels"],
+                                                                           self.params["coarse_size"])
+        self.levels = levels
+        omega = self.params["jacobi_omega"] or min(lv["omega"] for lv in levels if "omega" in lv) if len(levels) > 1 else 0.6
+        h = C.c_void_p()
+        _hx.check(_hx.lib.hx_amg_create(C.byref(h), len(levels), self.params["pre"], self.params["post"], float(omega)))
+        self.handle = h
+        self._keep = []                               # device arrays referenced by the handle
+        for l, lv in enumerate(levels):
+            Kd = K_csr if l == 0 else CSR.from_scipy(lv["K"])
+            if "P" in lv:
+                Pd, Rd = CSR.from_scipy(lv["P"]), CSR.from_scipy(lv["R"])
+                dinv = to_device(np.asarray(lv["dinv"], dtype=np.complex128))
+                self._keep += [Kd, Pd, Rd, dinv]
+                _hx.check(_hx.lib.hx_amg_set_level(h, l, lv["n"], Kd.nnz, _hx.ptr(Kd.rowptr), _hx.ptr(Kd.col),
+                                                   _hx.ptr(Kd.val), _hx.ptr(dinv), lv["n_coarse"], Pd.nnz,
+                                                   _hx.ptr(Pd.rowptr), _hx.ptr(Pd.col), _hx.ptr(Pd.val), Rd.nnz,
+                                                   _hx.ptr(Rd.rowptr), _hx.ptr(Rd.col), _hx.ptr(Rd.val)))
+            else:
+                self._keep += [Kd]
+                _hx.check(_hx.lib.hx_amg_set_level(h, l, lv["n"], Kd.nnz, _hx.ptr(Kd.rowptr), _hx.ptr(Kd.col),
+                                                   _hx.ptr(Kd.val), None, 0, 0, None, None, None, 0, None, None, None))
+                inv = np.linalg.inv(lv["K"].toarray())
+                Cd = CSR.from_scipy(sp.csr_matrix(inv))
+                self._keep.append(Cd)
+                _hx.check(_hx.lib.hx_amg_set_coarse(h, lv["n"], Cd.nnz, _hx.ptr(Cd.rowptr), _hx.ptr(Cd.col),
+                                                    _hx.ptr(Cd.val)))
+        self.ws = torch.empty(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), dtype=torch.complex128, device=dev)
+        self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
+        self.total_iters = 0
+        self.n_solves = 0
+        self.last = (0, 0.0)
+        info("- AMG hierarchy: " + " -> ".join("%d" % lv["n"] for lv in levels)
+             + "  (operator complexity %.2f)" % (sum(lv["K"].nnz for lv in levels) / levels[0]["K"].nnz))
+
+    def solve(self, b, x):
+        it, rr = C.c_int(0), C.c_double(0.0)
+        K = self.K
+        _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
+                                   _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
+                                   self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
+        self.total_iters += it.value
+        self.n_solves += 1
+        self.last = (it.value, rr.value)
+        if rr.value > 100 * self.params["rtol"]:
+            raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
+                                  % (rr.value, it.value))
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            _hx.lib.hx_amg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

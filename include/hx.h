@@ -143,6 +143,40 @@ int hx_sptrsv_info(const hx_sptrsv* t, int32_t* n_levels, int32_t* n_launches, i
 int hx_sptrsv_solve(hx_sptrsv* t, const hx_c128* b, hx_c128* x, hx_stream s);
 int hx_sptrsv_destroy(hx_sptrsv* t);
 
+/* ------------------------------------------------------------------ AMG-preconditioned GMRES (iterative MatSolve)
+ * replaces: the same KSP/PC solve as above for 3-D problems where a sparse direct factorisation does not fit
+ * (the reference switches PCLU to MUMPS/SuperLU_DIST there).  Hierarchy arrays are device pointers owned by
+ * the caller and must outlive the handle. */
+/* xout = xin + omega * dinv .* (b - A xin)   (fused damped-Jacobi sweep; xin != xout) */
+int hx_csr_jacobi_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                    const hx_c128* val, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin,
+                    hx_c128* xout, double omega, hx_stream s);
+/* x = scale * d .* b */
+int hx_zdiag_scale(int64_t n, double scale, const hx_c128* d, const hx_c128* b, hx_c128* x, hx_stream s);
+typedef struct hx_amg hx_amg;
+int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, double omega);
+/* level l (0 = finest): operator K_l, inverse diagonal, prolongator P_l (n x n_coarse) and restriction
+ * R_l = P_l^T (n_coarse x n); transfer operators are ignored on the coarsest level. */
+int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t* rpK, const int32_t* ciK,
+                     const hx_c128* vaK, const hx_c128* dinv, int32_t n_coarse, int64_t nnzP,
+                     const int32_t* rpP, const int32_t* ciP, const hx_c128* vaP, int64_t nnzR,
+                     const int32_t* rpR, const int32_t* ciR, const hx_c128* vaR);
+/* dense inverse of the coarsest operator, passed as a (dense) CSR */
+int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
+                      const hx_c128* va);
+/* x = one V-cycle applied to b from a zero initial guess (b != x) */
+int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream s);
+int hx_amg_destroy(hx_amg* h);
+/* Right-preconditioned restarted GMRES on K x = b (x0 = 0), CGS2 with the fused panel kernels; M may be NULL.
+ * ws: hx_gmres_ws(n, restart) complex numbers.  SYNC (one small D2H per orthogonalisation pass). */
+size_t hx_gmres_ws(int64_t n, int restart);
+int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+             const hx_c128* val, const hx_c128* b, hx_c128* x, double rtol, int max_it, int restart,
+             hx_c128* ws, int* h_iters, double* h_relres, hx_stream s);
+/* HOST: greedy aggregation of the strength graph (CSR of strong off-diagonal couplings, weights w). */
+int hx_host_aggregate(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_w,
+                      int32_t* h_agg, int32_t* h_n_agg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,3 +301,67 @@ def test_manufactured_2d_pep_against_dispersion_relation(ref_logs):
         k = dispersion_root(got / g["c0"], Z)
         assert abs(got / (2 * np.pi) - g["c0"] * k / (2 * np.pi)) < 2e-4 * abs(got / (2 * np.pi))
         omega = got
+
+
+def _annulus_case(shape):
+    import bench
+    return bench.build_case(shape)
+
+
+def test_amg_gmres_inner_solver_matches_direct():
+    """K^-1 b from the device AMG-GMRES equals the SuperLU solution on a 3-D annulus (complex shifted operator)."""
+    import scipy.sparse.linalg as spla
+    import torch
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.amg import AMGSolver
+    from helmholtz_x.petsc import combine_csr, to_device
+    case = _annulus_case((8, 96, 10))
+    P, mesh = case["P"], case["mesh"]
+    M = AcousticMatrices(mesh, case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    s = P.target
+    K = combine_csr(M.A.shape, M.A.csr_terms + [(s * c, m) for c, m in M.B.csr_terms]
+                    + [(s ** 2 * c, m) for c, m in M.C.csr_terms])
+    solver = AMGSolver(K)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(K.shape[0]) + 1j * rng.standard_normal(K.shape[0])
+    bd = to_device(b)
+    x = torch.empty_like(bd)
+    solver.solve(bd, x)
+    ref = spla.splu(K.to_scipy().tocsc()).solve(b)
+    assert solver.last[0] < 60
+    assert np.linalg.norm(x.cpu().numpy() - ref) <= 1e-9 * np.linalg.norm(ref)
+
+
+def test_annulus_fixed_point_amg_vs_lu_vs_oracle():
+    """Synthetic annular combustor (16 pointwise flames, state-space FTF, Robin outlet, PEP): the fixed-point
+    eigenvalue from the iterative (AMG-GMRES) and direct (LU) inner solvers and from the CPU oracle agree."""
+    import bench
+    from oracle import eigen, fem
+    shape = (6, 64, 8)
+    res = {}
+    for st in ("lu", "amg"):
+        case = _annulus_case(shape)
+        hist = []
+        E, _ = bench.hot_path(case, st_type=st, nev=4, tol=1e-9, history=hist)
+        res[st] = hist[-1]
+        assert E.getConverged() >= 3
+    assert abs(res["amg"] - res["lu"]) / abs(res["lu"]) < 1e-8
+    case = _annulus_case(shape)
+    P, mesh = case["P"], case["mesh"]
+    x, cells = mesh.geometry.x, mesh.topology.cells
+    n = x.shape[0]
+    c = case["c"].x.array
+    A = fem.assemble_A(x, cells, c, c_is_cellwise=True)
+    C = fem.assemble_C(x, cells)
+    sel = case["facet_tags"].find(11)
+    B = fem.assemble_B(x, n, [(mesh.facets[sel], fem.robin_Z(P.R_outlet), c, mesh.facet_cells[sel])])
+    tags = np.full(cells.shape[0], -1, np.int32)
+    tags[case["subdomains"].indices] = case["subdomains"].values
+    q = fem.q_multiple(x, cells, tags, P.N_sector)
+    D = None
+    for f, pt in enumerate(P.x_r()):
+        left = fem.threshold_pack(fem.pointwise_left(x, cells, tags, f, q, 1.4, P.q_0, P.u_b), 1e-10)
+        Df = fem.flame_outer(n, left, fem.pointwise_right(x, cells, pt, P.rho_amb))
+        D = Df if D is None else D + Df
+    _, ohist = eigen.fixed_point_iteration(A, B, C, eigen.OracleFlame(D, case["ftf"]), P.target, nev=4, i=0, tol=1e-9)
+    assert abs(res["lu"] - ohist[-1]) / abs(ohist[-1]) < 1e-8

@@ -35,6 +35,7 @@ WORKLOADS = {
     "annulus-260k": (20, 640, 18),     # 255,360 DOF
     "annulus-66k": (12, 384, 12),      # 64,896 DOF
     "annulus-34k": (10, 256, 11),      # 33,792 DOF ~ the reference's real MICCA mesh (34,787 DOF)
+    "annulus-16k": (8, 160, 10),       # 15,840 DOF (bounded CPU-baseline sample)
 }
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -97,7 +98,7 @@ def spmv_roofline(matrices, target, reps=50):
                 avg_launch_ms=round(ms, 5))
 
 
-def cpu_baseline(sample="annulus-34k", budget_s=40.0):
+def cpu_baseline(sample="annulus-16k"):
     """Oracle ("port") fixed-point iteration on the host, bounded sample of the same workload."""
     import numpy as np
     from oracle import eigen, fem
@@ -135,7 +136,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("HX_BENCH_WORKLOAD", "annulus-66k"))
     ap.add_argument("--st-type", default=None, help="inner solver for the shifted operator: lu | amg | auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="annulus-34k")
+    ap.add_argument("--cpu-sample", default="annulus-16k")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +194,7 @@ def main():
             "config": {"workload": args.workload, "grid_nr_ntheta_nz": list(shape), "dofs": n_dof, "tets": n_cells,
                        "nev": 4, "fpi_tol": 1e-3, "fpi_iterations": len(hist) - 1, "flames": 16,
                        "inner_solver": getattr(inner, "name", None),
+                       "inner_stats": inner.stats() if inner is not None else None,
                        "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
                        "omega": [[round(w.real, 6), round(w.imag, 6)] for w in omegas]},
             "roofline": roof,

@@ -106,6 +106,8 @@ class AMGSolver:
     name = "amg"
 
     def __init__(self, K_csr, hierarchy=None, **overrides):
+        import time
+        t_setup = time.perf_counter()
         self.params = dict(PARAMS, **overrides)
         self.n = K_csr.shape[0]
         self.K = K_csr
@@ -142,22 +144,33 @@ class AMGSolver:
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
         self.total_iters = 0
         self.n_solves = 0
+        self.solve_s = 0.0
         self.last = (0, 0.0)
+        torch.cuda.synchronize()
+        self.setup_s = time.perf_counter() - t_setup
         info("- AMG hierarchy: " + " -> ".join("%d" % lv["n"] for lv in levels)
              + "  (operator complexity %.2f)" % (sum(lv["K"].nnz for lv in levels) / levels[0]["K"].nnz))
 
     def solve(self, b, x):
+        import time
+        t0 = time.perf_counter()
         it, rr = C.c_int(0), C.c_double(0.0)
         K = self.K
         _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                    _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
                                    self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
+        self.solve_s += time.perf_counter() - t0        # hx_gmres synchronises internally
         self.total_iters += it.value
         self.n_solves += 1
         self.last = (it.value, rr.value)
         if rr.value > 100 * self.params["rtol"]:
             raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
                                   % (rr.value, it.value))
+
+    def stats(self):
+        return dict(levels=[lv["n"] for lv in self.levels], setup_s=round(self.setup_s, 3), solves=self.n_solves,
+                    gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
+                    iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1))
 
     def destroy(self):
         if getattr(self, "handle", None):

@@ -37,6 +37,8 @@ class LUSolver:
     name = "lu"
 
     def __init__(self, K_csr):
+        import time
+        t0 = time.perf_counter()
         n = K_csr.shape[0]
         Ks = K_csr.to_scipy().tocsc()
         lu = spla.splu(Ks, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.1,
@@ -64,6 +66,13 @@ class LUSolver:
         self.gather_in = to_device(np.argsort(lu.perm_r).astype(np.int32))
         self.gather_out = to_device(lu.perm_c.astype(np.int32))
         self.tmp = torch.empty(n, dtype=torch.complex128, device=self.gather_in.device)
+        self.setup_s = time.perf_counter() - t0
+        self.n_solves = 0
+
+    def stats(self):
+        lv = self.info()
+        return dict(setup_s=round(self.setup_s, 3), solves=self.n_solves, fill=round(self.fill, 1),
+                    levels_L_U=[lv[0][0], lv[1][0]], launches_L_U=[lv[0][1], lv[1][1]], nnz_L_U=[lv[0][2], lv[1][2]])
 
     def info(self):
         lv, ln, nz = C.c_int32(), C.c_int32(), C.c_int64()
@@ -76,6 +85,7 @@ class LUSolver:
     def solve(self, b, x):
         """x = K^-1 b (device tensors; b is preserved, may not alias x)."""
         s = _hx.stream()
+        self.n_solves += 1
         _hx.check(_hx.lib.hx_zgather(self.n, _hx.ptr(b), _hx.ptr(self.gather_in), _hx.ptr(self.tmp), s))
         _hx.check(_hx.lib.hx_sptrsv_solve(self.handles[0], _hx.ptr(self.tmp), _hx.ptr(self.tmp), s))
         _hx.check(_hx.lib.hx_sptrsv_solve(self.handles[1], _hx.ptr(self.tmp), _hx.ptr(self.tmp), s))

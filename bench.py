@@ -182,7 +182,7 @@ def main():
 
     if rank == 0:
         omegas = [E.getEigenvalue(i) for i in range(min(E.getConverged(), 4))]
-        inner = next(iter(E.inner_cache.values())) if E.inner_cache else None
+        inner = next((v for k, v in (E.inner_cache or {}).items() if k[0] != 'ops'), None)
         roof = spmv_roofline(matrices, case["P"].target)
         out = {
             "metric": "converged eigenpairs/sec + SpMV GB/s (% HBM roofline), AnnularCombustor",
@@ -195,6 +195,7 @@ def main():
                        "nev": 4, "fpi_tol": 1e-3, "fpi_iterations": len(hist) - 1, "flames": 16,
                        "inner_solver": getattr(inner, "name", None),
                        "inner_stats": inner.stats() if inner is not None else None,
+                       "krylov": {k: v for k, v in (E.state or {}).items() if k != "start"},
                        "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
                        "omega": [[round(w.real, 6), round(w.imag, 6)] for w in omegas]},
             "roofline": roof,

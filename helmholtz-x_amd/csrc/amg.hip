@@ -33,8 +33,14 @@ struct hx_amg {
 
 static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 0.0};
 
+int hx_csr_spmv_transfer(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, hx_c128*,
+                         const double*, const double*, hx_stream);
+
 static int spmv(const Csr& A, const hx_c128* x, hx_c128* y, const double* a, const double* b, hx_stream s) {
   return hx_csr_spmv_z(A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, 0, s);
+}
+static int spmv_t(const Csr& A, const hx_c128* x, hx_c128* y, const double* a, const double* b, hx_stream s) {
+  return hx_csr_spmv_transfer(A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, s);
 }
 
 extern "C" int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, double omega) {
@@ -87,7 +93,7 @@ extern "C" int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int3
 static int vcycle(hx_amg* h, int l, const hx_c128* b, hx_c128* xout, hx_stream s) {
   AmgLevel& L = h->L[l];
   int rc;
-  if (l == (int)h->L.size() - 1) return spmv(h->coarse_inv, b, xout, ONE, ZERO, s);
+  if (l == (int)h->L.size() - 1) return spmv_t(h->coarse_inv, b, xout, ONE, ZERO, s);
   hx_c128* cur = L.x;      // ping-pong between L.x and L.x2; final result copied/written to xout
   hx_c128* nxt = L.x2;
   // pre-smoothing: first sweep from x = 0 is a diagonal scaling
@@ -100,11 +106,11 @@ static int vcycle(hx_amg* h, int l, const hx_c128* b, hx_c128* xout, hx_stream s
   HX_HIP(hipMemcpyAsync(L.r, b, sizeof(hx_c128) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
   if ((rc = spmv(L.K, cur, L.r, MONE, ONE, s))) return rc;
   AmgLevel& Lc = h->L[l + 1];
-  if ((rc = spmv(L.R, L.r, Lc.b, ONE, ZERO, s))) return rc;
+  if ((rc = spmv_t(L.R, L.r, Lc.b, ONE, ZERO, s))) return rc;
   // coarse correction (result in Lc.r is free to use as the output buffer of the coarse level)
   hx_c128* ec = Lc.r;
   if ((rc = vcycle(h, l + 1, Lc.b, ec, s))) return rc;
-  if ((rc = spmv(L.P, ec, cur, ONE, ONE, s))) return rc;      // x += P e_c
+  if ((rc = spmv_t(L.P, ec, cur, ONE, ONE, s))) return rc;    // x += P e_c
   // post-smoothing: every sweep reads `cur` and writes the other buffer; the last one writes xout
   for (int k = 0; k < h->post; ++k) {
     hx_c128* dst = (k == h->post - 1) ? xout : (cur == L.x ? L.x2 : L.x);

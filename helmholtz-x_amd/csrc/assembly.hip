@@ -427,3 +427,71 @@ extern "C" int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const doub
   HX_LAUNCH_CHECK("k_load");
   return HX_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ cell volumes / point location
+template <int D>
+__global__ void k_cell_volumes(int32_t nc, const double* __restrict__ x, const int32_t* __restrict__ cells,
+                               double* __restrict__ vol) {
+  constexpr int K = D + 1;
+  for (int32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    int32_t v[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) v[a] = cells[(int64_t)c * K + a];
+    double G[K][D], w;
+    p1_geometry<D>(x, v, G, w);
+    vol[c] = w;
+  }
+}
+extern "C" int hx_p1_cell_volumes(int dim, int32_t n_cells, const double* x, const int32_t* cells, double* vol,
+                                  hx_stream s) {
+  HX_REQUIRE(dim >= 1 && dim <= 3 && n_cells > 0 && x && cells && vol, "bad argument");
+  const int grid = hx_grid(n_cells, 256);
+  if (dim == 1) k_cell_volumes<1><<<grid, 256, 0, hx_s(s)>>>(n_cells, x, cells, vol);
+  else if (dim == 2) k_cell_volumes<2><<<grid, 256, 0, hx_s(s)>>>(n_cells, x, cells, vol);
+  else k_cell_volumes<3><<<grid, 256, 0, hx_s(s)>>>(n_cells, x, cells, vol);
+  HX_LAUNCH_CHECK("k_cell_volumes");
+  return HX_OK;
+}
+
+// For every query point: the lowest-index cell whose barycentric coordinates are all >= -tol
+// (DOLFINx determine_point_ownership, flame_matrices.py:144-145).  out_cell must be pre-filled with INT32_MAX.
+template <int D>
+__global__ void k_locate_points(int32_t nc, const double* __restrict__ x, const int32_t* __restrict__ cells,
+                                int npts, const double* __restrict__ pts, double tol, int32_t* __restrict__ out_cell) {
+  constexpr int K = D + 1;
+  for (int32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) {
+    int32_t v[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) v[a] = cells[(int64_t)c * K + a];
+    double G[K][D], w;
+    p1_geometry<D>(x, v, G, w);
+    double x0[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x0[d] = x[(int64_t)v[0] * 3 + d];
+    for (int q = 0; q < npts; ++q) {
+      // lambda_i = grad(phi_i).(p - x0) for i >= 1, lambda_0 = 1 - sum
+      double lam0 = 1.0;
+      bool inside = true;
+#pragma unroll
+      for (int i = 1; i < K; ++i) {
+        double l = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) l += G[i][d] * (pts[q * 3 + d] - x0[d]);
+        lam0 -= l;
+        inside = inside && (l >= -tol);
+      }
+      if (inside && lam0 >= -tol) atomicMin(&out_cell[q], c);
+    }
+  }
+}
+extern "C" int hx_p1_locate_points(int dim, int32_t n_cells, const double* x, const int32_t* cells, int n_pts,
+                                   const double* pts, double tol, int32_t* out_cell, hx_stream s) {
+  HX_REQUIRE(dim >= 1 && dim <= 3 && n_cells > 0 && x && cells && n_pts > 0 && pts && out_cell, "bad argument");
+  const int grid = hx_grid(n_cells, 256);
+  if (dim == 1) k_locate_points<1><<<grid, 256, 0, hx_s(s)>>>(n_cells, x, cells, n_pts, pts, tol, out_cell);
+  else if (dim == 2) k_locate_points<2><<<grid, 256, 0, hx_s(s)>>>(n_cells, x, cells, n_pts, pts, tol, out_cell);
+  else k_locate_points<3><<<grid, 256, 0, hx_s(s)>>>(n_cells, x, cells, n_pts, pts, tol, out_cell);
+  HX_LAUNCH_CHECK("k_locate_points");
+  return HX_OK;
+}

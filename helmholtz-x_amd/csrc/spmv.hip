@@ -8,7 +8,9 @@
 // capped grid (>> 256 workgroups) so every XCD's L2 sees a contiguous band of rows per workgroup.
 #include "hx_common.h"
 
-template <int LPR>
+// ROLE only separates kernel symbols in profiles: 0 = operator product on the Arnoldi / GMRES path (the roofline
+// kernel), 1 = grid-transfer products (P, R) and coarse-grid solves inside the AMG V-cycle.
+template <int LPR, int ROLE>
 __global__ void __launch_bounds__(256)
 k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ val,
        const zc* __restrict__ x, zc* __restrict__ y, zc alpha, zc beta, int beta_is_zero) {
@@ -33,19 +35,20 @@ k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict_
   }
 }
 
-template <int LPR>
+template <int LPR, int ROLE>
 static int launch(int32_t n, const int32_t* rowptr, const int32_t* col, const zc* val, const zc* x, zc* y,
                   zc alpha, zc beta, hipStream_t s) {
   int64_t rows_per_block = 256 / LPR;
   int grid = hx_grid((int64_t)n, (int)rows_per_block, 256 * 16);
-  k_spmv<LPR><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, alpha, beta, (beta.x == 0.0 && beta.y == 0.0));
+  k_spmv<LPR, ROLE><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, alpha, beta, (beta.x == 0.0 && beta.y == 0.0));
   HX_LAUNCH_CHECK("k_spmv");
   return HX_OK;
 }
 
-extern "C" int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
-                             const hx_c128* val, const hx_c128* x, hx_c128* y, const double alpha[2],
-                             const double beta[2], int lanes_per_row, hx_stream s) {
+template <int ROLE>
+static int spmv_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+                         const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2], int lanes_per_row,
+                         hx_stream s) {
   HX_REQUIRE(n_rows >= 0 && nnz >= 0 && rowptr && x && y && alpha && beta && (nnz == 0 || (col && val)),
              "bad argument");
   if (n_rows == 0) return HX_OK;
@@ -59,17 +62,28 @@ extern "C" int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr,
   const zc* xx = (const zc*)x;
   zc* yy = (zc*)y;
   switch (lpr) {
-    case 1: return launch<1>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 2: return launch<2>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 4: return launch<4>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 8: return launch<8>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 16: return launch<16>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 32: return launch<32>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 64: return launch<64>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 1: return launch<1, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 2: return launch<2, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 4: return launch<4, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 8: return launch<8, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 16: return launch<16, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 32: return launch<32, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 64: return launch<64, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
     default: return hx_fail(HX_ERR_ARG, __func__, "lanes_per_row must be 0,1,2,4,8,16,32,64");
   }
 }
 
+extern "C" int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                             const hx_c128* val, const hx_c128* x, hx_c128* y, const double alpha[2],
+                             const double beta[2], int lanes_per_row, hx_stream s) {
+  return spmv_dispatch<0>(n_rows, nnz, rowptr, col, val, x, y, alpha, beta, lanes_per_row, s);
+}
+
+// internal: same kernel under the "transfer" symbol (used by amg.hip for P, R and the coarse solve)
+int hx_csr_spmv_transfer(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+                         const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2], hx_stream s) {
+  return spmv_dispatch<1>(n_rows, nnz, rowptr, col, val, x, y, alpha, beta, 0, s);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Fused damped-Jacobi sweep (AMG smoother):  xout = xin + omega * dinv .* (b - A xin).

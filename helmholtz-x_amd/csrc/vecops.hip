@@ -146,12 +146,14 @@ k_panel_dot_stage1(int64_t n, int k, const zc* __restrict__ V, int64_t ldv, cons
     __syncthreads();
   }
 }
-__global__ void k_panel_dot_stage2(int nblocks, int k, const zc* __restrict__ partials, zc* __restrict__ out) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > k) return;
+// One wave per output column: lane l sums partials l, l+64, ... in a fixed order, then a shuffle tree.
+__global__ void __launch_bounds__(HX_WAVE)
+k_panel_dot_stage2(int nblocks, int k, const zc* __restrict__ partials, zc* __restrict__ out) {
+  const int j = blockIdx.x;
   zc v = make_double2(0.0, 0.0);
-  for (int b = 0; b < nblocks; ++b) v = zadd(v, partials[(int64_t)b * (k + 1) + j]);
-  out[j] = v;
+  for (int b = threadIdx.x; b < nblocks; b += HX_WAVE) v = zadd(v, partials[(int64_t)b * (k + 1) + j]);
+  v = zreduce_sub<HX_WAVE>(v);
+  if (threadIdx.x == 0) out[j] = v;
 }
 extern "C" int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, hx_c128* out,
                              hx_c128* partials, hx_stream s) {
@@ -161,7 +163,7 @@ extern "C" int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, co
   int nblocks = (int)((n + rpb - 1) / rpb);
   k_panel_dot_stage1<<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, (const zc*)V, ldv, (const zc*)w, (zc*)partials, rpb);
   HX_LAUNCH_CHECK("k_panel_dot_stage1");
-  k_panel_dot_stage2<<<(k + 1 + 63) / 64, 64, 0, hx_s(s)>>>(nblocks, k, (const zc*)partials, (zc*)out);
+  k_panel_dot_stage2<<<k + 1, HX_WAVE, 0, hx_s(s)>>>(nblocks, k, (const zc*)partials, (zc*)out);
   HX_LAUNCH_CHECK("k_panel_dot_stage2");
   return HX_OK;
 }

@@ -22,7 +22,7 @@ from . import _hx
 from .petsc import CSR, to_device
 from .solver_utils import info
 
-PARAMS = dict(theta=0.08, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=40,
+PARAMS = dict(theta=0.08, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
               max_it=200)
 
 
@@ -142,6 +142,7 @@ class AMGSolver:
                                                     _hx.ptr(Cd.val)))
         self.ws = torch.empty(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), dtype=torch.complex128, device=dev)
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
+        self.krylov_tol_floor = 10.0 * self.params["rtol"]
         self.total_iters = 0
         self.n_solves = 0
         self.solve_s = 0.0

@@ -56,7 +56,7 @@ def eps_solver(A, C, target, nev, two_sided=False, print_results=False, st_type=
     E.setFromOptions()
     E.st_type = st_type
     if _caches is not None:
-        E.inner_cache, E.W_cache = _caches
+        E.inner_cache, E.W_cache, E.state = _caches
     info("- EPS solver started.")
     E.solve()
     info("- EPS solver converged. Eigenvalue computed.")
@@ -77,7 +77,7 @@ def pep_solver(A, B, C, target, nev, print_results=False, st_type=None, _caches=
     Q.setFromOptions()
     Q.st_type = st_type
     if _caches is not None:
-        Q.inner_cache, Q.W_cache = _caches
+        Q.inner_cache, Q.W_cache, Q.state = _caches
     info("- PEP solver started.")
     Q.solve()
     info("- PEP solver converged. Eigenvalue computed.")
@@ -133,7 +133,7 @@ def fixed_point_iteration_eps(operators, D, target, nev=2, i=0, tol=1e-8, maxite
                               problem_type='direct', two_sided=False, st_type=None, history=None):
     A, C = operators.A, operators.C
     B = operators.B_adj if problem_type == 'adjoint' else operators.B
-    caches = ({}, {})
+    caches = ({}, {}, {})       # inner solvers, Woodbury W, warm-start vector + counters
     s = _fmt(tol)
     info("--> Fixed point iteration started.\n")
 
@@ -158,7 +158,7 @@ def fixed_point_iteration_pep(operators, D, target, nev=2, i=0, tol=1e-8, maxite
                               problem_type='direct', st_type=None, history=None):
     A, C = operators.A, operators.C
     B = operators.B_adj if problem_type == 'adjoint' else operators.B
-    caches = ({}, {})
+    caches = ({}, {}, {})       # inner solvers, Woodbury W, warm-start vector + counters
     s = _fmt(tol)
 
     def passive():

@@ -290,9 +290,22 @@ class P1Assembler:
         return complex(panel_dot(self.lumped().reshape(1, -1), 1, f)[0])   # lumped weights are real: m^H f = m.f
 
     def cell_volumes(self):
-        """|K_c| on the host (tiny O(nc) input preparation for Q_multiple / Q_volumetric)."""
-        x, cells = self.mesh.geometry.x, self.mesh.topology.cells
-        d = self.dim
-        X = x[cells][:, :, :d]
-        J = X[:, 1:, :] - X[:, :1, :]
-        return np.abs(np.linalg.det(J)) / {1: 1, 2: 2, 3: 6}[d]
+        """|K_c| (device kernel, cached; returned as a host array for the per-flame volume sums)."""
+        if not hasattr(self, "_vol"):
+            vol = torch.empty(self.nc, dtype=torch.float64, device=self.x.device)
+            _hx.check(_hx.lib.hx_p1_cell_volumes(self.dim, self.nc, _hx.ptr(self.x), _hx.ptr(self.cells), _hx.ptr(vol),
+                                                 _hx.stream()))
+            self._vol = vol.cpu().numpy()
+        return self._vol
+
+    def locate_points(self, points, tol=1e-10):
+        """Lowest-index cell containing each point (n_pts x 3) -> int32 host array (raises if a point is outside)."""
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+        d_pts = to_device(pts)
+        out = torch.full((pts.shape[0],), 2 ** 31 - 1, dtype=torch.int32, device=self.x.device)
+        _hx.check(_hx.lib.hx_p1_locate_points(self.dim, self.nc, _hx.ptr(self.x), _hx.ptr(self.cells), pts.shape[0],
+                                              _hx.ptr(d_pts), float(tol), _hx.ptr(out), _hx.stream()))
+        cells = out.cpu().numpy()
+        if (cells == 2 ** 31 - 1).any():
+            raise ValueError("reference point(s) %s outside the mesh" % (pts[cells == 2 ** 31 - 1],))
+        return cells

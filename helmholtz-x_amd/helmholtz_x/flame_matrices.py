@@ -21,35 +21,13 @@ from .petsc import LowRank, Mat
 from .solver_utils import info
 
 
-def _locate_cell(mesh, point, tol=1e-10, ncand=256):
-    """First (lowest-index) cell containing ``point`` and the P1 gradients on it
-    (determine_point_ownership + Expression.eval of grad(phi), flame_matrices.py:144-152).
-
-    Candidates are the ``ncand`` cells with the nearest centroids (cached on the mesh), so the search is one O(nc)
-    distance pass per point even on 30 M-cell meshes; the candidate set is widened until a hit is found."""
+def _cell_gradients(mesh, c):
+    """grad(phi_i) (rows) on cell c: the values Expression(grad(TestFunction)).eval returns (flame_matrices.py:151-152)."""
     x, cells = mesh.geometry.x, mesh.topology.cells
     d = cells.shape[1] - 1
-    p = np.asarray(point, dtype=float).reshape(-1)[:d]
-    cent = getattr(mesh, "_centroids", None)
-    if cent is None:
-        cent = mesh._centroids = x[cells].mean(axis=1)
-    dist2 = ((cent[:, :d] - p[None, :]) ** 2).sum(axis=1)
-    while True:
-        ncand = min(ncand, cells.shape[0])
-        cand = np.sort(np.argpartition(dist2, ncand - 1)[:ncand])
-        X = x[cells[cand]][:, :, :d]
-        J = np.transpose(X[:, 1:, :] - X[:, :1, :], (0, 2, 1))
-        lam = np.linalg.solve(J, (p[None, :] - X[:, 0, :])[:, :, None])[:, :, 0]
-        bary = np.concatenate([1 - lam.sum(axis=1, keepdims=True), lam], axis=1)
-        hit = np.flatnonzero((bary >= -tol).all(axis=1))
-        if hit.size:
-            k = hit[0]
-            Jinv = np.linalg.inv(J[k])
-            grads = np.concatenate([-Jinv.sum(axis=0, keepdims=True), Jinv], axis=0)   # grads[i] = grad(phi_i)
-            return int(cand[k]), grads
-        if ncand == cells.shape[0]:
-            raise ValueError("reference point %s is outside the mesh" % (point,))
-        ncand *= 16
+    X = x[cells[c]][:, :d]
+    Jinv = np.linalg.inv((X[1:] - X[:1]).T)
+    return np.concatenate([-Jinv.sum(axis=0, keepdims=True), Jinv], axis=0)
 
 
 class FlameMatrix:
@@ -147,8 +125,10 @@ class PointwiseFlameMatrix(FlameMatrix):
         left = self.indices_and_values(asm.load(0, self._h_dev, scale=(self.gamma - 1) * self.q_0 / self.u_b,
                                                 cell_tag=asm.cell_tag_array(self.subdomains), tag=flame))
         # right: grad(phi_k).n_r / rho_u at x_r: 4 (d+1) numbers on the cell that holds the point
-        c, grads = _locate_cell(self.mesh, point)
-        right = (self.mesh.topology.cells[c].astype(np.int32), (grads @ self.n_r) / self.rho_u + 0j)
+        if getattr(self, "_x_r_cells", None) is None:                 # all reference points in ONE device pass
+            self._x_r_cells = asm.locate_points(self.x_r)
+        c = int(self._x_r_cells[flame])
+        right = (self.mesh.topology.cells[c].astype(np.int32), (_cell_gradients(self.mesh, c) @ self.n_r) / self.rho_u + 0j)
         return left, right
 
     def assemble_submatrices(self, problem_type='direct'):

@@ -341,6 +341,16 @@ class Mat:
         return sp.csr_matrix((av, aj, ai), shape=self.shape)
 
 
+from collections import OrderedDict
+
+_SLOT_CACHE = OrderedDict()     # (base pattern id, other pattern id) -> (device slot map, base, other); bounded LRU
+
+
+def clear_caches():
+    _SLOT_CACHE.clear()
+    _ws_cache.clear()
+
+
 def combine_csr(shape, terms):
     """sum_i coef_i CSR_i on the device.  Same-pattern terms are one fused lincomb kernel; terms on a different
     pattern are scatter-added through a host-computed slot map (integer work only)."""
@@ -353,6 +363,9 @@ def combine_csr(shape, terms):
     base = max(terms, key=lambda cm: cm[1].nnz)[1]
     others = [m for _, m in terms if m.pattern_id != base.pattern_id]
     slot_maps = {}
+    if others and all((base.pattern_id, m.pattern_id) in _SLOT_CACHE for m in others):
+        slot_maps = {m.pattern_id: _SLOT_CACHE[(base.pattern_id, m.pattern_id)][0] for m in others}
+        others = []
     if others:
         brp, bci = base.host_pattern()
         n = shape[0]
@@ -382,6 +395,10 @@ def combine_csr(shape, terms):
             rp, ci = m.host_pattern()
             keys = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp)) * shape[1] + ci
             slot_maps[m.pattern_id] = to_device(np.searchsorted(base_keys, keys).astype(np.int32))
+            if not need_union:
+                _SLOT_CACHE[(base.pattern_id, m.pattern_id)] = (slot_maps[m.pattern_id], base, m)   # keep ids alive
+                while len(_SLOT_CACHE) > 8:
+                    _SLOT_CACHE.popitem(last=False)
     same = [(c, m) for c, m in terms if m.pattern_id == base.pattern_id and m.val is not None]
     out = None
     i = 0

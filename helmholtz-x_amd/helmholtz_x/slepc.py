@@ -184,9 +184,10 @@ class WoodburySolver:
 class DeviceBasis:
     """(m, n) row-major block of Krylov vectors + the libhx CGS2 / rotation kernels."""
 
-    def __init__(self, n, m, apply_op, seed=0):
+    def __init__(self, n, m, apply_op, seed=0, start=None):
         dev = _hx.require_gpu()
         self.n, self.m = n, m
+        self.start = start
         self.V = torch.zeros((m, n), dtype=torch.complex128, device=dev)
         self.V2 = torch.zeros((m, n), dtype=torch.complex128, device=dev)
         self.apply_op = apply_op
@@ -204,9 +205,12 @@ class DeviceBasis:
                                         _hx.stream()))
 
     def set_start(self, j):
-        rng = np.random.default_rng(self.seed)
-        v = rng.standard_normal(self.n) + 1j * rng.standard_normal(self.n)
-        self.V[j].copy_(torch.from_numpy(v))
+        if self.start is not None and self.start.numel() == self.n:
+            self.V[j].copy_(self.start)              # warm start: previous Ritz vectors (fixed-point iteration)
+        else:
+            rng = np.random.default_rng(self.seed)
+            v = rng.standard_normal(self.n) + 1j * rng.standard_normal(self.n)
+            self.V[j].copy_(torch.from_numpy(v))
         self._dots(0, self.V[j])
         nrm = np.sqrt(self.h_dev[:1].cpu().numpy()[0].real)
         _hx.check(_hx.lib.hx_zscal(self.n, _hx.z2(1.0 / nrm), _hx.ptr(self.V[j]), _hx.stream()))
@@ -259,6 +263,8 @@ class _EigenSolverBase:
         self.st_type = None
         self.W_cache = None
         self.inner_cache = None
+        self.state = None            # shared across the solves of one fixed-point iteration (warm start, counters)
+        self._tol_floor = 0.0
 
     # --- slepc4py configuration surface (eigensolvers.py:43-60, 96-109)
     def create(self, comm=None):
@@ -332,10 +338,19 @@ class _EigenSolverBase:
 
     def _finish(self, basis, sigma):
         ncv = self._ncv_used
-        res = krylov_schur(basis, self._nev, ncv, tol=self._tol, max_it=self._max_it)
+        # an iterative inner solve bounds the accuracy of the Arnoldi relation: asking the Ritz estimate for more
+        # than ~10x its tolerance only burns restarts
+        tol = max(self._tol, self._tol_floor)
+        res = krylov_schur(basis, self._nev, ncv, tol=tol, max_it=self._max_it)
         self._result = res
         self._eigs = sigma + 1.0 / res.theta
         self._basis = basis
+        if self.state is not None:
+            k = max(1, min(res.nconv, self._nev))
+            self.state["start"] = basis.V[:k].sum(dim=0)
+            self.state["krylov_ops"] = self.state.get("krylov_ops", 0) + basis.n_ops
+            self.state["restarts"] = self.state.get("restarts", 0) + res.its
+            self.state["eig_solves"] = self.state.get("eig_solves", 0) + 1
         if res.nconv < self._nev:
             info("! only %d of %d eigenpairs reached tol=%g (max residual estimate %.2e)"
                  % (res.nconv, self._nev, self._tol, float(np.max(res.resid))))
@@ -355,6 +370,9 @@ class _EigenSolverBase:
             self.inner_cache[key] = solver
         return solver
 
+    def _start(self):
+        return None if self.state is None else self.state.get("start")
+
 
 def _term_key(mat):
     return tuple((c, m.pattern_id, id(m.val)) for c, m in mat.csr_terms)
@@ -370,10 +388,16 @@ class EPS(_EigenSolverBase):
         A, M = self._ops
         n = A.shape[0]
         sigma = self._target
-        K = combine_csr(A.shape, A.csr_terms + [(-sigma * c, m) for c, m in M.csr_terms])   # A - sigma M
         if M.lr_terms:
             raise NotImplementedError("low-rank terms in the mass operator")
-        inner = self._inner(K, ("eps", sigma, _term_key(A), _term_key(M)))
+        key = ("eps", sigma, _term_key(A), _term_key(M))
+        K = None if self.inner_cache is None else self.inner_cache.get(("ops",) + key)
+        if K is None:
+            K = combine_csr(A.shape, A.csr_terms + [(-sigma * c, m) for c, m in M.csr_terms])   # A - sigma M
+            if self.inner_cache is not None:
+                self.inner_cache[("ops",) + key] = K
+        inner = self._inner(K, key)
+        self._tol_floor = getattr(inner, "krylov_tol_floor", 0.0)
         solver = WoodburySolver(inner, A.lr_terms, self.W_cache)
         Mcsr = M.csr_part()
         tmp = torch.empty(n, dtype=torch.complex128, device=Mcsr.val.device)
@@ -382,7 +406,7 @@ class EPS(_EigenSolverBase):
             Mcsr.spmv(v, tmp)
             solver.solve(tmp, w)
 
-        self._finish(DeviceBasis(n, self._ncv_for(n) + 1, op), sigma)
+        self._finish(DeviceBasis(n, self._ncv_for(n) + 1, op, start=self._start()), sigma)
 
 
 class PEP(_EigenSolverBase):
@@ -396,11 +420,19 @@ class PEP(_EigenSolverBase):
         n = A.shape[0]
         sigma = self._target
         b_terms = B.csr_terms if B is not None else []
-        K = combine_csr(A.shape, A.csr_terms + [(sigma * c, m) for c, m in b_terms]
-                        + [(sigma ** 2 * c, m) for c, m in Cm.csr_terms])
-        BsC = combine_csr(A.shape, list(b_terms) + [(sigma * c, m) for c, m in Cm.csr_terms])
+        key = ("pep", sigma, _term_key(A), _term_key(B) if B is not None else None, _term_key(Cm))
+        ops = None if self.inner_cache is None else self.inner_cache.get(("ops",) + key)
+        if ops is None:
+            K = combine_csr(A.shape, A.csr_terms + [(sigma * c, m) for c, m in b_terms]
+                            + [(sigma ** 2 * c, m) for c, m in Cm.csr_terms])
+            BsC = combine_csr(A.shape, list(b_terms) + [(sigma * c, m) for c, m in Cm.csr_terms])
+            if self.inner_cache is not None:
+                self.inner_cache[("ops",) + key] = (K, BsC)
+        else:
+            K, BsC = ops
         Ccsr = Cm.csr_part()
-        inner = self._inner(K, ("pep", sigma, _term_key(A), _term_key(B) if B is not None else None, _term_key(Cm)))
+        inner = self._inner(K, key)
+        self._tol_floor = getattr(inner, "krylov_tol_floor", 0.0)
         solver = WoodburySolver(inner, A.lr_terms, self.W_cache)
         tmp = torch.empty(n, dtype=torch.complex128, device=Ccsr.val.device)
 
@@ -414,7 +446,7 @@ class PEP(_EigenSolverBase):
             cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
             _hx.check(_hx.lib.hx_zlincomb(n, 2, cf, arr, _hx.ptr(y2), _hx.stream()))   # y2 = x1 + sigma y1
 
-        self._finish(DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op), sigma)
+        self._finish(DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op, start=self._start()), sigma)
         self._n = n
 
 

@@ -130,6 +130,14 @@ int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const double* x, cons
                         const hx_c128* fb, const double scale[2], const int32_t* cell_tag, int32_t tag,
                         hx_c128* out, hx_stream s);
 
+/* |K_c| of every cell (assemble_scalar(Constant(1)*dx(tag)) in parameters_utils.py:215-216,235-236). */
+int hx_p1_cell_volumes(int dim, int32_t n_cells, const double* x, const int32_t* cells, double* vol,
+                       hx_stream s);
+/* Lowest-index cell containing each query point (pts: n_pts x 3), barycentric tolerance tol; replaces
+ * determine_point_ownership (flame_matrices.py:144-145).  out_cell must be pre-filled with INT32_MAX. */
+int hx_p1_locate_points(int dim, int32_t n_cells, const double* x, const int32_t* cells, int n_pts,
+                        const double* pts, double tol, int32_t* out_cell, hx_stream s);
+
 /* ------------------------------------------------------------------ sparse triangular solves (MatSolve)
  * replaces: KSP(preonly)+PC(LU) MatSolve inside ST sinvert (eigensolvers.py:49-50,102-103 -> :62,:113).
  * The factors come from a host factorisation (Pr*A*Pc = L*U); each triangle is passed as strictly

@@ -93,9 +93,22 @@ def spmv_roofline(matrices, target, reps=50):
     ms = e0.elapsed_time(e1) / reps
     alg_bytes = nnz * 20 + n * 36
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return dict(bound="hbm", kernel="k_spmv (hx_csr_spmv_z)", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, n_rows=n, nnz=nnz, bytes_per_launch=alg_bytes,
-                avg_launch_ms=round(ms, 5))
+    return dict(bound="hbm", kernel="k_spmv<8, 0> (hx_csr_spmv_z)", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=measured_traffic(n, nnz), n_rows=n, nnz=nnz,
+                bytes_per_launch=alg_bytes, avg_launch_ms=round(ms, 5))
+
+
+def measured_traffic(n, nnz):
+    """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/spmv_traffic.json): 2 x FETCH_SIZE
+    (gfx950 correction of MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, for the matrix of exactly this size; else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "spmv_traffic.json")) as fh:
+            for rec in json.load(fh)["records"]:
+                if rec["n_rows"] == n and rec["nnz"] == nnz:
+                    return rec["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(sample="annulus-16k"):
@@ -133,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--workload", default=os.environ.get("HX_BENCH_WORKLOAD", "annulus-66k"))
+    ap.add_argument("--workload", default=os.environ.get("HX_BENCH_WORKLOAD", "annulus-5M"))
     ap.add_argument("--st-type", default=None, help="inner solver for the shifted operator: lu | amg | auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="annulus-16k")

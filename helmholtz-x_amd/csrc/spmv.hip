@@ -10,6 +10,10 @@
 
 // ROLE only separates kernel symbols in profiles: 0 = operator product on the Arnoldi / GMRES path (the roofline
 // kernel), 1 = grid-transfer products (P, R) and coarse-grid solves inside the AMG V-cycle.
+//
+// Measured and rejected on MI355X at 1 M / 5 M rows (tools/run_spmv_modes.sh, round 1): (a) XCD-aware banding
+// (workgroups with equal blockIdx % 8 sweeping a contiguous eighth of the rows) -8 %; (b) non-temporal loads of
+// val/col -30 % (they split the 16-byte value load).  The plain grid-stride sweep below is the fastest form.
 template <int LPR, int ROLE>
 __global__ void __launch_bounds__(256)
 k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ val,

@@ -100,12 +100,17 @@ def _flame_matrix(D, omega, problem_type):
     raise ValueError("The problem type should be specified as 'direct' or 'adjoint'.")
 
 
-def _iterate(solve_passive, solve_active, tol, maxiter, s, history):
-    """Relaxed secant fixed-point loop shared by the EPS and PEP variants (eigensolvers.py:143-193, 213-257)."""
+def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history):
+    """Relaxed secant fixed-point loop shared by the EPS and PEP variants (eigensolvers.py:143-193, 213-257).
+
+    Only eigenpair ``i`` drives the iteration, so the intermediate solves ask the Krylov-Schur solver for i+1
+    pairs; once |domega| <= tol the solve of that last iteration (same omega_k, same operator) is repeated for
+    the full ``nev`` pairs and returned -- the object the reference returns from its last iteration."""
     omega = np.zeros(maxiter + 1, dtype=complex)
     f = np.zeros(maxiter, dtype=complex)
     alpha = np.zeros(maxiter, dtype=complex)
-    E, omega[0] = solve_passive()
+    lean = min(nev, i + 1)
+    E, omega[0] = solve_passive(lean)
     alpha[0] = 0.5
     if history is not None:
         history.append(omega[0])
@@ -117,7 +122,7 @@ def _iterate(solve_passive, solve_active, tol, maxiter, s, history):
             raise RuntimeError("fixed-point iteration did not converge in maxiter=%d iterations" % maxiter)
         E.destroy()
         print("* iter = {:2d}".format(k + 1))
-        E, f[k] = solve_active(omega[k])
+        E, f[k] = solve_active(omega[k], lean)
         if k != 0:
             alpha[k] = 1 / (1 - ((f[k] - f[k - 1]) / (omega[k] - omega[k - 1])))
         omega[k + 1] = alpha[k] * f[k] + (1 - alpha[k]) * omega[k]
@@ -126,6 +131,9 @@ def _iterate(solve_passive, solve_active, tol, maxiter, s, history):
             history.append(omega[k + 1])
         print('+ omega = {}  {}j,  |domega| = {:.2e}\n'.format(
             s.format(omega[k + 1].real), s.format(omega[k + 1].imag), abs(domega)))
+    if lean < nev:
+        E.destroy()
+        E, _ = solve_active(omega[k], nev) if k >= 0 else solve_passive(nev)
     return E
 
 
@@ -137,21 +145,21 @@ def fixed_point_iteration_eps(operators, D, target, nev=2, i=0, tol=1e-8, maxite
     s = _fmt(tol)
     info("--> Fixed point iteration started.\n")
 
-    def passive():
-        E = eps_solver(A, C, target, nev, print_results=print_results, st_type=st_type, _caches=caches)
+    def passive(nev_req):
+        E = eps_solver(A, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches)
         w0 = np.sqrt(E.getEigenvalue(i))
         print("+ Starting eigenvalue is found: {}  {}j. ".format(s.format(w0.real), s.format(w0.imag)))
         info("-> Iterations are starting.\n ")
         return E, w0
 
-    def active(omega_k):
+    def active(omega_k, nev_req):
         D_Mat = _flame_matrix(D, omega_k, problem_type)
         D_Mat = (A - D_Mat) if not B else (A + (omega_k * B) - D_Mat)
-        E = eps_solver(D_Mat, C, target, nev, two_sided=two_sided, print_results=print_results, st_type=st_type,
+        E = eps_solver(D_Mat, C, target, nev_req, two_sided=two_sided, print_results=print_results, st_type=st_type,
                        _caches=caches)
         return E, np.sqrt(E.getEigenvalue(i))
 
-    return _iterate(passive, active, tol, maxiter, s, history)
+    return _iterate(passive, active, nev, i, tol, maxiter, s, history)
 
 
 def fixed_point_iteration_pep(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,
@@ -161,17 +169,17 @@ def fixed_point_iteration_pep(operators, D, target, nev=2, i=0, tol=1e-8, maxite
     caches = ({}, {}, {})       # inner solvers, Woodbury W, warm-start vector + counters
     s = _fmt(tol)
 
-    def passive():
-        E = pep_solver(A, B, C, target, nev, print_results=print_results, st_type=st_type, _caches=caches)
+    def passive(nev_req):
+        E = pep_solver(A, B, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches)
         info("-> Fixed point iteration started.\n")
         return E, E.getEigenvalue(i)
 
-    def active(omega_k):
+    def active(omega_k, nev_req):
         D_Mat = A - _flame_matrix(D, omega_k, problem_type)
-        E = pep_solver(D_Mat, B, C, target, nev, print_results=print_results, st_type=st_type, _caches=caches)
+        E = pep_solver(D_Mat, B, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches)
         return E, E.getEigenvalue(i)
 
-    return _iterate(passive, active, tol, maxiter, s, history)
+    return _iterate(passive, active, nev, i, tol, maxiter, s, history)
 
 
 def fixed_point_iteration(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,

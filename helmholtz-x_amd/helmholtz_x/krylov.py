@@ -28,37 +28,44 @@ def default_ncv(nev):
     return max(2 * nev, nev + 15)
 
 
-def krylov_schur(basis, nev, ncv, tol=1e-15, max_it=100, keep_fraction=0.5, relaxed_tol=1e-12):
+def _ritz(S, mact, tol):
+    """Ritz pairs of the leading mact x mact block, sorted by |theta| descending, with residual estimates."""
+    theta, Y = sla.eig(S[:mact, :mact])
+    order = np.argsort(-np.abs(theta), kind="stable")
+    theta, Y = theta[order], Y[:, order]
+    Y = Y / np.linalg.norm(Y, axis=0, keepdims=True)
+    resid = np.abs(S[mact, :mact] @ Y)
+    nconv = int(np.sum(np.cumprod(resid <= tol * np.abs(theta))))
+    return theta, Y, resid, nconv
+
+
+def krylov_schur(basis, nev, ncv, tol=1e-15, max_it=100, keep_fraction=0.5, relaxed_tol=1e-12, check_every=2):
     """Largest-magnitude eigenvalues theta of OP (theta = 1/(lambda - sigma): closest to the target).
 
     Returns KrylovSchurResult with Ritz values sorted by |theta| descending; the first ``nconv`` have
-    residual estimate <= tol*|theta|.  After return, basis columns 0..nconv-1 hold the converged Ritz
-    VECTORS (not just Schur vectors)."""
+    residual estimate <= tol*|theta|.  After return, basis columns 0..nout-1 hold unit-norm Ritz VECTORS.
+    Convergence is also tested inside a cycle every ``check_every`` expansions (the projected problem is tiny),
+    so a warm-started solve stops as soon as the wanted pairs are there instead of filling all ncv columns."""
     m = ncv
     assert basis.m >= m + 1
-    S = np.zeros((m + 1, m), dtype=complex)      # OP V_m = V_{m+1} S
+    S = np.zeros((m + 1, m), dtype=complex)      # OP V_j = V_{j+1} S[:j+1, :j]
     basis.set_start(0)
     k = 0                                         # columns 0..k-1 are kept Schur vectors
     its = 0
-    nconv = 0
     prev_lead = np.inf
     while True:
         its += 1
+        mact = m
         for j in range(k, m):
             h, beta = basis.expand(j)
             S[:j + 1, j] = h
             S[j + 1, j] = beta
-        Sm = S[:m, :m]
-        b = S[m, :m].copy()                       # residual row: OP V_m = V_m S_m + v_{m+1} b
-        theta, Y = sla.eig(Sm)
-        order = np.argsort(-np.abs(theta), kind="stable")
-        theta, Y = theta[order], Y[:, order]
-        Y = Y / np.linalg.norm(Y, axis=0, keepdims=True)
-        resid = np.abs(b @ Y)
-        conv = resid <= tol * np.abs(theta)
-        nconv = 0
-        while nconv < m and conv[nconv]:
-            nconv += 1
+            cols = j + 1
+            if cols < m and cols >= k + nev + 1 and (cols - k) % check_every == 0:
+                if _ritz(S, cols, tol)[3] >= nev:
+                    mact = cols
+                    break
+        theta, Y, resid, nconv = _ritz(S, mact, tol)
         if nconv >= nev or its >= max_it:
             break
         # stagnation guard: the estimate cannot always reach tol = 1e-15 in double precision; once the wanted
@@ -72,12 +79,13 @@ def krylov_schur(basis, nev, ncv, tol=1e-15, max_it=100, keep_fraction=0.5, rela
         k = min(max(nconv + 1, nev + int(keep_fraction * (m - nev))), m - 1)
         Q, R = np.linalg.qr(Y[:, :k])
         T = R @ np.diag(theta[:k]) @ np.linalg.inv(R)          # upper triangular: Q^H S_m Q
+        b = S[m, :m].copy()
         basis.rotate(Q, k)
         S[:, :] = 0.0
         S[:k, :k] = T
         S[k, :k] = b @ Q
     # ---- Ritz vectors of the converged (or best available) pairs into the leading columns: Y has unit columns and
-    # V_m is orthonormal, so V_m Y[:, i] are unit-norm Ritz vectors.
-    nout = max(nconv, min(nev, m))
+    # V is orthonormal, so V Y[:, i] are unit-norm Ritz vectors.
+    nout = max(nconv, min(nev, mact))
     basis.rotate(Y[:, :nout], nout)
     return KrylovSchurResult(theta[:nout], nconv, its, resid[:nout])

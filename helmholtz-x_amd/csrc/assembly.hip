@@ -213,8 +213,10 @@ k_stiff_mass(int32_t n, const double* __restrict__ x, const int32_t* __restrict_
       for (int a = 0; a < K; ++a) { v[a] = cells[(int64_t)c * K + a]; if (v[a] == i) j = a; }
       double G[K][D], vol;
       p1_geometry<D>(x, v, G, vol);
-      zc w;  // int_K c^2 dx  (complex square, acoustic_matrices.py:101)
-      if (cellwise) {
+      zc w = make_double2(0.0, 0.0);  // int_K c^2 dx  (complex square, acoustic_matrices.py:101)
+      if (!A) {
+        // mass matrix only: the sound-speed field may be absent
+      } else if (cellwise) {
         zc cc = cf[c];
         w = zscale(vol, zmul(cc, cc));
       } else {

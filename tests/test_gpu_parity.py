@@ -365,3 +365,49 @@ def test_annulus_fixed_point_amg_vs_lu_vs_oracle():
         D = Df if D is None else D + Df
     _, ohist = eigen.fixed_point_iteration(A, B, C, eigen.OracleFlame(D, case["ftf"]), P.target, nev=4, i=0, tol=1e-9)
     assert abs(res["lu"] - ohist[-1]) / abs(ohist[-1]) < 1e-8
+
+
+def test_bloch_sector_equals_full_annulus_and_oracle():
+    """SURVEY 8d-5 self-consistency KAT: eigenvalues of the Bloch (b = 1, N = 16) problem on a 1/16 sector are
+    eigenvalues of the full welded annulus built from 16 copies of that sector; plus parity with the oracle's
+    restatement of bloch_operator.py on the same inputs."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.bloch_operator import Blochifier
+    from helmholtz_x.eigensolvers import eps_solver
+    from helmholtz_x.eigenvectors import normalize_eigenvector
+    from helmholtz_x.synthetic import annulus, micca_sound_speed
+    from oracle import eigen, fem
+    nr, nth, nz = 4, 3, 6
+    half = np.pi / 16
+
+    class Geometry:
+        pass
+    geo = Geometry()
+    geo.mesh, _, geo.facet_tags = annulus(nr, nth, nz, n_flames=1, sector=(-half, half))
+    bcs = {11: 'Neumann', 12: 'Master', 13: 'Slave'}
+    M = AcousticMatrices(geo.mesh, geo.facet_tags, bcs, micca_sound_speed(geo.mesh))
+    bloch = Blochifier(geo, bcs, 16, M)
+    target = 3000.0
+    E = eps_solver(bloch.A, bloch.C, target, nev=3)
+    sector = np.sort_complex(np.sqrt([E.getEigenvalue(k) for k in range(3)]))
+    # oracle, same pairing
+    x, cells = geo.mesh.geometry.x, geo.mesh.topology.cells
+    c = micca_sound_speed(geo.mesh).x.array
+    A = fem.assemble_A(x, cells, c, c_is_cellwise=True)
+    C = fem.assemble_C(x, cells)
+    BN, NB = eigen.bloch_maps(x.shape[0], bloch.dofs_master, bloch.dofs_slave, 16)
+    Eo = eigen.eps_solve(eigen.blochify(A, BN, NB), eigen.blochify(C, BN, NB), target, 3)
+    assert np.max(np.abs(np.sort_complex(np.sqrt(Eo.eigs)) - sector) / np.abs(sector)) < 1e-8
+    # full annulus: every sector eigenvalue must appear in its spectrum
+    full_mesh, _, full_tags = annulus(nr, 16 * nth, nz)
+    Mf = AcousticMatrices(full_mesh, full_tags, {11: 'Neumann'}, micca_sound_speed(full_mesh))
+    Ef = eps_solver(Mf.A, Mf.C, target, nev=8)
+    full = np.sqrt([Ef.getEigenvalue(k) for k in range(Ef.getConverged())])
+    for w in sector[:2]:
+        assert np.min(np.abs(full - w)) / abs(w) < 1e-7, (w, full)
+    # remapper + normalisation: int p p dx = 1 on the sector, and the Bloch phase relation holds
+    omega, p = normalize_eigenvector(geo.mesh, E, 0, BlochRemapper=bloch.remapper, print_eigs=False)
+    Cs = C
+    assert abs(p.x.array @ (Cs @ p.x.array) - 1.0) < 1e-10
+    pm, ps = p.x.array[bloch.dofs_master], p.x.array[bloch.dofs_slave]
+    assert np.max(np.abs(pm - bloch.f_b * ps)) < 1e-10 * np.max(np.abs(ps))

@@ -22,7 +22,7 @@ from . import _hx
 from .petsc import CSR, to_device
 from .solver_utils import info
 
-PARAMS = dict(theta=0.08, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
+PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
               max_it=200)
 
 

@@ -1,10 +1,15 @@
-// Algebraic-multigrid V-cycle + right-preconditioned GMRES for the shifted operator K (complex128).
+// Algebraic-multigrid V-cycle + flexible right-preconditioned GMRES for the shifted operator K (complex128).
 //
-// Used as the ST "inner solve" of shift-invert Arnoldi when a sparse direct factorisation of K does not fit
-// (3-D, >= 1e5 DOF; the reference would call MUMPS/SuperLU_DIST behind PCLU, eigensolvers.py:49-50,102-103).
+// Used as the ST "inner solve" of shift-invert Arnoldi when a sparse direct factorisation of K does not pay
+// (the reference calls MUMPS/SuperLU_DIST behind PCLU there, eigensolvers.py:49-50,102-103).
 // The hierarchy (aggregates, smoothed prolongators, Galerkin operators) is set up once per K by the host side
 // (amg.py + hx_host_aggregate below); everything inside a solve runs on the device and is SpMV-shaped:
 // fused Jacobi sweeps, residuals, P / R products, CGS2 panels -- i.e. HBM-bound streaming kernels.
+//
+// Precision: the Krylov iteration, its operator products, dot products and the solution update are complex128.
+// The V-cycle -- a preconditioner, i.e. only an approximation of K^-1 by construction -- may run on a complex64
+// copy of the hierarchy, which halves its HBM traffic; GMRES is therefore the FLEXIBLE variant (it stores
+// z_j = M^-1 v_j), which converges to the full double-precision residual whatever the preconditioner does.
 #include <cmath>
 #include <complex>
 #include <vector>
@@ -14,39 +19,65 @@
 extern "C" int hx_csr_jacobi_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*,
                                const hx_c128*, const hx_c128*, hx_c128*, double, hx_stream);
 extern "C" int hx_zdiag_scale(int64_t, double, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
+int hx_csr_spmv_transfer(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, hx_c128*,
+                         const double*, const double*, hx_stream);
+int hx_csr_spmv_c(int role, int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, float*, float,
+                  float, hx_stream);
+int hx_csr_jacobi_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                    const float*, float*, float, hx_stream);
+int hx_cdiag_scale(int64_t, float, const float*, const float*, float*, hx_stream);
+int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
+int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 
-struct Csr { int32_t rows = 0; int64_t nnz = 0; const int32_t* rp = nullptr; const int32_t* ci = nullptr; const hx_c128* va = nullptr; };
+static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 0.0};
 
-struct AmgLevel {
+// T = double: complex128 hierarchy; T = float: complex64 copy of it (values interleaved re, im: 2 T per entry).
+template <typename T> struct CsrT { int32_t rows = 0; int64_t nnz = 0; const int32_t* rp = nullptr; const int32_t* ci = nullptr; const T* va = nullptr; };
+template <typename T> struct LevelT {
   int32_t n = 0;
-  Csr K, P, R;                 // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
-  const hx_c128* dinv = nullptr;
-  hx_c128 *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors (b, x unused on level 0)
+  CsrT<T> K, P, R;             // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
+  const T* dinv = nullptr;
+  T *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
 };
+template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
 
 struct hx_amg {
-  std::vector<AmgLevel> L;
-  Csr coarse_inv;              // dense inverse of the coarsest operator, stored as CSR
+  HierT<double> D;
+  HierT<float> S;
+  bool single = false;         // run the V-cycle on the complex64 copy
   int pre = 2, post = 2;
   double omega = 0.6;
 };
 
-static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 0.0};
-
-int hx_csr_spmv_transfer(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, hx_c128*,
-                         const double*, const double*, hx_stream);
-
-static int spmv(const Csr& A, const hx_c128* x, hx_c128* y, const double* a, const double* b, hx_stream s) {
-  return hx_csr_spmv_z(A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, 0, s);
+// ---- per-precision kernel dispatch
+static int op_spmv(const CsrT<double>& A, const double* x, double* y, double a, double b, bool transfer, hx_stream s) {
+  const double aa[2] = {a, 0.0}, bb[2] = {b, 0.0};
+  if (transfer)
+    return hx_csr_spmv_transfer(A.rows, A.nnz, A.rp, A.ci, (const hx_c128*)A.va, (const hx_c128*)x, (hx_c128*)y, aa, bb, s);
+  return hx_csr_spmv_z(A.rows, A.nnz, A.rp, A.ci, (const hx_c128*)A.va, (const hx_c128*)x, (hx_c128*)y, aa, bb, 0, s);
 }
-static int spmv_t(const Csr& A, const hx_c128* x, hx_c128* y, const double* a, const double* b, hx_stream s) {
-  return hx_csr_spmv_transfer(A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, s);
+static int op_spmv(const CsrT<float>& A, const float* x, float* y, float a, float b, bool transfer, hx_stream s) {
+  return hx_csr_spmv_c(transfer ? 1 : 2, A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, s);
+}
+static int op_jacobi(const LevelT<double>& L, const double* b, const double* xin, double* xout, double w, hx_stream s) {
+  return hx_csr_jacobi_z(L.n, L.K.nnz, L.K.rp, L.K.ci, (const hx_c128*)L.K.va, (const hx_c128*)L.dinv, (const hx_c128*)b,
+                         (const hx_c128*)xin, (hx_c128*)xout, w, s);
+}
+static int op_jacobi(const LevelT<float>& L, const float* b, const float* xin, float* xout, double w, hx_stream s) {
+  return hx_csr_jacobi_c(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, xin, xout, (float)w, s);
+}
+static int op_diag(const LevelT<double>& L, double w, const double* b, double* x, hx_stream s) {
+  return hx_zdiag_scale(L.n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
+}
+static int op_diag(const LevelT<float>& L, double w, const float* b, float* x, hx_stream s) {
+  return hx_cdiag_scale(L.n, (float)w, L.dinv, b, x, s);
 }
 
 extern "C" int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, double omega) {
   HX_REQUIRE(out && n_levels >= 1 && pre >= 1 && post >= 0 && omega > 0, "bad argument");
   hx_amg* h = new hx_amg();
-  h->L.resize(n_levels);
+  h->D.L.resize(n_levels);
+  h->S.L.resize(n_levels);
   h->pre = pre; h->post = post; h->omega = omega;
   *out = h;
   return HX_OK;
@@ -54,8 +85,33 @@ extern "C" int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, doub
 
 extern "C" int hx_amg_destroy(hx_amg* h) {
   if (!h) return HX_OK;
-  for (auto& l : h->L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.b); (void)hipFree(l.r); }
+  for (auto& l : h->D.L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.b); (void)hipFree(l.r); }
+  for (auto& l : h->S.L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.b); (void)hipFree(l.r); }
   delete h;
+  return HX_OK;
+}
+
+template <typename T>
+static int set_level(HierT<T>& H, int l, int32_t n, int64_t nnzK, const int32_t* rpK, const int32_t* ciK, const T* vaK,
+                     const T* dinv, int32_t n_coarse, int64_t nnzP, const int32_t* rpP, const int32_t* ciP,
+                     const T* vaP, int64_t nnzR, const int32_t* rpR, const int32_t* ciR, const T* vaR) {
+  HX_REQUIRE(l >= 0 && l < (int)H.L.size() && n > 0 && rpK && ciK && vaK, "bad argument");
+  LevelT<T>& L = H.L[l];
+  L.n = n;
+  L.K.rows = n; L.K.nnz = nnzK; L.K.rp = rpK; L.K.ci = ciK; L.K.va = vaK;
+  L.dinv = dinv;
+  if (l != (int)H.L.size() - 1) {
+    HX_REQUIRE(dinv && n_coarse > 0 && rpP && ciP && vaP && rpR && ciR && vaR, "missing transfer operators");
+    L.P.rows = n; L.P.nnz = nnzP; L.P.rp = rpP; L.P.ci = ciP; L.P.va = vaP;
+    L.R.rows = n_coarse; L.R.nnz = nnzR; L.R.rp = rpR; L.R.ci = ciR; L.R.va = vaR;
+  }
+  if (!L.x) {
+    const size_t bytes = 2 * sizeof(T) * (size_t)n;
+    HX_HIP(hipMalloc((void**)&L.x, bytes));
+    HX_HIP(hipMalloc((void**)&L.x2, bytes));
+    HX_HIP(hipMalloc((void**)&L.b, bytes));
+    HX_HIP(hipMalloc((void**)&L.r, bytes));
+  }
   return HX_OK;
 }
 
@@ -63,76 +119,87 @@ extern "C" int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const
                                 const hx_c128* vaK, const hx_c128* dinv, int32_t n_coarse, int64_t nnzP,
                                 const int32_t* rpP, const int32_t* ciP, const hx_c128* vaP, int64_t nnzR,
                                 const int32_t* rpR, const int32_t* ciR, const hx_c128* vaR) {
-  HX_REQUIRE(h && l >= 0 && l < (int)h->L.size() && n > 0 && rpK && ciK && vaK, "bad argument");
-  AmgLevel& L = h->L[l];
-  L.n = n;
-  L.K = {n, nnzK, rpK, ciK, vaK};
-  L.dinv = dinv;
-  const bool coarsest = (l == (int)h->L.size() - 1);
-  if (!coarsest) {
-    HX_REQUIRE(dinv && n_coarse > 0 && rpP && ciP && vaP && rpR && ciR && vaR, "missing transfer operators");
-    L.P = {n, nnzP, rpP, ciP, vaP};
-    L.R = {n_coarse, nnzR, rpR, ciR, vaR};
-  }
-  const size_t bytes = sizeof(hx_c128) * (size_t)n;
-  HX_HIP(hipMalloc((void**)&L.x, bytes));
-  HX_HIP(hipMalloc((void**)&L.x2, bytes));
-  HX_HIP(hipMalloc((void**)&L.b, bytes));
-  HX_HIP(hipMalloc((void**)&L.r, bytes));
-  return HX_OK;
+  HX_REQUIRE(h, "null handle");
+  return set_level<double>(h->D, l, n, nnzK, rpK, ciK, (const double*)vaK, (const double*)dinv, n_coarse, nnzP, rpP, ciP,
+                           (const double*)vaP, nnzR, rpR, ciR, (const double*)vaR);
 }
-
+extern "C" int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t* rpK, const int32_t* ciK,
+                                  const hx_c64* vaK, const hx_c64* dinv, int32_t n_coarse, int64_t nnzP,
+                                  const int32_t* rpP, const int32_t* ciP, const hx_c64* vaP, int64_t nnzR,
+                                  const int32_t* rpR, const int32_t* ciR, const hx_c64* vaR) {
+  HX_REQUIRE(h, "null handle");
+  h->single = true;
+  return set_level<float>(h->S, l, n, nnzK, rpK, ciK, (const float*)vaK, (const float*)dinv, n_coarse, nnzP, rpP, ciP,
+                          (const float*)vaP, nnzR, rpR, ciR, (const float*)vaR);
+}
 extern "C" int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                                  const hx_c128* va) {
-  HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->L.back().n == n_c, "bad argument");
-  h->coarse_inv = {n_c, nnz, rp, ci, va};
+  HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->D.L.back().n == n_c, "bad argument");
+  h->D.coarse_inv.rows = n_c; h->D.coarse_inv.nnz = nnz; h->D.coarse_inv.rp = rp; h->D.coarse_inv.ci = ci;
+  h->D.coarse_inv.va = (const double*)va;
+  return HX_OK;
+}
+extern "C" int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
+                                   const hx_c64* va) {
+  HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->S.L.back().n == n_c, "bad argument");
+  h->S.coarse_inv.rows = n_c; h->S.coarse_inv.nnz = nnz; h->S.coarse_inv.rp = rp; h->S.coarse_inv.ci = ci;
+  h->S.coarse_inv.va = (const float*)va;
   return HX_OK;
 }
 
-// x = V-cycle(b) on level l with zero initial guess.  Result is left in *xres (one of the level's buffers or xout).
-static int vcycle(hx_amg* h, int l, const hx_c128* b, hx_c128* xout, hx_stream s) {
-  AmgLevel& L = h->L[l];
+// xout = V-cycle(b) on level l with zero initial guess (xout must not be L.x / L.x2 / b of that level).
+template <typename T>
+static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream s) {
+  LevelT<T>& L = H.L[l];
   int rc;
-  if (l == (int)h->L.size() - 1) return spmv_t(h->coarse_inv, b, xout, ONE, ZERO, s);
-  hx_c128* cur = L.x;      // ping-pong between L.x and L.x2; final result copied/written to xout
-  hx_c128* nxt = L.x2;
-  // pre-smoothing: first sweep from x = 0 is a diagonal scaling
-  if ((rc = hx_zdiag_scale(L.n, h->omega, L.dinv, b, cur, s))) return rc;
+  if (l == (int)H.L.size() - 1) return op_spmv(H.coarse_inv, b, xout, (T)1, (T)0, true, s);
+  T* cur = L.x;      // ping-pong between L.x and L.x2
+  // pre-smoothing: the first sweep from x = 0 is a diagonal scaling
+  if ((rc = op_diag(L, h->omega, b, cur, s))) return rc;
   for (int k = 1; k < h->pre; ++k) {
-    if ((rc = hx_csr_jacobi_z(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, cur, nxt, h->omega, s))) return rc;
-    std::swap(cur, nxt);
+    T* nxt = (cur == L.x) ? L.x2 : L.x;
+    if ((rc = op_jacobi(L, b, cur, nxt, h->omega, s))) return rc;
+    cur = nxt;
   }
   // residual r = b - K x, restrict
-  HX_HIP(hipMemcpyAsync(L.r, b, sizeof(hx_c128) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
-  if ((rc = spmv(L.K, cur, L.r, MONE, ONE, s))) return rc;
-  AmgLevel& Lc = h->L[l + 1];
-  if ((rc = spmv_t(L.R, L.r, Lc.b, ONE, ZERO, s))) return rc;
-  // coarse correction (result in Lc.r is free to use as the output buffer of the coarse level)
-  hx_c128* ec = Lc.r;
-  if ((rc = vcycle(h, l + 1, Lc.b, ec, s))) return rc;
-  if ((rc = spmv_t(L.P, ec, cur, ONE, ONE, s))) return rc;    // x += P e_c
+  HX_HIP(hipMemcpyAsync(L.r, b, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
+  if ((rc = op_spmv(L.K, cur, L.r, (T)-1, (T)1, false, s))) return rc;
+  LevelT<T>& Lc = H.L[l + 1];
+  if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
+  T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
+  if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s))) return rc;
+  if ((rc = op_spmv(L.P, ec, cur, (T)1, (T)1, true, s))) return rc;    // x += P e_c
   // post-smoothing: every sweep reads `cur` and writes the other buffer; the last one writes xout
   for (int k = 0; k < h->post; ++k) {
-    hx_c128* dst = (k == h->post - 1) ? xout : (cur == L.x ? L.x2 : L.x);
-    if ((rc = hx_csr_jacobi_z(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, cur, dst, h->omega, s))) return rc;
+    T* dst = (k == h->post - 1) ? xout : (cur == L.x ? L.x2 : L.x);
+    if ((rc = op_jacobi(L, b, cur, dst, h->omega, s))) return rc;
     cur = dst;
   }
   if (h->post == 0)
-    HX_HIP(hipMemcpyAsync(xout, cur, sizeof(hx_c128) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
+    HX_HIP(hipMemcpyAsync(xout, cur, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
   return HX_OK;
 }
 
 extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream s) {
-  HX_REQUIRE(h && b && x && b != x && !h->L.empty() && h->L[0].n > 0, "bad argument");
-  HX_REQUIRE(h->coarse_inv.rp, "coarse solver not set");
-  return vcycle(h, 0, b, x, s);
+  HX_REQUIRE(h && b && x && b != x && !h->D.L.empty(), "bad argument");
+  if (h->single) {
+    HX_REQUIRE(h->S.coarse_inv.rp && h->S.L[0].n > 0, "complex64 hierarchy not set");
+    LevelT<float>& L0 = h->S.L[0];
+    int rc;
+    if ((rc = hx_cast_z2c(L0.n, b, L0.b, s))) return rc;          // narrow the right-hand side
+    // on level 0 the residual buffer L0.r is consumed by the restriction before the last post-sweep writes it
+    if ((rc = vcycle<float>(h, h->S, 0, L0.b, L0.r, s))) return rc;
+    return hx_cast_c2z(L0.n, L0.r, x, s);                         // widen the result
+  }
+  HX_REQUIRE(h->D.coarse_inv.rp && h->D.L[0].n > 0, "coarse solver not set");
+  return vcycle<double>(h, h->D, 0, (const double*)b, (double*)x, s);
 }
 
-// ------------------------------------------------------------------------------------------------ GMRES
-// Right-preconditioned restarted GMRES, CGS2 orthogonalisation with the fused panel kernels.
-// workspace: (restart + 4) * n complex numbers + hx_panel_dot_ws(restart + 1) + (restart + 2).
+// ------------------------------------------------------------------------------------------------ FGMRES
+// Flexible right-preconditioned restarted GMRES on K x = b (x0 = 0); CGS2 orthogonalisation with the fused panel
+// kernels.  workspace: (2*restart + 2) * n complex numbers + hx_panel_dot_ws(restart + 1) + (restart + 2).
 extern "C" size_t hx_gmres_ws(int64_t n, int restart) {
-  return (size_t)(restart + 4) * (size_t)n + hx_panel_dot_ws(restart + 1) + (size_t)restart + 2;
+  return (size_t)(2 * restart + 2) * (size_t)n + hx_panel_dot_ws(restart + 1) + (size_t)restart + 2;
 }
 
 typedef std::complex<double> cd;
@@ -141,11 +208,12 @@ extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr
                         const hx_c128* val, const hx_c128* b, hx_c128* x, double rtol, int max_it, int restart,
                         hx_c128* ws, int* h_iters, double* h_relres, hx_stream s) {
   HX_REQUIRE(n > 0 && rowptr && col && val && b && x && ws && restart >= 1 && restart <= 120 && max_it >= 1, "bad argument");
-  const Csr K{n, nnz, rowptr, col, val};
+  auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) {
+    return hx_csr_spmv_z(n, nnz, rowptr, col, val, in, out, a, bt, 0, s);
+  };
   hx_c128* V = ws;                                   // (restart+1) x n, row j = v_j
-  hx_c128* z = V + (size_t)(restart + 1) * n;
-  hx_c128* u = z + n;
-  hx_c128* r = u + n;
+  hx_c128* Z = V + (size_t)(restart + 1) * n;        // restart x n,   row j = M^-1 v_j
+  hx_c128* r = Z + (size_t)restart * n;
   hx_c128* part = r + n;
   hx_c128* hdev = part + hx_panel_dot_ws(restart + 1);
   std::vector<cd> hh(restart + 2);
@@ -166,9 +234,9 @@ extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr
   double relres = 1.0;
   bool first = true;
   while (it < max_it) {
-    // r = b - K x
+    // r = b - K x   (true residual, double precision)
     HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
-    if (!first) { if ((rc = spmv(K, x, r, MONE, ONE, s))) return rc; }
+    if (!first) { if ((rc = Kx(x, r, MONE, ONE))) return rc; }
     first = false;
     if ((rc = dots(0, r))) return rc;
     const double beta = std::sqrt(hh[0].real());
@@ -180,11 +248,12 @@ extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr
     std::fill(g.begin(), g.end(), cd(0));
     g[0] = beta;
     int j = 0;
-    for (; j < restart && it < max_it; ++j, ++it) {
+    for (; j < restart && it < max_it;) {
       hx_c128* vj = V + (size_t)j * n;
+      hx_c128* zj = M ? Z + (size_t)j * n : vj;
       hx_c128* w = V + (size_t)(j + 1) * n;
-      if (M) { if ((rc = hx_amg_vcycle(M, vj, z, s))) return rc; if ((rc = spmv(K, z, w, ONE, ZERO, s))) return rc; }
-      else { if ((rc = spmv(K, vj, w, ONE, ZERO, s))) return rc; }
+      if (M) { if ((rc = hx_amg_vcycle(M, vj, zj, s))) return rc; }
+      if ((rc = Kx(zj, w, ONE, ZERO))) return rc;
       const int k = j + 1;
       // classical Gram-Schmidt, always twice ("twice is enough"): one pass loses orthogonality like eps*kappa^2 of
       // the Krylov matrix, which was measured to stall GMRES here (55 instead of 29 iterations per solve).
@@ -199,7 +268,7 @@ extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr
       const double hn = std::sqrt(n2 > 0 ? n2 : 0.0);
       H[k][j] = hn;
       if (hn > 0) { const double ih[2] = {1.0 / hn, 0.0}; if ((rc = hx_zscal(n, ih, w, s))) return rc; }
-      // Givens rotations (complex)
+      // complex Givens rotations
       for (int i = 0; i < j; ++i) {
         const cd t = std::conj(cs[i]) * H[i][j] + std::conj(sn[i]) * H[i + 1][j];
         H[i + 1][j] = -sn[i] * H[i][j] + cs[i] * H[i + 1][j];
@@ -207,33 +276,31 @@ extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr
       }
       const double denom = std::sqrt(std::norm(H[j][j]) + std::norm(H[j + 1][j]));
       if (denom == 0.0) return hx_fail(HX_ERR_BREAKDOWN, __func__, "zero Hessenberg column");
-      cs[j] = H[j][j] / denom;            // complex "cosine"
+      cs[j] = H[j][j] / denom;
       sn[j] = H[j + 1][j] / denom;
       H[j][j] = std::conj(cs[j]) * H[j][j] + std::conj(sn[j]) * H[j + 1][j];
       H[j + 1][j] = 0;
       g[j + 1] = -sn[j] * g[j];
       g[j] = std::conj(cs[j]) * g[j];
       relres = std::abs(g[j + 1]) / bnorm;
-      if (relres <= rtol || hn == 0.0) { ++j; ++it; break; }
+      ++j; ++it;
+      if (relres <= rtol || hn == 0.0) break;
     }
-    // y = H^-1 g ; x += M^-1 (V y)
+    // y = H^-1 g ;  x += Z y   (flexible: the stored preconditioned directions, no extra preconditioner call)
     std::vector<cd> y(j);
     for (int i = j - 1; i >= 0; --i) {
       cd t = g[i];
       for (int q = i + 1; q < j; ++q) t -= H[i][q] * y[q];
       y[i] = t / H[i][i];
     }
-    for (int i = 0; i < j; ++i) y[i] = -y[i];          // panel_sub computes w -= V h
+    for (int i = 0; i < j; ++i) y[i] = -y[i];          // panel_sub computes x -= Z h
     HX_HIP(hipMemcpyAsync(hdev, y.data(), sizeof(cd) * (size_t)j, hipMemcpyHostToDevice, hx_s(s)));
-    HX_HIP(hipMemsetAsync(u, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
-    if ((rc = hx_zpanel_sub(n, j, V, n, hdev, u, s))) return rc;
+    if ((rc = hx_zpanel_sub(n, j, M ? Z : V, n, hdev, x, s))) return rc;
     HX_HIP(hipStreamSynchronize(hx_s(s)));             // y (host vector) must outlive the copy
-    if (M) { if ((rc = hx_amg_vcycle(M, u, z, s))) return rc; if ((rc = hx_zaxpy(n, ONE, z, x, s))) return rc; }
-    else { if ((rc = hx_zaxpy(n, ONE, u, x, s))) return rc; }
     if (relres <= rtol) {
-      // confirm with the true residual on the next loop entry only if more iterations are allowed
+      // accept only against the TRUE residual; otherwise keep iterating from the updated x
       HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
-      if ((rc = spmv(K, x, r, MONE, ONE, s))) return rc;
+      if ((rc = Kx(x, r, MONE, ONE))) return rc;
       if ((rc = dots(0, r))) return rc;
       relres = std::sqrt(hh[0].real()) / bnorm;
       if (relres <= 10 * rtol) break;

@@ -60,6 +60,32 @@ __device__ __forceinline__ zc zreduce_sub(zc v) {  // sum over aligned groups of
   return v;
 }
 
+// ---- complex64 (float2) counterparts: the AMG V-cycle may run in single precision inside flexible GMRES
+typedef float2 cc;
+__device__ __forceinline__ cc zmul(cc a, cc b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cc zadd(cc a, cc b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cc zsub(cc a, cc b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cc zscale(float s, cc a) { return make_float2(s * a.x, s * a.y); }
+__device__ __forceinline__ void zfma(cc& acc, cc a, cc b) {
+  acc.x = fmaf(a.x, b.x, acc.x); acc.x = fmaf(-a.y, b.y, acc.x);
+  acc.y = fmaf(a.x, b.y, acc.y); acc.y = fmaf(a.y, b.x, acc.y);
+}
+template <int W>
+__device__ __forceinline__ cc zreduce_sub(cc v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    v.x += __shfl_down(v.x, o, W);
+    v.y += __shfl_down(v.y, o, W);
+  }
+  return v;
+}
+template <typename V> __device__ __forceinline__ V czero();
+template <> __device__ __forceinline__ zc czero<zc>() { return make_double2(0.0, 0.0); }
+template <> __device__ __forceinline__ cc czero<cc>() { return make_float2(0.0f, 0.0f); }
+template <typename V> struct real_of;
+template <> struct real_of<zc> { typedef double type; };
+template <> struct real_of<cc> { typedef float type; };
+
 static inline int hx_grid(int64_t work_items, int block, int max_blocks = 256 * 8) {
   int64_t g = (work_items + block - 1) / block;
   if (g < 1) g = 1;

@@ -14,10 +14,10 @@
 // Measured and rejected on MI355X at 1 M / 5 M rows (tools/run_spmv_modes.sh, round 1): (a) XCD-aware banding
 // (workgroups with equal blockIdx % 8 sweeping a contiguous eighth of the rows) -8 %; (b) non-temporal loads of
 // val/col -30 % (they split the 16-byte value load).  The plain grid-stride sweep below is the fastest form.
-template <int LPR, int ROLE>
+template <int LPR, int ROLE, typename V>
 __global__ void __launch_bounds__(256)
-k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ val,
-       const zc* __restrict__ x, zc* __restrict__ y, zc alpha, zc beta, int beta_is_zero) {
+k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const V* __restrict__ val,
+       const V* __restrict__ x, V* __restrict__ y, V alpha, V beta, int beta_is_zero) {
   constexpr int RPB = 256 / LPR;                       // rows per block per sweep
   const int sub = threadIdx.x % LPR;
   const int64_t stride = (int64_t)gridDim.x * RPB;
@@ -25,54 +25,49 @@ k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict_
   const int64_t sweeps = ((int64_t)n + stride - 1) / stride;
   int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
   for (int64_t it = 0; it < sweeps; ++it, row += stride) {
-    zc acc = make_double2(0.0, 0.0);
+    V acc = czero<V>();
     if (row < n) {
       const int32_t s = rowptr[row], e = rowptr[row + 1];
       for (int32_t p = s + sub; p < e; p += LPR) zfma(acc, val[p], x[col[p]]);
     }
     if (LPR > 1) acc = zreduce_sub<LPR>(acc);
     if (row < n && sub == 0) {
-      zc r = zmul(alpha, acc);
+      V r = zmul(alpha, acc);
       if (!beta_is_zero) zfma(r, beta, y[row]);
       y[row] = r;
     }
   }
 }
 
-template <int LPR, int ROLE>
-static int launch(int32_t n, const int32_t* rowptr, const int32_t* col, const zc* val, const zc* x, zc* y,
-                  zc alpha, zc beta, hipStream_t s) {
+template <int LPR, int ROLE, typename V>
+static int launch(int32_t n, const int32_t* rowptr, const int32_t* col, const V* val, const V* x, V* y,
+                  V alpha, V beta, hipStream_t s) {
   int64_t rows_per_block = 256 / LPR;
   int grid = hx_grid((int64_t)n, (int)rows_per_block, 256 * 16);
-  k_spmv<LPR, ROLE><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, alpha, beta, (beta.x == 0.0 && beta.y == 0.0));
+  k_spmv<LPR, ROLE, V><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, alpha, beta, (beta.x == 0 && beta.y == 0));
   HX_LAUNCH_CHECK("k_spmv");
   return HX_OK;
 }
 
-template <int ROLE>
-static int spmv_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
-                         const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2], int lanes_per_row,
-                         hx_stream s) {
-  HX_REQUIRE(n_rows >= 0 && nnz >= 0 && rowptr && x && y && alpha && beta && (nnz == 0 || (col && val)),
-             "bad argument");
+static inline int pick_lpr(int64_t nnz, int32_t n_rows) {
+  const double avg = (double)nnz / (double)n_rows;
+  return avg <= 2.0 ? 1 : avg <= 4.5 ? 2 : avg <= 9.0 ? 4 : avg <= 24.0 ? 8 : avg <= 64.0 ? 16 : avg <= 160 ? 32 : 64;
+}
+
+template <int ROLE, typename V>
+static int spmv_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const V* val,
+                         const V* x, V* y, V a, V b, int lanes_per_row, hx_stream s) {
+  HX_REQUIRE(n_rows >= 0 && nnz >= 0 && rowptr && x && y && (nnz == 0 || (col && val)), "bad argument");
   if (n_rows == 0) return HX_OK;
-  int lpr = lanes_per_row;
-  if (lpr == 0) {
-    double avg = (double)nnz / (double)n_rows;
-    lpr = avg <= 2.0 ? 1 : avg <= 4.5 ? 2 : avg <= 9.0 ? 4 : avg <= 24.0 ? 8 : avg <= 64.0 ? 16 : avg <= 160 ? 32 : 64;
-  }
-  const zc a = hx_z(alpha), b = hx_z(beta);
-  const zc* v = (const zc*)val;
-  const zc* xx = (const zc*)x;
-  zc* yy = (zc*)y;
+  const int lpr = lanes_per_row ? lanes_per_row : pick_lpr(nnz, n_rows);
   switch (lpr) {
-    case 1: return launch<1, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 2: return launch<2, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 4: return launch<4, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 8: return launch<8, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 16: return launch<16, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 32: return launch<32, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
-    case 64: return launch<64, ROLE>(n_rows, rowptr, col, v, xx, yy, a, b, hx_s(s));
+    case 1: return launch<1, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
+    case 2: return launch<2, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
+    case 4: return launch<4, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
+    case 8: return launch<8, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
+    case 16: return launch<16, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
+    case 32: return launch<32, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
+    case 64: return launch<64, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
     default: return hx_fail(HX_ERR_ARG, __func__, "lanes_per_row must be 0,1,2,4,8,16,32,64");
   }
 }
@@ -80,53 +75,64 @@ static int spmv_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, con
 extern "C" int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                              const hx_c128* val, const hx_c128* x, hx_c128* y, const double alpha[2],
                              const double beta[2], int lanes_per_row, hx_stream s) {
-  return spmv_dispatch<0>(n_rows, nnz, rowptr, col, val, x, y, alpha, beta, lanes_per_row, s);
+  HX_REQUIRE(alpha && beta, "bad argument");
+  return spmv_dispatch<0, zc>(n_rows, nnz, rowptr, col, (const zc*)val, (const zc*)x, (zc*)y, hx_z(alpha), hx_z(beta),
+                              lanes_per_row, s);
 }
 
-// internal: same kernel under the "transfer" symbol (used by amg.hip for P, R and the coarse solve)
+// internal entry points for amg.hip: ROLE 1 = transfer / coarse products; complex64 variants for the
+// single-precision V-cycle (role 2 = its operator products, so profiles keep the roofline kernel separate)
 int hx_csr_spmv_transfer(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
                          const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2], hx_stream s) {
-  return spmv_dispatch<1>(n_rows, nnz, rowptr, col, val, x, y, alpha, beta, 0, s);
+  return spmv_dispatch<1, zc>(n_rows, nnz, rowptr, col, (const zc*)val, (const zc*)x, (zc*)y, hx_z(alpha), hx_z(beta), 0, s);
+}
+int hx_csr_spmv_c(int role, int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val,
+                  const float* x, float* y, float alpha, float beta, hx_stream s) {
+  const cc a = make_float2(alpha, 0.f), b = make_float2(beta, 0.f);
+  if (role == 1) return spmv_dispatch<1, cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)x, (cc*)y, a, b, 0, s);
+  return spmv_dispatch<2, cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)x, (cc*)y, a, b, 0, s);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Fused damped-Jacobi sweep (AMG smoother):  xout = xin + omega * dinv .* (b - A xin).
 // Same streaming pattern and traffic as the SpMV plus one read of b, dinv and xin per row.
-template <int LPR>
+template <int LPR, typename V>
 __global__ void __launch_bounds__(256)
-k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ val,
-         const zc* __restrict__ dinv, const zc* __restrict__ b, const zc* __restrict__ xin, zc* __restrict__ xout,
-         double omega) {
+k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const V* __restrict__ val,
+         const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xin, V* __restrict__ xout,
+         typename real_of<V>::type omega) {
   constexpr int RPB = 256 / LPR;
   const int sub = threadIdx.x % LPR;
   const int64_t stride = (int64_t)gridDim.x * RPB;
   const int64_t sweeps = ((int64_t)n + stride - 1) / stride;
   int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
   for (int64_t it = 0; it < sweeps; ++it, row += stride) {
-    zc acc = make_double2(0.0, 0.0);
+    V acc = czero<V>();
     if (row < n) {
       const int32_t s = rowptr[row], e = rowptr[row + 1];
       for (int32_t p = s + sub; p < e; p += LPR) zfma(acc, val[p], xin[col[p]]);
     }
     if (LPR > 1) acc = zreduce_sub<LPR>(acc);
     if (row < n && sub == 0) {
-      const zc r = zsub(b[row], acc);
-      zc x = xin[row];
+      const V r = zsub(b[row], acc);
+      V x = xin[row];
       zfma(x, zscale(omega, dinv[row]), r);
       xout[row] = x;
     }
   }
 }
 
-extern "C" int hx_csr_jacobi_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
-                               const hx_c128* val, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin,
-                               hx_c128* xout, double omega, hx_stream s) {
+template <typename V>
+static int jacobi_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const V* val,
+                           const V* dinv, const V* b, const V* xin, V* xout, typename real_of<V>::type omega,
+                           hx_stream s) {
   HX_REQUIRE(n_rows >= 0 && rowptr && col && val && dinv && b && xin && xout && xin != xout, "bad argument");
   if (n_rows == 0) return HX_OK;
-  const double avg = (double)nnz / (double)n_rows;
-  const int lpr = avg <= 4.5 ? 2 : avg <= 9.0 ? 4 : avg <= 24.0 ? 8 : avg <= 64.0 ? 16 : 32;
-#define HX_GO(L) k_jacobi<L><<<hx_grid((int64_t)n_rows, 256 / L, 256 * 16), 256, 0, hx_s(s)>>>(                  \
-      n_rows, rowptr, col, (const zc*)val, (const zc*)dinv, (const zc*)b, (const zc*)xin, (zc*)xout, omega)
+  int lpr = pick_lpr(nnz, n_rows);
+  if (lpr < 2) lpr = 2;
+  if (lpr > 32) lpr = 32;
+#define HX_GO(L) k_jacobi<L, V><<<hx_grid((int64_t)n_rows, 256 / L, 256 * 16), 256, 0, hx_s(s)>>>(                \
+      n_rows, rowptr, col, val, dinv, b, xin, xout, omega)
   switch (lpr) {
     case 2: HX_GO(2); break;
     case 4: HX_GO(4); break;
@@ -139,15 +145,61 @@ extern "C" int hx_csr_jacobi_z(int32_t n_rows, int64_t nnz, const int32_t* rowpt
   return HX_OK;
 }
 
+extern "C" int hx_csr_jacobi_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                               const hx_c128* val, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin,
+                               hx_c128* xout, double omega, hx_stream s) {
+  return jacobi_dispatch<zc>(n_rows, nnz, rowptr, col, (const zc*)val, (const zc*)dinv, (const zc*)b, (const zc*)xin,
+                             (zc*)xout, omega, s);
+}
+int hx_csr_jacobi_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val,
+                    const float* dinv, const float* b, const float* xin, float* xout, float omega, hx_stream s) {
+  return jacobi_dispatch<cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)dinv, (const cc*)b, (const cc*)xin,
+                             (cc*)xout, omega, s);
+}
+
 // x = scale .* d .* b  (first Jacobi sweep from a zero initial guess; also a diagonal preconditioner)
-__global__ void k_diag_scale(int64_t n, double scale, const zc* __restrict__ d, const zc* __restrict__ b, zc* __restrict__ x) {
+template <typename V>
+__global__ void k_diag_scale(int64_t n, typename real_of<V>::type scale, const V* __restrict__ d, const V* __restrict__ b,
+                             V* __restrict__ x) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     x[i] = zscale(scale, zmul(d[i], b[i]));
 }
 extern "C" int hx_zdiag_scale(int64_t n, double scale, const hx_c128* d, const hx_c128* b, hx_c128* x, hx_stream s) {
   HX_REQUIRE(n >= 0 && d && b && x, "bad argument");
   if (n == 0) return HX_OK;
-  k_diag_scale<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, scale, (const zc*)d, (const zc*)b, (zc*)x);
+  k_diag_scale<zc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, scale, (const zc*)d, (const zc*)b, (zc*)x);
   HX_LAUNCH_CHECK("k_diag_scale");
+  return HX_OK;
+}
+int hx_cdiag_scale(int64_t n, float scale, const float* d, const float* b, float* x, hx_stream s) {
+  if (n == 0) return HX_OK;
+  k_diag_scale<cc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, scale, (const cc*)d, (const cc*)b, (cc*)x);
+  HX_LAUNCH_CHECK("k_diag_scale<c64>");
+  return HX_OK;
+}
+
+// precision casts at the V-cycle boundary
+__global__ void k_z2c(int64_t n, const zc* __restrict__ x, cc* __restrict__ y) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const zc v = x[i];
+    y[i] = make_float2((float)v.x, (float)v.y);
+  }
+}
+__global__ void k_c2z(int64_t n, const cc* __restrict__ x, zc* __restrict__ y) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const cc v = x[i];
+    y[i] = make_double2((double)v.x, (double)v.y);
+  }
+}
+int hx_cast_z2c(int64_t n, const hx_c128* x, float* y, hx_stream s) {
+  if (n == 0) return HX_OK;
+  k_z2c<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, (const zc*)x, (cc*)y);
+  HX_LAUNCH_CHECK("k_z2c");
+  return HX_OK;
+}
+int hx_cast_c2z(int64_t n, const float* x, hx_c128* y, hx_stream s) {
+  if (n == 0) return HX_OK;
+  k_c2z<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, (const cc*)x, (zc*)y);
+  HX_LAUNCH_CHECK("k_c2z");
   return HX_OK;
 }

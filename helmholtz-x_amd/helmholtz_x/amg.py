@@ -23,7 +23,7 @@ from .petsc import CSR, to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200)
+              max_it=200, precision="mixed")
 
 
 def _aggregate(S):
@@ -126,25 +126,40 @@ class AMGSolver:
         _hx.check(_hx.lib.hx_amg_create(C.byref(h), len(levels), self.params["pre"], self.params["post"], float(omega)))
         self.handle = h
         self._keep = []                               # device arrays referenced by the handle
+        mixed = self.params["precision"] == "mixed"   # complex64 V-cycle inside complex128 flexible GMRES
+        cdt = torch.complex64 if mixed else torch.complex128
+        set_level = _hx.lib.hx_amg_set_level_c if mixed else _hx.lib.hx_amg_set_level
+        set_coarse = _hx.lib.hx_amg_set_coarse_c if mixed else _hx.lib.hx_amg_set_coarse
+
+        def dev_csr(M):
+            """(rowptr, col, val) device tensors of a scipy CSR in the hierarchy's working precision."""
+            M = sp.csr_matrix(M)
+            M.sort_indices()
+            t = (to_device(M.indptr.astype(np.int32)), to_device(M.indices.astype(np.int32)),
+                 to_device(M.data.astype(np.complex128)).to(cdt))
+            self._keep.append(t)
+            return t, int(M.nnz)
+
         for l, lv in enumerate(levels):
-            Kd = K_csr if l == 0 else CSR.from_scipy(lv["K"])
-            if "P" in lv:
-                Pd, Rd = CSR.from_scipy(lv["P"]), CSR.from_scipy(lv["R"])
-                dinv = to_device(np.asarray(lv["dinv"], dtype=np.complex128))
-                self._keep += [Kd, Pd, Rd, dinv]
-                _hx.check(_hx.lib.hx_amg_set_level(h, l, lv["n"], Kd.nnz, _hx.ptr(Kd.rowptr), _hx.ptr(Kd.col),
-                                                   _hx.ptr(Kd.val), _hx.ptr(dinv), lv["n_coarse"], Pd.nnz,
-                                                   _hx.ptr(Pd.rowptr), _hx.ptr(Pd.col), _hx.ptr(Pd.val), Rd.nnz,
-                                                   _hx.ptr(Rd.rowptr), _hx.ptr(Rd.col), _hx.ptr(Rd.val)))
+            if l == 0:
+                k0 = K_csr.val.to(cdt) if mixed else K_csr.val
+                self._keep.append(k0)
+                (krp, kci, kva), knnz = (K_csr.rowptr, K_csr.col, k0), K_csr.nnz
             else:
-                self._keep += [Kd]
-                _hx.check(_hx.lib.hx_amg_set_level(h, l, lv["n"], Kd.nnz, _hx.ptr(Kd.rowptr), _hx.ptr(Kd.col),
-                                                   _hx.ptr(Kd.val), None, 0, 0, None, None, None, 0, None, None, None))
-                inv = np.linalg.inv(lv["K"].toarray())
-                Cd = CSR.from_scipy(sp.csr_matrix(inv))
-                self._keep.append(Cd)
-                _hx.check(_hx.lib.hx_amg_set_coarse(h, lv["n"], Cd.nnz, _hx.ptr(Cd.rowptr), _hx.ptr(Cd.col),
-                                                    _hx.ptr(Cd.val)))
+                (krp, kci, kva), knnz = dev_csr(lv["K"])
+            if "P" in lv:
+                (prp, pci, pva), pnnz = dev_csr(lv["P"])
+                (rrp, rci, rva), rnnz = dev_csr(lv["R"])
+                dinv = to_device(np.asarray(lv["dinv"], dtype=np.complex128)).to(cdt)
+                self._keep.append(dinv)
+                _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), _hx.ptr(dinv),
+                                    lv["n_coarse"], pnnz, _hx.ptr(prp), _hx.ptr(pci), _hx.ptr(pva), rnnz,
+                                    _hx.ptr(rrp), _hx.ptr(rci), _hx.ptr(rva)))
+            else:
+                _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), None, 0, 0, None,
+                                    None, None, 0, None, None, None))
+                (crp, cci, cva), cnnz = dev_csr(sp.csr_matrix(np.linalg.inv(lv["K"].toarray())))
+                _hx.check(set_coarse(h, lv["n"], cnnz, _hx.ptr(crp), _hx.ptr(cci), _hx.ptr(cva)))
         self.ws = torch.empty(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), dtype=torch.complex128, device=dev)
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
         self.krylov_tol_floor = 10.0 * self.params["rtol"]
@@ -174,7 +189,8 @@ class AMGSolver:
                                   % (rr.value, it.value))
 
     def stats(self):
-        return dict(levels=[lv["n"] for lv in self.levels], setup_s=round(self.setup_s, 3), solves=self.n_solves,
+        return dict(levels=[lv["n"] for lv in self.levels], vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
+                    setup_s=round(self.setup_s, 3), solves=self.n_solves,
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1))
 

@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 typedef struct { double re, im; } hx_c128;
+typedef struct { float re, im; } hx_c64;   /* complex64: single-precision copy of the AMG hierarchy only */
 typedef void* hx_stream;
 
 enum hx_status {
@@ -172,10 +173,19 @@ int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t* r
 /* dense inverse of the coarsest operator, passed as a (dense) CSR */
 int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                       const hx_c128* va);
+/* Optional complex64 copy of every level (same integer arrays may be shared).  Once set, hx_amg_vcycle narrows
+ * its input, runs the whole cycle in single precision (half the HBM traffic) and widens the result; use it only
+ * as the preconditioner of hx_gmres, which is flexible and measures residuals in double precision. */
+int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t* rpK, const int32_t* ciK,
+                       const hx_c64* vaK, const hx_c64* dinv, int32_t n_coarse, int64_t nnzP,
+                       const int32_t* rpP, const int32_t* ciP, const hx_c64* vaP, int64_t nnzR,
+                       const int32_t* rpR, const int32_t* ciR, const hx_c64* vaR);
+int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
+                        const hx_c64* va);
 /* x = one V-cycle applied to b from a zero initial guess (b != x) */
 int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream s);
 int hx_amg_destroy(hx_amg* h);
-/* Right-preconditioned restarted GMRES on K x = b (x0 = 0), CGS2 with the fused panel kernels; M may be NULL.
+/* FLEXIBLE right-preconditioned restarted GMRES on K x = b (x0 = 0), CGS2 with the fused panel kernels; M may be NULL.
  * ws: hx_gmres_ws(n, restart) complex numbers.  SYNC (one small D2H per orthogonalisation pass). */
 size_t hx_gmres_ws(int64_t n, int restart);
 int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,

@@ -158,9 +158,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    local_rank %= torch.cuda.device_count()       # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("HX_DIST_BACKEND", "nccl")     # "gloo" only for single-GPU rehearsals of the N>1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         torch.cuda.synchronize()
@@ -174,20 +179,23 @@ def main():
     mesh.assembler()                           # mesh arrays -> HBM (outside the timed region)
     n_dof, n_cells = mesh.num_vertices, mesh.num_cells
 
-    for _ in range(args.warmup):
-        hot_path(case, args.st_type)
-    barrier()
-    t0 = time.perf_counter()
-    pairs = 0
-    hist = []
-    for _ in range(args.steps):
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the library logs like the reference; stdout = the JSON line
+        for _ in range(args.warmup):
+            hot_path(case, args.st_type)
+        barrier()
+        t0 = time.perf_counter()
+        pairs = 0
         hist = []
-        E, matrices = hot_path(case, args.st_type, history=hist)
-        pairs += min(E.getConverged(), 4)
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(pairs)], dtype=torch.float64, device="cuda")
+        for _ in range(args.steps):
+            hist = []
+            E, matrices = hot_path(case, args.st_type, history=hist)
+            pairs += min(E.getConverged(), 4)
+        barrier()
+        dt = time.perf_counter() - t0
+    red_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(pairs)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -196,7 +204,8 @@ def main():
     if rank == 0:
         omegas = [E.getEigenvalue(i) for i in range(min(E.getConverged(), 4))]
         inner = next((v for k, v in (E.inner_cache or {}).items() if k[0] != 'ops'), None)
-        roof = spmv_roofline(matrices, case["P"].target)
+        with contextlib.redirect_stdout(sys.stderr):
+            roof = spmv_roofline(matrices, case["P"].target)
         out = {
             "metric": "converged eigenpairs/sec + SpMV GB/s (% HBM roofline), AnnularCombustor",
             "value": round(pairs_all / dt, 5), "unit": "eigenpairs/s",
@@ -214,7 +223,8 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            with contextlib.redirect_stdout(sys.stderr):
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

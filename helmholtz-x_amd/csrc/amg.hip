@@ -319,12 +319,16 @@ extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci
   HX_REQUIRE(n > 0 && rp && agg && n_agg, "bad argument");
   for (int32_t i = 0; i < n; ++i) agg[i] = -1;
   int32_t na = 0;
-  // pass 1: roots whose whole strong neighbourhood is free
+  // pass 1: roots whose whole strong neighbourhood is free (a stored diagonal entry is not a neighbour)
   for (int32_t i = 0; i < n; ++i) {
-    if (agg[i] != -1 || rp[i + 1] == rp[i]) continue;
-    bool free_nb = true;
-    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (agg[ci[p]] != -1) { free_nb = false; break; }
-    if (!free_nb) continue;
+    if (agg[i] != -1) continue;
+    bool free_nb = true, has_nb = false;
+    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+      if (ci[p] == i) continue;
+      has_nb = true;
+      if (agg[ci[p]] != -1) { free_nb = false; break; }
+    }
+    if (!free_nb || !has_nb) continue;
     agg[i] = na;
     for (int32_t p = rp[i]; p < rp[i + 1]; ++p) agg[ci[p]] = na;
     ++na;
@@ -335,8 +339,10 @@ extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci
     if (agg[i] != -1) continue;
     double best = -1.0; int32_t tgt = -1;
     for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+      if (ci[p] == i) continue;
       const int32_t a = pass1[ci[p]];
-      if (a >= 0 && w[p] > best) { best = w[p]; tgt = a; }
+      const double wp = std::fabs(w[p]);
+      if (a >= 0 && wp > best) { best = wp; tgt = a; }
     }
     if (tgt >= 0) agg[i] = tgt;
   }
@@ -348,5 +354,88 @@ extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci
     ++na;
   }
   *n_agg = na;
+  return HX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ SA set-up passes (host)
+// One sweep over the Laplacian-like matrix L (CSR, real values, positive diagonal): keep the diagonal and the strong
+// off-diagonal couplings |l_ij| >= theta*sqrt(l_ii l_jj); weak couplings are lumped onto the diagonal.  Output is the
+// filtered matrix Lf in compact CSR (diagonal entry included).  Call once with out_ci == NULL to get the row pointer
+// (count pass), then again to fill.  Replaces ~15 NumPy passes over the nnz arrays.
+extern "C" int hx_host_sa_filter(int32_t n, const int32_t* rp, const int32_t* ci, const double* lv, double theta,
+                                 int32_t* out_rp, int32_t* out_ci, double* out_v) {
+  HX_REQUIRE(n > 0 && rp && ci && lv && out_rp, "bad argument");
+  std::vector<double> sd(n);
+  for (int32_t i = 0; i < n; ++i) {
+    double d = 0.0;
+    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] == i) d = lv[p];
+    d = std::fabs(d);
+    sd[i] = std::sqrt(d == 0.0 ? 1.0 : d);
+  }
+  if (!out_ci) {
+    out_rp[0] = 0;
+    for (int32_t i = 0; i < n; ++i) {
+      int32_t cnt = 1;                                  // the diagonal always stays
+      const double ti = theta * sd[i];
+      for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+        const int32_t j = ci[p];
+        if (j != i && std::fabs(lv[p]) >= ti * sd[j]) ++cnt;
+      }
+      out_rp[i + 1] = out_rp[i] + cnt;
+    }
+    return HX_OK;
+  }
+  HX_REQUIRE(out_v, "bad argument");
+  for (int32_t i = 0; i < n; ++i) {
+    const double ti = theta * sd[i];
+    double diag = 0.0, lump = 0.0;
+    int32_t q = out_rp[i], qd = -1;
+    bool placed = false;
+    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+      const int32_t j = ci[p];
+      if (j == i) { diag = lv[p]; qd = q; out_ci[q] = i; ++q; placed = true; continue; }
+      if (!placed && j > i) { qd = q; out_ci[q] = i; ++q; placed = true; }      // keep columns sorted if no diagonal stored
+      if (std::fabs(lv[p]) >= ti * sd[j]) { out_ci[q] = j; out_v[q] = lv[p]; ++q; }
+      else lump += lv[p];
+    }
+    if (!placed) { qd = q; out_ci[q] = i; ++q; }
+    out_v[qd] = diag + lump;
+  }
+  return HX_OK;
+}
+
+// Smoothed prolongator P = (I - omega Df^-1 Lf) P0 with the piecewise-constant tentative P0[i, agg(i)] = 1/sqrt(|agg|).
+// Rows have at most (row length of Lf) distinct aggregates; columns are merged and sorted per row.
+// Count pass with out_ci == NULL.
+extern "C" int hx_host_sa_prolongator(int32_t n, const int32_t* rp, const int32_t* ci, const double* lf,
+                                      const int32_t* agg, const double* inv_sqrt_cnt, double omega,
+                                      int32_t* out_rp, int32_t* out_ci, double* out_v) {
+  HX_REQUIRE(n > 0 && rp && ci && lf && agg && inv_sqrt_cnt && out_rp, "bad argument");
+  std::vector<int32_t> cols;
+  std::vector<double> vals;
+  if (!out_ci) out_rp[0] = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    cols.clear(); vals.clear();
+    double dii = 1.0;
+    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] == i) dii = lf[p];
+    if (dii == 0.0) dii = 1.0;
+    auto add = [&](int32_t c, double v) {
+      size_t k = 0;
+      while (k < cols.size() && cols[k] < c) ++k;
+      if (k < cols.size() && cols[k] == c) { vals[k] += v; return; }
+      cols.insert(cols.begin() + k, c);
+      vals.insert(vals.begin() + k, v);
+    };
+    add(agg[i], inv_sqrt_cnt[agg[i]]);
+    const double w = omega / dii;
+    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+      const int32_t a = agg[ci[p]];
+      add(a, -w * lf[p] * inv_sqrt_cnt[a]);
+    }
+    if (!out_ci) { out_rp[i + 1] = out_rp[i] + (int32_t)cols.size(); continue; }
+    int32_t q = out_rp[i];
+    for (size_t k = 0; k < cols.size(); ++k, ++q) { out_ci[q] = cols[k]; out_v[q] = vals[k]; }
+  }
   return HX_OK;
 }

@@ -61,6 +61,8 @@ SIGNATURES = {
     "hx_gmres": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp,
                            C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_host_aggregate": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
+    "hx_host_sa_filter": (C.c_int, [_i32, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
+    "hx_host_sa_prolongator": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -27,7 +27,7 @@ PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_o
 
 
 def _aggregate(S):
-    """Greedy aggregation of the (symmetric) strength graph S (CSR, weights = coupling magnitude)."""
+    """Greedy aggregation of the (symmetric) strength graph S (CSR; diagonal entries ignored, |value| = strength)."""
     n = S.shape[0]
     rp = np.ascontiguousarray(S.indptr, dtype=np.int32)
     ci = np.ascontiguousarray(S.indices, dtype=np.int32)
@@ -38,66 +38,82 @@ def _aggregate(S):
     return agg, na.value
 
 
-def _spectral_radius(M, iters=10, seed=0):
-    """Power-iteration estimate of rho(M) (M = D^-1 L is similar to an SPD matrix, so the norm ratio converges from
-    below; the smoothing weights derived from it carry a 4/3 safety factor).  Norms avoid BLAS ddot on purpose:
-    multi-threaded BLAS start-up costs more than the reduction itself at these sizes."""
+def _filter(L, theta):
+    """Filtered Laplacian Lf (strong couplings + lumped diagonal) as scipy CSR -- one native pass (hx_host_sa_filter)."""
+    n = L.shape[0]
+    rp = np.ascontiguousarray(L.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(L.indices, dtype=np.int32)
+    lv = np.ascontiguousarray(L.data, dtype=np.float64)
+    orp = np.empty(n + 1, dtype=np.int32)
+    _hx.check(_hx.lib.hx_host_sa_filter(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(lv), float(theta), _hx.nptr(orp), None, None))
+    oci = np.empty(orp[-1], dtype=np.int32)
+    ov = np.empty(orp[-1], dtype=np.float64)
+    _hx.check(_hx.lib.hx_host_sa_filter(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(lv), float(theta), _hx.nptr(orp),
+                                        _hx.nptr(oci), _hx.nptr(ov)))
+    return sp.csr_matrix((ov, oci, orp), shape=L.shape)
+
+
+def _prolongator(Lf, agg, na, omega):
+    """P = (I - omega Df^-1 Lf) P0 as scipy CSR with sorted columns (hx_host_sa_prolongator)."""
+    n = Lf.shape[0]
+    rp = np.ascontiguousarray(Lf.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(Lf.indices, dtype=np.int32)
+    lf = np.ascontiguousarray(Lf.data, dtype=np.float64)
+    isc = 1.0 / np.sqrt(np.bincount(agg, minlength=na).astype(np.float64))
+    orp = np.empty(n + 1, dtype=np.int32)
+    args = (n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(lf), _hx.nptr(agg), _hx.nptr(isc), float(omega))
+    _hx.check(_hx.lib.hx_host_sa_prolongator(*args, _hx.nptr(orp), None, None))
+    oci = np.empty(orp[-1], dtype=np.int32)
+    ov = np.empty(orp[-1], dtype=np.float64)
+    _hx.check(_hx.lib.hx_host_sa_prolongator(*args, _hx.nptr(orp), _hx.nptr(oci), _hx.nptr(ov)))
+    return sp.csr_matrix((ov, oci, orp), shape=(n, na))
+
+
+def _spectral_radius_dinv(Lf, iters=10, seed=0):
+    """Power-iteration estimate of rho(Df^-1 Lf) (similar to an SPD matrix: the norm ratio converges from below; the
+    smoothing weights derived from it carry a 4/3 safety factor).  Norms avoid BLAS ddot on purpose: multi-threaded
+    BLAS start-up costs more than the reduction itself at these sizes."""
+    dinv = 1.0 / Lf.diagonal()
     rng = np.random.default_rng(seed)
-    v = rng.standard_normal(M.shape[0])
+    v = rng.standard_normal(Lf.shape[0])
     v /= np.sqrt((v * v).sum())
     lam = 1.0
     for _ in range(iters):
-        w = M @ v
+        w = dinv * (Lf @ v)
         lam = float(np.sqrt((w * w).sum()))
         v = w / lam
     return lam
 
 
 def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], coarse_size=PARAMS["coarse_size"]):
-    """K: scipy CSR (complex).  Returns a list of dicts {K, dinv, P, R, rho} (host scipy objects), finest first."""
+    """K: scipy CSR (complex).  Returns a list of dicts {K, n, dinv, P, R, omega, n_coarse} (host scipy objects),
+    finest first.  Graph passes (filter, aggregation, prolongator) are native host code in libhx; the Galerkin
+    triple products are SciPy SpGEMMs."""
     levels = []
     Kl = sp.csr_matrix(K, dtype=np.complex128)
     th = theta
     while True:
         n = Kl.shape[0]
         diag = Kl.diagonal()
-        # Laplacian-like real part with positive diagonal drives strength / prolongator smoothing
-        sgn = -1.0 if np.median(diag.real) < 0 else 1.0
-        L = sp.csr_matrix((sgn * Kl.data.real, Kl.indices, Kl.indptr), shape=Kl.shape)
-        d = np.abs(L.diagonal())
-        d[d == 0] = 1.0
         level = dict(K=Kl, n=n)
         if n <= coarse_size or len(levels) == max_levels - 1:
             levels.append(level)
             break
-        # ---- strength filter: |l_ij| >= theta * sqrt(l_ii l_jj), off-diagonal
-        coo = L.tocoo()
-        off = coo.row != coo.col
-        strong = off & (np.abs(coo.data) >= th * np.sqrt(d[coo.row] * d[coo.col]))
-        S = sp.csr_matrix((np.abs(coo.data[strong]), (coo.row[strong], coo.col[strong])), shape=L.shape)
-        agg, na = _aggregate(S)
+        # Laplacian-like real part with positive diagonal drives strength / prolongator smoothing
+        sgn = -1.0 if np.median(diag.real) < 0 else 1.0
+        L = sp.csr_matrix((sgn * Kl.data.real, Kl.indices, Kl.indptr), shape=Kl.shape)
+        Lf = _filter(L, th)
+        agg, na = _aggregate(Lf)
         if na >= 0.8 * n:                          # coarsening stalled
             levels.append(level)
             break
-        cnt = np.bincount(agg, minlength=na).astype(np.float64)
-        P0 = sp.csr_matrix((1.0 / np.sqrt(cnt[agg]), (np.arange(n), agg)), shape=(n, na))
-        # ---- filtered matrix: weak couplings lumped onto the diagonal, then P = (I - w Df^-1 Lf) P0
-        weak = off & ~strong
-        lump = np.bincount(coo.row[weak], weights=coo.data[weak], minlength=n)
-        keep = ~weak
-        Lf = sp.csr_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=L.shape) + sp.diags(lump)
-        df = Lf.diagonal()
-        df[df == 0] = 1.0
-        DinvLf = sp.diags(1.0 / df) @ Lf
-        rho = _spectral_radius(DinvLf)
-        P = (P0 - (4.0 / (3.0 * rho)) * (DinvLf @ P0)).tocsr()
-        P.sort_indices()
+        rho = _spectral_radius_dinv(Lf)
+        P = _prolongator(Lf, agg, na, 4.0 / (3.0 * rho))
         R = P.T.tocsr()
         R.sort_indices()
         # smoother: damped Jacobi on K itself; rho(D^-1 L) differs from rho(Df^-1 Lf) only by the lumped weak
         # couplings (a few per cent), so the estimate is reused with a margin instead of a second power iteration
-        rhoK = 1.05 * rho
-        level.update(P=P, R=R, dinv=1.0 / diag, omega=4.0 / (3.0 * rhoK), n_coarse=na)
+        level.update(P=P, R=R, dinv=1.0 / diag, omega=4.0 / (3.0 * 1.05 * rho), n_coarse=na)
         levels.append(level)
         Kl = (R @ Kl @ P).tocsr()
         Kl.sort_indices()

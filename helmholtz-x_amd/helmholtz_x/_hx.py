@@ -47,6 +47,8 @@ SIGNATURES = {
     "hx_sptrsv_solve": (C.c_int, [_vp, _vp, _vp, _vp]),
     "hx_sptrsv_destroy": (C.c_int, [_vp]),
     "hx_csr_jacobi_z": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp]),
+    "hx_csr_spmv_c64": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp]),
+    "hx_csr_jacobi_c64": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp]),
     "hx_zdiag_scale": (C.c_int, [_i64, C.c_double, _vp, _vp, _vp, _vp]),
     "hx_amg_create": (C.c_int, [C.POINTER(_vp), _int, _int, _int, C.c_double]),
     "hx_amg_set_level": (C.c_int, [_vp, _int, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp,

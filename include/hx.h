@@ -160,6 +160,12 @@ int hx_sptrsv_destroy(hx_sptrsv* t);
 int hx_csr_jacobi_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                     const hx_c128* val, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin,
                     hx_c128* xout, double omega, hx_stream s);
+/* complex64 forms of the two kernels above (y = alpha*A*x + beta*y with real alpha, beta). */
+int hx_csr_spmv_c64(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                    const hx_c64* val, const hx_c64* x, hx_c64* y, float alpha, float beta, hx_stream s);
+int hx_csr_jacobi_c64(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                      const hx_c64* val, const hx_c64* dinv, const hx_c64* b, const hx_c64* xin,
+                      hx_c64* xout, float omega, hx_stream s);
 /* x = scale * d .* b */
 int hx_zdiag_scale(int64_t n, double scale, const hx_c128* d, const hx_c128* b, hx_c128* x, hx_stream s);
 typedef struct hx_amg hx_amg;

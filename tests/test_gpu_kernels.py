@@ -196,3 +196,31 @@ def test_lu_solver_matches_splu(hx):
     S.solve(bd, x)
     ref = spla.splu(K.tocsc()).solve(b)
     assert np.max(np.abs(x.cpu().numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("n,density", [(1, 1.0), (999, 0.02), (30000, 0.0006)])
+def test_complex64_spmv_and_jacobi(hx, n, density):
+    """Single-precision copies used by the AMG V-cycle: ragged rows, an empty row."""
+    import torch
+    rng = np.random.default_rng(n)
+    M = sp.random(n, n, density=density, random_state=rng, format="csr") + 1j * sp.random(n, n, density=density, random_state=rng, format="csr")
+    M = sp.csr_matrix(M + sp.diags(3.0 + rng.random(n)))
+    if n > 10:
+        M = sp.csr_matrix(sp.vstack([M[:5], sp.csr_matrix((1, n)), M[6:]]))       # one empty row
+    M.sort_indices()
+    rp, ci = _dev(M.indptr.astype(np.int32)), _dev(M.indices.astype(np.int32))
+    va = _dev(M.data.astype(np.complex64))
+    x = _rand_c(rng, n).astype(np.complex64)
+    y0 = _rand_c(rng, n).astype(np.complex64)
+    xd, yd = _dev(x), _dev(y0.copy())
+    hx.check(hx.lib.hx_csr_spmv_c64(n, M.nnz, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), hx.ptr(xd), hx.ptr(yd), -1.0, 1.0, hx.stream()))
+    ref = y0.astype(np.complex128) - M @ x.astype(np.complex128)
+    assert np.max(np.abs(yd.cpu().numpy() - ref)) <= 2e-5 * max(np.max(np.abs(ref)), 1.0)
+    d = M.diagonal()
+    d[d == 0] = 1.0
+    dinv, b = _dev((1.0 / d).astype(np.complex64)), _dev(y0)
+    out = torch.empty_like(xd)
+    hx.check(hx.lib.hx_csr_jacobi_c64(n, M.nnz, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), hx.ptr(dinv), hx.ptr(b), hx.ptr(xd),
+                                      hx.ptr(out), 0.7, hx.stream()))
+    refj = x + 0.7 * (1.0 / d) * (y0 - M @ x.astype(np.complex128))
+    assert np.max(np.abs(out.cpu().numpy() - refj)) <= 2e-5 * max(np.max(np.abs(refj)), 1.0)

@@ -1,0 +1,229 @@
+"""CPU tests of the product's HOST logic (no GPU, no compute kernels): Krylov-Schur driver with a NumPy basis
+double, native host set-up passes of the AMG hierarchy, mesh generators / readers, flame transfer functions,
+C-ABI argument checking."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from cases import Micca, Rijke
+
+
+class NumpyBasis:
+    """Test double for slepc.DeviceBasis: same interface, NumPy arithmetic (lives in tests/ only)."""
+
+    def __init__(self, n, m, op, start=None):
+        self.V = np.zeros((m, n), complex)
+        self.m, self.n, self.op, self.start, self.n_ops = m, n, op, start, 0
+
+    def set_start(self, j):
+        if self.start is not None:
+            v = self.start.copy()
+        else:
+            rng = np.random.default_rng(0)
+            v = rng.standard_normal(self.n) + 1j * rng.standard_normal(self.n)
+        self.V[j] = v / np.linalg.norm(v)
+
+    def expand(self, j):
+        w = self.op(self.V[j])
+        self.n_ops += 1
+        Vj = self.V[:j + 1]
+        h1 = Vj.conj() @ w
+        w = w - Vj.T @ h1
+        h2 = Vj.conj() @ w
+        w = w - Vj.T @ h2
+        beta = np.linalg.norm(w)
+        self.V[j + 1] = w / beta
+        return h1 + h2, beta
+
+    def rotate(self, Q, k):
+        mact = Q.shape[0]
+        new = Q.T @ self.V[:mact]
+        res = self.V[mact].copy() if mact < self.m else None
+        self.V[:k] = new
+        if res is not None:
+            self.V[k] = res
+
+
+def _box_problem():
+    from oracle import fem, meshes
+    m = meshes.rectangle(48, 12, 0.4, 0.1)
+    c = np.full(m.x.shape[0], 450.0)
+    return fem.assemble_A(m.x, m.cells, c), fem.assemble_C(m.x, m.cells)
+
+
+@pytest.mark.parametrize("nev,ncv,target_hz", [(2, 17, 600.0), (4, 8, 2500.0), (1, 16, 1200.0)])
+def test_krylov_schur_matches_arpack(nev, ncv, target_hz):
+    from helmholtz_x.krylov import krylov_schur
+    from oracle import eigen
+    A, Cm = _box_problem()
+    n = A.shape[0]
+    target = target_hz * 2 * np.pi
+    sigma = target ** 2
+    lu = spla.splu((A + sigma * Cm).tocsc())
+    mC = (-Cm).tocsr()
+    basis = NumpyBasis(n, ncv + 1, lambda v: lu.solve(mC @ v))
+    res = krylov_schur(basis, nev, ncv)
+    assert res.nconv >= nev
+    lam = sigma + 1.0 / res.theta[:nev]
+    ref = eigen.eps_solve(A, Cm, target, nev).eigs
+    assert np.max(np.abs(np.sort_complex(lam) - np.sort_complex(ref)) / np.abs(ref).max()) < 1e-10
+    for i in range(nev):                      # basis rows are unit Ritz VECTORS
+        x = basis.V[i]
+        assert abs(np.linalg.norm(x) - 1) < 1e-8
+        r = A @ x + lam[i] * (Cm @ x)
+        assert np.linalg.norm(r) <= 1e-9 * abs(A).max() * np.linalg.norm(x)
+
+
+def test_krylov_schur_warm_start_needs_fewer_operator_applications():
+    from helmholtz_x.krylov import krylov_schur
+    A, Cm = _box_problem()
+    n = A.shape[0]
+    sigma = (600.0 * 2 * np.pi) ** 2
+    lu = spla.splu((A + sigma * Cm).tocsc())
+    mC = (-Cm).tocsr()
+    cold = NumpyBasis(n, 18, lambda v: lu.solve(mC @ v))
+    r0 = krylov_schur(cold, 1, 17)
+    # slightly perturbed operator, started from the previous Ritz vector
+    lu2 = spla.splu((A + 1.001 * sigma * Cm).tocsc())
+    warm = NumpyBasis(n, 18, lambda v: lu2.solve(mC @ v), start=cold.V[0])
+    r1 = krylov_schur(warm, 1, 17)
+    assert r1.nconv >= 1 and warm.n_ops < cold.n_ops
+    assert abs((1.001 * sigma + 1 / r1.theta[0]) - (sigma + 1 / r0.theta[0])) < 1e-6 * abs(sigma)
+
+
+def test_native_amg_setup_passes_match_numpy():
+    from helmholtz_x import amg
+    from oracle import fem, meshes
+    m = meshes.rectangle(30, 9, 0.4, 0.1)
+    rng = np.random.default_rng(1)
+    m.x[:, 1] *= 3.0                                        # anisotropy => some weak couplings
+    S = -fem.assemble_A(m.x, m.cells, 300.0 + 50 * rng.random(m.x.shape[0])).real.tocsr()
+    theta = 0.25
+    Lf = amg._filter(S, theta)
+    d = np.abs(S.diagonal())
+    coo = S.tocoo()
+    off = coo.row != coo.col
+    strong = off & (np.abs(coo.data) >= theta * np.sqrt(d[coo.row] * d[coo.col]))
+    weak = off & ~strong
+    assert weak.sum() > 0 and strong.sum() > 0
+    ref = sp.csr_matrix((coo.data[~weak], (coo.row[~weak], coo.col[~weak])), shape=S.shape) \
+        + sp.diags(np.bincount(coo.row[weak], weights=coo.data[weak], minlength=S.shape[0]))
+    assert abs(Lf - ref).max() < 1e-12 * abs(ref).max()
+    assert np.all(np.diff(Lf.indices)[np.diff(np.repeat(np.arange(S.shape[0]), np.diff(Lf.indptr))) == 0] > 0)  # sorted rows
+    agg, na = amg._aggregate(Lf)
+    assert agg.min() == 0 and agg.max() == na - 1 and len(np.unique(agg)) == na and na < 0.5 * S.shape[0]
+    # every aggregate is connected through strong couplings to its root neighbourhood: members share a strong edge
+    G = sp.csr_matrix((np.ones(Lf.nnz), Lf.indices, Lf.indptr), shape=Lf.shape)
+    same = sp.csr_matrix((np.ones(len(agg)), (np.arange(len(agg)), agg)))
+    assert ((G @ same).multiply(same).sum(axis=1) > 0).all()          # each node has a neighbour (or itself) in its aggregate
+    omega = 0.6
+    P = amg._prolongator(Lf, agg, na, omega)
+    cnt = np.bincount(agg, minlength=na).astype(float)
+    P0 = sp.csr_matrix((1 / np.sqrt(cnt[agg]), (np.arange(len(agg)), agg)), shape=(len(agg), na))
+    refP = P0 - omega * (sp.diags(1 / Lf.diagonal()) @ Lf @ P0)
+    assert abs(P - refP).max() < 1e-13
+    lv = amg.build_hierarchy(sp.csr_matrix(-S + (50.0 + 5j) * sp.eye(S.shape[0])), coarse_size=40)
+    assert len(lv) >= 2 and lv[-1]["n"] <= 40 or len(lv) == 8
+    for a, b in zip(lv, lv[1:]):
+        assert abs(b["K"] - a["R"] @ a["K"] @ a["P"]).max() < 1e-9 * abs(b["K"]).max()      # Galerkin
+
+
+def test_cabi_argument_checks_return_codes_without_gpu():
+    from helmholtz_x import _hx
+    lib = _hx.lib
+    one = (C.c_double * 2)(1.0, 0.0)
+    assert lib.hx_zaxpy(-1, one, None, None, None) == -1                     # HX_ERR_ARG
+    assert b"hx_zaxpy" in lib.hx_last_error()
+    assert lib.hx_csr_spmv_z(5, 3, None, None, None, None, None, one, one, 0, None) == -1
+    assert lib.hx_assemble_p1_stiff_mass(4, 10, None, None, None, None, None, None, None, 0, None, None, None) == -1
+    # non-triangular factor is rejected by the host analysis before anything touches the device
+    rp = np.array([0, 1, 2], np.int32)
+    ci = np.array([1, 0], np.int32)
+    va = np.ones(2, np.complex128)
+    inv = np.ones(2, np.complex128)
+    h = C.c_void_p()
+    assert lib.hx_sptrsv_create(C.byref(h), 2, 1, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(va), _hx.nptr(inv)) == -1
+    assert b"lower" in lib.hx_last_error()
+    with pytest.raises(_hx.HxError):
+        _hx.check(-1)
+
+
+def test_annulus_generator_geometry_and_tags():
+    from helmholtz_x.synthetic import annulus, box, micca_sound_speed
+    from oracle import fem
+    mesh, sub, ft = annulus(6, 48, 8)
+    x, cells = mesh.geometry.x, mesh.topology.cells
+    assert x.shape[0] == 7 * 48 * 9 and cells.shape[0] == 6 * 48 * 8 * 6
+    _, vol = fem.cell_geometry(x, cells)
+    assert vol.min() > 0
+    exact = np.pi * (0.21 ** 2 - 0.14 ** 2) * 0.29
+    assert abs(vol.sum() - exact) / exact < 0.01                      # polygonal ring
+    area = fem.facet_measure(x, mesh.facets[ft.find(11)]).sum()
+    assert abs(area - np.pi * (0.21 ** 2 - 0.14 ** 2)) / area < 0.01
+    assert np.allclose(x[mesh.facets[ft.find(11)]][:, :, 2], 0.2)
+    assert sorted(np.unique(sub.values)) == list(range(16))
+    counts = np.bincount(sub.values)
+    assert counts.min() == counts.max() > 0                           # 16 identical burners
+    c = micca_sound_speed(mesh).x.array
+    zc = x[cells].mean(axis=1)[:, 2]
+    assert np.allclose(c, Micca.c_of_z(zc))
+    bm, _, bft = box(3, 2, 2)
+    assert bm.num_vertices == 4 * 3 * 3 and set(np.unique(bft.values)) == {1, 2, 3, 4, 5, 6}
+
+
+def test_gmsh_reader_agrees_with_oracle_reader(golden_dir):
+    from helmholtz_x.io_utils import XDMFReader
+    from oracle import meshes
+    for name, dim in (("rijke2d", 2), ("rijke3d", 3), ("micca_bloch_sector", 3)):
+        r = XDMFReader(os.path.join(golden_dir, "meshes", name))
+        mesh, ct, ft = r.getAll()
+        o = meshes.read_gmsh41(os.path.join(golden_dir, "meshes", name + ".msh"), dim)
+        assert np.array_equal(mesh.topology.cells, o.cells) and np.allclose(mesh.geometry.x, o.x)
+        assert np.array_equal(mesh.facets, o.facets) and np.array_equal(mesh.facet_cells, o.facet_cells)
+        assert np.array_equal(ft.values, o.facet_tags) and np.array_equal(ct.values, o.cell_tags)
+        assert r.dimension == dim
+
+
+def test_builtin_setups_and_fields_match_oracle():
+    from helmholtz_x.dolfinx_utils import OneDimensionalSetup, RectangleSetup
+    from helmholtz_x.parameters_utils import (c_step, density_step, gamma_function, gaussian, rho_step,
+                                              sound_speed_variable_gamma, temperature_step)
+    from oracle import fem, meshes
+    mesh, sub, ft = OneDimensionalSetup(50)
+    o = meshes.interval(50)
+    assert np.array_equal(mesh.topology.cells, o.cells) and np.allclose(mesh.geometry.x, o.x)
+    assert np.array_equal(mesh.facets[ft.find(1)].ravel(), [0]) and np.array_equal(mesh.facets[ft.find(2)].ravel(), [50])
+    assert np.array_equal(sub.indices, np.flatnonzero(o.cell_tags == 0))
+    mesh, sub, ft = RectangleSetup(8, 3, 0.4, 0.1)
+    o = meshes.rectangle(8, 3, 0.4, 0.1)
+    assert np.array_equal(np.sort(mesh.topology.cells, axis=1)[np.lexsort(np.sort(mesh.topology.cells, axis=1).T[::-1])],
+                          np.sort(o.cells, axis=1)[np.lexsort(np.sort(o.cells, axis=1).T[::-1])])
+    for tag in (1, 2, 3, 4):
+        assert len(ft.find(tag)) == (o.facet_tags == tag).sum()
+    T = temperature_step(mesh, Rijke.x_f(2), Rijke.T_u, Rijke.T_d)
+    assert T.name == "temperature"
+    assert np.allclose(sound_speed_variable_gamma(mesh, T).x.array, fem.sound_speed_variable_gamma(T.x.array))
+    assert np.allclose(gamma_function(T).x.array, fem.gamma_of_T(T.x.array))
+    assert np.isclose(gamma_function(300.0), fem.gamma_of_T(300.0))
+    assert c_step(mesh, Rijke.x_f(2), 1.0, 2.0).name == "soundspeed"
+    rho = rho_step(mesh, Rijke.x_f(2), Rijke.a_f, Rijke.rho_d, Rijke.rho_u)
+    assert np.allclose(rho.x.array, density_step(mesh.geometry.x[:, 0], 0.25, Rijke.a_f, Rijke.rho_d, Rijke.rho_u))
+    pts = mesh.geometry.x
+    assert np.allclose(gaussian(pts.T, Rijke.x_r(2), 0.025, 2), fem.gaussian(pts, Rijke.x_r(2)[0], 0.025, 2))
+
+
+def test_flame_transfer_functions_match_oracle(golden_dir):
+    from scipy.io import loadmat
+    from helmholtz_x.flame_transfer_function import nTau, stateSpace
+    from oracle import eigen
+    mat = loadmat(os.path.join(golden_dir, "micca_ftf.mat"))
+    a, b = stateSpace(mat['A'], mat['b'], mat['c'], mat['d']), eigen.StateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+    for w in (3225.12 + 481j, 1000.0, 50 - 20j):
+        assert np.isclose(a(w), b(w), rtol=1e-13) and np.isclose(a.derivative(w), b.derivative(w), rtol=1e-13)
+    n1, n2 = nTau(0.7, 1.5e-3), eigen.NTau(0.7, 1.5e-3)
+    for w in (1242.2 + 6.7j, 3.4):
+        assert np.isclose(n1(w), n2(w)) and np.isclose(n1.derivative(w), n2.derivative(w))

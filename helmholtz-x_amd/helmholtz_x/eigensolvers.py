@@ -100,7 +100,7 @@ def _flame_matrix(D, omega, problem_type):
     raise ValueError("The problem type should be specified as 'direct' or 'adjoint'.")
 
 
-def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history):
+def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history, state=None):
     """Relaxed secant fixed-point loop shared by the EPS and PEP variants (eigensolvers.py:143-193, 213-257).
 
     Only eigenpair ``i`` drives the iteration, so the intermediate solves ask the Krylov-Schur solver for i+1
@@ -110,6 +110,9 @@ def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history):
     f = np.zeros(maxiter, dtype=complex)
     alpha = np.zeros(maxiter, dtype=complex)
     lean = min(nev, i + 1)
+    if state is not None:
+        state["warm_pairs"] = nev - lean        # lean solves also hand over their best unconverged Ritz directions
+        state["lean_nev"] = lean
     E, omega[0] = solve_passive(lean)
     alpha[0] = 0.5
     if history is not None:
@@ -159,7 +162,7 @@ def fixed_point_iteration_eps(operators, D, target, nev=2, i=0, tol=1e-8, maxite
                        _caches=caches)
         return E, np.sqrt(E.getEigenvalue(i))
 
-    return _iterate(passive, active, nev, i, tol, maxiter, s, history)
+    return _iterate(passive, active, nev, i, tol, maxiter, s, history, caches[2])
 
 
 def fixed_point_iteration_pep(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,
@@ -179,7 +182,7 @@ def fixed_point_iteration_pep(operators, D, target, nev=2, i=0, tol=1e-8, maxite
         E = pep_solver(D_Mat, B, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches)
         return E, E.getEigenvalue(i)
 
-    return _iterate(passive, active, nev, i, tol, maxiter, s, history)
+    return _iterate(passive, active, nev, i, tol, maxiter, s, history, caches[2])
 
 
 def fixed_point_iteration(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,

@@ -411,3 +411,25 @@ def test_bloch_sector_equals_full_annulus_and_oracle():
     assert abs(p.x.array @ (Cs @ p.x.array) - 1.0) < 1e-10
     pm, ps = p.x.array[bloch.dofs_master], p.x.array[bloch.dofs_slave]
     assert np.max(np.abs(pm - bloch.f_b * ps)) < 1e-10 * np.max(np.abs(ps))
+
+
+def test_annulus_adjoint_eigenvalue_is_conjugate():
+    """MICCA-style adjoint run (active_fpi.py:64-69): D^T with conj(FTF(conj w)), B_adj = B^H, target conj(target).
+    The adjoint fixed point converges to the complex conjugate of the direct eigenvalue (as in the reference's
+    eigenvalues_adj.txt vs eigenvalues_dir.txt)."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.flame_matrices import PointwiseFlameMatrix
+    from helmholtz_x.parameters_utils import Q_multiple
+    case = _annulus_case((6, 64, 8))
+    P, mesh = case["P"], case["mesh"]
+    M = AcousticMatrices(mesh, case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    h = Q_multiple(mesh, case["subdomains"], P.N_sector)
+    D = PointwiseFlameMatrix(mesh, case["subdomains"], P.x_r(), h, P.rho_amb, P.q_0, P.u_b, case["ftf"])
+    D.assemble_submatrices('direct')
+    hd = []
+    fixed_point_iteration(M, D, P.target, i=0, nev=2, tol=1e-9, history=hd)
+    D.assemble_submatrices('adjoint')
+    ha = []
+    fixed_point_iteration(M, D, np.conj(P.target), i=0, nev=2, tol=1e-9, problem_type='adjoint', history=ha)
+    assert abs(ha[-1] - np.conj(hd[-1])) / abs(hd[-1]) < 1e-8

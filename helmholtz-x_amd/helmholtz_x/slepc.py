@@ -427,6 +427,15 @@ class PEP(_EigenSolverBase):
     def getType(self):
         return "toar"
 
+    def getEigenvector(self, i, vr, vi=None):
+        """x from the Ritz vector z = [x; lambda x] of the companion form: taken from the block of larger norm
+        (the relative accuracy of the small block is worse by the factor |lambda|), then normalised."""
+        n = vr.t.numel()
+        lam = self._eigs[i]
+        z = self._basis.V[i]
+        vr.t.copy_(z[n:2 * n] if abs(lam) >= 1.0 else z[:n])
+        vr.scale(1.0 / vr.norm())
+
     def solve(self):
         A, B, Cm = self._ops
         n = A.shape[0]

@@ -433,3 +433,81 @@ def test_annulus_adjoint_eigenvalue_is_conjugate():
     ha = []
     fixed_point_iteration(M, D, np.conj(P.target), i=0, nev=2, tol=1e-9, problem_type='adjoint', history=ha)
     assert abs(ha[-1] - np.conj(hd[-1])) / abs(hd[-1]) < 1e-8
+
+
+@pytest.mark.parametrize("workload", ["annulus-1M", "annulus-5M"])
+def test_full_size_operator_properties(workload):
+    """Size-independent properties at BASELINE's full sizes (no oracle run needed):
+    A 1 = 0 (constants are in the kernel of the stiffness form), 1^T C 1 = |Omega|, 1^T B 1 = (i/Z) int c ds,
+    symmetry x^T A y = y^T A x, and SpMV linearity."""
+    import bench
+    import torch
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.petsc import Vec
+    nr, nth, nz = bench.WORKLOADS[workload]
+    case = bench.build_case((nr, nth, nz))
+    P, mesh = case["P"], case["mesh"]
+    M = AcousticMatrices(mesh, case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    n = mesh.num_vertices
+    assert n == (nr + 1) * nth * (nz + 1)
+    ones = Vec(np.ones(n, dtype=complex))
+    y = Vec.zeros(n)
+    M.A.mult(ones, y)
+    scale = float(torch.abs(M.A.csr_part().val).max().item())
+    assert float(torch.abs(y.t).max().item()) < 1e-10 * scale
+    M.C.mult(ones, y)
+    vol = y.sum()
+    # volume of the polygonal ring (nth straight segments)
+    exact = 0.5 * nth * np.sin(2 * np.pi / nth) * (0.21 ** 2 - 0.14 ** 2) * 0.29
+    assert abs(vol - exact) / exact < 1e-10
+    M.B.mult(ones, y)
+    Z = (1 + P.R_outlet) / (1 - P.R_outlet)
+    c_out = np.sqrt(P.gamma * P.r * P.T_b)              # outlet cells: z > l_cc/ ... top layer has z_mid < l_cc -> profile
+    area = 0.5 * nth * np.sin(2 * np.pi / nth) * (0.21 ** 2 - 0.14 ** 2)
+    zc = 0.2 - 0.29 / nz * 0.25                          # centroid height of the tets touching the outlet plane
+    c_top = np.sqrt(P.gamma * P.r * ((P.T_b - P.T_a) * (zc / P.l_cc) ** 2 + P.T_a))
+    got = y.sum()
+    assert abs(got - 1j / Z * c_top * area) / abs(got) < 2e-2      # DG0 c of the adjacent cells (centroid rule)
+    rng = np.random.default_rng(0)
+    u = Vec(rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    v = Vec(rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    Au, Av = Vec.zeros(n), Vec.zeros(n)
+    M.A.mult(u, Au)
+    M.A.mult(v, Av)
+    vAu = torch.dot(v.t, Au.t).item()                  # bilinear (no conjugate)
+    uAv = torch.dot(u.t, Av.t).item()
+    assert abs(vAu - uAv) <= 1e-10 * abs(vAu)
+    w = u.copy()
+    w.axpy(2.0 - 1.0j, v)
+    Aw = Vec.zeros(n)
+    M.A.mult(w, Aw)
+    Aw.axpy(-1.0, Au)
+    Aw.axpy(-(2.0 - 1.0j), Av)
+    assert Aw.norm() <= 1e-12 * (Au.norm() + 3 * Av.norm())
+
+
+def test_full_size_eigenpair_residual_1M():
+    """The eigenpair returned by the 1 M-DOF fixed point satisfies (A + w B + w^2 C - FTF(w_k) sum a_f b_f^T) p = 0
+    with a backward error ~1e-9: residual checked with the product's own operators (size-independent property)."""
+    import bench
+    import torch
+    from helmholtz_x.petsc import Vec
+    case = bench.build_case(bench.WORKLOADS["annulus-1M"])
+    hist = []
+    E, M = bench.hot_path(case, None, nev=2, tol=1e-3, history=hist)
+    assert E.getConverged() >= 2
+    A_active = E.getOperators()[0]                     # A - D(w_k) as a lazy Mat (CSR + rank-16)
+    n = M.A.shape[0]
+    for i in range(2):
+        w = E.getEigenvalue(i)
+        p, _ = M.A.createVecs()
+        E.getEigenvector(i, p)
+        r, t = Vec.zeros(n), Vec.zeros(n)
+        A_active.mult(p, r)
+        M.B.mult(p, t)
+        r.axpy(w, t)
+        M.C.mult(p, t)
+        r.axpy(w * w, t)
+        # backward error: relative to ||A|| ||p|| (for a smooth mode ||A p|| itself is ~(h/wavelength)^2 ||A|| ||p||)
+        scale = float(torch.abs(A_active.csr_part().val).max().item()) * p.norm()
+        assert r.norm() <= 1e-9 * scale, (r.norm(), scale)

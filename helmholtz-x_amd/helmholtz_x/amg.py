@@ -19,7 +19,7 @@ import scipy.sparse as sp
 import torch
 
 from . import _hx
-from .petsc import CSR, to_device
+from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,

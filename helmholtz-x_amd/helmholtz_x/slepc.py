@@ -24,7 +24,7 @@ import torch
 
 from . import _hx
 from .krylov import default_ncv, krylov_schur
-from .petsc import Mat, Vec, combine_csr, panel_dot, to_device
+from .petsc import combine_csr, to_device
 from .solver_utils import info
 
 DEFAULTS = {"st_type": "auto", "lu_max_dofs": 20_000}

@@ -87,18 +87,6 @@ def sound_speed_variable_gamma(T):
     return np.sqrt(gamma_of_T(T) * 287.1 * T)
 
 
-def int_c2(c, cells, vol):
-    """int_K c^2 dx.  P1 c: exact (the degree-2 rule FFCx picks is exact for it); DG0 c: c_K^2 |K|.
-
-    acoustic_matrices.py:101 uses ``c**2``: the complex square, not |c|^2."""
-    c = np.asarray(c)
-    d = cells.shape[1] - 1
-    if c.shape[0] == cells.shape[0] and c.shape[0] != cells.max() + 1:
-        return c ** 2 * vol
-    cc = c[cells]
-    return vol / ((d + 1) * (d + 2)) * (cc.sum(axis=1) ** 2 + (cc ** 2).sum(axis=1))
-
-
 # ----------------------------------------------------------------------------- operators
 def apply_dirichlet(M, dofs):
     """DOLFINx assemble_matrix(bcs=...) semantics: zero rows+cols, diagonal = 1."""

@@ -26,6 +26,10 @@ int hx_csr_spmv_c(int role, int32_t, int64_t, const int32_t*, const int32_t*, co
 int hx_csr_jacobi_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
                     const float*, float*, float, hx_stream);
 int hx_cdiag_scale(int64_t, float, const float*, const float*, float*, hx_stream);
+int hx_csr_smooth_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, const hx_c128*,
+                    const hx_c128*, hx_c128*, double, const hx_c128*, double, hx_stream);
+int hx_csr_smooth_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
+                    const float*, float*, float, const float*, float, hx_stream);
 int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
 int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 
@@ -37,7 +41,8 @@ template <typename T> struct LevelT {
   int32_t n = 0;
   CsrT<T> K, P, R;             // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
   const T* dinv = nullptr;
-  T *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
+  double rho = 0.0;            // estimate of rho(D^-1 K) for the Chebyshev smoother (0: damped Jacobi with h->omega)
+  T *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
 };
 template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
 
@@ -59,12 +64,15 @@ static int op_spmv(const CsrT<double>& A, const double* x, double* y, double a, 
 static int op_spmv(const CsrT<float>& A, const float* x, float* y, float a, float b, bool transfer, hx_stream s) {
   return hx_csr_spmv_c(transfer ? 1 : 2, A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, s);
 }
-static int op_jacobi(const LevelT<double>& L, const double* b, const double* xin, double* xout, double w, hx_stream s) {
-  return hx_csr_jacobi_z(L.n, L.K.nnz, L.K.rp, L.K.ci, (const hx_c128*)L.K.va, (const hx_c128*)L.dinv, (const hx_c128*)b,
-                         (const hx_c128*)xin, (hx_c128*)xout, w, s);
+// xout = xin + w D^-1 (b - K xin) + mom (xin - xprev)     (xprev may be NULL)
+static int op_smooth(const LevelT<double>& L, const double* b, const double* xin, double* xout, double w,
+                     const double* xprev, double mom, hx_stream s) {
+  return hx_csr_smooth_z(L.n, L.K.nnz, L.K.rp, L.K.ci, (const hx_c128*)L.K.va, (const hx_c128*)L.dinv, (const hx_c128*)b,
+                         (const hx_c128*)xin, (hx_c128*)xout, w, (const hx_c128*)xprev, mom, s);
 }
-static int op_jacobi(const LevelT<float>& L, const float* b, const float* xin, float* xout, double w, hx_stream s) {
-  return hx_csr_jacobi_c(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, xin, xout, (float)w, s);
+static int op_smooth(const LevelT<float>& L, const float* b, const float* xin, float* xout, double w, const float* xprev,
+                     double mom, hx_stream s) {
+  return hx_csr_smooth_c(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, xin, xout, (float)w, xprev, (float)mom, s);
 }
 static int op_diag(const LevelT<double>& L, double w, const double* b, double* x, hx_stream s) {
   return hx_zdiag_scale(L.n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
@@ -85,8 +93,8 @@ extern "C" int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, doub
 
 extern "C" int hx_amg_destroy(hx_amg* h) {
   if (!h) return HX_OK;
-  for (auto& l : h->D.L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.b); (void)hipFree(l.r); }
-  for (auto& l : h->S.L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.b); (void)hipFree(l.r); }
+  for (auto& l : h->D.L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.x3); (void)hipFree(l.b); (void)hipFree(l.r); }
+  for (auto& l : h->S.L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.x3); (void)hipFree(l.b); (void)hipFree(l.r); }
   delete h;
   return HX_OK;
 }
@@ -109,6 +117,7 @@ static int set_level(HierT<T>& H, int l, int32_t n, int64_t nnzK, const int32_t*
     const size_t bytes = 2 * sizeof(T) * (size_t)n;
     HX_HIP(hipMalloc((void**)&L.x, bytes));
     HX_HIP(hipMalloc((void**)&L.x2, bytes));
+    HX_HIP(hipMalloc((void**)&L.x3, bytes));
     HX_HIP(hipMalloc((void**)&L.b, bytes));
     HX_HIP(hipMalloc((void**)&L.r, bytes));
   }
@@ -132,6 +141,13 @@ extern "C" int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, con
   return set_level<float>(h->S, l, n, nnzK, rpK, ciK, (const float*)vaK, (const float*)dinv, n_coarse, nnzP, rpP, ciP,
                           (const float*)vaP, nnzR, rpR, ciR, (const float*)vaR);
 }
+extern "C" int hx_amg_set_smoother(hx_amg* h, int l, double rho) {
+  HX_REQUIRE(h && l >= 0 && l < (int)h->D.L.size() && rho >= 0.0, "bad argument");
+  h->D.L[l].rho = rho;
+  h->S.L[l].rho = rho;
+  return HX_OK;
+}
+
 extern "C" int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                                  const hx_c128* va) {
   HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->D.L.back().n == n_c, "bad argument");
@@ -147,19 +163,44 @@ extern "C" int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const in
   return HX_OK;
 }
 
-// xout = V-cycle(b) on level l with zero initial guess (xout must not be L.x / L.x2 / b of that level).
+// Chebyshev coefficients for eigenvalues of D^-1 K in [lo, hi]: x_{k+1} = x_k + a_k D^-1 (b - K x_k) + c_k (x_k - x_{k-1})
+struct Cheb { double a[4], c[4]; };
+static Cheb cheb_coeffs(double rho) {
+  const double hi = 1.1 * rho, lo = 0.1 * hi;
+  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+  Cheb C;
+  double r_old = 1.0 / sigma;
+  C.a[0] = 1.0 / theta; C.c[0] = 0.0;
+  for (int k = 1; k < 4; ++k) {
+    const double r_new = 1.0 / (2.0 * sigma - r_old);
+    C.a[k] = 2.0 * r_new / delta;
+    C.c[k] = r_new * r_old;
+    r_old = r_new;
+  }
+  return C;
+}
+
+// xout = V-cycle(b) on level l with zero initial guess (xout must not be one of the level's x buffers or b).
+// Smoother: `pre` / `post` steps of damped Jacobi (rho == 0) or of a Chebyshev polynomial in D^-1 K (rho > 0).
 template <typename T>
 static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream s) {
   LevelT<T>& L = H.L[l];
   int rc;
   if (l == (int)H.L.size() - 1) return op_spmv(H.coarse_inv, b, xout, (T)1, (T)0, true, s);
-  T* cur = L.x;      // ping-pong between L.x and L.x2
-  // pre-smoothing: the first sweep from x = 0 is a diagonal scaling
-  if ((rc = op_diag(L, h->omega, b, cur, s))) return rc;
+  const bool cheb = L.rho > 0.0;
+  const Cheb C = cheb ? cheb_coeffs(L.rho) : Cheb();
+  T* bufs[3] = {L.x, L.x2, L.x3};
+  auto other = [&](const T* a, const T* c) -> T* { for (T* q : bufs) if (q != a && q != c) return q; return nullptr; };
+  T* cur = L.x;
+  T* prev = nullptr;
+  // pre-smoothing from x = 0: the first step is a diagonal scaling
+  if ((rc = op_diag(L, cheb ? C.a[0] : h->omega, b, cur, s))) return rc;
   for (int k = 1; k < h->pre; ++k) {
-    T* nxt = (cur == L.x) ? L.x2 : L.x;
-    if ((rc = op_jacobi(L, b, cur, nxt, h->omega, s))) return rc;
-    cur = nxt;
+    T* nxt = other(cur, prev);
+    if (cheb) {   // for k = 1 the previous iterate is the zero start vector (prev == nullptr)
+      if ((rc = op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], s))) return rc;
+    } else if ((rc = op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s))) return rc;
+    prev = cur; cur = nxt;
   }
   // residual r = b - K x, restrict
   HX_HIP(hipMemcpyAsync(L.r, b, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
@@ -169,11 +210,13 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
   if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s))) return rc;
   if ((rc = op_spmv(L.P, ec, cur, (T)1, (T)1, true, s))) return rc;    // x += P e_c
-  // post-smoothing: every sweep reads `cur` and writes the other buffer; the last one writes xout
+  // post-smoothing: a fresh polynomial started from the corrected x; the last step writes xout
+  prev = nullptr;
   for (int k = 0; k < h->post; ++k) {
-    T* dst = (k == h->post - 1) ? xout : (cur == L.x ? L.x2 : L.x);
-    if ((rc = op_jacobi(L, b, cur, dst, h->omega, s))) return rc;
-    cur = dst;
+    T* dst = (k == h->post - 1) ? xout : other(cur, prev);
+    if (cheb) { if ((rc = op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s))) return rc; }
+    else if ((rc = op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s))) return rc;
+    prev = cur; cur = dst;
   }
   if (h->post == 0)
     HX_HIP(hipMemcpyAsync(xout, cur, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));

@@ -109,13 +109,15 @@ int hx_csr_spmv_c(int role, int32_t n_rows, int64_t nnz, const int32_t* rowptr, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused damped-Jacobi sweep (AMG smoother):  xout = xin + omega * dinv .* (b - A xin).
-// Same streaming pattern and traffic as the SpMV plus one read of b, dinv and xin per row.
+// Fused smoother sweep (AMG):  xout = xin + omega * dinv .* (b - A xin) + mom * (xin - xprev).
+// mom = 0: damped Jacobi (xprev unused; a NULL xprev with mom != 0 means the previous iterate was 0); with the Chebyshev coefficients (omega_k, mom_k) the same kernel is one
+// step of the Chebyshev three-term recurrence on D^-1 A.  Same streaming pattern and traffic as the SpMV plus one
+// read of b, dinv, xin (and xprev) per row.
 template <int LPR, typename V>
 __global__ void __launch_bounds__(256)
 k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const V* __restrict__ val,
          const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xin, V* __restrict__ xout,
-         typename real_of<V>::type omega) {
+         typename real_of<V>::type omega, const V* __restrict__ xprev, typename real_of<V>::type mom) {
   constexpr int RPB = 256 / LPR;
   const int sub = threadIdx.x % LPR;
   const int64_t stride = (int64_t)gridDim.x * RPB;
@@ -127,8 +129,10 @@ k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restric
     if (LPR > 1) acc = zreduce_sub<LPR>(acc);
     if (row < n && sub == 0) {
       const V r = zsub(b[row], acc);
-      V x = xin[row];
+      const V x0 = xin[row];
+      V x = x0;
       zfma(x, zscale(omega, dinv[row]), r);
+      if (mom != 0) x = zadd(x, zscale(mom, xprev ? zsub(x0, xprev[row]) : x0));   // xprev == NULL: previous iterate is 0
       xout[row] = x;
     }
   }
@@ -137,14 +141,14 @@ k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restric
 template <typename V>
 static int jacobi_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const V* val,
                            const V* dinv, const V* b, const V* xin, V* xout, typename real_of<V>::type omega,
-                           hx_stream s) {
+                           const V* xprev, typename real_of<V>::type mom, hx_stream s) {
   HX_REQUIRE(n_rows >= 0 && rowptr && col && val && dinv && b && xin && xout && xin != xout, "bad argument");
   if (n_rows == 0) return HX_OK;
   int lpr = pick_lpr(nnz, n_rows);
   if (lpr < 2) lpr = 2;
   if (lpr > 32) lpr = 32;
 #define HX_GO(L) k_jacobi<L, V><<<hx_grid((int64_t)n_rows, 256 / L, 256 * 16), 256, 0, hx_s(s)>>>(                \
-      n_rows, rowptr, col, val, dinv, b, xin, xout, omega)
+      n_rows, rowptr, col, val, dinv, b, xin, xout, omega, xprev, mom)
   switch (lpr) {
     case 2: HX_GO(2); break;
     case 4: HX_GO(4); break;
@@ -161,12 +165,25 @@ extern "C" int hx_csr_jacobi_z(int32_t n_rows, int64_t nnz, const int32_t* rowpt
                                const hx_c128* val, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin,
                                hx_c128* xout, double omega, hx_stream s) {
   return jacobi_dispatch<zc>(n_rows, nnz, rowptr, col, (const zc*)val, (const zc*)dinv, (const zc*)b, (const zc*)xin,
-                             (zc*)xout, omega, s);
+                             (zc*)xout, omega, nullptr, 0.0, s);
+}
+// internal: three-term (Chebyshev) form; xprev may be NULL (plain damped Jacobi)
+int hx_csr_smooth_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+                    const hx_c128* dinv, const hx_c128* b, const hx_c128* xin, hx_c128* xout, double omega,
+                    const hx_c128* xprev, double mom, hx_stream s) {
+  return jacobi_dispatch<zc>(n_rows, nnz, rowptr, col, (const zc*)val, (const zc*)dinv, (const zc*)b, (const zc*)xin,
+                             (zc*)xout, omega, (const zc*)xprev, mom, s);
 }
 int hx_csr_jacobi_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val,
                     const float* dinv, const float* b, const float* xin, float* xout, float omega, hx_stream s) {
   return jacobi_dispatch<cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)dinv, (const cc*)b, (const cc*)xin,
-                             (cc*)xout, omega, s);
+                             (cc*)xout, omega, nullptr, 0.f, s);
+}
+int hx_csr_smooth_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val,
+                    const float* dinv, const float* b, const float* xin, float* xout, float omega, const float* xprev,
+                    float mom, hx_stream s) {
+  return jacobi_dispatch<cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)dinv, (const cc*)b, (const cc*)xin,
+                             (cc*)xout, omega, (const cc*)xprev, mom, s);
 }
 
 // x = scale .* d .* b  (first Jacobi sweep from a zero initial guess; also a diagonal preconditioner)

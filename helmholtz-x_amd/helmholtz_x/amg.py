@@ -23,7 +23,7 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed")
+              max_it=200, precision="mixed", smoother="chebyshev")
 
 
 def _aggregate(S):
@@ -113,7 +113,7 @@ def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], c
         R.sort_indices()
         # smoother: damped Jacobi on K itself; rho(D^-1 L) differs from rho(Df^-1 Lf) only by the lumped weak
         # couplings (a few per cent), so the estimate is reused with a margin instead of a second power iteration
-        level.update(P=P, R=R, dinv=1.0 / diag, omega=4.0 / (3.0 * 1.05 * rho), n_coarse=na)
+        level.update(P=P, R=R, dinv=1.0 / diag, omega=4.0 / (3.0 * 1.05 * rho), rho=1.05 * rho, n_coarse=na)
         levels.append(level)
         Kl = (R @ Kl @ P).tocsr()
         Kl.sort_indices()
@@ -171,6 +171,8 @@ class AMGSolver:
                 _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), _hx.ptr(dinv),
                                     lv["n_coarse"], pnnz, _hx.ptr(prp), _hx.ptr(pci), _hx.ptr(pva), rnnz,
                                     _hx.ptr(rrp), _hx.ptr(rci), _hx.ptr(rva)))
+                if self.params["smoother"] == "chebyshev":
+                    _hx.check(_hx.lib.hx_amg_set_smoother(h, l, float(lv["rho"])))
             else:
                 _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), None, 0, 0, None,
                                     None, None, 0, None, None, None))

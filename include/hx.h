@@ -176,6 +176,10 @@ int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t* r
                      const hx_c128* vaK, const hx_c128* dinv, int32_t n_coarse, int64_t nnzP,
                      const int32_t* rpP, const int32_t* ciP, const hx_c128* vaP, int64_t nnzR,
                      const int32_t* rpR, const int32_t* ciR, const hx_c128* vaR);
+/* Smoother of level l: rho = 0 -> `pre`/`post` damped-Jacobi sweeps with the weight given to hx_amg_create;
+ * rho > 0 (estimate of the spectral radius of D^-1 K_l) -> Chebyshev polynomial of degree pre/post on D^-1 K_l
+ * targeting [0.11 rho, 1.1 rho], evaluated by the same fused kernel as a three-term recurrence. */
+int hx_amg_set_smoother(hx_amg* h, int l, double rho);
 /* dense inverse of the coarsest operator, passed as a (dense) CSR */
 int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                       const hx_c128* va);

@@ -10,8 +10,10 @@
 // The V-cycle -- a preconditioner, i.e. only an approximation of K^-1 by construction -- may run on a complex64
 // copy of the hierarchy, which halves its HBM traffic; GMRES is therefore the FLEXIBLE variant (it stores
 // z_j = M^-1 v_j), which converges to the full double-precision residual whatever the preconditioner does.
+#include <algorithm>
 #include <cmath>
 #include <complex>
+#include <thread>
 #include <vector>
 
 #include "hx_common.h"
@@ -479,6 +481,65 @@ extern "C" int hx_host_sa_prolongator(int32_t n, const int32_t* rp, const int32_
     if (!out_ci) { out_rp[i + 1] = out_rp[i] + (int32_t)cols.size(); continue; }
     int32_t q = out_rp[i];
     for (size_t k = 0; k < cols.size(); ++k, ++q) { out_ci[q] = cols[k]; out_v[q] = vals[k]; }
+  }
+  return HX_OK;
+}
+
+
+// Galerkin coarse operator Kc = R K P in ONE fused pass over the coarse rows (host, multi-threaded):
+//   Kc[I, J] = sum_{i in R(I)} sum_{j in K(i)} sum_{J in P(j)} R_Ii K_ij P_jJ        (R, P real; K complex)
+// Each thread owns a contiguous block of coarse rows and a private dense marker/accumulator, so no intermediate
+// K P is ever materialised (SciPy's two SpGEMMs were ~55 % of the hierarchy set-up at 5 M DOF).
+// Two calls: out_ci == NULL -> row pointer (count pass); then fill (columns sorted per row).
+extern "C" int hx_host_galerkin_rap(int32_t n_c, const int32_t* Rrp, const int32_t* Rci, const double* Rv,
+                                    const int32_t* Krp, const int32_t* Kci, const hx_c128* Kv,
+                                    const int32_t* Prp, const int32_t* Pci, const double* Pv,
+                                    int32_t* out_rp, int32_t* out_ci, hx_c128* out_v, int n_threads) {
+  HX_REQUIRE(n_c > 0 && Rrp && Rci && Rv && Krp && Kci && Kv && Prp && Pci && Pv && out_rp, "bad argument");
+  const bool fill = out_ci != nullptr;
+  HX_REQUIRE(!fill || out_v, "bad argument");
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 64) n_threads = 64;
+  if (n_threads > n_c) n_threads = n_c;
+  std::vector<int32_t> counts(fill ? 0 : (size_t)n_c);
+  auto work = [&](int t) {
+    const int32_t I0 = (int32_t)((int64_t)n_c * t / n_threads), I1 = (int32_t)((int64_t)n_c * (t + 1) / n_threads);
+    std::vector<int32_t> marker((size_t)n_c, -1);      // marker[J] = position of J in the current row's list
+    std::vector<int32_t> cols;
+    std::vector<cd> vals;
+    std::vector<int32_t> order;
+    for (int32_t I = I0; I < I1; ++I) {
+      cols.clear(); vals.clear();
+      for (int32_t a = Rrp[I]; a < Rrp[I + 1]; ++a) {
+        const int32_t i = Rci[a];
+        const double r = Rv[a];
+        for (int32_t b = Krp[i]; b < Krp[i + 1]; ++b) {
+          const int32_t j = Kci[b];
+          const cd rk = r * cd(Kv[b].re, Kv[b].im);
+          for (int32_t c = Prp[j]; c < Prp[j + 1]; ++c) {
+            const int32_t J = Pci[c];
+            int32_t pos = marker[J];
+            if (pos < 0) { pos = (int32_t)cols.size(); marker[J] = pos; cols.push_back(J); if (fill) vals.push_back(cd(0)); }
+            if (fill) vals[pos] += rk * Pv[c];
+          }
+        }
+      }
+      for (int32_t J : cols) marker[J] = -1;
+      if (!fill) { counts[I] = (int32_t)cols.size(); continue; }
+      order.resize(cols.size());
+      for (size_t q = 0; q < cols.size(); ++q) order[q] = (int32_t)q;
+      std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cols[x] < cols[y]; });
+      int32_t o = out_rp[I];
+      for (int32_t q : order) { out_ci[o] = cols[q]; out_v[o].re = vals[q].real(); out_v[o].im = vals[q].imag(); ++o; }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto& th : pool) th.join();
+  if (!fill) {
+    out_rp[0] = 0;
+    for (int32_t I = 0; I < n_c; ++I) out_rp[I + 1] = out_rp[I] + counts[I];
   }
   return HX_OK;
 }

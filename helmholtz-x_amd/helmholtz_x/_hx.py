@@ -65,6 +65,7 @@ SIGNATURES = {
                            C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_host_aggregate": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "hx_host_sa_filter": (C.c_int, [_i32, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
+    "hx_host_galerkin_rap": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "hx_host_sa_prolongator": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
 }
 

@@ -214,6 +214,12 @@ int hx_host_aggregate(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const
 int hx_host_sa_prolongator(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_lf,
                            const int32_t* h_agg, const double* h_inv_sqrt_cnt, double omega,
                            int32_t* h_out_rp, int32_t* h_out_ci, double* h_out_v);
+/* HOST, multi-threaded: Galerkin product Kc = R K P (R, P real CSR; K complex CSR) fused over coarse rows, no
+ * intermediate K P.  Same two-call protocol (h_out_ci == NULL: count pass); columns sorted per row. */
+int hx_host_galerkin_rap(int32_t n_c, const int32_t* h_Rrp, const int32_t* h_Rci, const double* h_Rv,
+                         const int32_t* h_Krp, const int32_t* h_Kci, const hx_c128* h_Kv,
+                         const int32_t* h_Prp, const int32_t* h_Pci, const double* h_Pv,
+                         int32_t* h_out_rp, int32_t* h_out_ci, hx_c128* h_out_v, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -247,3 +247,30 @@ extern "C" int hx_zsparse_dots(int nvec, const int32_t* ptr, const int32_t* idx,
   HX_LAUNCH_CHECK("k_sparse_dots");
   return HX_OK;
 }
+
+
+// ---------------------------------------------------------------- threshold + compaction of a load vector
+// flame_matrices.py:66-72: zero |Re| < tol and |Im| < tol separately, keep the non-zeros as (index, value) pairs.
+// The supports are tiny compared with n, so only the packed pairs travel to the host (order fixed there by sorting
+// the indices; the atomic counter only hands out slots).
+__global__ void k_threshold_pack(int64_t n, const zc* __restrict__ x, double tol, int32_t cap, int32_t* __restrict__ count,
+                                 int32_t* __restrict__ idx, zc* __restrict__ val) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    zc v = x[i];
+    if (fabs(v.x) < tol) v.x = 0.0;
+    if (fabs(v.y) < tol) v.y = 0.0;
+    if (v.x != 0.0 || v.y != 0.0) {
+      const int32_t pos = atomicAdd(count, 1);
+      if (pos < cap) { idx[pos] = (int32_t)i; val[pos] = v; }
+    }
+  }
+}
+extern "C" int hx_zthreshold_pack(int64_t n, const hx_c128* x, double tol, int32_t cap, int32_t* count, int32_t* idx,
+                                  hx_c128* val, hx_stream s) {
+  HX_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX && x && cap >= 0 && count && idx && val, "bad argument");
+  HX_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), hx_s(s)));
+  if (n == 0) return HX_OK;
+  k_threshold_pack<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, (const zc*)x, tol, cap, count, idx, (zc*)val);
+  HX_LAUNCH_CHECK("k_threshold_pack");
+  return HX_OK;
+}

@@ -32,6 +32,7 @@ SIGNATURES = {
     "hx_zpanel_sub": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp]),
     "hx_zpanel_mul": (C.c_int, [_i64, _int, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
     "hx_zsparse_dots": (C.c_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hx_zthreshold_pack": (C.c_int, [_i64, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp]),
     "hx_csr_spmv_z": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _dp, _dp, _int, _vp]),
     "hx_build_v2e": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp]),
     "hx_p1_pattern_count": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),

@@ -65,11 +65,26 @@ class FlameMatrix:
         return self._D_ij_adj
 
     def indices_and_values(self, device_vector):
-        packed = device_vector.cpu().numpy().copy()
-        packed.real[np.abs(packed.real) < self.tol] = 0.0
-        packed.imag[np.abs(packed.imag) < self.tol] = 0.0
-        indices = np.flatnonzero(packed).astype(np.int32)
-        return indices, packed[indices]
+        """Threshold rule of the reference (:66-72) applied on the device; only the packed support travels to the host."""
+        import torch
+        from . import _hx
+        n = device_vector.numel()
+        cap = min(n, 1 << 20)
+        count = torch.zeros(1, dtype=torch.int32, device=device_vector.device)
+        idx = torch.empty(cap, dtype=torch.int32, device=device_vector.device)
+        val = torch.empty(cap, dtype=torch.complex128, device=device_vector.device)
+        _hx.check(_hx.lib.hx_zthreshold_pack(n, _hx.ptr(device_vector), float(self.tol), cap, _hx.ptr(count), _hx.ptr(idx),
+                                             _hx.ptr(val), _hx.stream()))
+        m = int(count.item())
+        if m > cap:                                   # very wide support: fall back to one full download
+            packed = device_vector.cpu().numpy().copy()
+            packed.real[np.abs(packed.real) < self.tol] = 0.0
+            packed.imag[np.abs(packed.imag) < self.tol] = 0.0
+            indices = np.flatnonzero(packed).astype(np.int32)
+            return indices, packed[indices]
+        indices, values = idx[:m].cpu().numpy(), val[:m].cpu().numpy()
+        order = np.argsort(indices, kind="stable")
+        return indices[order].astype(np.int32), values[order]
 
     def _store(self, pairs, problem_type):
         n = self.global_size

@@ -76,6 +76,12 @@ int hx_zpanel_mul(int64_t n, int m, int kout, const hx_c128* V, int64_t ldv, con
 int hx_zsparse_dots(int nvec, const int32_t* ptr, const int32_t* idx, const hx_c128* vals,
                     const hx_c128* y, hx_c128* out, hx_stream s);
 
+/* Threshold + pack a load vector (flame_matrices.py:66-72): entries with |Re| < tol / |Im| < tol zeroed separately,
+ * surviving (index, value) pairs written to idx/val (capacity cap) in arbitrary order, *count = number found
+ * (may exceed cap: then only cap pairs were stored). */
+int hx_zthreshold_pack(int64_t n, const hx_c128* x, double tol, int32_t cap, int32_t* count, int32_t* idx,
+                       hx_c128* val, hx_stream s);
+
 /* ------------------------------------------------------------------ CSR SpMV (PETSc MatMult)
  * replaces: MatMult inside EPSSolve/PEPSolve (eigensolvers.py:62,113), Mat.mult
  * (petsc4py_utils.py:85,95).  y = alpha*A*x + beta*y.  lanes_per_row: 0 = choose from nnz/n_rows,

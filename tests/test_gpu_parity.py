@@ -511,3 +511,41 @@ def test_full_size_eigenpair_residual_1M():
         # backward error: relative to ||A|| ||p|| (for a smooth mode ||A p|| itself is ~(h/wavelength)^2 ||A|| ||p||)
         scale = float(torch.abs(A_active.csr_part().val).max().item()) * p.norm()
         assert r.norm() <= 1e-9 * scale, (r.norm(), scale)
+
+
+def test_rijke3d_logged_trajectory_with_iterative_inner_solver(ref_logs, golden_dir):
+    """The AMG + flexible-GMRES inner solver (complex64 V-cycle) reproduces the reference's LOGGED Rijke-3D active
+    trajectory to 1e-8, i.e. the iterative path is pinned to the reference directly, not only to the direct path."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.parameters_utils import c_step
+    g = ref_logs["rijke3d"]
+    mesh, subdomains, facet_tags = XDMFReader(os.path.join(golden_dir, "meshes", "rijke3d")).getAll()
+    M = AcousticMatrices(mesh, facet_tags, {t: {'Neumann'} for t in (1, 2, 3)}, c_step(mesh, Rijke.x_f(3), Rijke.c_u, Rijke.c_d))
+    D = _distributed_flame(mesh, 3)[0]
+    D.assemble_submatrices()
+    hist = []
+    fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, st_type="amg", history=hist)
+    _check_traj(hist, g["trajectory"])
+
+
+def test_dirichlet_eigenproblem_matches_oracle():
+    """Dirichlet rows/cols (acoustic_matrices.py:60-66,102,122): spurious unit eigenvalues aside, the physical modes
+    of a box with one pressure-release wall agree with the oracle."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.dolfinx_utils import RectangleSetup
+    from helmholtz_x.eigensolvers import eps_solver
+    from helmholtz_x.parameters_utils import c_uniform
+    from oracle import eigen, fem
+    mesh, subdomains, facet_tags = RectangleSetup(40, 10, 0.4, 0.1)
+    M = AcousticMatrices(mesh, facet_tags, {2: {'Dirichlet'}, 1: {'Neumann'}}, c_uniform(mesh, 450.0))
+    assert len(M.bcs_Dirichlet) == 1
+    target = 2 * np.pi * 300.0                          # quarter-wave mode: c/(4L) = 281 Hz
+    E = eps_solver(M.A, M.C, target, nev=1)
+    x, cells = mesh.geometry.x, mesh.topology.cells
+    dofs = np.unique(mesh.facets[facet_tags.find(2)])
+    ref = eigen.eps_solve(fem.assemble_A(x, cells, np.full(x.shape[0], 450.0), dofs), fem.assemble_C(x, cells, dofs), target, 1)
+    w, wr = np.sqrt(E.getEigenvalue(0)), np.sqrt(ref.eigs[0])
+    assert abs(w - wr) / abs(wr) < 1e-8
+    assert abs(w / (2 * np.pi) - 450.0 / 1.6) < 1.0       # analytic quarter-wave frequency 281.25 Hz

@@ -149,6 +149,10 @@ class AMGSolver:
         import time
         t_setup = time.perf_counter()
         self.params = dict(PARAMS, **overrides)
+        import os
+        for key in ("pre", "post"):                       # experiment hooks (tools/): HX_AMG_PRE / HX_AMG_POST
+            if os.environ.get("HX_AMG_" + key.upper()):
+                self.params[key] = int(os.environ["HX_AMG_" + key.upper()])
         self.n = K_csr.shape[0]
         self.K = K_csr
         dev = K_csr.val.device

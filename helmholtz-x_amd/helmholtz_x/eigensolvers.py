@@ -1,7 +1,8 @@
 """Eigen-solvers with the reference's signatures, running on the GPU.
 
 Drop-in for ``helmholtz_x.eigensolvers`` (reference: eigensolvers.py:8-276): ``results``, ``eps_solver``,
-``pep_solver``, ``fixed_point_iteration_eps``, ``fixed_point_iteration_pep``, ``fixed_point_iteration``.
+``pep_solver``, ``fixed_point_iteration_eps``, ``fixed_point_iteration_pep``, ``fixed_point_iteration``,
+``newtonSolver``.
 Same update rule (relaxed secant fixed point, alpha_0 = 0.5), same printed log lines, same returned
 solver object ``E``.
 
@@ -190,3 +191,47 @@ def fixed_point_iteration(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50
     solver = fixed_point_iteration_pep if operators.B else fixed_point_iteration_eps
     return solver(operators, D, target, nev=nev, i=i, tol=tol, maxiter=maxiter, print_results=print_results,
                   problem_type=problem_type, st_type=st_type, history=history)
+
+
+def newtonSolver(operators, D, init, nev=2, i=0, tol=1e-3, maxiter=100, print_results=False, st_type=None):
+    """Two-sided Newton iteration on lambda(omega) of L(omega) p = lambda C p (reference: eigensolvers.py:278-348).
+
+    Same update as the reference, including its geometrically decaying relaxation (relaxation *= 0.8 every
+    iteration, :336-337) -- which is why the reference's own Newton logs stop short of the fixed-point eigenvalue;
+    ``maxiter`` is enforced.  Returns (omega, p) like the reference."""
+    from .eigenvectors import normalize_eigenvector
+    from .petsc4py_utils import vector_matrix_vector
+    A, B, C = operators.A, operators.B, operators.C
+    omega = np.zeros(maxiter + 1, dtype=complex)
+    omega[0] = init
+    domega = 2 * tol
+    k = 0
+    s = _fmt(tol)
+    relaxation = 1.0
+    info("-> Newton solver started.\n")
+    p = None
+    while abs(domega) > tol and k < maxiter:
+        D.assemble_matrix(omega[k])
+        if not B:
+            L = A + omega[k] ** 2 * C - D.matrix
+            dL_domega = 2 * omega[k] * C - D.get_derivative(omega[k])
+        else:
+            L = A + omega[k] * B + omega[k] ** 2 * C - D.matrix
+            dL_domega = B + (2 * omega[k] * C) - D.get_derivative(omega[k])
+        # L(omega) p = lambda C p, eigenvalue nearest zero (shift-and-invert at 0), with left eigenvectors
+        E = eps_solver(L, -C, 0, nev, two_sided=True, print_results=print_results, st_type=st_type)
+        eig = E.getEigenvalue(i)
+        omega_dir, p = normalize_eigenvector(operators.mesh, E, i, degree=1, which='right', print_eigs=False)
+        omega_adj, p_adj = normalize_eigenvector(operators.mesh, E, i, degree=1, which='left', print_eigs=False)
+        p_vec, p_adj_vec = p.x.petsc_vec, p_adj.x.petsc_vec
+        num = vector_matrix_vector(p_adj_vec, dL_domega, p_vec)
+        den = vector_matrix_vector(p_adj_vec, C, p_vec)
+        deig = num / den
+        domega = -relaxation * eig / deig
+        relaxation *= 0.8
+        omega[k + 1] = omega[k] + domega
+        print('iter = {:2d},  omega = {}  {}j,  |domega| = {:.2e}'.format(
+            k, s.format(omega[k + 1].real), s.format(omega[k + 1].imag), abs(domega)))
+        k += 1
+        E.destroy()
+    return omega[k], p

@@ -18,9 +18,10 @@ def normalize_eigenvector(mesh, obj, i, absolute=False, degree=1, which='right',
     vr, vi = A.createVecs()
     if isinstance(obj, EPS):
         omega = np.sqrt(obj.getEigenvalue(i))
-        if which != 'right':
-            raise NotImplementedError("left eigenvectors belong to the newtonSolver row (SURVEY.md 8f-2)")
-        obj.getEigenvector(i, vr, vi)
+        if which == 'right':
+            obj.getEigenvector(i, vr, vi)
+        elif which == 'left':
+            obj.getLeftEigenvector(i, vr, vi)
     elif isinstance(obj, PEP):
         omega = obj.getEigenpair(i, vr, vi)
     else:

@@ -201,7 +201,9 @@ class P1Assembler:
         return rowptr, col
 
     def _csr(self, val):
-        return CSR((self.n, self.n), self.rowptr, self.col, val, pattern_id=self.pattern_id)
+        out = CSR((self.n, self.n), self.rowptr, self.col, val, pattern_id=self.pattern_id)
+        out.symmetric = True            # Galerkin P1 operators are (complex) symmetric: transpose() is the identity
+        return out
 
     @staticmethod
     def _field(f):

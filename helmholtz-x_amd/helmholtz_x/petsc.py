@@ -148,7 +148,9 @@ class CSR:
         return sp.csr_matrix((self.val.cpu().numpy(), ci.copy(), rp.copy()), shape=self.shape)
 
     def with_values(self, val):
-        return CSR(self.shape, self.rowptr, self.col, val, self._h_rowptr, self._h_col, self.pattern_id)
+        out = CSR(self.shape, self.rowptr, self.col, val, self._h_rowptr, self._h_col, self.pattern_id)
+        out.symmetric = getattr(self, "symmetric", False)
+        return out
 
     def spmv(self, x, y, alpha=1.0, beta=0.0, lanes=0):
         _hx.check(_hx.lib.hx_csr_spmv_z(self.shape[0], self.nnz, _hx.ptr(self.rowptr), _hx.ptr(self.col),
@@ -283,8 +285,9 @@ class Mat:
 
     def transpose(self):
         """In place, like petsc4py (acoustic_matrices.py:113).  The CSR transpose is integer/structural work done
-        once on the host; values are re-uploaded."""
-        self.csr_terms = [(c, CSR.from_scipy(m.to_scipy().T.tocsr())) for c, m in self.csr_terms]
+        once on the host; values are re-uploaded.  Terms flagged symmetric (the P1 operators A, B, C) are kept."""
+        self.csr_terms = [(c, m if getattr(m, "symmetric", False) else CSR.from_scipy(m.to_scipy().T.tocsr()))
+                          for c, m in self.csr_terms]
         self.lr_terms = [(c, m.transposed()) for c, m in self.lr_terms]
         self._mat = None
         return self

@@ -265,6 +265,7 @@ class _EigenSolverBase:
         self.inner_cache = None
         self.state = None            # shared across the solves of one fixed-point iteration (warm start, counters)
         self._tol_floor = 0.0
+        self._left = None            # solver of the transposed pencil (two-sided mode)
 
     # --- slepc4py configuration surface (eigensolvers.py:43-60, 96-109)
     def create(self, comm=None):
@@ -290,8 +291,16 @@ class _EigenSolverBase:
         pass                        # TARGET_MAGNITUDE only
 
     def setTwoSided(self, flag):
-        if flag:
-            raise NotImplementedError("two-sided solves belong to the newtonSolver row (SURVEY.md 8f-2)")
+        self._two_sided = bool(flag)
+
+    def getLeftEigenvector(self, i, vr, vi=None):
+        """y with y^H A = lambda y^H M: the conjugate of the i-th right eigenvector of the TRANSPOSED pencil (same
+        spectrum), computed by a second Krylov-Schur run when two-sided mode is on (eigensolvers.py:56,319)."""
+        if self._left is None:
+            raise RuntimeError("left eigenvectors need setTwoSided(True) before solve()")
+        lam = self._eigs[i]
+        j = int(np.argmin(np.abs(self._left._eigs - lam)))
+        vr.t.copy_(torch.conj_physical(self._left._basis.V[j][:vr.t.numel()]))
 
     def setDimensions(self, nev, ncv=None, mpd=None):
         self._nev = int(nev)
@@ -419,6 +428,18 @@ class EPS(_EigenSolverBase):
             solver.solve(tmp, w)
 
         self._finish(DeviceBasis(n, self._ncv_for(n) + 1, op, start=self._start()), sigma)
+        if self._two_sided:
+            left = EPS()
+            At, Mt = A.copy(), M.copy()
+            At.transpose()
+            Mt.transpose()
+            left.setOperators(At, Mt)
+            left.setTarget(sigma)
+            left.setDimensions(self._nev, self._ncv)
+            left.setTolerances(self._tol, self._max_it)
+            left.st_type = self.st_type
+            left.solve()
+            self._left = left
 
 
 class PEP(_EigenSolverBase):

@@ -179,3 +179,31 @@ def bloch_maps(n, dofs_master, dofs_slave, N, b=1.0):
 def blochify(M, BN, NB):
     """bloch_operator.py:104-111."""
     return (NB @ M.tocsr() @ BN).tocsr()
+
+
+def newton_solver(A, B, C, flame, dflame, init, i=0, tol=1e-3, maxiter=100):
+    """eigensolvers.py:278-348 restated with dense LAPACK (small cases only).  ``flame(omega)`` / ``dflame(omega)``
+    return the explicit D(omega) and dD/domega.  Reproduces the reference's quirks: relaxation *= 0.8 per iteration
+    and ``vector_matrix_vector`` = PETSc ``y.dot(A x)`` = (A x)^H y, i.e. the conjugate of y^H A x (petsc4py_utils.py:57-87)."""
+    import scipy.linalg as sla
+    omega = [complex(init)]
+    relaxation = 1.0
+    domega = 2 * tol
+    k = 0
+    Cd = C.toarray()
+    while abs(domega) > tol and k < maxiter:
+        w = omega[-1]
+        Bk = B if B is not None else sp.csr_matrix(A.shape, dtype=complex)
+        L = (A + w * Bk + w ** 2 * C - flame(w)).toarray()
+        dL = (Bk + 2 * w * C - dflame(w)).toarray()
+        lam, vl, vr = sla.eig(L, Cd, left=True, right=True)
+        order = np.argsort(np.abs(lam))
+        j = order[i]
+        x, y = vr[:, j], vl[:, j]
+        num = np.vdot(dL @ x, y)          # (dL x)^H y
+        den = np.vdot(Cd @ x, y)
+        domega = -relaxation * lam[j] / (num / den)
+        relaxation *= 0.8
+        omega.append(w + domega)
+        k += 1
+    return np.array(omega)

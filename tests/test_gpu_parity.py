@@ -549,3 +549,44 @@ def test_dirichlet_eigenproblem_matches_oracle():
     w, wr = np.sqrt(E.getEigenvalue(0)), np.sqrt(ref.eigs[0])
     assert abs(w - wr) / abs(wr) < 1e-8
     assert abs(w / (2 * np.pi) - 450.0 / 1.6) < 1.0       # analytic quarter-wave frequency 281.25 Hz
+
+
+def test_two_sided_eps_and_newton_solver_match_oracle():
+    """newtonSolver row (eigensolvers.py:278-348): left eigenvectors from the two-sided solve satisfy y^H L = lambda y^H C,
+    and the Newton iterates equal the oracle's dense restatement (same decaying relaxation, same PETSc dot convention)."""
+    import torch
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.dolfinx_utils import OneDimensionalSetup
+    from helmholtz_x.eigensolvers import eps_solver, newtonSolver
+    from helmholtz_x.parameters_utils import temperature_step
+    from helmholtz_x.petsc import Vec
+    from oracle import eigen, fem
+    mesh, subdomains, facet_tags = OneDimensionalSetup(200)
+    T = temperature_step(mesh, Rijke.x_f(1), Rijke.T_u, Rijke.T_d)
+    M = AcousticMatrices(mesh, facet_tags, {1: {'Neumann'}, 2: {'Robin': -0.9 - 0.1j}}, T)
+    D = _distributed_flame(mesh, 1)[0]
+    D.assemble_submatrices()
+    w0 = 1200.0 + 5.0j
+    D.assemble_matrix(w0)
+    L = M.A + w0 * M.B + w0 ** 2 * M.C - D.matrix
+    E = eps_solver(L, -M.C, 0, 2, two_sided=True)
+    lam = E.getEigenvalue(0)
+    x, y = Vec.zeros(201), Vec.zeros(201)
+    E.getEigenvector(0, x)
+    E.getLeftEigenvector(0, y)
+    Ls, Cs = L.to_scipy().toarray(), M.C.to_scipy().toarray()
+    xa, ya = x.array, y.array
+    assert np.linalg.norm(Ls @ xa - lam * (Cs @ xa)) <= 1e-8 * np.abs(Ls).max() * np.linalg.norm(xa)
+    assert np.linalg.norm(ya.conj() @ Ls - lam * (ya.conj() @ Cs)) <= 1e-8 * np.abs(Ls).max() * np.linalg.norm(ya)
+    # Newton iterates vs the oracle (5 iterations)
+    omega, p = newtonSolver(M, D, w0, nev=2, i=0, tol=1e-12, maxiter=5)
+    x_, cells = mesh.geometry.x, mesh.topology.cells
+    A = M.A.to_scipy()
+    B = M.B.to_scipy()
+    C = M.C.to_scipy()
+    Dij = D.submatrices.to_scipy()
+    ftf = D.FTF
+    ref = eigen.newton_solver(A, B, C, lambda w: Dij * ftf(w), lambda w: Dij * ftf.derivative(w), w0, i=0, tol=1e-12, maxiter=5)
+    assert abs(omega - ref[-1]) / abs(ref[-1]) < 1e-8
+    assert abs(p.x.array @ (C @ p.x.array) - 1.0) < 1e-9
+    torch.cuda.synchronize()

@@ -127,3 +127,26 @@ def dispersion_root(k0, Z, L=0.4, h=0.1):
         d = (f(k + 1e-7) - f(k - 1e-7)) / 2e-7
         k = k - f(k) / d
     return k
+
+
+class RijkeFFD:
+    """ShapeSensitivities/RijkeFFD/params.py + main.py (degree 1)."""
+    r_gas = 287.0
+    gamma = 1.4
+    p_amb = 1e5
+    rho_u = 1.22
+    rho_d = 0.85
+    T_in = p_amb / (r_gas * rho_u)
+    T_out = p_amb / (r_gas * rho_d)
+    R_in = -0.975 - 0.05j
+    R_out = -0.975 - 0.05j
+    q_0 = 200.0
+    u_b = 0.1
+    n = 0.014
+    tau = 0.0015
+    x_f = np.array([[0.0, 0.0, 0.25]])
+    x_r = np.array([[0.0, 0.0, 0.20]])
+    a_f = 0.025
+    a_r = 0.025
+    target = 180 * 2 * np.pi
+    bcs = {1: {'Neumann'}, 2: {'Robin': R_out}, 3: {'Robin': R_in}}

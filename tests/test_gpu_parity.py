@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from cases import PRF, Rijke, dispersion_root
+from cases import PRF, Rijke, RijkeFFD, dispersion_root
 
 pytestmark = pytest.mark.gpu
 
@@ -590,3 +590,35 @@ def test_two_sided_eps_and_newton_solver_match_oracle():
     assert abs(omega - ref[-1]) / abs(ref[-1]) < 1e-8
     assert abs(p.x.array @ (C @ p.x.array) - 1.0) < 1e-9
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("st_type", ["lu", "amg"])
+def test_rijkeffd_degree1_sixteen_digit_golden(ref_logs, golden_dir, st_type):
+    """ShapeSensitivities/RijkeFFD/main.py (degree 1) through the drop-in API: 3-D quadratic problem, Robin walls with
+    nodal variable-gamma sound speed, scalar-gamma Gaussian flame; direct and adjoint eigenvalues against the
+    reference's 16-digit eigenvalues.txt and its logged trajectory, for both inner solvers."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.flame_matrices import DistributedFlameMatrix
+    from helmholtz_x.flame_transfer_function import nTau
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.parameters_utils import gaussianFunction, rho_step, temperature_step
+    g = ref_logs["rijkeffd_degree1"]
+    F = RijkeFFD
+    mesh, subdomains, facet_tags = XDMFReader(os.path.join(golden_dir, "meshes", "rijkeffd_original")).getAll()
+    T = temperature_step(mesh, F.x_f, F.T_in, F.T_out)
+    M = AcousticMatrices(mesh, facet_tags, F.bcs, T, degree=1)
+    rho = rho_step(mesh, F.x_f, F.a_f, F.rho_d, F.rho_u)
+    w = gaussianFunction(mesh, F.x_r, F.a_r)
+    h = gaussianFunction(mesh, F.x_f, F.a_f)
+    D = DistributedFlameMatrix(mesh, w, h, rho, T, F.q_0, F.u_b, nTau(F.n, F.tau), degree=1, gamma=F.gamma)
+    D.assemble_submatrices('direct')
+    hist = []
+    E = fixed_point_iteration(M, D, F.target, nev=2, i=0, st_type=st_type, history=hist)
+    _check_traj(hist[1:], g["trajectory"])
+    ref = complex(*g["direct"])
+    assert abs(E.getEigenvalue(0) - ref) / abs(ref) < 1e-8
+    D.assemble_submatrices('adjoint')
+    E = fixed_point_iteration(M, D, F.target, nev=2, i=0, problem_type='adjoint', st_type=st_type)
+    ref = complex(*g["adjoint"])
+    assert abs(E.getEigenvalue(0) - ref) / abs(ref) < 1e-8

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from cases import PRF, Rijke, dispersion_root
+from cases import PRF, Rijke, RijkeFFD, dispersion_root
 from oracle import eigen, fem, meshes
 
 
@@ -132,3 +132,27 @@ def test_flame_transfer_functions(golden_dir):
     assert np.max(np.abs(np.abs(z) - np.abs(f))) < 0.15
     nt = eigen.NTau(2.0, 1e-3)
     assert abs((nt(w + d) - nt(w - d)) / (2 * d) - nt.derivative(w)) < 1e-6
+
+
+def test_rijkeffd_degree1_sixteen_digit_golden(ref_logs, golden_dir):
+    """3-D PEP case with Robin walls (nodal variable-gamma c) and a Gaussian flame: the reference stores the final
+    eigenvalue with 16 digits (eigenvalues.txt) and logs the 5-step trajectory."""
+    g = ref_logs["rijkeffd_degree1"]
+    F = RijkeFFD
+    m = meshes.read_gmsh41(os.path.join(golden_dir, "meshes", "rijkeffd_original.msh"), 3)
+    n = m.x.shape[0]
+    T = fem.step_field(m.x, 3, F.x_f, F.T_in, F.T_out)
+    c = fem.sound_speed_variable_gamma(T)
+    A = fem.assemble_A(m.x, m.cells, c)
+    C = fem.assemble_C(m.x, m.cells)
+    B = fem.assemble_B(m.x, n, [(m.facets[m.facet_tags == t], fem.robin_Z(F.R_in), c, None) for t in (2, 3)])
+    rho = fem.density_step(m.x[:, 2], 0.25, F.a_f, F.rho_d, F.rho_u)
+    w = fem.gaussian_function(m.x, m.cells, F.x_r, F.a_r)
+    h = fem.gaussian_function(m.x, m.cells, F.x_f, F.a_f)
+    left = fem.threshold_pack(fem.distributed_left(m.x, m.cells, F.gamma, h, F.q_0, F.u_b), 1e-5)
+    right = fem.threshold_pack(fem.distributed_right(m.x, m.cells, rho, w), 1e-5)
+    flame = eigen.OracleFlame(fem.flame_outer(n, left, right), eigen.NTau(F.n, F.tau))
+    E, hist = eigen.fixed_point_iteration(A, B, C, flame, F.target, nev=2, i=0)
+    for z, ref in zip(hist[1:], g["trajectory"]):
+        _close(z, ref)
+    assert abs(E.eigs[0] - complex(*g["direct"])) / abs(E.eigs[0]) < 1e-10

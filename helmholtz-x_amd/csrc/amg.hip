@@ -32,6 +32,13 @@ int hx_csr_smooth_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c
                     const hx_c128*, hx_c128*, double, const hx_c128*, double, hx_stream);
 int hx_csr_smooth_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
                     const float*, float*, float, const float*, float, hx_stream);
+struct hx_sell;
+extern "C" int hx_sell_spmv_z(const hx_sell*, const hx_c128*, hx_c128*, const double*, const double*, hx_stream);
+extern "C" int hx_sell_spmv_c64(const hx_sell*, const hx_c64*, hx_c64*, float, float, hx_stream);
+extern "C" int hx_sell_smooth_z(const hx_sell*, const hx_c128*, const hx_c128*, const hx_c128*, hx_c128*, double,
+                                const hx_c128*, double, hx_stream);
+extern "C" int hx_sell_smooth_c64(const hx_sell*, const hx_c64*, const hx_c64*, const hx_c64*, hx_c64*, float,
+                                  const hx_c64*, float, hx_stream);
 int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
 int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 
@@ -44,6 +51,7 @@ template <typename T> struct LevelT {
   CsrT<T> K, P, R;             // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
   const T* dinv = nullptr;
   double rho = 0.0;            // estimate of rho(D^-1 K) for the Chebyshev smoother (0: damped Jacobi with h->omega)
+  const hx_sell* sell = nullptr;   // optional SELL-64 companion of K (fine level): used for the K products
   T *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
 };
 template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
@@ -57,6 +65,8 @@ struct hx_amg {
 };
 
 // ---- per-precision kernel dispatch
+static int op_kmult(const LevelT<double>& L, const double* x, double* y, double a, double b, hx_stream s);
+static int op_kmult(const LevelT<float>& L, const float* x, float* y, float a, float b, hx_stream s);
 static int op_spmv(const CsrT<double>& A, const double* x, double* y, double a, double b, bool transfer, hx_stream s) {
   const double aa[2] = {a, 0.0}, bb[2] = {b, 0.0};
   if (transfer)
@@ -66,14 +76,28 @@ static int op_spmv(const CsrT<double>& A, const double* x, double* y, double a, 
 static int op_spmv(const CsrT<float>& A, const float* x, float* y, float a, float b, bool transfer, hx_stream s) {
   return hx_csr_spmv_c(transfer ? 1 : 2, A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, s);
 }
+// y = a K x + b y through the SELL companion when the level has one
+static int op_kmult(const LevelT<double>& L, const double* x, double* y, double a, double b, hx_stream s) {
+  if (L.sell) { const double aa[2] = {a, 0.0}, bb[2] = {b, 0.0};
+                return hx_sell_spmv_z(L.sell, (const hx_c128*)x, (hx_c128*)y, aa, bb, s); }
+  return op_spmv(L.K, x, y, a, b, false, s);
+}
+static int op_kmult(const LevelT<float>& L, const float* x, float* y, float a, float b, hx_stream s) {
+  if (L.sell) return hx_sell_spmv_c64(L.sell, (const hx_c64*)x, (hx_c64*)y, a, b, s);
+  return op_spmv(L.K, x, y, a, b, false, s);
+}
 // xout = xin + w D^-1 (b - K xin) + mom (xin - xprev)     (xprev may be NULL)
 static int op_smooth(const LevelT<double>& L, const double* b, const double* xin, double* xout, double w,
                      const double* xprev, double mom, hx_stream s) {
+  if (L.sell) return hx_sell_smooth_z(L.sell, (const hx_c128*)L.dinv, (const hx_c128*)b, (const hx_c128*)xin, (hx_c128*)xout,
+                                      w, (const hx_c128*)xprev, mom, s);
   return hx_csr_smooth_z(L.n, L.K.nnz, L.K.rp, L.K.ci, (const hx_c128*)L.K.va, (const hx_c128*)L.dinv, (const hx_c128*)b,
                          (const hx_c128*)xin, (hx_c128*)xout, w, (const hx_c128*)xprev, mom, s);
 }
 static int op_smooth(const LevelT<float>& L, const float* b, const float* xin, float* xout, double w, const float* xprev,
                      double mom, hx_stream s) {
+  if (L.sell) return hx_sell_smooth_c64(L.sell, (const hx_c64*)L.dinv, (const hx_c64*)b, (const hx_c64*)xin, (hx_c64*)xout,
+                                        (float)w, (const hx_c64*)xprev, (float)mom, s);
   return hx_csr_smooth_c(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, xin, xout, (float)w, xprev, (float)mom, s);
 }
 static int op_diag(const LevelT<double>& L, double w, const double* b, double* x, hx_stream s) {
@@ -143,6 +167,13 @@ extern "C" int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, con
   return set_level<float>(h->S, l, n, nnzK, rpK, ciK, (const float*)vaK, (const float*)dinv, n_coarse, nnzP, rpP, ciP,
                           (const float*)vaP, nnzR, rpR, ciR, (const float*)vaR);
 }
+extern "C" int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell) {
+  HX_REQUIRE(h && l >= 0 && l < (int)h->D.L.size(), "bad argument");
+  h->D.L[l].sell = sell;       // the handle must carry the value copy of the precision the V-cycle runs in
+  h->S.L[l].sell = sell;
+  return HX_OK;
+}
+
 extern "C" int hx_amg_set_smoother(hx_amg* h, int l, double rho) {
   HX_REQUIRE(h && l >= 0 && l < (int)h->D.L.size() && rho >= 0.0, "bad argument");
   h->D.L[l].rho = rho;
@@ -206,7 +237,7 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   }
   // residual r = b - K x, restrict
   HX_HIP(hipMemcpyAsync(L.r, b, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
-  if ((rc = op_spmv(L.K, cur, L.r, (T)-1, (T)1, false, s))) return rc;
+  if ((rc = op_kmult(L, cur, L.r, (T)-1, (T)1, s))) return rc;
   LevelT<T>& Lc = H.L[l + 1];
   if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
@@ -250,10 +281,11 @@ extern "C" size_t hx_gmres_ws(int64_t n, int restart) {
 typedef std::complex<double> cd;
 
 extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
-                        const hx_c128* val, const hx_c128* b, hx_c128* x, double rtol, int max_it, int restart,
-                        hx_c128* ws, int* h_iters, double* h_relres, hx_stream s) {
+                        const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
+                        int restart, hx_c128* ws, int* h_iters, double* h_relres, hx_stream s) {
   HX_REQUIRE(n > 0 && rowptr && col && val && b && x && ws && restart >= 1 && restart <= 120 && max_it >= 1, "bad argument");
   auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) {
+    if (Ksell) return hx_sell_spmv_z(Ksell, in, out, a, bt, s);       // same operator, SELL-64 layout
     return hx_csr_spmv_z(n, nnz, rowptr, col, val, in, out, a, bt, 0, s);
   };
   hx_c128* V = ws;                                   // (restart+1) x n, row j = v_j

@@ -34,6 +34,13 @@ SIGNATURES = {
     "hx_zsparse_dots": (C.c_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hx_zthreshold_pack": (C.c_int, [_i64, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp]),
     "hx_csr_spmv_z": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _dp, _dp, _int, _vp]),
+    "hx_sell_create": (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _vp, _int, _int, _vp]),
+    "hx_sell_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64)]),
+    "hx_sell_spmv_z": (C.c_int, [_vp, _vp, _vp, _dp, _dp, _vp]),
+    "hx_sell_spmv_c64": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
+    "hx_sell_smooth_z": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, _vp, C.c_double, _vp]),
+    "hx_sell_smooth_c64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, C.c_float, _vp]),
+    "hx_sell_destroy": (C.c_int, [_vp]),
     "hx_build_v2e": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp]),
     "hx_p1_pattern_count": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     "hx_p1_pattern_fill": (C.c_int, [_i32, _int, _vp, _vp, _vp, _vp, _vp]),
@@ -62,8 +69,9 @@ SIGNATURES = {
     "hx_amg_vcycle": (C.c_int, [_vp, _vp, _vp, _vp]),
     "hx_amg_destroy": (C.c_int, [_vp]),
     "hx_gmres_ws": (C.c_size_t, [_i64, _int]),
-    "hx_gmres": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp,
+    "hx_gmres": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp,
                            C.POINTER(_int), C.POINTER(C.c_double), _vp]),
+    "hx_amg_set_level_sell": (C.c_int, [_vp, _int, _vp]),
     "hx_host_aggregate": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "hx_host_sa_filter": (C.c_int, [_i32, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "hx_host_galerkin_rap": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),

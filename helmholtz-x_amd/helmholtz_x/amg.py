@@ -23,7 +23,7 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed", smoother="chebyshev")
+              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000)
 
 
 def _aggregate(S):
@@ -179,6 +179,14 @@ class AMGSolver:
             self._keep.append(t)
             return t, int(M.nnz)
 
+        # SELL-64 companion of the fine operator (complex128 for K z in GMRES, working precision for the V-cycle)
+        self.sell = None
+        if self.n >= self.params["sell_min_rows"] and len(levels) > 1:
+            sh = C.c_void_p()
+            _hx.check(_hx.lib.hx_sell_create(C.byref(sh), self.n, _hx.ptr(K_csr.rowptr), _hx.ptr(K_csr.col),
+                                             _hx.ptr(K_csr.val), 1, int(mixed), _hx.stream()))
+            self.sell = sh
+            _hx.check(_hx.lib.hx_amg_set_level_sell(h, 0, sh))
         for l, lv in enumerate(levels):
             if l == 0:
                 k0 = K_csr.val.to(cdt) if mixed else K_csr.val
@@ -219,7 +227,7 @@ class AMGSolver:
         it, rr = C.c_int(0), C.c_double(0.0)
         K = self.K
         _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
-                                   _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
+                                   self.sell, _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
                                    self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
         self.solve_s += time.perf_counter() - t0        # hx_gmres synchronises internally
         self.total_iters += it.value
@@ -230,7 +238,7 @@ class AMGSolver:
                                   % (rr.value, it.value))
 
     def stats(self):
-        return dict(levels=[lv["n"] for lv in self.levels], vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
+        return dict(levels=[lv["n"] for lv in self.levels], fine_format="sell64" if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
                     setup_s=round(self.setup_s, 3), solves=self.n_solves,
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1))
@@ -239,6 +247,9 @@ class AMGSolver:
         if getattr(self, "handle", None):
             _hx.lib.hx_amg_destroy(self.handle)
             self.handle = None
+        if getattr(self, "sell", None):
+            _hx.lib.hx_sell_destroy(self.sell)
+            self.sell = None
 
     def __del__(self):
         try:

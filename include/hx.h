@@ -92,6 +92,25 @@ int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int3
 /* y = alpha*A^T*x + beta*y is not provided: the operators of this path are complex symmetric or are
  * transposed once on the host (B_adj = B^H, acoustic_matrices.py:112-114). */
 
+/* ------------------------------------------------------------------ SELL-64 companion of a CSR operator
+ * Sliced ELLPACK with slice height 64 (= one wavefront): entries column-major inside a slice, padded to the slice's
+ * longest row.  For the short, nearly uniform rows of P1 operators every wave-level load is one coalesced 1 KiB
+ * transaction and a lane owns a whole row (no shuffle reduction, no row-pointer chase).  Same products as
+ * hx_csr_spmv_z / hx_csr_jacobi_*; the handle owns its arrays.  hx_sell_create is SYNC. */
+typedef struct hx_sell hx_sell;
+int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+                   int want_c128, int want_c64, hx_stream s);
+int hx_sell_info(const hx_sell* h, int32_t* n_slices, int64_t* padded_entries);
+int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
+                   hx_stream s);
+int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, float alpha, float beta, hx_stream s);
+/* xout = xin + omega*dinv.*(b - A xin) + mom*(xin - xprev); xprev may be NULL (previous iterate = 0 when mom != 0) */
+int hx_sell_smooth_z(const hx_sell* h, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin, hx_c128* xout,
+                     double omega, const hx_c128* xprev, double mom, hx_stream s);
+int hx_sell_smooth_c64(const hx_sell* h, const hx_c64* dinv, const hx_c64* b, const hx_c64* xin, hx_c64* xout,
+                       float omega, const hx_c64* xprev, float mom, hx_stream s);
+int hx_sell_destroy(hx_sell* h);
+
 /* ------------------------------------------------------------------ P1 assembly (DOLFINx assemble_*)
  * Vertex-centric "owner computes" assembly: one CSR row per vertex, gathered from the cells incident
  * to that vertex in ascending cell order => deterministic, no atomics, no inter-GPU exchange.
@@ -182,6 +201,9 @@ int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t* r
                      const hx_c128* vaK, const hx_c128* dinv, int32_t n_coarse, int64_t nnzP,
                      const int32_t* rpP, const int32_t* ciP, const hx_c128* vaP, int64_t nnzR,
                      const int32_t* rpR, const int32_t* ciR, const hx_c128* vaR);
+/* Optional SELL-64 companion of K_l (must hold the value copy of the precision the V-cycle runs in): the smoother
+ * steps and the residual product of that level then use the SELL kernels. */
+int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell);
 /* Smoother of level l: rho = 0 -> `pre`/`post` damped-Jacobi sweeps with the weight given to hx_amg_create;
  * rho > 0 (estimate of the spectral radius of D^-1 K_l) -> Chebyshev polynomial of degree pre/post on D^-1 K_l
  * targeting [0.11 rho, 1.1 rho], evaluated by the same fused kernel as a three-term recurrence. */
@@ -205,7 +227,8 @@ int hx_amg_destroy(hx_amg* h);
  * ws: hx_gmres_ws(n, restart) complex numbers.  SYNC (one small D2H per orthogonalisation pass). */
 size_t hx_gmres_ws(int64_t n, int restart);
 int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
-             const hx_c128* val, const hx_c128* b, hx_c128* x, double rtol, int max_it, int restart,
+             const hx_c128* val, const hx_sell* Ksell /* optional SELL-64 companion of the same K */,
+             const hx_c128* b, hx_c128* x, double rtol, int max_it, int restart,
              hx_c128* ws, int* h_iters, double* h_relres, hx_stream s);
 /* HOST set-up passes of the smoothed-aggregation hierarchy (graph / integer work, once per K):
  * hx_host_sa_filter: strength filter |l_ij| >= theta*sqrt(l_ii l_jj) with weak couplings lumped on the diagonal;

@@ -223,3 +223,46 @@ def test_complex64_spmv_and_jacobi(hx, n, density):
                                       hx.ptr(out), 0.7, hx.stream()))
     refj = x + 0.7 * (1.0 / d) * (y0 - M @ x.astype(np.complex128))
     assert np.max(np.abs(out.cpu().numpy() - refj)) <= 2e-5 * max(np.max(np.abs(refj)), 1.0)
+
+
+@pytest.mark.parametrize("n,density", [(1, 1.0), (63, 0.2), (64, 0.2), (1000, 0.02), (40000, 0.0005)])
+def test_sell64_products_match_csr(hx, n, density):
+    """SELL-64 companion: SpMV (c128, c64) and the smoother step against SciPy; ragged rows, an empty row, sizes around
+    the slice height."""
+    import torch
+    rng = np.random.default_rng(n)
+    M = sp.random(n, n, density=density, random_state=rng, format="csr") + 1j * sp.random(n, n, density=density, random_state=rng, format="csr")
+    M = sp.csr_matrix(M + sp.diags(3.0 + rng.random(n)))
+    if n > 10:
+        M = sp.csr_matrix(sp.vstack([M[:5], sp.csr_matrix((1, n)), M[6:]]))
+        M[7, :] = _rand_c(rng, n) * (rng.random(n) < 0.3)          # one long row
+        M = sp.csr_matrix(M)
+    M.sort_indices()
+    rp, ci, va = _dev(M.indptr.astype(np.int32)), _dev(M.indices.astype(np.int32)), _dev(M.data.astype(np.complex128))
+    h = C.c_void_p()
+    hx.check(hx.lib.hx_sell_create(C.byref(h), n, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), 1, 1, hx.stream()))
+    ns, pad = C.c_int32(), C.c_int64()
+    hx.check(hx.lib.hx_sell_info(h, C.byref(ns), C.byref(pad)))
+    assert ns.value == (n + 63) // 64 and pad.value >= M.nnz and pad.value % 64 == 0
+    x, y0 = _rand_c(rng, n), _rand_c(rng, n)
+    xd, yd = _dev(x), _dev(y0.copy())
+    a, b = 0.7 - 0.2j, -1.3 + 0.4j
+    hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(xd), hx.ptr(yd), hx.z2(a), hx.z2(b), hx.stream()))
+    ref = a * (M @ x) + b * y0
+    assert np.max(np.abs(yd.cpu().numpy() - ref)) <= 1e-13 * max(np.max(np.abs(ref)), 1.0)
+    d = M.diagonal()
+    d[d == 0] = 1.0
+    dinv, bb, xprev = _dev(1.0 / d), _dev(y0), _dev(_rand_c(rng, n))
+    out = torch.empty_like(xd)
+    hx.check(hx.lib.hx_sell_smooth_z(h, hx.ptr(dinv), hx.ptr(bb), hx.ptr(xd), hx.ptr(out), 0.7, hx.ptr(xprev), 0.3, hx.stream()))
+    refs = x + 0.7 * (1.0 / d) * (y0 - M @ x) + 0.3 * (x - xprev.cpu().numpy())
+    assert np.max(np.abs(out.cpu().numpy() - refs)) <= 1e-13 * max(np.max(np.abs(refs)), 1.0)
+    x32, y32 = _dev(x.astype(np.complex64)), _dev(y0.astype(np.complex64))
+    hx.check(hx.lib.hx_sell_spmv_c64(h, hx.ptr(x32), hx.ptr(y32), -1.0, 1.0, hx.stream()))
+    ref32 = y0 - M @ x
+    assert np.max(np.abs(y32.cpu().numpy() - ref32)) <= 3e-5 * max(np.max(np.abs(ref32)), 1.0)
+    d32, b32, o32 = _dev((1.0 / d).astype(np.complex64)), _dev(y0.astype(np.complex64)), torch.empty_like(x32)
+    hx.check(hx.lib.hx_sell_smooth_c64(h, hx.ptr(d32), hx.ptr(b32), hx.ptr(x32), hx.ptr(o32), 0.7, None, 0.25, hx.stream()))
+    refs32 = x + 0.7 * (1.0 / d) * (y0 - M @ x) + 0.25 * x
+    assert np.max(np.abs(o32.cpu().numpy() - refs32)) <= 3e-5 * max(np.max(np.abs(refs32)), 1.0)
+    hx.check(hx.lib.hx_sell_destroy(h))

@@ -308,8 +308,11 @@ def _annulus_case(shape):
     return bench.build_case(shape)
 
 
-def test_amg_gmres_inner_solver_matches_direct():
-    """K^-1 b from the device AMG-GMRES equals the SuperLU solution on a 3-D annulus (complex shifted operator)."""
+@pytest.mark.parametrize("overrides", [dict(), dict(sell_min_rows=0), dict(precision="double", smoother="jacobi"),
+                                       dict(precision="double", sell_min_rows=0)])
+def test_amg_gmres_inner_solver_matches_direct(overrides):
+    """K^-1 b from the device AMG-GMRES equals the SuperLU solution on a 3-D annulus (complex shifted operator):
+    default (CSR, complex64 Chebyshev V-cycle), SELL-64 fine level, and the all-double variants."""
     import scipy.sparse.linalg as spla
     import torch
     from helmholtz_x.acoustic_matrices import AcousticMatrices
@@ -321,7 +324,7 @@ def test_amg_gmres_inner_solver_matches_direct():
     s = P.target
     K = combine_csr(M.A.shape, M.A.csr_terms + [(s * c, m) for c, m in M.B.csr_terms]
                     + [(s ** 2 * c, m) for c, m in M.C.csr_terms])
-    solver = AMGSolver(K)
+    solver = AMGSolver(K, **overrides)
     rng = np.random.default_rng(0)
     b = rng.standard_normal(K.shape[0]) + 1j * rng.standard_normal(K.shape[0])
     bd = to_device(b)

@@ -181,6 +181,7 @@ class AMGSolver:
 
         # SELL-64 companion of the fine operator (complex128 for K z in GMRES, working precision for the V-cycle)
         self.sell = None
+        self.coarse_sells = []
         if self.n >= self.params["sell_min_rows"] and len(levels) > 1:
             sh = C.c_void_p()
             _hx.check(_hx.lib.hx_sell_create(C.byref(sh), self.n, _hx.ptr(K_csr.rowptr), _hx.ptr(K_csr.col),
@@ -194,6 +195,15 @@ class AMGSolver:
                 (krp, kci, kva), knnz = (K_csr.rowptr, K_csr.col, k0), K_csr.nnz
             else:
                 (krp, kci, kva), knnz = dev_csr(lv["K"])
+                if "P" in lv and lv["n"] >= self.params["sell_min_rows"] :
+                    # coarse operators with enough rows also get a SELL-64 companion (values in the working precision)
+                    tmp = to_device(sp.csr_matrix(lv["K"]).data.astype(np.complex128))
+                    shl = C.c_void_p()
+                    _hx.check(_hx.lib.hx_sell_create(C.byref(shl), lv["n"], _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(tmp),
+                                                     int(not mixed), int(mixed), _hx.stream()))
+                    del tmp
+                    self.coarse_sells.append(shl)
+                    _hx.check(_hx.lib.hx_amg_set_level_sell(h, l, shl))
             if "P" in lv:
                 (prp, pci, pva), pnnz = dev_csr(lv["P"])
                 (rrp, rci, rva), rnnz = dev_csr(lv["R"])
@@ -250,6 +260,9 @@ class AMGSolver:
         if getattr(self, "sell", None):
             _hx.lib.hx_sell_destroy(self.sell)
             self.sell = None
+        for shl in getattr(self, "coarse_sells", []):
+            _hx.lib.hx_sell_destroy(shl)
+        self.coarse_sells = []
 
     def __del__(self):
         try:

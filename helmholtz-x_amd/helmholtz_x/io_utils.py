@@ -116,12 +116,69 @@ def read_gmsh(path, dim=None):
     return mesh, cell_tags, facet_tags
 
 
+def _xdmf_items(path):
+    """(h5 file, dataset) of the DataItems of a meshio-written .xdmf, in document order: geometry, topology, tags."""
+    import os
+    import re
+    text = open(path).read()
+    here = os.path.dirname(path)
+    return [(os.path.join(here, f), d) for f, d in re.findall(r">\s*([^<>:\s]+\.h5):/([^<\s]+)\s*<", text)]
+
+
+def read_xdmf(name):
+    """``name.xdmf`` + ``name_tags.xdmf`` (HDF5 heavy data, as written by the reference's write_xdmf_mesh,
+    io_utils.py:96-139) -> (Mesh, cell MeshTags, facet MeshTags)."""
+    from ._h5lite import H5File
+    files = {}
+
+    def load(item):
+        f, d = item
+        if f not in files:
+            files[f] = H5File(f)
+        return files[f].read(d)
+
+    geo, topo, tags = _xdmf_items(name + ".xdmf")
+    x = np.asarray(load(geo), dtype=np.float64)
+    if x.shape[1] == 2:
+        x = np.concatenate([x, np.zeros((x.shape[0], 1))], axis=1)
+    cells = np.asarray(load(topo), dtype=np.int64)
+    cell_values = np.asarray(load(tags), dtype=np.int32)
+    _, ftopo, ftags = _xdmf_items(name + "_tags.xdmf")
+    fv = np.asarray(load(ftopo), dtype=np.int64)
+    facet_values = np.asarray(load(ftags), dtype=np.int32)
+    dim = cells.shape[1] - 1
+    used = np.unique(cells)
+    renum = np.full(x.shape[0], -1, dtype=np.int64)
+    renum[used] = np.arange(used.size)
+    cells = renum[cells].astype(np.int32)
+    facets = np.sort(renum[fv], axis=1).astype(np.int32)
+    combos = list(combinations(range(dim + 1), dim))
+    allf = np.sort(np.concatenate([cells[:, c] for c in combos], axis=0), axis=1)
+    owner = np.tile(np.arange(cells.shape[0]), len(combos))
+    base = int(used.size) + 1
+    key_all = np.zeros(allf.shape[0], dtype=np.int64)
+    key_f = np.zeros(facets.shape[0], dtype=np.int64)
+    for c in range(dim):
+        key_all = key_all * base + allf[:, c]
+        key_f = key_f * base + facets[:, c]
+    order = np.argsort(key_all, kind="stable")
+    facet_cells = owner[order[np.searchsorted(key_all[order], key_f)]].astype(np.int32)
+    mesh = Mesh(x[used], cells, facets=facets, facet_cells=facet_cells)
+    return (mesh, MeshTags(mesh, dim, np.arange(cells.shape[0]), cell_values),
+            MeshTags(mesh, dim - 1, np.arange(facets.shape[0]), facet_values))
+
+
 class XDMFReader:
-    """Same accessors as the reference's reader (io_utils.py:160-217); the source is ``name.msh``."""
+    """Same accessors as the reference's reader (io_utils.py:160-217).  Reads ``name.xdmf`` / ``name_tags.xdmf`` with
+    their HDF5 heavy data when present (the reference's own format), else the ASCII gmsh file ``name.msh``."""
 
     def __init__(self, name, dim=None):
+        import os
         self.name = name
-        self._mesh, self._cell_tags, self._facet_tags = read_gmsh(name + ".msh", dim)
+        if os.path.exists(name + ".xdmf") and os.path.exists(name + "_tags.xdmf"):
+            self._mesh, self._cell_tags, self._facet_tags = read_xdmf(name)
+        else:
+            self._mesh, self._cell_tags, self._facet_tags = read_gmsh(name + ".msh", dim)
         info("\nXDMF Mesh - Cell data loaded.")
         info("XDMF Mesh - Facet data loaded.")
 

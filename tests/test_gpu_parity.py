@@ -625,3 +625,38 @@ def test_rijkeffd_degree1_sixteen_digit_golden(ref_logs, golden_dir, st_type):
     E = fixed_point_iteration(M, D, F.target, nev=2, i=0, problem_type='adjoint', st_type=st_type)
     ref = complex(*g["adjoint"])
     assert abs(E.getEigenvalue(0) - ref) / abs(ref) < 1e-8
+
+
+@pytest.mark.parametrize("st_type", ["amg", "lu"])
+def test_micca_full_annulus_flagship_case(ref_logs, golden_dir, st_type):
+    """The reference's flagship example on its real mesh (XDMF/HDF5 read by the package's own reader) through the
+    drop-in API, exactly as active_fpi.py:20-47 is written: logged trajectory (3 decimals) and the two stored
+    eigenvalues (16 digits) to 1e-8."""
+    from scipy.io import loadmat
+    from cases import Micca
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.fem import Function, FunctionSpace
+    from helmholtz_x.flame_matrices import PointwiseFlameMatrix
+    from helmholtz_x.flame_transfer_function import stateSpace
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.parameters_utils import Q_multiple
+    g = ref_logs["micca_full"]
+    micca = XDMFReader(os.path.join(golden_dir, "meshes", "micca_full", "mesh"))
+    mesh, subdomains, facet_tags = micca.getAll()
+    c = Function(FunctionSpace(mesh, "DG", 0), "soundspeed")          # params.c(mesh): DG0, cell-midpoint rule
+    c.x.array[:] = Micca.c_of_z(c.function_space.tabulate_dof_coordinates()[:, 2])
+    matrices = AcousticMatrices(mesh, facet_tags, {11: {'Robin': Micca.R_outlet}}, c, degree=1)
+    mat = loadmat(os.path.join(golden_dir, "micca_ftf.mat"))
+    FTF = stateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+    h = Q_multiple(mesh, subdomains, Micca.N_sector)
+    D = PointwiseFlameMatrix(mesh, subdomains, Micca.x_r(), h, Micca.rho_amb, Micca.q_0, Micca.u_b, FTF, degree=1)
+    D.assemble_submatrices('direct')
+    hist = []
+    E = fixed_point_iteration(matrices, D, Micca.target, i=0, nev=4, tol=1e-3, st_type=st_type, history=hist)
+    assert len(hist) - 1 == len(g["trajectory_3dec"])
+    for z, ref in zip(hist[1:], g["trajectory_3dec"]):
+        assert abs(z - complex(*ref)) < 6e-4
+    for i, ref in enumerate(g["direct"]):
+        ref = complex(*ref)
+        assert abs(E.getEigenvalue(i) - ref) / abs(ref) < 1e-8, (i, E.getEigenvalue(i), ref)

@@ -53,8 +53,9 @@ def build_case(shape):
     return dict(mesh=mesh, subdomains=subdomains, facet_tags=facet_tags, c=c, ftf=ftf, P=Micca, np=np)
 
 
-def hot_path(case, st_type=None, nev=4, tol=1e-3, history=None):
-    """One full pass: assembly + flame vectors + fixed-point iteration.  Returns (E, matrices)."""
+def hot_path(case, st_type=None, nev=4, tol=1e-3, history=None, sharded=False):
+    """One full pass: assembly + flame vectors + fixed-point iteration.  Returns (E, matrices).
+    ``sharded``: collective row-sharded solve over the default torch.distributed group (theta-slab partition)."""
     from helmholtz_x.acoustic_matrices import AcousticMatrices
     from helmholtz_x.eigensolvers import fixed_point_iteration
     from helmholtz_x.flame_matrices import PointwiseFlameMatrix
@@ -67,8 +68,22 @@ def hot_path(case, st_type=None, nev=4, tol=1e-3, history=None):
         h = case["h"] = Q_multiple(mesh, case["subdomains"], P.N_sector)
     D = PointwiseFlameMatrix(mesh, case["subdomains"], P.x_r(), h, P.rho_amb, P.q_0, P.u_b, case["ftf"])
     D.assemble_submatrices('direct')
-    E = fixed_point_iteration(matrices, D, P.target, i=0, nev=nev, tol=tol, st_type=st_type, history=history)
+    shard = None
+    if sharded:
+        from helmholtz_x.sharded import ShardContext
+        x = mesh.geometry.x
+        plane = int(np_count_plane(x))                     # rows per theta-plane: cut the slabs between planes
+        shard = case["shard"] = ShardContext(matrices.A.shape[0], align=plane)
+    E = fixed_point_iteration(matrices, D, P.target, i=0, nev=nev, tol=tol, st_type=st_type, history=history,
+                              shard=shard)
     return E, matrices
+
+
+def np_count_plane(x):
+    """Vertices per theta-plane of the synthetic annulus (theta-major numbering: the first plane is theta = theta_0)."""
+    import numpy as np
+    th = np.arctan2(x[:, 1], x[:, 0])
+    return int(np.argmax(np.abs(th - th[0]) > 1e-12))
 
 
 def spmv_roofline(matrices, target, reps=50):

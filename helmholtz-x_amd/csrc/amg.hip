@@ -53,16 +53,40 @@ template <typename T> struct LevelT {
   double rho = 0.0;            // estimate of rho(D^-1 K) for the Chebyshev smoother (0: damped Jacobi with h->omega)
   const hx_sell* sell = nullptr;   // optional SELL-64 companion of K (fine level): used for the K products
   T *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
+  bool ext_x = false, ext_b = false;   // x/x2/x3 (resp. b) are caller-owned (row-sharded mode)
 };
 template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
 
+// Row-sharded mode (one process per GPU): level 0 holds this rank's rows over [owned | ghost] columns, every coarser
+// level is replicated.  The two exchange steps of the path are delegated to the host side (torch.distributed over
+// RCCL): `halo(ctx, id)` fills the ghost block of registered buffer `id`, `allreduce(ctx, id, count)` sums a registered
+// buffer over the ranks.  Both are enqueued on / ordered against the stream the kernels run on.
 struct hx_amg {
   HierT<double> D;
   HierT<float> S;
   bool single = false;         // run the V-cycle on the complex64 copy
   int pre = 2, post = 2;
   double omega = 0.6;
+  bool sharded = false;
+  hx_halo_fn halo = nullptr;
+  hx_allreduce_fn allreduce = nullptr;
+  void* ctx = nullptr;
+  int32_t n_ext = 0;           // owned + ghost length of the level-0 iterates
 };
+static int buf_id(const hx_amg* h, const void* p) {
+  const void* ids[3] = {h->single ? (const void*)h->S.L[0].x : (const void*)h->D.L[0].x,
+                        h->single ? (const void*)h->S.L[0].x2 : (const void*)h->D.L[0].x2,
+                        h->single ? (const void*)h->S.L[0].x3 : (const void*)h->D.L[0].x3};
+  for (int i = 0; i < 3; ++i) if (ids[i] == p) return HX_BUF_VCYCLE_X0 + i;
+  return -1;
+}
+// ghost block of a level-0 iterate must be current before K is applied to it
+static int halo_before_k(hx_amg* h, int l, const void* v) {
+  if (!h->sharded || l != 0) return HX_OK;
+  const int id = buf_id(h, v);
+  if (id < 0) return hx_fail(HX_ERR_ARG, __func__, "K applied to an unregistered buffer in sharded mode");
+  return h->halo(h->ctx, id) == 0 ? HX_OK : hx_fail(HX_ERR_COMM, __func__, "halo exchange callback failed");
+}
 
 // ---- per-precision kernel dispatch
 static int op_kmult(const LevelT<double>& L, const double* x, double* y, double a, double b, hx_stream s);
@@ -119,8 +143,13 @@ extern "C" int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, doub
 
 extern "C" int hx_amg_destroy(hx_amg* h) {
   if (!h) return HX_OK;
-  for (auto& l : h->D.L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.x3); (void)hipFree(l.b); (void)hipFree(l.r); }
-  for (auto& l : h->S.L) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.x3); (void)hipFree(l.b); (void)hipFree(l.r); }
+  auto release = [](auto& l) {
+    if (!l.ext_x) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.x3); }
+    if (!l.ext_b) (void)hipFree(l.b);
+    (void)hipFree(l.r);
+  };
+  for (auto& l : h->D.L) release(l);
+  for (auto& l : h->S.L) release(l);
   delete h;
   return HX_OK;
 }
@@ -181,6 +210,27 @@ extern "C" int hx_amg_set_smoother(hx_amg* h, int l, double rho) {
   return HX_OK;
 }
 
+template <typename T>
+static int adopt_buffers(HierT<T>& H, void* x, void* x2, void* x3, void* coarse_b) {
+  LevelT<T>& L0 = H.L[0];
+  LevelT<T>& L1 = H.L[1];
+  if (!L0.ext_x) { (void)hipFree(L0.x); (void)hipFree(L0.x2); (void)hipFree(L0.x3); }
+  if (!L1.ext_b) (void)hipFree(L1.b);
+  L0.x = (T*)x; L0.x2 = (T*)x2; L0.x3 = (T*)x3; L0.ext_x = true;
+  L1.b = (T*)coarse_b; L1.ext_b = true;
+  return HX_OK;
+}
+extern "C" int hx_amg_set_sharded(hx_amg* h, int32_t n_ext, void* x, void* x2, void* x3, void* coarse_b,
+                                  hx_halo_fn halo, hx_allreduce_fn allreduce, void* ctx) {
+  HX_REQUIRE(h && x && x2 && x3 && coarse_b && halo && allreduce, "bad argument");
+  const size_t nl = h->single ? h->S.L.size() : h->D.L.size();
+  HX_REQUIRE(nl >= 2, "row-sharded mode needs at least one replicated coarse level");
+  const int32_t n_own = h->single ? h->S.L[0].n : h->D.L[0].n;
+  HX_REQUIRE(n_own > 0 && n_ext >= n_own, "set level 0 (local rows) before hx_amg_set_sharded");
+  h->sharded = true; h->halo = halo; h->allreduce = allreduce; h->ctx = ctx; h->n_ext = n_ext;
+  return h->single ? adopt_buffers<float>(h->S, x, x2, x3, coarse_b) : adopt_buffers<double>(h->D, x, x2, x3, coarse_b);
+}
+
 extern "C" int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                                  const hx_c128* va) {
   HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->D.L.back().n == n_c, "bad argument");
@@ -231,15 +281,21 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   for (int k = 1; k < h->pre; ++k) {
     T* nxt = other(cur, prev);
     if (cheb) {   // for k = 1 the previous iterate is the zero start vector (prev == nullptr)
+      if ((rc = halo_before_k(h, l, cur))) return rc;
       if ((rc = op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], s))) return rc;
-    } else if ((rc = op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s))) return rc;
+    } else { if ((rc = halo_before_k(h, l, cur))) return rc;
+             if ((rc = op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s))) return rc; }
     prev = cur; cur = nxt;
   }
   // residual r = b - K x, restrict
   HX_HIP(hipMemcpyAsync(L.r, b, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
+  if ((rc = halo_before_k(h, l, cur))) return rc;
   if ((rc = op_kmult(L, cur, L.r, (T)-1, (T)1, s))) return rc;
   LevelT<T>& Lc = H.L[l + 1];
   if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
+  if (h->sharded && l == 0) {   // R holds this rank's columns only: the coarse right-hand side is the sum over ranks
+    if (h->allreduce(h->ctx, HX_BUF_COARSE_RHS, Lc.n) != 0) return hx_fail(HX_ERR_COMM, __func__, "all-reduce callback failed");
+  }
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
   if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s))) return rc;
   if ((rc = op_spmv(L.P, ec, cur, (T)1, (T)1, true, s))) return rc;    // x += P e_c
@@ -247,6 +303,7 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   prev = nullptr;
   for (int k = 0; k < h->post; ++k) {
     T* dst = (k == h->post - 1) ? xout : other(cur, prev);
+    if ((rc = halo_before_k(h, l, cur))) return rc;
     if (cheb) { if ((rc = op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s))) return rc; }
     else if ((rc = op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s))) return rc;
     prev = cur; cur = dst;
@@ -280,11 +337,20 @@ extern "C" size_t hx_gmres_ws(int64_t n, int restart) {
 
 typedef std::complex<double> cd;
 
-extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
-                        const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
-                        int restart, hx_c128* ws, int* h_iters, double* h_relres, hx_stream s) {
+// xe / hbuf: row-sharded mode only (registered buffers HX_BUF_GMRES_XE: owned + ghost staging vector for K products,
+// HX_BUF_GMRES_DOTS: restart + 2 complex numbers for the all-reduced inner products); n is then the OWNED row count.
+static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                      const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
+                      int restart, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s) {
   HX_REQUIRE(n > 0 && rowptr && col && val && b && x && ws && restart >= 1 && restart <= 120 && max_it >= 1, "bad argument");
-  auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) {
+  const bool sharded = xe != nullptr;
+  HX_REQUIRE(!sharded || (M && M->sharded && hbuf), "row-sharded GMRES needs a sharded preconditioner handle");
+  auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) -> int {
+    if (sharded) {   // stage the owned block, let the host side fill the ghost block, multiply the local rows
+      HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+      if (M->halo(M->ctx, HX_BUF_GMRES_XE) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange callback failed");
+      in = xe;
+    }
     if (Ksell) return hx_sell_spmv_z(Ksell, in, out, a, bt, s);       // same operator, SELL-64 layout
     return hx_csr_spmv_z(n, nnz, rowptr, col, val, in, out, a, bt, 0, s);
   };
@@ -292,13 +358,15 @@ extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr
   hx_c128* Z = V + (size_t)(restart + 1) * n;        // restart x n,   row j = M^-1 v_j
   hx_c128* r = Z + (size_t)restart * n;
   hx_c128* part = r + n;
-  hx_c128* hdev = part + hx_panel_dot_ws(restart + 1);
+  hx_c128* hdev = sharded ? hbuf : part + hx_panel_dot_ws(restart + 1);
   std::vector<cd> hh(restart + 2);
   std::vector<std::vector<cd>> H(restart + 1, std::vector<cd>(restart, cd(0)));
   std::vector<cd> cs(restart), sn(restart), g(restart + 1);
   auto dots = [&](int k, const hx_c128* w) -> int {
     int rc = hx_zpanel_dot(n, k, V, n, w, hdev, part, s);
     if (rc) return rc;
+    if (sharded && M->allreduce(M->ctx, HX_BUF_GMRES_DOTS, k + 1) != 0)
+      return hx_fail(HX_ERR_COMM, "hx_gmres", "all-reduce callback failed");
     HX_HIP(hipMemcpyAsync(hh.data(), hdev, sizeof(cd) * (size_t)(k + 1), hipMemcpyDeviceToHost, hx_s(s)));
     HX_HIP(hipStreamSynchronize(hx_s(s)));
     return HX_OK;
@@ -386,6 +454,23 @@ extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr
   if (h_iters) *h_iters = it;
   if (h_relres) *h_relres = relres;
   return HX_OK;
+}
+
+extern "C" int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                        const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
+                        int restart, hx_c128* ws, int* h_iters, double* h_relres, hx_stream s) {
+  HX_REQUIRE(!M || !M->sharded, "use hx_gmres_sharded with a row-sharded preconditioner");
+  return gmres_impl(M, n, nnz, rowptr, col, val, Ksell, b, x, rtol, max_it, restart, ws, nullptr, nullptr, h_iters,
+                    h_relres, s);
+}
+
+extern "C" int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                                const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol,
+                                int max_it, int restart, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters,
+                                double* h_relres, hx_stream s) {
+  HX_REQUIRE(M && M->sharded && xe && hbuf, "bad argument");
+  return gmres_impl(M, n_own, nnz, rowptr, col, val, Ksell, b, x, rtol, max_it, restart, ws, xe, hbuf, h_iters,
+                    h_relres, s);
 }
 
 // ------------------------------------------------------------------------------------------------ aggregation (host)

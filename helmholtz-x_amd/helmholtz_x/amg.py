@@ -23,7 +23,8 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000)
+              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, recycle=6,
+              recycle_min_rows=100_000)
 
 
 def _aggregate(S):
@@ -152,7 +153,7 @@ class AMGSolver:
         t_setup = time.perf_counter()
         self.params = dict(PARAMS, **overrides)
         import os
-        for key in ("pre", "post"):                       # experiment hooks (tools/): HX_AMG_PRE / HX_AMG_POST
+        for key in ("pre", "post", "restart"):            # experiment hooks (tools/): HX_AMG_PRE / HX_AMG_POST / HX_AMG_RESTART
             if os.environ.get("HX_AMG_" + key.upper()):
                 self.params[key] = int(os.environ["HX_AMG_" + key.upper()])
         self.shard = shard
@@ -239,13 +240,24 @@ class AMGSolver:
             self._bufs = {0: shard.ext_vector(cdt), 1: shard.ext_vector(cdt), 2: shard.ext_vector(cdt),
                           _hx.BUF_COARSE_RHS: torch.zeros(n1, dtype=cdt, device=dev),
                           _hx.BUF_GMRES_XE: shard.ext_vector(torch.complex128),
-                          _hx.BUF_GMRES_DOTS: torch.zeros(self.params["restart"] + 2, dtype=torch.complex128, device=dev)}
+                          _hx.BUF_GMRES_DOTS: torch.zeros(self.params["restart"] + 2 + 32, dtype=torch.complex128,
+                                                          device=dev)}
             self._cb = ShardedCallbacks(shard, self._bufs)
             _hx.check(_hx.lib.hx_amg_set_sharded(h, shard.n_ext, _hx.ptr(self._bufs[0]), _hx.ptr(self._bufs[1]),
                                                  _hx.ptr(self._bufs[2]), _hx.ptr(self._bufs[_hx.BUF_COARSE_RHS]),
                                                  self._cb.halo, self._cb.allreduce, None))
         self.ws = torch.empty(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), dtype=torch.complex128, device=dev)
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
+        # subspace recycling (all solves of a fixed-point call share K): worth its panel rows once the hierarchy is deep
+        # enough for the preconditioned operator to show a few near-null modes (measured: plateau of 5 its at 1 M DOF,
+        # 9 at 5 M; none below ~100 k)
+        n_glob = self.n if shard is None else shard.n_global
+        self.recycle_k = int(os.environ.get("HX_AMG_RECYCLE", self.params["recycle"])) if len(levels) > 1 else 0
+        if n_glob < self.params["recycle_min_rows"] and "HX_AMG_RECYCLE" not in os.environ:
+            self.recycle_k = 0
+        self.recycled = 0
+        if self.recycle_k > 0:
+            _hx.check(_hx.lib.hx_amg_enable_recycling(h, self.n, self.recycle_k, self.params["restart"]))
         self.krylov_tol_floor = 10.0 * self.params["rtol"]
         self.total_iters = 0
         self.n_solves = 0
@@ -273,6 +285,8 @@ class AMGSolver:
             _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                        self.sell, _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
                                        self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
+        if self.recycle_k > 0 and not self.recycled:
+            self._harvest()
         self.solve_s += time.perf_counter() - t0        # hx_gmres synchronises internally
         self.total_iters += it.value
         self.n_solves += 1
@@ -281,8 +295,33 @@ class AMGSolver:
             raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
                                   % (rr.value, it.value))
 
+    def _harvest(self):
+        """Install the k harmonic Ritz vectors of smallest |theta| of the solve that just finished as recycled pairs
+        (U, C = K U): with K Z_m = V_{m+1} Hbar_m,  U = Z_m G R^-1, C = V_{m+1} Q  where Hbar_m G = Q R.
+        The small dense algebra runs on the host from all-reduced numbers, i.e. identically on every rank."""
+        m = C.c_int(0)
+        _hx.check(_hx.lib.hx_gmres_hessenberg(self.handle, C.byref(m), None))
+        m, k = m.value, self.recycle_k
+        if m < k + 2:
+            return                                  # restarted / too short: try again after the next solve
+        Hb = np.zeros((m + 1) * m, dtype=np.complex128)
+        _hx.check(_hx.lib.hx_gmres_hessenberg(self.handle, C.byref(C.c_int(0)), _hx.nptr(Hb)))
+        Hb = Hb.reshape(m, m + 1).T                 # column-major -> (m+1, m)
+        Hm, h = Hb[:m, :m], Hb[m, m - 1]
+        em = np.zeros(m, dtype=np.complex128)
+        em[-1] = 1.0
+        f = np.linalg.solve(Hm.conj().T, em)
+        theta, G = np.linalg.eig(Hm + abs(h) ** 2 * np.outer(f, em))
+        Gk = G[:, np.argsort(np.abs(theta), kind="stable")[:k]]
+        Q, R = np.linalg.qr(Hb @ Gk)
+        Uc = np.asfortranarray(Gk @ np.linalg.inv(R))
+        Cc = np.asfortranarray(Q)
+        _hx.check(_hx.lib.hx_amg_set_recycle(self.handle, k, _hx.nptr(Uc), _hx.nptr(Cc), _hx.ptr(self.ws), _hx.stream()))
+        self.recycled = k
+        self.harmonic_ritz = np.sort(np.abs(theta))[:k]
+
     def stats(self):
-        return dict(levels=[lv["n"] for lv in self.levels], fine_format="sell64" if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
+        return dict(recycled_pairs=self.recycled, levels=[lv["n"] for lv in self.levels], fine_format="sell64" if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
                     setup_s=round(self.setup_s, 3), solves=self.n_solves,
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1))

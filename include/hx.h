@@ -231,6 +231,19 @@ int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int
              const hx_c128* val, const hx_sell* Ksell /* optional SELL-64 companion of the same K */,
              const hx_c128* b, hx_c128* x, double rtol, int max_it, int restart,
              hx_c128* ws, int* h_iters, double* h_relres, hx_stream s);
+/* ---- Krylov subspace recycling across the solves of one fixed-point call (all of them share K; the reference instead
+ * re-factorises A - D(omega_k) every iteration, eigensolvers.py:165-178).  GCRO with a fixed operator: k pairs (U, C),
+ * K U = C, C^H C = I, harvested once as the harmonic Ritz vectors of the first solve.  hx_gmres / hx_gmres_sharded
+ * then start every cycle from the Galerkin guess on span(U) and keep the Arnoldi vectors orthogonal to C, which
+ * removes the initial plateau caused by the few near-null modes of the preconditioned operator.
+ *   hx_amg_enable_recycling  allocate the [C; V] panel and U inside the handle (n = rows of the local operator)
+ *   hx_gmres_hessenberg      raw (m+1) x m Hessenberg of the last solve (column-major, ld m+1); *m = 0 if that solve
+ *                            restarted or already used recycled pairs.  Call with H = NULL to query m.
+ *   hx_amg_set_recycle       U = Z_m Ucoef, C = V_{m+1} Ccoef (HOST coefficients, column-major m x k and (m+1) x k);
+ *                            must directly follow the harvested solve, with the same ws. */
+int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int restart);
+int hx_gmres_hessenberg(const hx_amg* h, int* m, hx_c128* H);
+int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const hx_c128* Ccoef, hx_c128* ws, hx_stream s);
 /* ---- Row-sharded mode (one process per GPU).  Replaces what the reference gets from PETSc's
  * parallel Mat/KSP under mpirun (eigensolvers.py:43-62 with a distributed A): level 0 of the hierarchy holds THIS rank's
  * rows of K over [owned | ghost] columns (hx_amg_set_level* with n = owned rows, R = (P rows owned)^T), every coarser
@@ -243,7 +256,7 @@ enum {
   HX_BUF_VCYCLE_X0 = 0,   /* level-0 iterates x, x2, x3 (ids 0..2; working precision of the V-cycle; n_ext entries) */
   HX_BUF_COARSE_RHS = 3,  /* level-1 right-hand side (working precision; n_1 entries; summed over ranks)        */
   HX_BUF_GMRES_XE = 4,    /* complex128 staging vector for K products of hx_gmres_sharded (n_ext entries)        */
-  HX_BUF_GMRES_DOTS = 5   /* complex128 inner products of hx_gmres_sharded (restart + 2 entries)                 */
+  HX_BUF_GMRES_DOTS = 5   /* complex128 inner products of hx_gmres_sharded (restart + 2 + k_max entries)         */
 };
 typedef int (*hx_halo_fn)(void* ctx, int buf);
 typedef int (*hx_allreduce_fn)(void* ctx, int buf, int count);
@@ -252,7 +265,7 @@ typedef int (*hx_allreduce_fn)(void* ctx, int buf, int count);
 int hx_amg_set_sharded(hx_amg* h, int32_t n_ext, void* x, void* x2, void* x3, void* coarse_b, hx_halo_fn halo,
                        hx_allreduce_fn allreduce, void* ctx);
 /* hx_gmres on the row-sharded operator: K = local rows over [owned | ghost] columns, b / x / ws sized by n_own;
- * xe (n_ext) and hbuf (restart + 2) are the registered buffers above.  Every rank must call it collectively. */
+ * xe (n_ext) and hbuf (restart + 2 + k_max recycled pairs) are the registered buffers above.  Every rank must call it collectively. */
 int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                      const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
                      int restart, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s);

@@ -248,7 +248,7 @@ def main():
                        "nev": 4, "fpi_tol": 1e-3, "fpi_iterations": len(hist) - 1, "flames": 16,
                        "inner_solver": getattr(inner, "name", None),
                        "inner_stats": inner.stats() if inner is not None else None,
-                       "krylov": {k: v for k, v in (E.state or {}).items() if not k.startswith("start")},
+                       "krylov": {k: v for k, v in (E.state or {}).items() if not k.startswith(("start", "_"))},
                        "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
                        "omega": [[round(w.real, 6), round(w.imag, 6)] for w in omegas]},
             "roofline": roof,

@@ -627,6 +627,26 @@ extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci
 
 
 // ------------------------------------------------------------------------------------------------ SA set-up passes (host)
+// Row-parallel helper for the host passes: contiguous row blocks, one std::thread each (HX_HOST_THREADS, default
+// min(16, hardware threads)); every row is produced by exactly one thread, so results do not depend on the count.
+static int host_threads() {
+  static const int nt = [] {
+    const char* e = getenv("HX_HOST_THREADS");
+    int v = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return std::max(1, std::min(v, 64));
+  }();
+  return nt;
+}
+template <typename F> static void parallel_rows(int32_t n, F&& fn) {   // fn(thread, row_begin, row_end)
+  int nt = host_threads();
+  if (n < 50000) nt = 1;
+  std::vector<std::thread> pool;
+  auto blk = [&](int t) { return (int32_t)((int64_t)n * t / nt); };
+  for (int t = 1; t < nt; ++t) pool.emplace_back([&, t] { fn(t, blk(t), blk(t + 1)); });
+  fn(0, blk(0), blk(1));
+  for (auto& th : pool) th.join();
+}
+
 // One sweep over the Laplacian-like matrix L (CSR, real values, positive diagonal): keep the diagonal and the strong
 // off-diagonal couplings |l_ij| >= theta*sqrt(l_ii l_jj); weak couplings are lumped onto the diagonal.  Output is the
 // filtered matrix Lf in compact CSR (diagonal entry included).  Call once with out_ci == NULL to get the row pointer
@@ -634,42 +654,49 @@ extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci
 extern "C" int hx_host_sa_filter(int32_t n, const int32_t* rp, const int32_t* ci, const double* lv, double theta,
                                  int32_t* out_rp, int32_t* out_ci, double* out_v) {
   HX_REQUIRE(n > 0 && rp && ci && lv && out_rp, "bad argument");
+  HX_REQUIRE(out_ci == nullptr || out_v != nullptr, "bad argument");
   std::vector<double> sd(n);
-  for (int32_t i = 0; i < n; ++i) {
-    double d = 0.0;
-    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] == i) d = lv[p];
-    d = std::fabs(d);
-    sd[i] = std::sqrt(d == 0.0 ? 1.0 : d);
-  }
-  if (!out_ci) {
-    out_rp[0] = 0;
-    for (int32_t i = 0; i < n; ++i) {
-      int32_t cnt = 1;                                  // the diagonal always stays
-      const double ti = theta * sd[i];
-      for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
-        const int32_t j = ci[p];
-        if (j != i && std::fabs(lv[p]) >= ti * sd[j]) ++cnt;
-      }
-      out_rp[i + 1] = out_rp[i] + cnt;
+  parallel_rows(n, [&](int, int32_t i0, int32_t i1) {
+    for (int32_t i = i0; i < i1; ++i) {
+      double d = 0.0;
+      for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] == i) d = lv[p];
+      d = std::fabs(d);
+      sd[i] = std::sqrt(d == 0.0 ? 1.0 : d);
     }
+  });
+  if (!out_ci) {
+    parallel_rows(n, [&](int, int32_t i0, int32_t i1) {
+      for (int32_t i = i0; i < i1; ++i) {
+        int32_t cnt = 1;                                  // the diagonal always stays
+        const double ti = theta * sd[i];
+        for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+          const int32_t j = ci[p];
+          if (j != i && std::fabs(lv[p]) >= ti * sd[j]) ++cnt;
+        }
+        out_rp[i + 1] = cnt;
+      }
+    });
+    out_rp[0] = 0;
+    for (int32_t i = 0; i < n; ++i) out_rp[i + 1] += out_rp[i];
     return HX_OK;
   }
-  HX_REQUIRE(out_v, "bad argument");
-  for (int32_t i = 0; i < n; ++i) {
-    const double ti = theta * sd[i];
-    double diag = 0.0, lump = 0.0;
-    int32_t q = out_rp[i], qd = -1;
-    bool placed = false;
-    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
-      const int32_t j = ci[p];
-      if (j == i) { diag = lv[p]; qd = q; out_ci[q] = i; ++q; placed = true; continue; }
-      if (!placed && j > i) { qd = q; out_ci[q] = i; ++q; placed = true; }      // keep columns sorted if no diagonal stored
-      if (std::fabs(lv[p]) >= ti * sd[j]) { out_ci[q] = j; out_v[q] = lv[p]; ++q; }
-      else lump += lv[p];
+  parallel_rows(n, [&](int, int32_t i0, int32_t i1) {
+    for (int32_t i = i0; i < i1; ++i) {
+      const double ti = theta * sd[i];
+      double diag = 0.0, lump = 0.0;
+      int32_t q = out_rp[i], qd = -1;
+      bool placed = false;
+      for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+        const int32_t j = ci[p];
+        if (j == i) { diag = lv[p]; qd = q; out_ci[q] = i; ++q; placed = true; continue; }
+        if (!placed && j > i) { qd = q; out_ci[q] = i; ++q; placed = true; }      // keep columns sorted if no diagonal stored
+        if (std::fabs(lv[p]) >= ti * sd[j]) { out_ci[q] = j; out_v[q] = lv[p]; ++q; }
+        else lump += lv[p];
+      }
+      if (!placed) { qd = q; out_ci[q] = i; ++q; }
+      out_v[qd] = diag + lump;
     }
-    if (!placed) { qd = q; out_ci[q] = i; ++q; }
-    out_v[qd] = diag + lump;
-  }
+  });
   return HX_OK;
 }
 
@@ -680,31 +707,73 @@ extern "C" int hx_host_sa_prolongator(int32_t n, const int32_t* rp, const int32_
                                       const int32_t* agg, const double* inv_sqrt_cnt, double omega,
                                       int32_t* out_rp, int32_t* out_ci, double* out_v) {
   HX_REQUIRE(n > 0 && rp && ci && lf && agg && inv_sqrt_cnt && out_rp, "bad argument");
-  std::vector<int32_t> cols;
-  std::vector<double> vals;
-  if (!out_ci) out_rp[0] = 0;
-  for (int32_t i = 0; i < n; ++i) {
-    cols.clear(); vals.clear();
-    double dii = 1.0;
-    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] == i) dii = lf[p];
-    if (dii == 0.0) dii = 1.0;
-    auto add = [&](int32_t c, double v) {
-      size_t k = 0;
-      while (k < cols.size() && cols[k] < c) ++k;
-      if (k < cols.size() && cols[k] == c) { vals[k] += v; return; }
-      cols.insert(cols.begin() + k, c);
-      vals.insert(vals.begin() + k, v);
-    };
-    add(agg[i], inv_sqrt_cnt[agg[i]]);
-    const double w = omega / dii;
-    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
-      const int32_t a = agg[ci[p]];
-      add(a, -w * lf[p] * inv_sqrt_cnt[a]);
+  HX_REQUIRE(out_ci == nullptr || out_v != nullptr, "bad argument");
+  parallel_rows(n, [&](int, int32_t i0, int32_t i1) {
+    std::vector<int32_t> cols;
+    std::vector<double> vals;
+    for (int32_t i = i0; i < i1; ++i) {
+      cols.clear(); vals.clear();
+      double dii = 1.0;
+      for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] == i) dii = lf[p];
+      if (dii == 0.0) dii = 1.0;
+      auto add = [&](int32_t c, double v) {
+        size_t k = 0;
+        while (k < cols.size() && cols[k] < c) ++k;
+        if (k < cols.size() && cols[k] == c) { vals[k] += v; return; }
+        cols.insert(cols.begin() + k, c);
+        vals.insert(vals.begin() + k, v);
+      };
+      add(agg[i], inv_sqrt_cnt[agg[i]]);
+      const double w = omega / dii;
+      for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+        const int32_t a = agg[ci[p]];
+        add(a, -w * lf[p] * inv_sqrt_cnt[a]);
+      }
+      if (!out_ci) { out_rp[i + 1] = (int32_t)cols.size(); continue; }
+      int32_t q = out_rp[i];
+      for (size_t k = 0; k < cols.size(); ++k, ++q) { out_ci[q] = cols[k]; out_v[q] = vals[k]; }
     }
-    if (!out_ci) { out_rp[i + 1] = out_rp[i] + (int32_t)cols.size(); continue; }
-    int32_t q = out_rp[i];
-    for (size_t k = 0; k < cols.size(); ++k, ++q) { out_ci[q] = cols[k]; out_v[q] = vals[k]; }
+  });
+  if (!out_ci) {
+    out_rp[0] = 0;
+    for (int32_t i = 0; i < n; ++i) out_rp[i + 1] += out_rp[i];
   }
+  return HX_OK;
+}
+
+// Power iteration for rho(Df^-1 Lf) (Lf CSR with positive diagonal): v <- Df^-1 Lf v / ||.||, `iters` times from the
+// caller's start vector v (overwritten); returns the last norm ratio.  Row-parallel matvec; the norm is summed per
+// row block and combined in block order.
+extern "C" int hx_host_power_rho(int32_t n, const int32_t* rp, const int32_t* ci, const double* lf, double* v,
+                                 int iters, double* rho) {
+  HX_REQUIRE(n > 0 && rp && ci && lf && v && rho && iters >= 1, "bad argument");
+  std::vector<double> w(n), part(64, 0.0);
+  double nrm = 0.0;
+  for (int32_t i = 0; i < n; ++i) nrm += v[i] * v[i];
+  nrm = std::sqrt(nrm);
+  HX_REQUIRE(nrm > 0.0, "zero start vector");
+  for (int32_t i = 0; i < n; ++i) v[i] /= nrm;
+  double lam = 1.0;
+  for (int it = 0; it < iters; ++it) {
+    std::fill(part.begin(), part.end(), 0.0);
+    parallel_rows(n, [&](int t, int32_t i0, int32_t i1) {
+      double acc = 0.0;
+      for (int32_t i = i0; i < i1; ++i) {
+        double d = 1.0, sum = 0.0;
+        for (int32_t p = rp[i]; p < rp[i + 1]; ++p) { if (ci[p] == i) d = lf[p]; sum += lf[p] * v[ci[p]]; }
+        w[i] = sum / d;
+        acc += w[i] * w[i];
+      }
+      part[t] = acc;
+    });
+    double s2 = 0.0;
+    for (double q : part) s2 += q;
+    lam = std::sqrt(s2);
+    if (lam == 0.0) break;
+    const double inv = 1.0 / lam;
+    parallel_rows(n, [&](int, int32_t i0, int32_t i1) { for (int32_t i = i0; i < i1; ++i) v[i] = w[i] * inv; });
+  }
+  *rho = lam;
   return HX_OK;
 }
 

@@ -92,18 +92,16 @@ def _galerkin(R, K, P, n_threads=None):
 
 def _spectral_radius_dinv(Lf, iters=10, seed=0):
     """Power-iteration estimate of rho(Df^-1 Lf) (similar to an SPD matrix: the norm ratio converges from below; the
-    smoothing weights derived from it carry a 4/3 safety factor).  Norms avoid BLAS ddot on purpose: multi-threaded
-    BLAS start-up costs more than the reduction itself at these sizes."""
-    dinv = 1.0 / Lf.diagonal()
-    rng = np.random.default_rng(seed)
-    v = rng.standard_normal(Lf.shape[0])
-    v /= np.sqrt((v * v).sum())
-    lam = 1.0
-    for _ in range(iters):
-        w = dinv * (Lf @ v)
-        lam = float(np.sqrt((w * w).sum()))
-        v = w / lam
-    return lam
+    smoothing weights derived from it carry a 4/3 safety factor).  Native row-parallel pass (hx_host_power_rho)."""
+    n = Lf.shape[0]
+    v = np.random.default_rng(seed).standard_normal(n)
+    rp = np.ascontiguousarray(Lf.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(Lf.indices, dtype=np.int32)
+    lf = np.ascontiguousarray(Lf.data, dtype=np.float64)
+    rho = C.c_double(0.0)
+    _hx.check(_hx.lib.hx_host_power_rho(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(lf), _hx.nptr(v), int(iters),
+                                        C.byref(rho)))
+    return rho.value
 
 
 def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], coarse_size=PARAMS["coarse_size"]):

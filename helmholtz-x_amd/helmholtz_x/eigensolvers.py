@@ -116,6 +116,7 @@ def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history, stat
     if state is not None:
         state["warm_pairs"] = nev - lean        # lean solves also hand over their best unconverged Ritz directions
         state["lean_nev"] = lean
+        state["nev_max"] = nev
     E, omega[0] = solve_passive(lean)
     alpha[0] = 0.5
     if history is not None:

@@ -199,15 +199,29 @@ class WoodburySolver:
 class DeviceBasis:
     """(m, n) row-major block of Krylov vectors + the libhx CGS2 / rotation kernels."""
 
-    def __init__(self, n, m, apply_op, seed=0, start=None, shard=None, blocks=1):
+    def __init__(self, n, m, apply_op, seed=0, start=None, shard=None, blocks=1, pool=None):
         """Row-sharded mode: ``n`` is the LOCAL length (``blocks`` stacked owned blocks: 1 for EPS, 2 for the companion
         vector [x; lambda x]); inner products are summed over the ranks."""
         dev = _hx.require_gpu()
         self.shard, self.blocks = shard, blocks
         self.n, self.m = n, m
         self.start = start
-        self.V = torch.zeros((m, n), dtype=torch.complex128, device=dev)
-        self.V2 = torch.zeros((m, n), dtype=torch.complex128, device=dev)
+        # The two panels are the largest allocations of the path (m x n complex128 each: 2 x 6 GB for the 5 M-DOF
+        # companion vectors); consecutive solves of one fixed-point call reuse them through ``pool``.  Rows are always
+        # written (set_start / expand / rotate) before they are read, so no zero fill is needed.
+        got = None if pool is None else pool.get("basis")
+        if got is not None and got[0].shape[1] == n and got[0].shape[0] >= m and got[0].device == dev:
+            self.V, self.V2 = got[0][:m], got[1][:m]
+        else:
+            rows = m
+            if pool is not None:
+                pool.pop("basis", None)          # release a smaller pair before allocating the larger one
+                rows = max(m, min(int(pool.get("rows_hint", 0)), n))   # size once for the widest solve of the call
+            Va = torch.empty((rows, n), dtype=torch.complex128, device=dev)
+            Vb = torch.empty((rows, n), dtype=torch.complex128, device=dev)
+            if pool is not None:
+                pool["basis"] = (Va, Vb)
+            self.V, self.V2 = Va[:m], Vb[:m]
         self.apply_op = apply_op
         self.seed = seed
         self.h_dev = torch.empty(m + 1, dtype=torch.complex128, device=dev)
@@ -423,6 +437,15 @@ class _EigenSolverBase:
             self.inner_cache[key] = solver
         return solver
 
+    def _pool(self):
+        """Buffer pool shared by the solves of one fixed-point call (lives in ``state``; None for a single solve)."""
+        if self.state is None:
+            return None
+        pool = self.state.setdefault("_pool", {})
+        if "nev_max" in self.state and self._ncv is None:
+            pool["rows_hint"] = 2 * default_ncv(int(self.state["nev_max"])) + 1
+        return pool
+
     def _start(self):
         if self.state is None:
             return None
@@ -473,7 +496,7 @@ class EPS(_EigenSolverBase):
                 Mloc.spmv(xe, tmp)
                 solver.solve(tmp, w)
 
-            self._finish(DeviceBasis(n_loc, self._ncv_for(n) + 1, op, start=self._start(), shard=sh), sigma)
+            self._finish(DeviceBasis(n_loc, self._ncv_for(n) + 1, op, start=self._start(), shard=sh, pool=self._pool()), sigma)
             return
         tmp = torch.empty(n, dtype=torch.complex128, device=Mcsr.val.device)
 
@@ -481,7 +504,7 @@ class EPS(_EigenSolverBase):
             Mcsr.spmv(v, tmp)
             solver.solve(tmp, w)
 
-        self._finish(DeviceBasis(n, self._ncv_for(n) + 1, op, start=self._start()), sigma)
+        self._finish(DeviceBasis(n, self._ncv_for(n) + 1, op, start=self._start(), pool=self._pool()), sigma)
         if self._two_sided:
             left = EPS()
             At, Mt = A.copy(), M.copy()
@@ -550,7 +573,8 @@ class PEP(_EigenSolverBase):
                 cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
                 _hx.check(_hx.lib.hx_zlincomb(m, 2, cf, arr, _hx.ptr(y2), _hx.stream()))
 
-            self._finish(DeviceBasis(2 * m, self._ncv_for(2 * n) + 1, op, start=self._start(), shard=sh, blocks=2),
+            self._finish(DeviceBasis(2 * m, self._ncv_for(2 * n) + 1, op, start=self._start(), shard=sh, blocks=2,
+                                     pool=self._pool()),
                          sigma)
             self._n = m
             return
@@ -566,7 +590,7 @@ class PEP(_EigenSolverBase):
             cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
             _hx.check(_hx.lib.hx_zlincomb(n, 2, cf, arr, _hx.ptr(y2), _hx.stream()))   # y2 = x1 + sigma y1
 
-        self._finish(DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op, start=self._start()), sigma)
+        self._finish(DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op, start=self._start(), pool=self._pool()), sigma)
         self._n = n
 
 

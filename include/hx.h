@@ -282,6 +282,9 @@ int hx_host_aggregate(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const
 int hx_host_sa_prolongator(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_lf,
                            const int32_t* h_agg, const double* h_inv_sqrt_cnt, double omega,
                            int32_t* h_out_rp, int32_t* h_out_ci, double* h_out_v);
+/* rho(Df^-1 Lf) by `iters` power iterations from the start vector v (length n, overwritten); row-parallel. */
+int hx_host_power_rho(int32_t n, const int32_t* rp, const int32_t* ci, const double* lf, double* v, int iters,
+                      double* rho);
 /* HOST, multi-threaded: Galerkin product Kc = R K P (R, P real CSR; K complex CSR) fused over coarse rows, no
  * intermediate K P.  Same two-call protocol (h_out_ci == NULL: count pass); columns sorted per row. */
 int hx_host_galerkin_rap(int32_t n_c, const int32_t* h_Rrp, const int32_t* h_Rci, const double* h_Rv,

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Where the one-off AMG set-up time goes (host passes vs transfers), for one workload.  Usage: setup_breakdown.py [workload]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "helmholtz-x_amd"), os.path.join(ROOT, "tests")]
+os.environ.setdefault("HX_QUIET", "1")
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from helmholtz_x import amg  # noqa: E402
+
+acc = {}
+
+
+def timed(name, fn):
+    def wrap(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn(*a, **k)
+        torch.cuda.synchronize()
+        acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+        return out
+    return wrap
+
+
+for f in ("_filter", "_aggregate", "_prolongator", "_galerkin", "_spectral_radius_dinv", "build_hierarchy"):
+    setattr(amg, f, timed(f, getattr(amg, f)))
+from helmholtz_x.petsc import CSR  # noqa: E402
+CSR.to_scipy = timed("K.to_scipy (D2H + scipy)", CSR.to_scipy)
+
+case = bench.build_case(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "annulus-5M"])
+case["mesh"].assembler()
+import contextlib  # noqa: E402
+with contextlib.redirect_stdout(sys.stderr):
+    E, _ = bench.hot_path(case)
+inner = next(v for v in E.inner_cache.values() if hasattr(v, "stats"))
+print("AMGSolver set-up total %.3f s" % inner.setup_s)
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+    print("  %-28s %.3f s" % (k, v))

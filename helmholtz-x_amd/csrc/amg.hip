@@ -651,10 +651,13 @@ template <typename F> static void parallel_rows(int32_t n, F&& fn) {   // fn(thr
 // off-diagonal couplings |l_ij| >= theta*sqrt(l_ii l_jj); weak couplings are lumped onto the diagonal.  Output is the
 // filtered matrix Lf in compact CSR (diagonal entry included).  Call once with out_ci == NULL to get the row pointer
 // (count pass), then again to fill.  Replaces ~15 NumPy passes over the nnz arrays.
-extern "C" int hx_host_sa_filter(int32_t n, const int32_t* rp, const int32_t* ci, const double* lv, double theta,
-                                 int32_t* out_rp, int32_t* out_ci, double* out_v) {
-  HX_REQUIRE(n > 0 && rp && ci && lv && out_rp, "bad argument");
+extern "C" int hx_host_sa_filter(int32_t n, const int32_t* rp, const int32_t* ci, const double* lv_in, int stride,
+                                 double sign, double theta, int32_t* out_rp, int32_t* out_ci, double* out_v) {
+  HX_REQUIRE(n > 0 && rp && ci && lv_in && out_rp && stride >= 1, "bad argument");
   HX_REQUIRE(out_ci == nullptr || out_v != nullptr, "bad argument");
+  // entry p of L is sign * lv_in[p * stride]: stride 2 reads the real parts of an interleaved complex128 array in place
+  struct View { const double* p; int st; double sg; double operator[](int64_t i) const { return sg * p[i * st]; } };
+  const View lv{lv_in, stride, sign};
   std::vector<double> sd(n);
   parallel_rows(n, [&](int, int32_t i0, int32_t i1) {
     for (int32_t i = i0; i < i1; ++i) {

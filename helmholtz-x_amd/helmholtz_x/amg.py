@@ -39,19 +39,20 @@ def _aggregate(S):
     return agg, na.value
 
 
-def _filter(L, theta):
-    """Filtered Laplacian Lf (strong couplings + lumped diagonal) as scipy CSR -- one native pass (hx_host_sa_filter)."""
-    n = L.shape[0]
-    rp = np.ascontiguousarray(L.indptr, dtype=np.int32)
-    ci = np.ascontiguousarray(L.indices, dtype=np.int32)
-    lv = np.ascontiguousarray(L.data, dtype=np.float64)
+def _filter(K, sign, theta):
+    """Filtered Laplacian Lf (strong couplings + lumped diagonal) of L = sign * Re(K) as scipy CSR -- one native pass
+    (hx_host_sa_filter) that reads the real parts of K's complex values in place."""
+    n = K.shape[0]
+    rp = np.ascontiguousarray(K.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(K.indices, dtype=np.int32)
+    kv = np.ascontiguousarray(K.data, dtype=np.complex128)
     orp = np.empty(n + 1, dtype=np.int32)
-    _hx.check(_hx.lib.hx_host_sa_filter(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(lv), float(theta), _hx.nptr(orp), None, None))
+    args = (n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(kv), 2, float(sign), float(theta))
+    _hx.check(_hx.lib.hx_host_sa_filter(*args, _hx.nptr(orp), None, None))
     oci = np.empty(orp[-1], dtype=np.int32)
     ov = np.empty(orp[-1], dtype=np.float64)
-    _hx.check(_hx.lib.hx_host_sa_filter(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(lv), float(theta), _hx.nptr(orp),
-                                        _hx.nptr(oci), _hx.nptr(ov)))
-    return sp.csr_matrix((ov, oci, orp), shape=L.shape)
+    _hx.check(_hx.lib.hx_host_sa_filter(*args, _hx.nptr(orp), _hx.nptr(oci), _hx.nptr(ov)))
+    return sp.csr_matrix((ov, oci, orp), shape=K.shape)
 
 
 def _prolongator(Lf, agg, na, omega):
@@ -119,9 +120,8 @@ def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], c
             levels.append(level)
             break
         # Laplacian-like real part with positive diagonal drives strength / prolongator smoothing
-        sgn = -1.0 if np.median(diag.real) < 0 else 1.0
-        L = sp.csr_matrix((sgn * Kl.data.real, Kl.indices, Kl.indptr), shape=Kl.shape)
-        Lf = _filter(L, th)
+        sgn = -1.0 if 2 * np.count_nonzero(diag.real < 0) > n else 1.0
+        Lf = _filter(Kl, sgn, th)
         agg, na = _aggregate(Lf)
         if na >= 0.8 * n:                          # coarsening stalled
             levels.append(level)

@@ -271,12 +271,13 @@ int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowpt
                      int restart, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s);
 /* HOST set-up passes of the smoothed-aggregation hierarchy (graph / integer work, once per K):
  * hx_host_sa_filter: strength filter |l_ij| >= theta*sqrt(l_ii l_jj) with weak couplings lumped on the diagonal;
- *   L is the Laplacian-like real part (CSR); output = filtered matrix in compact CSR.  Call with h_out_ci == NULL
+ *   L is the Laplacian-like real part (CSR), entry p = sign * h_lv[p * stride] (stride 2 = the real parts of an
+ *   interleaved complex128 value array, read in place); output = filtered matrix in compact CSR.  Call with h_out_ci == NULL
  *   for the count pass (fills h_out_rp), then again to fill.
  * hx_host_aggregate: greedy aggregation on that graph (diagonal entries are ignored, |w| is the coupling strength).
  * hx_host_sa_prolongator: P = (I - omega Df^-1 Lf) P0 with P0[i, agg(i)] = inv_sqrt_cnt[agg(i)]; same two-call protocol. */
-int hx_host_sa_filter(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_lv, double theta,
-                      int32_t* h_out_rp, int32_t* h_out_ci, double* h_out_v);
+int hx_host_sa_filter(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_lv, int stride, double sign,
+                      double theta, int32_t* h_out_rp, int32_t* h_out_ci, double* h_out_v);
 int hx_host_aggregate(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_w,
                       int32_t* h_agg, int32_t* h_n_agg);
 int hx_host_sa_prolongator(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_lf,

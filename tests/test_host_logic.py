@@ -103,7 +103,7 @@ def test_native_amg_setup_passes_match_numpy():
     m.x[:, 1] *= 3.0                                        # anisotropy => some weak couplings
     S = -fem.assemble_A(m.x, m.cells, 300.0 + 50 * rng.random(m.x.shape[0])).real.tocsr()
     theta = 0.25
-    Lf = amg._filter(S, theta)
+    Lf = amg._filter((-S).astype(np.complex128) + 0.3j * sp.eye(S.shape[0]), -1.0, theta)   # L = sign * Re(K), read in place
     d = np.abs(S.diagonal())
     coo = S.tocoo()
     off = coo.row != coo.col
@@ -114,6 +114,7 @@ def test_native_amg_setup_passes_match_numpy():
         + sp.diags(np.bincount(coo.row[weak], weights=coo.data[weak], minlength=S.shape[0]))
     assert abs(Lf - ref).max() < 1e-12 * abs(ref).max()
     assert np.all(np.diff(Lf.indices)[np.diff(np.repeat(np.arange(S.shape[0]), np.diff(Lf.indptr))) == 0] > 0)  # sorted rows
+    assert abs(amg._spectral_radius_dinv(Lf, iters=60) - np.max(np.abs(np.linalg.eigvals((sp.diags(1 / Lf.diagonal()) @ Lf).toarray())))) < 2e-2
     agg, na = amg._aggregate(Lf)
     assert agg.min() == 0 and agg.max() == na - 1 and len(np.unique(agg)) == na and na < 0.5 * S.shape[0]
     # every aggregate is connected through strong couplings to its root neighbourhood: members share a strong edge
@@ -252,3 +253,32 @@ def test_h5lite_reads_reference_mesh_files(golden_dir):
     assert len(ft.find(11)) > 0
     with pytest.raises(KeyError):
         h.read("nope")
+
+
+def test_locate_slots_of_a_sub_pattern():
+    """Host integer logic behind combine_csr: positions of a boundary-only pattern (B) inside the volume pattern (A/C)."""
+    from helmholtz_x.petsc import locate_slots
+    rng = np.random.default_rng(5)
+    n = 400
+    base = sp.random(n, n, density=0.03, random_state=3, format="csr") + sp.eye(n, format="csr")
+    base.sort_indices()
+    keep = rng.random(base.nnz) < 0.2
+    keep[base.indptr[50]:base.indptr[300]] = False                     # whole row ranges untouched
+    rows = np.repeat(np.arange(n), np.diff(base.indptr))
+    sub = sp.csr_matrix((np.ones(keep.sum()), (rows[keep], base.indices[keep])), shape=(n, n))
+    sub.sort_indices()
+    slots = locate_slots(n, base.indptr.astype(np.int32), base.indices.astype(np.int32),
+                         sub.indptr.astype(np.int32), sub.indices.astype(np.int32))
+    assert slots.dtype == np.int32 and np.array_equal(slots, np.flatnonzero(keep))
+    # an entry that is not in the base pattern -> None (caller falls back to the union pattern)
+    extra = sub.tolil()
+    r = 10
+    missing = np.setdiff1d(np.arange(n), base.indices[base.indptr[r]:base.indptr[r + 1]])[0]
+    extra[r, missing] = 1.0
+    extra = extra.tocsr()
+    extra.sort_indices()
+    assert locate_slots(n, base.indptr.astype(np.int32), base.indices.astype(np.int32),
+                        extra.indptr.astype(np.int32), extra.indices.astype(np.int32)) is None
+    empty = sp.csr_matrix((n, n))
+    assert locate_slots(n, base.indptr.astype(np.int32), base.indices.astype(np.int32),
+                        empty.indptr.astype(np.int32), empty.indices.astype(np.int32)).size == 0

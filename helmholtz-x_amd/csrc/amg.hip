@@ -33,6 +33,7 @@ int hx_csr_smooth_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c
                     const hx_c128*, hx_c128*, double, const hx_c128*, double, hx_stream);
 int hx_csr_smooth_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
                     const float*, float*, float, const float*, float, hx_stream);
+extern "C" int hx_zpanel_dot_c64(int64_t, int, const hx_c64*, int64_t, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
 struct hx_sell;
 extern "C" int hx_sell_spmv_z(const hx_sell*, const hx_c128*, hx_c128*, const double*, const double*, hx_stream);
 extern "C" int hx_sell_spmv_c64(const hx_sell*, const hx_c64*, hx_c64*, float, float, hx_stream);
@@ -65,6 +66,7 @@ struct Recycle {
   int64_t n = 0;
   hx_c128* U = nullptr;        // kmax x n
   hx_c128* CV = nullptr;       // (kmax + restart + 1) x n : rows [0, k) = C, then the Arnoldi vectors
+  float* CVf = nullptr;        // complex64 copy of CV, read by the inner-product passes (hx_zpanel_dot_c64)
   std::vector<cd> Hraw;        // raw Hessenberg of the last first cycle, column-major, ld = restart + 1
 };
 // Row-sharded mode (one process per GPU): level 0 holds this rank's rows over [owned | ghost] columns, every coarser
@@ -161,7 +163,7 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
   };
   for (auto& l : h->D.L) release(l);
   for (auto& l : h->S.L) release(l);
-  (void)hipFree(h->rec.U); (void)hipFree(h->rec.CV);
+  (void)hipFree(h->rec.U); (void)hipFree(h->rec.CV); (void)hipFree(h->rec.CVf);
   delete h;
   return HX_OK;
 }
@@ -386,9 +388,16 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
   std::vector<std::vector<cd>> H(restart + 1, std::vector<cd>(restart, cd(0)));
   std::vector<std::vector<cd>> B(kc > 0 ? kc : 1, std::vector<cd>(restart, cd(0)));
   std::vector<cd> cs(restart), sn(restart), g(restart + 1);
-  // out[0..k) = panel rows [row0, row0 + k)^H w, out[k] = w^H w   (all-reduced in sharded mode)
+  // out[0..k) = panel rows [0, k)^H w, out[k] = w^H w   (all-reduced in sharded mode).  With the recycling workspace the
+  // inner products read the complex64 copy of the panel; the subtractions always use the complex128 rows.
+  float* Pf = rec ? rec->CVf : nullptr;
+  auto mirror = [&](const hx_c128* row) -> int {      // refresh the complex64 copy of one finished panel row
+    if (!Pf) return HX_OK;
+    return hx_cast_z2c(n, row, Pf + 2 * (size_t)(row - Pn), s);
+  };
   auto dots = [&](const hx_c128* panel, int k, const hx_c128* w) -> int {
-    int rc = hx_zpanel_dot(n, k, panel, n, w, hdev, part, s);
+    int rc = (Pf && k > 0) ? hx_zpanel_dot_c64(n, k, (const hx_c64*)Pf, n, w, hdev, part, s)
+                           : hx_zpanel_dot(n, k, panel, n, w, hdev, part, s);
     if (rc) return rc;
     if (sharded && M->allreduce(M->ctx, HX_BUF_GMRES_DOTS, k + 1) != 0)
       return hx_fail(HX_ERR_COMM, "hx_gmres", "all-reduce callback failed");
@@ -430,6 +439,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
     HX_HIP(hipMemcpyAsync(V, r, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
     const double ib[2] = {1.0 / beta, 0.0};
     if ((rc = hx_zscal(n, ib, V, s))) return rc;
+    if ((rc = mirror(V))) return rc;
     std::fill(g.begin(), g.end(), cd(0));
     g[0] = beta;
     int j = 0;
@@ -459,6 +469,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
         for (int i = 0; i <= j + 1; ++i) rec->Hraw[(size_t)j * (restart + 1) + i] = H[i][j];
       }
       if (hn > 0) { const double ih[2] = {1.0 / hn, 0.0}; if ((rc = hx_zscal(n, ih, w, s))) return rc; }
+      if ((rc = mirror(w))) return rc;
       // complex Givens rotations
       for (int i = 0; i < j; ++i) {
         const cd t = std::conj(cs[i]) * H[i][j] + std::conj(sn[i]) * H[i + 1][j];
@@ -516,6 +527,7 @@ extern "C" int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int rest
   HX_REQUIRE(R.kmax == 0, "recycling already enabled");
   HX_HIP(hipMalloc((void**)&R.U, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
   HX_HIP(hipMalloc((void**)&R.CV, sizeof(hx_c128) * (size_t)(k_max + restart + 1) * (size_t)n));
+  HX_HIP(hipMalloc((void**)&R.CVf, sizeof(hx_c64) * (size_t)(k_max + restart + 1) * (size_t)n));
   R.kmax = k_max; R.k = 0; R.n = n; R.restart = restart; R.m_last = 0;
   R.Hraw.assign((size_t)(restart + 1) * restart, cd(0));
   return HX_OK;
@@ -554,6 +566,7 @@ extern "C" int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const 
     // V (rows 0..m of CV, since k was 0) -> C: staged through the Z panel, which is free now
     rc = hx_zpanel_mul(n, m + 1, k, R.CV, n, coef, Z, n, s);
     if (!rc) HX_HIP(hipMemcpyAsync(R.CV, Z, sizeof(hx_c128) * (size_t)k * n, hipMemcpyDeviceToDevice, hx_s(s)));
+    if (!rc) rc = hx_cast_z2c((int64_t)k * n, R.CV, R.CVf, s);
     HX_HIP(hipStreamSynchronize(hx_s(s)));
   }
   (void)hipFree(coef);

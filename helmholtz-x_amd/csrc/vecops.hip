@@ -111,34 +111,53 @@ extern "C" int hx_zgather(int64_t m, const hx_c128* x, const int32_t* idx, hx_c1
 
 extern "C" size_t hx_panel_dot_ws(int k) { return (size_t)PD_MAXBLOCKS * (size_t)(k + 1); }
 
+__device__ __forceinline__ zc pd_load(const zc* p) { return *p; }
+__device__ __forceinline__ zc pd_load(const cc* p) { const cc v = *p; return make_double2((double)v.x, (double)v.y); }
+// PT = zc: complex128 panel.  PT = cc: a complex64 COPY of the panel (half the traffic); w and the accumulation stay
+// complex128.  The coefficients then carry a 6e-8 relative error, which classical Gram-Schmidt applied twice removes:
+// the subtraction w -= V h always uses the complex128 panel, so the Arnoldi relation holds for whatever h was used.
+template <typename PT, int JT>
 __global__ void __launch_bounds__(PD_BLOCK)
-k_panel_dot_stage1(int64_t n, int k, const zc* __restrict__ V, int64_t ldv, const zc* __restrict__ w,
+k_panel_dot_stage1(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, const zc* __restrict__ w,
                    zc* __restrict__ partials, int64_t rows_per_block) {
-  __shared__ zc red[PD_BLOCK / HX_WAVE][PD_JT];
+  __shared__ zc red[PD_BLOCK / HX_WAVE][JT];
   const int64_t r0 = blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
   const int lane = threadIdx.x & (HX_WAVE - 1), wv = threadIdx.x / HX_WAVE;
-  for (int j0 = 0; j0 <= k; j0 += PD_JT) {           // column k is w itself (w^H w)
-    zc acc[PD_JT];
+  for (int j0 = 0; j0 <= k; j0 += JT) {           // column k is w itself (w^H w)
+    zc acc[JT];
 #pragma unroll
-    for (int t = 0; t < PD_JT; ++t) acc[t] = make_double2(0.0, 0.0);
-    for (int64_t i = r0 + threadIdx.x; i < r1; i += PD_BLOCK) {
+    for (int t = 0; t < JT; ++t) acc[t] = make_double2(0.0, 0.0);
+    int64_t i = r0 + threadIdx.x;
+    for (; i + PD_BLOCK < r1; i += 2 * PD_BLOCK) {     // two rows per trip: 2 x JT independent loads in flight
+      const zc wa = w[i], wb = w[i + PD_BLOCK];
+#pragma unroll
+      for (int t = 0; t < JT; ++t) {
+        const int j = j0 + t;
+        if (j < k) {
+          const zc va = pd_load(V + (int64_t)j * ldv + i), vb = pd_load(V + (int64_t)j * ldv + i + PD_BLOCK);
+          zcfma(acc[t], va, wa);
+          zcfma(acc[t], vb, wb);
+        } else if (j == k) { zcfma(acc[t], wa, wa); zcfma(acc[t], wb, wb); }
+      }
+    }
+    for (; i < r1; i += PD_BLOCK) {
       const zc wi = w[i];
 #pragma unroll
-      for (int t = 0; t < PD_JT; ++t) {
+      for (int t = 0; t < JT; ++t) {
         const int j = j0 + t;
-        if (j < k) zcfma(acc[t], V[(int64_t)j * ldv + i], wi);
+        if (j < k) zcfma(acc[t], pd_load(V + (int64_t)j * ldv + i), wi);
         else if (j == k) zcfma(acc[t], wi, wi);
       }
     }
 #pragma unroll
-    for (int t = 0; t < PD_JT; ++t) {
+    for (int t = 0; t < JT; ++t) {
       zc v = zreduce_sub<HX_WAVE>(acc[t]);
       if (lane == 0) red[wv][t] = v;
     }
     __syncthreads();
-    if (threadIdx.x < PD_JT && j0 + (int)threadIdx.x <= k) {
+    if (threadIdx.x < JT && j0 + (int)threadIdx.x <= k) {
       zc v = red[0][threadIdx.x];
       for (int q = 1; q < PD_BLOCK / HX_WAVE; ++q) v = zadd(v, red[q][threadIdx.x]);
       partials[(int64_t)blockIdx.x * (k + 1) + j0 + threadIdx.x] = v;
@@ -155,17 +174,27 @@ k_panel_dot_stage2(int nblocks, int k, const zc* __restrict__ partials, zc* __re
   v = zreduce_sub<HX_WAVE>(v);
   if (threadIdx.x == 0) out[j] = v;
 }
-extern "C" int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, hx_c128* out,
-                             hx_c128* partials, hx_stream s) {
+template <typename PT, int JT>
+static int panel_dot_launch(int64_t n, int k, const PT* V, int64_t ldv, const hx_c128* w, hx_c128* out, hx_c128* partials,
+                            hx_stream s) {
   HX_REQUIRE(n > 0 && k >= 0 && w && out && partials && (k == 0 || V) && ldv >= n, "bad argument");
   int64_t rpb = (n + PD_MAXBLOCKS - 1) / PD_MAXBLOCKS;
   if (rpb < PD_BLOCK * 4) rpb = PD_BLOCK * 4;
   int nblocks = (int)((n + rpb - 1) / rpb);
-  k_panel_dot_stage1<<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, (const zc*)V, ldv, (const zc*)w, (zc*)partials, rpb);
+  k_panel_dot_stage1<PT, JT><<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, V, ldv, (const zc*)w, (zc*)partials, rpb);
   HX_LAUNCH_CHECK("k_panel_dot_stage1");
   k_panel_dot_stage2<<<k + 1, HX_WAVE, 0, hx_s(s)>>>(nblocks, k, (const zc*)partials, (zc*)out);
   HX_LAUNCH_CHECK("k_panel_dot_stage2");
   return HX_OK;
+}
+extern "C" int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, hx_c128* out,
+                             hx_c128* partials, hx_stream s) {
+  return panel_dot_launch<zc, PD_JT>(n, k, (const zc*)V, ldv, w, out, partials, s);
+}
+extern "C" int hx_zpanel_dot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_c128* w, hx_c128* out,
+                                 hx_c128* partials, hx_stream s) {
+  return panel_dot_launch<cc, PD_JT>(   // (a 16-wide register tile was measured: 371 vs 223 us per launch)
+      n, k, (const cc*)Vf, ldv, w, out, partials, s);
 }
 
 // ---------------------------------------------------------------- w -= V h

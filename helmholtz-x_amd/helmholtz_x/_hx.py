@@ -33,6 +33,7 @@ SIGNATURES = {
     "hx_zgather": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "hx_panel_dot_ws": (C.c_size_t, [_int]),
     "hx_zpanel_dot": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "hx_zpanel_dot_c64": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hx_zpanel_sub": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp]),
     "hx_zpanel_mul": (C.c_int, [_i64, _int, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
     "hx_zsparse_dots": (C.c_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp]),

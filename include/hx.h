@@ -66,6 +66,11 @@ int hx_zgather(int64_t m, const hx_c128* x, const int32_t* idx, hx_c128* y, hx_s
 size_t hx_panel_dot_ws(int k);
 int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, hx_c128* out,
                   hx_c128* partials, hx_stream s);
+/* Same inner products from a complex64 COPY of the panel (half the HBM traffic; w and the accumulation stay
+ * complex128).  For Gram-Schmidt applied twice: the coefficients carry a 6e-8 relative error that the second pass
+ * removes, while w -= V h keeps using the complex128 panel, so the Arnoldi relation holds exactly. */
+int hx_zpanel_dot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_c128* w, hx_c128* out,
+                      hx_c128* partials, hx_stream s);
 /* w -= V[:, :k] h   (h: k complex numbers on the device) */
 int hx_zpanel_sub(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* h, hx_c128* w,
                   hx_stream s);

@@ -34,6 +34,7 @@ int hx_csr_smooth_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c
 int hx_csr_smooth_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
                     const float*, float*, float, const float*, float, hx_stream);
 extern "C" int hx_zpanel_dot_c64(int64_t, int, const hx_c64*, int64_t, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
+extern "C" int hx_zpanel_sub_c64(int64_t, int, const hx_c64*, int64_t, const hx_c128*, hx_c128*, hx_stream);
 struct hx_sell;
 extern "C" int hx_sell_spmv_z(const hx_sell*, const hx_c128*, hx_c128*, const double*, const double*, hx_stream);
 extern "C" int hx_sell_spmv_c64(const hx_sell*, const hx_c64*, hx_c64*, float, float, hx_stream);
@@ -457,9 +458,13 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
       for (int i = 0; i < kc; ++i) B[i][j] = hh[i];
       for (int i = 0; i <= j; ++i) H[i][j] = hh[kc + i];
       if ((rc = dots(Pn, k, w))) return rc;
-      if ((rc = hx_zpanel_sub(n, k, Pn, n, hdev, w, s))) return rc;
-      double n2 = hh[k].real();
-      for (int i = 0; i < k; ++i) n2 -= std::norm(hh[i]);
+      double h2sq = 0.0;
+      for (int i = 0; i < k; ++i) h2sq += std::norm(hh[i]);
+      // second (correction) pass: its coefficients are ~1e-7 |w|, so the update may read the complex64 mirror too
+      // (relation error 6e-8 |h2|); a large correction falls back to the complex128 panel
+      if (Pf && h2sq <= 1e-10 * hh[k].real()) { if ((rc = hx_zpanel_sub_c64(n, k, (const hx_c64*)Pf, n, hdev, w, s))) return rc; }
+      else if ((rc = hx_zpanel_sub(n, k, Pn, n, hdev, w, s))) return rc;
+      double n2 = hh[k].real() - h2sq;
       for (int i = 0; i < kc; ++i) B[i][j] += hh[i];
       for (int i = 0; i <= j; ++i) H[i][j] += hh[kc + i];
       if (n2 <= 1e-8 * hh[k].real()) { if ((rc = dots(Pn, 0, w))) return rc; n2 = hh[0].real(); }

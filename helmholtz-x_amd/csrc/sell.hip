@@ -8,6 +8,7 @@
 // shuffle reduction, no row-pointer chasing: the slice offset is wave-uniform), and y is written as one coalesced
 // 1 KiB store.  Padding on the annulus operator is ~2 % (interior rows all have 15 entries).
 // Algorithmic bytes are still counted with the CSR formula nnz*20 + n*36.
+#include <hip/hip_fp16.h>
 #include <hipcub/hipcub.hpp>
 
 #include "hx_common.h"
@@ -21,7 +22,31 @@ struct hx_sell {
   int32_t* col = nullptr;
   zc* val_z = nullptr;               // complex128 values (may be null)
   cc* val_c = nullptr;               // complex64 values (may be null)
+  // complex-half STORAGE of the values for the complex64 kernels (8 instead of 12 bytes per entry with the int32
+  // column): value = h_scale * half2.  Only for the V-cycle, a preconditioner inside flexible GMRES -- measured:
+  // identical iteration counts with fp16-rounded fine-level values (bf16: +3..9 %).  May be null.
+  __half2* val_h = nullptr;
+  float h_scale = 1.0f;
 };
+typedef __half2 ch;
+__device__ __forceinline__ zc mload(const zc* p) { return *p; }
+__device__ __forceinline__ cc mload(const cc* p) { return *p; }
+__device__ __forceinline__ cc mload(const ch* p) { return __half22float2(*p); }
+
+// max over |re|, |im| of a complex128 array (non-negative floats order like their bit patterns)
+__global__ void k_absmax(int64_t n, const zc* __restrict__ v, unsigned int* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const zc a = v[i];
+    m = fmaxf(m, fmaxf(fabsf((float)a.x), fabsf((float)a.y)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+template <>
+__device__ __forceinline__ ch czero<ch>() { return __floats2half2_rn(0.f, 0.f); }
 
 __global__ void k_sell_widths(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, int64_t* __restrict__ slice_sz) {
   const int lane = threadIdx.x & 63;
@@ -37,7 +62,7 @@ __global__ void k_sell_widths(int32_t n, int32_t n_slices, const int32_t* __rest
 template <typename VOUT>
 __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                             const zc* __restrict__ val, const int64_t* __restrict__ slice_ptr, int32_t* __restrict__ scol,
-                            VOUT* __restrict__ sval) {
+                            VOUT* __restrict__ sval, float inv_scale) {
   const int lane = threadIdx.x & 63;
   const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
   if (slice >= n_slices) return;
@@ -51,7 +76,9 @@ __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restri
     if (k < len) {
       const zc v = val[s + k];
       if (scol) scol[o] = col[s + k];
-      if constexpr (sizeof(VOUT) == sizeof(zc)) sval[o] = v; else sval[o] = make_float2((float)v.x, (float)v.y);
+      if constexpr (sizeof(VOUT) == sizeof(zc)) sval[o] = v;
+      else if constexpr (sizeof(VOUT) == sizeof(cc)) sval[o] = make_float2((float)v.x, (float)v.y);
+      else sval[o] = __floats2half2_rn((float)v.x * inv_scale, (float)v.y * inv_scale);
     } else {
       if (scol) scol[o] = pad_col;
       sval[o] = czero<VOUT>();
@@ -61,13 +88,14 @@ __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restri
 
 extern "C" int hx_sell_destroy(hx_sell* h) {
   if (!h) return HX_OK;
-  (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->val_z); (void)hipFree(h->val_c);
+  (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->val_z); (void)hipFree(h->val_c); (void)hipFree(h->val_h);
   delete h;
   return HX_OK;
 }
 
 // Build the SELL-64 companion of a device CSR (complex128 values).  want_z / want_c select which value copies to
-// keep (complex128 for the operator product, complex64 for the single-precision V-cycle).  SYNC.
+// keep (complex128 for the operator product, complex64 for the single-precision V-cycle; want_c == 2 stores that copy
+// as scaled complex-half instead: same complex64 arithmetic, 8 instead of 12 bytes per entry).  SYNC.
 extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
                               int want_z, int want_c, hx_stream s_) {
   HX_REQUIRE(out && n > 0 && rowptr && col && val && (want_z || want_c), "bad argument");
@@ -94,13 +122,37 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   const size_t ne = (size_t)(total > 0 ? total : 1);
   if (hipMalloc((void**)&h->col, sizeof(int32_t) * ne) != hipSuccess ||
       (want_z && hipMalloc((void**)&h->val_z, sizeof(zc) * ne) != hipSuccess) ||
-      (want_c && hipMalloc((void**)&h->val_c, sizeof(cc) * ne) != hipSuccess)) {
+      (want_c == 1 && hipMalloc((void**)&h->val_c, sizeof(cc) * ne) != hipSuccess) ||
+      (want_c == 2 && hipMalloc((void**)&h->val_h, sizeof(ch) * ne) != hipSuccess)) {
     hx_sell_destroy(h);
     return hx_fail(HX_ERR_ALLOC, __func__, "SELL arrays");
   }
-  if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z);
-  if (want_c) k_sell_fill<cc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
-                                                     want_z ? nullptr : h->col, h->val_c);
+  if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f);
+  if (want_c == 1) k_sell_fill<cc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
+                                                          want_z ? nullptr : h->col, h->val_c, 1.f);
+  if (want_c == 2) {
+    // scale so that the largest component maps to 2^14: five binary orders of head-room below the fp16 maximum, and
+    // entries down to ~4e-9 of the largest stay normal numbers
+    unsigned int* dmax = nullptr;
+    unsigned int hmax = 0;
+    int32_t nnz = 0;
+    e = hipMalloc((void**)&dmax, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemsetAsync(dmax, 0, sizeof(unsigned int), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nnz, rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {
+      k_absmax<<<hx_grid(nnz, 256), 256, 0, s>>>(nnz, (const zc*)val, dmax);
+      e = hipMemcpyAsync(&hmax, dmax, sizeof(unsigned int), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dmax);
+    if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
+    float vmax;
+    memcpy(&vmax, &hmax, sizeof(float));
+    h->h_scale = vmax > 0.f ? vmax / 16384.f : 1.f;
+    k_sell_fill<ch><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
+                                           want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale);
+  }
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
   HX_LAUNCH_CHECK("hx_sell_create");
@@ -116,12 +168,13 @@ extern "C" int hx_sell_info(const hx_sell* h, int32_t* n_slices, int64_t* padded
 }
 
 // MODE 0: y = alpha*A*x + beta*y.   MODE 1: xout = xin + omega*dinv.*(b - A*xin) + mom*(xin - xprev)  (smoother step)
-template <typename V, int MODE>
+// MV = storage type of the matrix values (V itself, or complex-half for V = complex64: entries are then vscale * half2).
+template <typename V, int MODE, typename MV = V>
 __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
-       const V* __restrict__ val, const V* __restrict__ x, V* __restrict__ y, V alpha, V beta, int beta_is_zero,
+       const MV* __restrict__ val, const V* __restrict__ x, V* __restrict__ y, V alpha, V beta, int beta_is_zero,
        const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev,
-       typename real_of<V>::type omega, typename real_of<V>::type mom) {
+       typename real_of<V>::type omega, typename real_of<V>::type mom, typename real_of<V>::type vscale) {
   const int lane = threadIdx.x & 63;
   const int32_t wave = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
   const int32_t n_waves = (int32_t)(((int64_t)gridDim.x * blockDim.x) >> 6);
@@ -131,16 +184,17 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     const int32_t row = slice * SELL_C + lane;
     V acc0 = czero<V>(), acc1 = czero<V>();
     const int32_t* cp = col + base + lane;
-    const V* vp = val + base + lane;
+    const MV* vp = val + base + lane;
     int k = 0;
     for (; k + 1 < width; k += 2) {                      // two independent chains: 4 loads in flight per lane per step
       const int32_t c0 = cp[(int64_t)k * SELL_C], c1 = cp[(int64_t)(k + 1) * SELL_C];
-      const V v0 = vp[(int64_t)k * SELL_C], v1 = vp[(int64_t)(k + 1) * SELL_C];
+      const V v0 = mload(vp + (int64_t)k * SELL_C), v1 = mload(vp + (int64_t)(k + 1) * SELL_C);
       zfma(acc0, v0, x[c0]);
       zfma(acc1, v1, x[c1]);
     }
-    if (k < width) zfma(acc0, vp[(int64_t)k * SELL_C], x[cp[(int64_t)k * SELL_C]]);
-    const V acc = zadd(acc0, acc1);
+    if (k < width) zfma(acc0, mload(vp + (int64_t)k * SELL_C), x[cp[(int64_t)k * SELL_C]]);
+    V acc = zadd(acc0, acc1);
+    if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(vscale, acc);
     if (row < n) {
       if (MODE == 0) {
         V r = zmul(alpha, acc);
@@ -169,25 +223,36 @@ extern "C" int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, co
   HX_REQUIRE(h && h->val_z && x && y && alpha && beta, "bad argument");
   const zc a = hx_z(alpha), b = hx_z(beta);
   k_sell<zc, 0><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_z, (const zc*)x,
-                                                              (zc*)y, a, b, (b.x == 0 && b.y == 0), nullptr, nullptr, nullptr, 0.0, 0.0);
+                                                              (zc*)y, a, b, (b.x == 0 && b.y == 0), nullptr, nullptr, nullptr, 0.0, 0.0, 1.0);
   HX_LAUNCH_CHECK("k_sell<c128,spmv>");
   return HX_OK;
 }
 extern "C" int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, float alpha, float beta, hx_stream s) {
-  HX_REQUIRE(h && h->val_c && x && y, "bad argument");
+  HX_REQUIRE(h && (h->val_c || h->val_h) && x && y, "bad argument");
+  if (h->val_h)
+    k_sell<cc, 0, ch><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_h, (const cc*)x,
+                                                                    (cc*)y, make_float2(alpha, 0.f), make_float2(beta, 0.f), beta == 0.f,
+                                                                    nullptr, nullptr, nullptr, 0.f, 0.f, h->h_scale);
+  else
   k_sell<cc, 0><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_c, (const cc*)x,
                                                               (cc*)y, make_float2(alpha, 0.f), make_float2(beta, 0.f), beta == 0.f,
-                                                              nullptr, nullptr, nullptr, 0.f, 0.f);
+                                                              nullptr, nullptr, nullptr, 0.f, 0.f, 1.f);
   HX_LAUNCH_CHECK("k_sell<c64,spmv>");
   return HX_OK;
 }
 // smoother step (see hx_csr_jacobi_* / the Chebyshev recurrence in amg.hip); xprev may be NULL
 extern "C" int hx_sell_smooth_c64(const hx_sell* h, const hx_c64* dinv, const hx_c64* b, const hx_c64* xin, hx_c64* xout,
                                   float omega, const hx_c64* xprev, float mom, hx_stream s) {
-  HX_REQUIRE(h && h->val_c && dinv && b && xin && xout && xin != xout, "bad argument");
+  HX_REQUIRE(h && (h->val_c || h->val_h) && dinv && b && xin && xout && xin != xout, "bad argument");
+  if (h->val_h)
+    k_sell<cc, 1, ch><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_h, (const cc*)xin,
+                                                                    (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1,
+                                                                    (const cc*)dinv, (const cc*)b, (const cc*)xprev, omega, mom,
+                                                                    h->h_scale);
+  else
   k_sell<cc, 1><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_c, (const cc*)xin,
                                                               (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1,
-                                                              (const cc*)dinv, (const cc*)b, (const cc*)xprev, omega, mom);
+                                                              (const cc*)dinv, (const cc*)b, (const cc*)xprev, omega, mom, 1.f);
   HX_LAUNCH_CHECK("k_sell<c64,smooth>");
   return HX_OK;
 }
@@ -196,7 +261,7 @@ extern "C" int hx_sell_smooth_z(const hx_sell* h, const hx_c128* dinv, const hx_
   HX_REQUIRE(h && h->val_z && dinv && b && xin && xout && xin != xout, "bad argument");
   k_sell<zc, 1><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_z, (const zc*)xin,
                                                               (zc*)xout, make_double2(0, 0), make_double2(0, 0), 1,
-                                                              (const zc*)dinv, (const zc*)b, (const zc*)xprev, omega, mom);
+                                                              (const zc*)dinv, (const zc*)b, (const zc*)xprev, omega, mom, 1.0);
   HX_LAUNCH_CHECK("k_sell<c128,smooth>");
   return HX_OK;
 }

@@ -199,15 +199,16 @@ extern "C" int hx_zpanel_dot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv
 
 // ---------------------------------------------------------------- w -= V h
 #define PS_MAXK 128
+template <typename PT>
 __global__ void __launch_bounds__(256)
-k_panel_sub(int64_t n, int k, const zc* __restrict__ V, int64_t ldv, const zc* __restrict__ h, zc* __restrict__ w) {
+k_panel_sub(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, const zc* __restrict__ h, zc* __restrict__ w) {
   __shared__ zc hs[PS_MAXK];
   for (int j = threadIdx.x; j < k; j += blockDim.x) hs[j] = h[j];
   __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     zc acc = w[i];
     for (int j = 0; j < k; ++j) {
-      zc v = V[(int64_t)j * ldv + i], hj = hs[j];
+      zc v = pd_load(V + (int64_t)j * ldv + i), hj = hs[j];
       acc.x = fma(-v.x, hj.x, acc.x); acc.x = fma(v.y, hj.y, acc.x);
       acc.y = fma(-v.x, hj.y, acc.y); acc.y = fma(-v.y, hj.x, acc.y);
     }
@@ -218,7 +219,15 @@ extern "C" int hx_zpanel_sub(int64_t n, int k, const hx_c128* V, int64_t ldv, co
                              hx_stream s) {
   HX_REQUIRE(n > 0 && k >= 0 && k <= PS_MAXK && w && (k == 0 || (V && h)) && ldv >= n, "bad argument");
   if (k == 0) return HX_OK;
-  k_panel_sub<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const zc*)V, ldv, (const zc*)h, (zc*)w);
+  k_panel_sub<zc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const zc*)V, ldv, (const zc*)h, (zc*)w);
+  HX_LAUNCH_CHECK("k_panel_sub");
+  return HX_OK;
+}
+extern "C" int hx_zpanel_sub_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_c128* h, hx_c128* w,
+                                 hx_stream s) {
+  HX_REQUIRE(n > 0 && k >= 0 && k <= PS_MAXK && w && (k == 0 || (Vf && h)) && ldv >= n, "bad argument");
+  if (k == 0) return HX_OK;
+  k_panel_sub<cc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const cc*)Vf, ldv, (const zc*)h, (zc*)w);
   HX_LAUNCH_CHECK("k_panel_sub");
   return HX_OK;
 }

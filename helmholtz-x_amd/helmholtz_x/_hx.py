@@ -35,6 +35,7 @@ SIGNATURES = {
     "hx_zpanel_dot": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hx_zpanel_dot_c64": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hx_zpanel_sub": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp]),
+    "hx_zpanel_sub_c64": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp]),
     "hx_zpanel_mul": (C.c_int, [_i64, _int, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
     "hx_zsparse_dots": (C.c_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hx_zthreshold_pack": (C.c_int, [_i64, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp]),

@@ -23,7 +23,7 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, recycle=6,
+              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, vcycle_values="fp16", recycle=6,
               recycle_min_rows=100_000)
 
 
@@ -192,8 +192,12 @@ class AMGSolver:
         self.coarse_sells = []
         if self.n >= self.params["sell_min_rows"] and len(levels) > 1:
             sh = C.c_void_p()
+            # complex128 copy for K z in GMRES; V-cycle copy in the working precision -- stored as scaled complex-half
+            # when the cycle runs in complex64 (8 instead of 12 bytes per entry; same GMRES iteration counts measured)
+            half = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
+            self.fine_values = "fp16" if half else ("c64" if mixed else "c128")
             _hx.check(_hx.lib.hx_sell_create(C.byref(sh), self.n, _hx.ptr(K_csr.rowptr), _hx.ptr(K_csr.col),
-                                             _hx.ptr(K_csr.val), 1, int(mixed), _hx.stream()))
+                                             _hx.ptr(K_csr.val), 1, 2 if half else int(mixed), _hx.stream()))
             self.sell = sh
             _hx.check(_hx.lib.hx_amg_set_level_sell(h, 0, sh))
         for l, lv in enumerate(levels):
@@ -319,7 +323,8 @@ class AMGSolver:
         self.harmonic_ritz = np.sort(np.abs(theta))[:k]
 
     def stats(self):
-        return dict(recycled_pairs=self.recycled, levels=[lv["n"] for lv in self.levels], fine_format="sell64" if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
+        return dict(recycled_pairs=self.recycled, levels=[lv["n"] for lv in self.levels],
+                    fine_format=("sell64/" + self.fine_values) if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
                     setup_s=round(self.setup_s, 3), solves=self.n_solves,
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1))

@@ -74,6 +74,9 @@ int hx_zpanel_dot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_
 /* w -= V[:, :k] h   (h: k complex numbers on the device) */
 int hx_zpanel_sub(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* h, hx_c128* w,
                   hx_stream s);
+/* The same update from the complex64 copy of the panel: only for a correction pass whose coefficients are tiny
+ * (|h| <= 1e-5 |w|): the Arnoldi relation then keeps an error of 6e-8 |h|, below the working precision. */
+int hx_zpanel_sub_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_c128* h, hx_c128* w, hx_stream s);
 /* Vout[:, :kout] = V[:, :m] Q,  Q (m x kout) column-major on the device (Krylov-Schur restart). */
 int hx_zpanel_mul(int64_t n, int m, int kout, const hx_c128* V, int64_t ldv, const hx_c128* Q,
                   hx_c128* Vout, int64_t ldvout, hx_stream s);
@@ -102,7 +105,9 @@ int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int3
  * Sliced ELLPACK with slice height 64 (= one wavefront): entries column-major inside a slice, padded to the slice's
  * longest row.  For the short, nearly uniform rows of P1 operators every wave-level load is one coalesced 1 KiB
  * transaction and a lane owns a whole row (no shuffle reduction, no row-pointer chase).  Same products as
- * hx_csr_spmv_z / hx_csr_jacobi_*; the handle owns its arrays.  hx_sell_create is SYNC. */
+ * hx_csr_spmv_z / hx_csr_jacobi_*; the handle owns its arrays.  hx_sell_create is SYNC.
+ * want_c64: 0 none, 1 complex64 value copy for the *_c64 entry points, 2 the same copy STORED as scaled complex-half
+ * (8 instead of 12 bytes per entry, arithmetic still complex64) -- for the V-cycle preconditioner only. */
 typedef struct hx_sell hx_sell;
 int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
                    int want_c128, int want_c64, hx_stream s);

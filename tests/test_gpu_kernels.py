@@ -266,3 +266,36 @@ def test_sell64_products_match_csr(hx, n, density):
     refs32 = x + 0.7 * (1.0 / d) * (y0 - M @ x) + 0.25 * x
     assert np.max(np.abs(o32.cpu().numpy() - refs32)) <= 3e-5 * max(np.max(np.abs(refs32)), 1.0)
     hx.check(hx.lib.hx_sell_destroy(h))
+
+
+@pytest.mark.parametrize("n,scale", [(64, 1.0), (5000, 3.0e6), (5000, 2.0e-7)])
+def test_sell64_complex_half_storage(hx, n, scale):
+    """want_c64 = 2: values stored as scaled complex-half, arithmetic in complex64.  The products must equal those of the
+    matrix whose entries were rounded to fp16 relative to the largest component (no overflow / underflow for entries
+    seven orders of magnitude apart in absolute size: the handle rescales), to complex64 accuracy."""
+    import torch
+    rng = np.random.default_rng(n)
+    M = sp.random(n, n, density=min(1.0, 12.0 / n), random_state=rng, format="csr") \
+        + 1j * sp.random(n, n, density=min(1.0, 12.0 / n), random_state=rng, format="csr")
+    M = sp.csr_matrix((M + sp.diags(3.0 + rng.random(n))) * scale)
+    M.sort_indices()
+    rp, ci, va = _dev(M.indptr.astype(np.int32)), _dev(M.indices.astype(np.int32)), _dev(M.data.astype(np.complex128))
+    h = C.c_void_p()
+    hx.check(hx.lib.hx_sell_create(C.byref(h), n, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), 0, 2, hx.stream()))
+    vmax = max(np.abs(M.data.real).max(), np.abs(M.data.imag).max())
+    s = np.float32(vmax) / np.float32(16384.0)
+    q = (M.data.real / s).astype(np.float16).astype(np.float64) * s + 1j * (M.data.imag / s).astype(np.float16).astype(np.float64) * s
+    Mq = sp.csr_matrix((q, M.indices, M.indptr), shape=M.shape)
+    assert np.isfinite(q).all() and abs(Mq - M).max() <= 1e-3 * vmax
+    x, y0 = _rand_c(rng, n), _rand_c(rng, n) * scale
+    x32, y32 = _dev(x.astype(np.complex64)), _dev(y0.astype(np.complex64))
+    hx.check(hx.lib.hx_sell_spmv_c64(h, hx.ptr(x32), hx.ptr(y32), -1.0, 1.0, hx.stream()))
+    ref = y0 - Mq @ x
+    flip = 1e-3 * vmax * np.max(np.abs(x))     # one entry per row may round to the neighbouring fp16 (device multiplies by 1/s)
+    assert np.max(np.abs(y32.cpu().numpy() - ref)) <= 3e-5 * np.max(np.abs(ref)) + flip
+    d = M.diagonal()
+    d32, b32, o32 = _dev((1.0 / d).astype(np.complex64)), _dev(y0.astype(np.complex64)), torch.empty_like(x32)
+    hx.check(hx.lib.hx_sell_smooth_c64(h, hx.ptr(d32), hx.ptr(b32), hx.ptr(x32), hx.ptr(o32), 0.7, None, 0.25, hx.stream()))
+    refs = x + 0.7 * (1.0 / d) * (y0 - Mq @ x) + 0.25 * x
+    assert np.max(np.abs(o32.cpu().numpy() - refs)) <= 3e-5 * np.max(np.abs(refs)) + flip * np.max(np.abs(1.0 / d))
+    hx.check(hx.lib.hx_sell_destroy(h))

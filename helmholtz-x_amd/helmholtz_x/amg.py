@@ -200,6 +200,8 @@ class AMGSolver:
                                              _hx.ptr(K_csr.val), 1, 2 if half else int(mixed), _hx.stream()))
             self.sell = sh
             _hx.check(_hx.lib.hx_amg_set_level_sell(h, 0, sh))
+        # coarse SELL levels take the same storage (5 M DOF: iterations unchanged, 8.38 -> 8.27 s)
+        half_coarse = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
         for l, lv in enumerate(levels):
             if l == 0:
                 k0 = K_csr.val.to(cdt) if mixed else K_csr.val
@@ -212,7 +214,7 @@ class AMGSolver:
                     tmp = to_device(sp.csr_matrix(lv["K"]).data.astype(np.complex128))
                     shl = C.c_void_p()
                     _hx.check(_hx.lib.hx_sell_create(C.byref(shl), lv["n"], _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(tmp),
-                                                     int(not mixed), int(mixed), _hx.stream()))
+                                                     int(not mixed), (2 if half_coarse else int(mixed)), _hx.stream()))
                     del tmp
                     self.coarse_sells.append(shl)
                     _hx.check(_hx.lib.hx_amg_set_level_sell(h, l, shl))

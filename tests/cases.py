@@ -74,6 +74,18 @@ class PRF:
     a_r = 0.025
     target = np.pi
 
+    # PRF/RijkeTube2D and RijkeTube3D/params.py: same non-dimensionalisation; the interaction index is divided by the
+    # tube cross-section in 1-D, by (pi/4) d in 2-D and not at all in 3-D; flame / reference points on the tube axis
+    @staticmethod
+    def n_dim(dim):
+        return {1: PRF.n, 2: 0.014 / ((np.pi / 4) * 0.047) / PRF.p_ref, 3: 0.014 / PRF.p_ref}[dim]
+
+    @staticmethod
+    def point(dim, s):
+        return np.array([[s, 0.0, 0.0]]) if dim < 3 else np.array([[0.0, 0.0, s]])
+
+    robin_tags = {2: (1, 4), 3: (3, 2)}          # (inlet, outlet) physical tags of the gmsh meshes
+
 
 class Micca:
     """AnnularCombustor/Micca/fullAnnulus/params.py."""

@@ -281,6 +281,42 @@ def test_rijke_gmsh_fixed_point(ref_logs, golden_dir, dim):
     _check_traj(hist, g["trajectory"])
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_prf_gmsh_pep_fixed_point_direct_and_adjoint(ref_logs, golden_dir, dim):
+    """PRF/RijkeTube2D and RijkeTube3D (active.py:18-62, written the same way): Robin inlet and outlet, distributed n-tau
+    flame; logged direct trajectory and adjoint eigenvalue (8 decimals of an O(3) number)."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.flame_matrices import DistributedFlameMatrix
+    from helmholtz_x.flame_transfer_function import nTau
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.parameters_utils import c_step, gaussianFunction, rho_step, temperature_step
+    g = ref_logs["prf%dd_active" % dim]
+    P = PRF
+    mesh, subdomains, facet_tags = XDMFReader(os.path.join(golden_dir, "meshes", "rijke%dd" % dim)).getAll()
+    x_f, x_r = P.point(dim, 0.25), P.point(dim, 0.20)
+    t_in, t_out = P.robin_tags[dim]
+    bcs = {t_out: {'Robin': P.R_out}, t_in: {'Robin': P.R_in}}
+    bcs.update({t: {'Neumann'} for t in (1, 2, 3, 4) if t not in bcs and (dim == 2 or t < 4)})
+    c = c_step(mesh, x_f, P.c_u, P.c_d)
+    M = AcousticMatrices(mesh, facet_tags, bcs, c, degree=1)
+    rho = rho_step(mesh, x_f, P.a_f, P.rho_d, P.rho_u)
+    T = temperature_step(mesh, x_f, P.T_u, P.T_d)
+    w = gaussianFunction(mesh, x_r, P.a_r)
+    h = gaussianFunction(mesh, x_f, P.a_f)
+    D = DistributedFlameMatrix(mesh, w, h, rho, T, P.q_0, P.u_b, nTau(P.n_dim(dim), P.tau), degree=1, gamma=P.gamma)
+    D.assemble_submatrices()
+    hist = []
+    fixed_point_iteration(M, D, P.target, nev=2, i=0, print_results=False, history=hist)
+    assert len(hist) - 1 == len(g["trajectory"])
+    _check_traj(hist[1:], g["trajectory"], tol=3e-9)
+    D.assemble_submatrices('adjoint')
+    hist = []
+    fixed_point_iteration(M, D, P.target, nev=2, i=0, problem_type='adjoint', print_results=False, history=hist)
+    r = complex(*g["adjoint_omega"])
+    assert abs(hist[-1] - r) / abs(r) < 3e-9
+
+
 def test_manufactured_2d_pep_against_dispersion_relation(ref_logs):
     from helmholtz_x.acoustic_matrices import AcousticMatrices
     from helmholtz_x.dolfinx_utils import RectangleSetup

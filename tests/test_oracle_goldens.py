@@ -87,6 +87,36 @@ def test_prf1d_pep_direct_and_adjoint(ref_logs):
 
 
 @pytest.mark.parametrize("dim", [2, 3])
+def test_prf_gmsh_cases_pep_direct_and_adjoint(ref_logs, golden_dir, dim):
+    """PRF/RijkeTube2D, RijkeTube3D (active.py): Robin inlet + outlet -> quadratic problem, distributed n-tau flame,
+    non-dimensional parameters; logged direct trajectory (8 decimals) and adjoint eigenvalue."""
+    g = ref_logs["prf%dd_active" % dim]
+    P = PRF
+    m = meshes.read_gmsh41(os.path.join(golden_dir, "meshes", "rijke%dd.msh" % dim), dim)
+    n = m.x.shape[0]
+    x_f, x_r = P.point(dim, 0.25), P.point(dim, 0.20)
+    c = fem.step_field(m.x, dim, x_f, P.c_u, P.c_d)
+    A = fem.assemble_A(m.x, m.cells, c)
+    C = fem.assemble_C(m.x, m.cells)
+    B = fem.assemble_B(m.x, n, [(m.facets[m.facet_tags == t], fem.robin_Z(P.R_in), c, None) for t in P.robin_tags[dim]])
+    axis = 0 if dim < 3 else 2
+    rho = fem.density_step(m.x[:, axis], 0.25, P.a_f, P.rho_d, P.rho_u)
+    w = fem.gaussian_function(m.x, m.cells, x_r, P.a_r)
+    h = fem.gaussian_function(m.x, m.cells, x_f, P.a_f)
+    left = fem.threshold_pack(fem.distributed_left(m.x, m.cells, P.gamma, h, P.q_0, P.u_b), 1e-5)
+    right = fem.threshold_pack(fem.distributed_right(m.x, m.cells, rho, w), 1e-5)
+    flame = eigen.OracleFlame(fem.flame_outer(n, left, right), eigen.NTau(P.n_dim(dim), P.tau),
+                              fem.flame_outer(n, left, right, 'adjoint'))
+    _, hist = eigen.fixed_point_iteration(A, B, C, flame, P.target, nev=2, i=0)
+    assert len(hist) - 1 == len(g["trajectory"])
+    for z, ref in zip(hist[1:], g["trajectory"]):
+        _close(z, ref)
+    _, hist = eigen.fixed_point_iteration(A, B, C, flame, P.target, nev=2, i=0, problem_type='adjoint',
+                                          B_adj=B.conj().T.tocsr())
+    _close(hist[-1], g["adjoint_omega"])
+
+
+@pytest.mark.parametrize("dim", [2, 3])
 def test_rijke_gmsh_cases(ref_logs, golden_dir, dim):
     g = ref_logs["rijke%dd" % dim]
     m = meshes.read_gmsh41(os.path.join(golden_dir, "meshes", "rijke%dd.msh" % dim), dim)

@@ -703,6 +703,16 @@ def test_micca_full_annulus_flagship_case(ref_logs, golden_dir, st_type):
     for i, ref in enumerate(g["direct"]):
         ref = complex(*ref)
         assert abs(E.getEigenvalue(i) - ref) / abs(ref) < 1e-8, (i, E.getEigenvalue(i), ref)
+    # adjoint problem as active_fpi.py:64-69 runs it (conjugate target, default nev = 2): eigenvalues_adj.txt
+    D.assemble_submatrices('adjoint')
+    hist = []
+    E_adj = fixed_point_iteration(matrices, D, Micca.target.conjugate(), i=0, tol=1e-3, problem_type='adjoint',
+                                  print_results=False, st_type=st_type, history=hist)
+    for z, ref in zip(hist[1:], g["trajectory_3dec"]):
+        assert abs(z - complex(*ref).conjugate()) < 7.5e-4
+    for i, ref in enumerate(g["adjoint"]):
+        ref = complex(*ref)
+        assert abs(E_adj.getEigenvalue(i) - ref) / abs(ref) < 1e-8, (i, E_adj.getEigenvalue(i), ref)
 
 
 def test_micca_full_annulus_modes_at_six_targets(ref_logs, golden_dir):

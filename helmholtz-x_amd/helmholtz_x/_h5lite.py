@@ -1,6 +1,7 @@
-"""Minimal read-only HDF5 reader for the mesh files the reference ships (meshio/h5py output): superblock version 0,
-version-1 object headers, contiguous or chunked (B-tree v1) layouts, optional deflate filter, little-endian integer /
-IEEE float datasets in the root group.  h5py is not a dependency of this package; mesh ingestion is a one-off host
+"""Minimal read-only HDF5 reader for the mesh files the reference ships (meshio/h5py output) and for the eigenvector
+files its examples commit (DOLFINx XDMFFile output): superblock version 0, version-1 object headers, symbol-table
+groups (nested), contiguous or chunked (B-tree v1) layouts, optional deflate filter, little-endian integer / IEEE
+float datasets.  h5py is not a dependency of this package; mesh ingestion is a one-off host
 step.  Only what those files use is implemented; anything else raises NotImplementedError.
 """
 import struct
@@ -26,11 +27,25 @@ class H5File:
         if cache != 1:
             raise NotImplementedError("root group without cached B-tree/heap addresses")
         btree, heap = struct.unpack_from("<QQ", b, ent + 24)
-        self.datasets = {}
+        self.datasets = {}                        # "name" or "group/sub/name" -> object header address
+        self._walk("", btree, heap, 0)
+
+    def _walk(self, prefix, btree, heap, depth):
+        """Symbol-table group: members that carry a symbol-table message (0x0011) are groups and are descended into
+        (DOLFINx writes /Mesh/<name>/geometry, /Function/real_f/0), everything else is recorded as a dataset."""
+        if depth > 8:
+            raise ValueError("group nesting too deep")
+        b = self.b
         heap_data = self._heap_data(heap)
         for name_off, obj in self._group_entries(btree):
             end = b.index(b"\x00", heap_data + name_off)
-            self.datasets[b[heap_data + name_off:end].decode()] = obj
+            name = prefix + b[heap_data + name_off:end].decode()
+            sub = next(((body) for mtype, body, _ in self._messages(obj) if mtype == 0x0011), None)
+            if sub is not None:
+                bt, hp = struct.unpack_from("<QQ", b, sub)
+                self._walk(name + "/", bt, hp, depth + 1)
+            else:
+                self.datasets[name] = obj
 
     # ---- group structures
     def _heap_data(self, addr):

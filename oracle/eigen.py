@@ -207,3 +207,13 @@ def newton_solver(A, B, C, flame, dflame, init, i=0, tol=1e-3, maxiter=100):
         omega.append(w + domega)
         k += 1
     return np.array(omega)
+
+
+def normalize_eigenvector(vec, C):
+    """eigenvectors.py:11-64 + petsc4py_utils.py:100-111: phase fixed so that entry 0 is real positive, then scaled so
+    that the BILINEAR integral  int p p dx = p^T C p = 1  (C = mass matrix; principal complex square root).  The
+    reference's entry 0 is DOLFINx's dof 0, so results agree with its files up to the sign +-1 that p^T C p = 1 leaves."""
+    v = np.asarray(vec, dtype=complex)
+    v = v / (v[0] / abs(v[0]))
+    meas = np.sqrt(v @ (C @ v))
+    return v / meas

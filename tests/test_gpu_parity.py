@@ -176,6 +176,15 @@ def test_pointwise_flame_vectors(golden_dir):
     assert np.array_equal(ri, ori) and _rel(rv, orv) < 1e-12
 
 
+def _eigvec_error(golden_dir, key, mesh, p):
+    """|p -+ p_ref| / |p_ref| against the normalised eigenvector the reference committed (tests/golden/eigenvectors;
+    int p p dx = 1 leaves the sign free; the reference writes DOLFINx's node order, matched by coordinates)."""
+    from test_oracle_goldens import match_nodes, sign_free_error
+    vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))
+    x = mesh.geometry.x[:, :mesh.geometry.dim]
+    return sign_free_error(np.asarray(p.x.array), vecs[key + "_p"][match_nodes(x, vecs[key + "_x"])])
+
+
 def _check_traj(hist, ref, tol=1e-8):
     assert len(hist) == len(ref), (hist, ref)
     for z, r in zip(hist, ref):
@@ -277,8 +286,11 @@ def test_rijke_gmsh_fixed_point(ref_logs, golden_dir, dim):
     D = _distributed_flame(mesh, dim)[0]
     D.assemble_submatrices()
     hist = []
-    fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, history=hist)
+    E = fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, history=hist)
     _check_traj(hist, g["trajectory"])
+    from helmholtz_x.eigenvectors import normalize_eigenvector
+    omega, uh = normalize_eigenvector(mesh, E, 0, degree=1, which='right')
+    assert _eigvec_error(golden_dir, "rijke%dd_dir" % dim, mesh, uh) < 1e-7        # Results/Active/p.h5 (EPS path)
 
 
 @pytest.mark.parametrize("dim", [2, 3])
@@ -306,15 +318,20 @@ def test_prf_gmsh_pep_fixed_point_direct_and_adjoint(ref_logs, golden_dir, dim):
     h = gaussianFunction(mesh, x_f, P.a_f)
     D = DistributedFlameMatrix(mesh, w, h, rho, T, P.q_0, P.u_b, nTau(P.n_dim(dim), P.tau), degree=1, gamma=P.gamma)
     D.assemble_submatrices()
+    from helmholtz_x.eigenvectors import normalize_eigenvector
     hist = []
-    fixed_point_iteration(M, D, P.target, nev=2, i=0, print_results=False, history=hist)
+    E = fixed_point_iteration(M, D, P.target, nev=2, i=0, print_results=False, history=hist)
     assert len(hist) - 1 == len(g["trajectory"])
     _check_traj(hist[1:], g["trajectory"], tol=3e-9)
+    omega, uh = normalize_eigenvector(mesh, E, 0, degree=1, which='right')
+    assert _eigvec_error(golden_dir, "prf%dd_dir" % dim, mesh, uh) < 1e-7          # Results/Active/p.h5
     D.assemble_submatrices('adjoint')
     hist = []
-    fixed_point_iteration(M, D, P.target, nev=2, i=0, problem_type='adjoint', print_results=False, history=hist)
+    E = fixed_point_iteration(M, D, P.target, nev=2, i=0, problem_type='adjoint', print_results=False, history=hist)
     r = complex(*g["adjoint_omega"])
     assert abs(hist[-1] - r) / abs(r) < 3e-9
+    omega_adj, p_adjoint = normalize_eigenvector(mesh, E, 0, degree=1, which='right')
+    assert _eigvec_error(golden_dir, "prf%dd_adj" % dim, mesh, p_adjoint) < 1e-7   # Results/Active/p_adj.h5
 
 
 def test_manufactured_2d_pep_against_dispersion_relation(ref_logs):
@@ -657,10 +674,15 @@ def test_rijkeffd_degree1_sixteen_digit_golden(ref_logs, golden_dir, st_type):
     _check_traj(hist[1:], g["trajectory"])
     ref = complex(*g["direct"])
     assert abs(E.getEigenvalue(0) - ref) / abs(ref) < 1e-8
+    from helmholtz_x.eigenvectors import normalize_eigenvector
+    omega_dir, p_dir = normalize_eigenvector(mesh, E, 0, degree=1, which='right')          # main.py: p_dir.h5
+    assert _eigvec_error(golden_dir, "rijkeffd_dir", mesh, p_dir) < 1e-7
     D.assemble_submatrices('adjoint')
     E = fixed_point_iteration(M, D, F.target, nev=2, i=0, problem_type='adjoint', st_type=st_type)
     ref = complex(*g["adjoint"])
     assert abs(E.getEigenvalue(0) - ref) / abs(ref) < 1e-8
+    omega_adj, p_adj = normalize_eigenvector(mesh, E, 0, degree=1, which='right')          # main.py: p_adj.h5
+    assert _eigvec_error(golden_dir, "rijkeffd_adj", mesh, p_adj) < 1e-7
 
 
 def _micca_full_problem(golden_dir):

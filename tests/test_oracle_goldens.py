@@ -86,6 +86,19 @@ def test_prf1d_pep_direct_and_adjoint(ref_logs):
     _close(hist[-1], g["adjoint_omega"])
 
 
+def match_nodes(x_mine, x_ref):
+    """Permutation q with x_ref[q] == x_mine (the reference writes DOLFINx's node order)."""
+    d = x_mine.shape[1] if x_mine.ndim == 2 else 1
+    key = lambda a: [tuple(r) for r in np.round(np.asarray(a)[:, :d] if d > 1 else np.asarray(a).reshape(len(a), -1)[:, :1], 10)]
+    where = {k: i for i, k in enumerate(key(x_ref))}
+    return np.array([where[k] for k in key(x_mine)])
+
+
+def sign_free_error(p, ref):
+    """int p p dx = 1 fixes an eigenvector up to +-1."""
+    return min(np.max(np.abs(p - ref)), np.max(np.abs(p + ref))) / np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_prf_gmsh_cases_pep_direct_and_adjoint(ref_logs, golden_dir, dim):
     """PRF/RijkeTube2D, RijkeTube3D (active.py): Robin inlet + outlet -> quadratic problem, distributed n-tau flame,
@@ -107,13 +120,19 @@ def test_prf_gmsh_cases_pep_direct_and_adjoint(ref_logs, golden_dir, dim):
     right = fem.threshold_pack(fem.distributed_right(m.x, m.cells, rho, w), 1e-5)
     flame = eigen.OracleFlame(fem.flame_outer(n, left, right), eigen.NTau(P.n_dim(dim), P.tau),
                               fem.flame_outer(n, left, right, 'adjoint'))
-    _, hist = eigen.fixed_point_iteration(A, B, C, flame, P.target, nev=2, i=0)
+    E, hist = eigen.fixed_point_iteration(A, B, C, flame, P.target, nev=2, i=0)
     assert len(hist) - 1 == len(g["trajectory"])
     for z, ref in zip(hist[1:], g["trajectory"]):
         _close(z, ref)
-    _, hist = eigen.fixed_point_iteration(A, B, C, flame, P.target, nev=2, i=0, problem_type='adjoint',
-                                          B_adj=B.conj().T.tocsr())
+    E_adj, hist = eigen.fixed_point_iteration(A, B, C, flame, P.target, nev=2, i=0, problem_type='adjoint',
+                                              B_adj=B.conj().T.tocsr())
     _close(hist[-1], g["adjoint_omega"])
+    # eigenVECTORS: the normalised direct and adjoint modes the reference committed (Results/Active/p.h5, p_adj.h5)
+    vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))
+    for kind, Ek in (("dir", E), ("adj", E_adj)):
+        q = match_nodes(m.x[:, :dim], vecs["prf%dd_%s_x" % (dim, kind)])
+        p = eigen.normalize_eigenvector(Ek.vecs[:, 0], C)
+        assert sign_free_error(p, vecs["prf%dd_%s_p" % (dim, kind)][q]) < 1e-7
 
 
 @pytest.mark.parametrize("dim", [2, 3])
@@ -124,10 +143,14 @@ def test_rijke_gmsh_cases(ref_logs, golden_dir, dim):
     E = eigen.eps_solve(fem.assemble_A(m.x, m.cells, c), fem.assemble_C(m.x, m.cells), Rijke.target, 2)
     assert abs(E.eigs[0] - g["passive_lambda0"]) < 2e-6
     A, C, flame, _, _ = _rijke_distributed(m, dim, A_from_T=(dim == 2))
-    _, hist = eigen.fixed_point_iteration(A, None, C, flame, Rijke.target, nev=2, i=0)
+    E, hist = eigen.fixed_point_iteration(A, None, C, flame, Rijke.target, nev=2, i=0)
     assert len(hist) == len(g["trajectory"])
     for z, ref in zip(hist, g["trajectory"]):
         _close(z, ref)
+    vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))     # Results/Active/p.h5
+    p = eigen.normalize_eigenvector(E.vecs[:, 0], C)
+    err = sign_free_error(p, vecs["rijke%dd_dir_p" % dim][match_nodes(m.x[:, :dim], vecs["rijke%dd_dir_x" % dim])])
+    assert err < 1e-7, err
 
 
 def test_manufactured_2d_against_dispersion_relation(ref_logs):
@@ -186,6 +209,10 @@ def test_rijkeffd_degree1_sixteen_digit_golden(ref_logs, golden_dir):
     for z, ref in zip(hist[1:], g["trajectory"]):
         _close(z, ref)
     assert abs(E.eigs[0] - complex(*g["direct"])) / abs(E.eigs[0]) < 1e-10
+    vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))     # Results/Original/p_dir.h5
+    p = eigen.normalize_eigenvector(E.vecs[:, 0], C)
+    err = sign_free_error(p, vecs["rijkeffd_dir_p"][match_nodes(m.x, vecs["rijkeffd_dir_x"])])
+    assert err < 1e-7, err
 
 
 def test_micca_full_annulus_flagship_case(ref_logs, golden_dir):

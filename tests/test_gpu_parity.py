@@ -181,7 +181,7 @@ def _eigvec_error(golden_dir, key, mesh, p):
     int p p dx = 1 leaves the sign free; the reference writes DOLFINx's node order, matched by coordinates)."""
     from test_oracle_goldens import match_nodes, sign_free_error
     vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))
-    x = mesh.geometry.x[:, :mesh.geometry.dim]
+    x = mesh.geometry.x[:, :mesh.geometry.dim]          # (1-D files carry (x, 0): match_nodes keys on x's own columns)
     return sign_free_error(np.asarray(p.x.array), vecs[key + "_p"][match_nodes(x, vecs[key + "_x"])])
 
 
@@ -215,7 +215,7 @@ def test_rijke1d_passive_eps(ref_logs):
     assert np.linalg.norm(A @ xv + lam[0] * (Cm @ xv)) <= 1e-9 * np.linalg.norm(lam[0] * (Cm @ xv))
 
 
-def test_rijke1d_active_fixed_point_direct_and_adjoint(ref_logs):
+def test_rijke1d_active_fixed_point_direct_and_adjoint(ref_logs, golden_dir):
     from helmholtz_x.acoustic_matrices import AcousticMatrices
     from helmholtz_x.dolfinx_utils import OneDimensionalSetup
     from helmholtz_x.eigensolvers import fixed_point_iteration
@@ -230,14 +230,19 @@ def test_rijke1d_active_fixed_point_direct_and_adjoint(ref_logs):
     E = fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, history=hist)
     _check_traj(hist, g["trajectory"])
     assert abs(np.sqrt(E.getEigenvalue(0)) - hist[-1]) < 1e-6
+    from helmholtz_x.eigenvectors import normalize_eigenvector
+    omega, p = normalize_eigenvector(mesh, E, 0, degree=1, which='right')
+    assert _eigvec_error(golden_dir, "rijke1d_dir", mesh, p) < 1e-7                 # Results/Active/p.h5
     D.assemble_submatrices('adjoint')
     hist = []
-    fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, problem_type='adjoint', history=hist)
+    E = fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, problem_type='adjoint', history=hist)
     r = complex(*ref_logs["rijke1d_active_adjoint"]["omega"])
     assert abs(hist[-1] - r) / abs(r) < 1e-8
+    omega, p = normalize_eigenvector(mesh, E, 0, degree=1, which='right')
+    assert _eigvec_error(golden_dir, "rijke1d_adj", mesh, p) < 1e-7                 # Results/Active/p_adj.h5
 
 
-def test_prf1d_pep_fixed_point_direct_and_adjoint(ref_logs):
+def test_prf1d_pep_fixed_point_direct_and_adjoint(ref_logs, golden_dir):
     from helmholtz_x.acoustic_matrices import AcousticMatrices
     from helmholtz_x.dolfinx_utils import OneDimensionalSetup
     from helmholtz_x.eigensolvers import fixed_point_iteration
@@ -255,14 +260,19 @@ def test_prf1d_pep_fixed_point_direct_and_adjoint(ref_logs):
     h = gaussianFunction(mesh, P.x_f, P.a_f)
     D = DistributedFlameMatrix(mesh, w, h, rho, T, P.q_0, P.u_b, nTau(P.n, P.tau), gamma=P.gamma)
     D.assemble_submatrices()
+    from helmholtz_x.eigenvectors import normalize_eigenvector
     hist = []
-    fixed_point_iteration(M, D, P.target, nev=2, i=0, history=hist)
+    E = fixed_point_iteration(M, D, P.target, nev=2, i=0, history=hist)
     _check_traj(hist[1:], g["trajectory"], tol=3e-9)       # log prints 8 decimals of a O(3) number
+    omega, p = normalize_eigenvector(mesh, E, 0, degree=1, which='right')
+    assert _eigvec_error(golden_dir, "prf1d_dir", mesh, p) < 1e-7                   # Results/Active/p_dir.h5
     D.assemble_submatrices('adjoint')
     hist = []
-    fixed_point_iteration(M, D, P.target, nev=2, i=0, problem_type='adjoint', history=hist)
+    E = fixed_point_iteration(M, D, P.target, nev=2, i=0, problem_type='adjoint', history=hist)
     r = complex(*g["adjoint_omega"])
     assert abs(hist[-1] - r) / abs(r) < 3e-9
+    omega, p = normalize_eigenvector(mesh, E, 0, degree=1, which='right')
+    assert _eigvec_error(golden_dir, "prf1d_adj", mesh, p) < 1e-7                   # Results/Active/p_adj.h5
 
 
 @pytest.mark.parametrize("dim", [2, 3])

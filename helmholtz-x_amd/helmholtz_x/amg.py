@@ -182,8 +182,14 @@ class AMGSolver:
             """(rowptr, col, val) device tensors of a scipy CSR in the hierarchy's working precision."""
             M = sp.csr_matrix(M)
             M.sort_indices()
-            t = (to_device(M.indptr.astype(np.int32)), to_device(M.indices.astype(np.int32)),
-                 to_device(M.data.astype(np.complex128)).to(cdt))
+            if np.isrealobj(M.data):
+                # transfer operators are real: ship the real parts in the working precision (4x / 2x less H2D traffic
+                # than complex128) and widen to complex on the device
+                re = to_device(M.data.astype(np.float32 if mixed else np.float64))
+                val = torch.complex(re, torch.zeros_like(re))
+            else:
+                val = to_device(M.data.astype(np.complex64 if mixed else np.complex128))
+            t = (to_device(M.indptr.astype(np.int32, copy=False)), to_device(M.indices.astype(np.int32, copy=False)), val)
             self._keep.append(t)
             return t, int(M.nnz)
 

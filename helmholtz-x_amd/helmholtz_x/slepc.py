@@ -242,14 +242,15 @@ class DeviceBasis:
         if self.start is not None and self.start.numel() == self.n:
             self.V[j].copy_(self.start)              # warm start: previous Ritz vectors (fixed-point iteration)
         else:
-            rng = np.random.default_rng(self.seed)
-            if self.shard is None:
-                v = rng.standard_normal(self.n) + 1j * rng.standard_normal(self.n)
-            else:      # the same global start vector as the single-GPU run, owned rows of every block
-                ng = self.shard.n_global * self.blocks
-                v = (rng.standard_normal(ng) + 1j * rng.standard_normal(ng)).reshape(self.blocks, -1)
-                v = np.ascontiguousarray(v[:, self.shard.r0:self.shard.r1]).ravel()
-            self.V[j].copy_(torch.from_numpy(v))
+            # seeded device generator (10 M host normals cost 0.26 s); the row-sharded run draws the same GLOBAL vector
+            # and keeps its owned rows of every block, so both runs start from the same vector
+            gen = torch.Generator(device=self.V.device)
+            gen.manual_seed(1234567 + self.seed)
+            ng = self.n if self.shard is None else self.shard.n_global * self.blocks
+            v = torch.view_as_complex(torch.randn((ng, 2), generator=gen, device=self.V.device, dtype=torch.float64))
+            if self.shard is not None:
+                v = v.view(self.blocks, -1)[:, self.shard.r0:self.shard.r1].reshape(-1)
+            self.V[j].copy_(v)
         self._dots(0, self.V[j])
         nrm = np.sqrt(self.h_dev[:1].cpu().numpy()[0].real)
         _hx.check(_hx.lib.hx_zscal(self.n, _hx.z2(1.0 / nrm), _hx.ptr(self.V[j]), _hx.stream()))

@@ -288,13 +288,15 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   if (l == (int)H.L.size() - 1) return op_spmv(H.coarse_inv, b, xout, (T)1, (T)0, true, s);
   const bool cheb = L.rho > 0.0;
   const Cheb C = cheb ? cheb_coeffs(L.rho) : Cheb();
+  static const int extra = getenv("HX_AMG_COARSE_EXTRA") ? atoi(getenv("HX_AMG_COARSE_EXTRA")) : 0;   // experiment hook
+  const int n_pre = h->pre + (l > 0 ? extra : 0), n_post = h->post + (l > 0 ? extra : 0);
   T* bufs[3] = {L.x, L.x2, L.x3};
   auto other = [&](const T* a, const T* c) -> T* { for (T* q : bufs) if (q != a && q != c) return q; return nullptr; };
   T* cur = L.x;
   T* prev = nullptr;
   // pre-smoothing from x = 0: the first step is a diagonal scaling
   if ((rc = op_diag(L, cheb ? C.a[0] : h->omega, b, cur, s))) return rc;
-  for (int k = 1; k < h->pre; ++k) {
+  for (int k = 1; k < n_pre; ++k) {
     T* nxt = other(cur, prev);
     if (cheb) {   // for k = 1 the previous iterate is the zero start vector (prev == nullptr)
       if ((rc = halo_before_k(h, l, cur))) return rc;
@@ -317,14 +319,14 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   if ((rc = op_spmv(L.P, ec, cur, (T)1, (T)1, true, s))) return rc;    // x += P e_c
   // post-smoothing: a fresh polynomial started from the corrected x; the last step writes xout
   prev = nullptr;
-  for (int k = 0; k < h->post; ++k) {
-    T* dst = (k == h->post - 1) ? xout : other(cur, prev);
+  for (int k = 0; k < n_post; ++k) {
+    T* dst = (k == n_post - 1) ? xout : other(cur, prev);
     if ((rc = halo_before_k(h, l, cur))) return rc;
     if (cheb) { if ((rc = op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s))) return rc; }
     else if ((rc = op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s))) return rc;
     prev = cur; cur = dst;
   }
-  if (h->post == 0)
+  if (n_post == 0)
     HX_HIP(hipMemcpyAsync(xout, cur, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
   return HX_OK;
 }
@@ -406,7 +408,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
     HX_HIP(hipStreamSynchronize(hx_s(s)));
     return HX_OK;
   };
-  int rc, it = 0, cycles = 0, m_last = 0;
+  int rc, it = 0, m_last = 0;
   static const bool trace = getenv("HX_GMRES_TRACE") != nullptr;     // convergence history on stderr (diagnostics)
   HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
   if ((rc = dots(Pn, 0, b))) return rc;
@@ -436,7 +438,6 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
     const double beta = std::sqrt(hh[0].real());
     relres = beta / bnorm;
     if (relres <= rtol) break;
-    ++cycles;
     HX_HIP(hipMemcpyAsync(V, r, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
     const double ib[2] = {1.0 / beta, 0.0};
     if ((rc = hx_zscal(n, ib, V, s))) return rc;
@@ -470,7 +471,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
       if (n2 <= 1e-8 * hh[k].real()) { if ((rc = dots(Pn, 0, w))) return rc; n2 = hh[0].real(); }
       const double hn = std::sqrt(n2 > 0 ? n2 : 0.0);
       H[j + 1][j] = hn;
-      if (rec && cycles == 1) {                        // raw Hessenberg column, kept for the harvest
+      if (rec && kc == 0) {                            // raw Hessenberg column of the current cycle, kept for the harvest
         for (int i = 0; i <= j + 1; ++i) rec->Hraw[(size_t)j * (restart + 1) + i] = H[i][j];
       }
       if (hn > 0) { const double ih[2] = {1.0 / hn, 0.0}; if ((rc = hx_zscal(n, ih, w, s))) return rc; }
@@ -519,7 +520,9 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
       if (relres <= 10 * rtol) break;
     }
   }
-  if (rec) { rec->m_last = (cycles == 1 && kc == 0) ? m_last : 0; }   // harvestable: one plain cycle, panels intact
+  // harvestable: a plain solve; the panels and Hraw describe its LAST cycle (K Z_m = V_{m+1} Hbar_m holds per cycle; a
+  // restarted solve stagnates on exactly the modes worth recycling, so its last cycle is the richest one)
+  if (rec) { rec->m_last = (kc == 0) ? m_last : 0; }
   if (h_iters) *h_iters = it;
   if (h_relres) *h_relres = relres;
   return HX_OK;
@@ -537,8 +540,8 @@ extern "C" int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int rest
   R.Hraw.assign((size_t)(restart + 1) * restart, cd(0));
   return HX_OK;
 }
-// (m+1) x m raw Hessenberg of the last solve, column-major with leading dimension m+1; *m = 0 when the last solve is not
-// harvestable (restarted, or run with recycled pairs already installed).
+// (m+1) x m raw Hessenberg of the last cycle of the last solve, column-major with leading dimension m+1; *m = 0 when that
+// solve is not harvestable (it already used recycled pairs).
 extern "C" int hx_gmres_hessenberg(const hx_amg* h, int* m, hx_c128* H) {
   HX_REQUIRE(h && m, "bad argument");
   const Recycle& R = h->rec;

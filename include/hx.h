@@ -247,8 +247,8 @@ int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int
  * then start every cycle from the Galerkin guess on span(U) and keep the Arnoldi vectors orthogonal to C, which
  * removes the initial plateau caused by the few near-null modes of the preconditioned operator.
  *   hx_amg_enable_recycling  allocate the [C; V] panel and U inside the handle (n = rows of the local operator)
- *   hx_gmres_hessenberg      raw (m+1) x m Hessenberg of the last solve (column-major, ld m+1); *m = 0 if that solve
- *                            restarted or already used recycled pairs.  Call with H = NULL to query m.
+ *   hx_gmres_hessenberg      raw (m+1) x m Hessenberg of the last cycle of the last solve (column-major, ld m+1);
+ *                            *m = 0 if that solve already used recycled pairs.  Call with H = NULL to query m.
  *   hx_amg_set_recycle       U = Z_m Ucoef, C = V_{m+1} Ccoef (HOST coefficients, column-major m x k and (m+1) x k);
  *                            must directly follow the harvested solve, with the same ws. */
 int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int restart);

@@ -34,7 +34,7 @@ for Z in np.linspace(-10, 10, 10)[:5]:
     t3 = time.perf_counter()
     omega = E.getEigenvalue(0)
     k = dispersion_root(omega / 450.0, Z)
-    inner = next(v for kk, v in caches[0].items() if kk[0] != 'ops')
+    inner = next(v for v in caches[0].values() if hasattr(v, 'stats'))
     print("Z=%6.2f f=%.6f%+.6fj analytic=%.6f%+.6fj rel=%.1e | assemble %.3f s, solve %.3f s, %s, krylov %s" % (
         Z, (omega / 2 / np.pi).real, (omega / 2 / np.pi).imag, (450 * k / 2 / np.pi).real, (450 * k / 2 / np.pi).imag,
-        abs(omega - 450 * k) / abs(omega), t2 - t1, t3 - t2, inner.stats(), {a: b for a, b in caches[2].items() if not a.startswith('start')}))
+        abs(omega - 450 * k) / abs(omega), t2 - t1, t3 - t2, inner.stats(), {a: b for a, b in caches[2].items() if not a.startswith(('start', '_'))}))

@@ -139,6 +139,25 @@ def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], c
     return levels
 
 
+def harmonic_ritz_recycle(Hb, k):
+    """Coefficients of the GCRO recycle pair from one (flexible) GMRES cycle  K Z_m = V_{m+1} Hbar_m  (Hb: (m+1) x m raw
+    Hessenberg): the k harmonic Ritz vectors g of smallest |theta|,
+        (H_m + |h_{m+1,m}|^2 H_m^-H e_m e_m^T) g = theta g,
+    give  U = Z_m (G R^-1),  C = V_{m+1} Q  with the thin QR  Hbar_m G = Q R,  so that  K U = C  and  C^H C = I.
+    Returns (Ucoef (m x k), Ccoef ((m+1) x k), |theta| of the chosen vectors)."""
+    Hb = np.asarray(Hb, dtype=np.complex128)
+    m = Hb.shape[1]
+    Hm, h = Hb[:m, :m], Hb[m, m - 1]
+    em = np.zeros(m, dtype=np.complex128)
+    em[-1] = 1.0
+    f = np.linalg.solve(Hm.conj().T, em)
+    theta, G = np.linalg.eig(Hm + abs(h) ** 2 * np.outer(f, em))
+    pick = np.argsort(np.abs(theta), kind="stable")[:k]
+    Gk = G[:, pick]
+    Q, R = np.linalg.qr(Hb @ Gk)
+    return Gk @ np.linalg.inv(R), Q, np.abs(theta[pick])
+
+
 class AMGSolver:
     """K^-1 b by V-cycle-preconditioned GMRES on the device (hx_gmres)."""
 
@@ -317,18 +336,11 @@ class AMGSolver:
         Hb = np.zeros((m + 1) * m, dtype=np.complex128)
         _hx.check(_hx.lib.hx_gmres_hessenberg(self.handle, C.byref(C.c_int(0)), _hx.nptr(Hb)))
         Hb = Hb.reshape(m, m + 1).T                 # column-major -> (m+1, m)
-        Hm, h = Hb[:m, :m], Hb[m, m - 1]
-        em = np.zeros(m, dtype=np.complex128)
-        em[-1] = 1.0
-        f = np.linalg.solve(Hm.conj().T, em)
-        theta, G = np.linalg.eig(Hm + abs(h) ** 2 * np.outer(f, em))
-        Gk = G[:, np.argsort(np.abs(theta), kind="stable")[:k]]
-        Q, R = np.linalg.qr(Hb @ Gk)
-        Uc = np.asfortranarray(Gk @ np.linalg.inv(R))
-        Cc = np.asfortranarray(Q)
+        Uc, Cc, theta = harmonic_ritz_recycle(Hb, k)
+        Uc, Cc = np.asfortranarray(Uc), np.asfortranarray(Cc)
         _hx.check(_hx.lib.hx_amg_set_recycle(self.handle, k, _hx.nptr(Uc), _hx.nptr(Cc), _hx.ptr(self.ws), _hx.stream()))
         self.recycled = k
-        self.harmonic_ritz = np.sort(np.abs(theta))[:k]
+        self.harmonic_ritz = theta
 
     def stats(self):
         return dict(recycled_pairs=self.recycled, levels=[lv["n"] for lv in self.levels],

@@ -282,3 +282,61 @@ def test_locate_slots_of_a_sub_pattern():
     empty = sp.csr_matrix((n, n))
     assert locate_slots(n, base.indptr.astype(np.int32), base.indices.astype(np.int32),
                         empty.indptr.astype(np.int32), empty.indices.astype(np.int32)).size == 0
+
+
+def test_harmonic_ritz_recycle_pair_algebra():
+    """Host algebra of the Krylov-subspace recycling (amg.harmonic_ritz_recycle): from the Arnoldi relation of one GMRES
+    cycle, K U = C and C^H C = I must hold, span(U) must contain the eigenvectors of smallest |eigenvalue|, and a GCRO
+    solve that starts from the Galerkin guess on span(U) and stays orthogonal to C needs fewer steps."""
+    from helmholtz_x.amg import harmonic_ritz_recycle
+    rng = np.random.default_rng(11)
+    n, m, k = 300, 40, 4
+    lam = np.concatenate([[0.002, 0.004 + 0.001j, 0.007, 0.011], 1.0 + 0.3 * rng.random(n - 4) + 0.2j * rng.random(n - 4)])
+    X = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0]
+    K = X @ np.diag(lam) @ X.conj().T                    # normal matrix with four tiny eigenvalues
+
+    def arnoldi(b, steps, Cm=None):
+        V = [b / np.linalg.norm(b)]
+        H = np.zeros((steps + 1, steps), dtype=complex)
+        for j in range(steps):
+            w = K @ V[j]
+            if Cm is not None:
+                w = w - Cm @ (Cm.conj().T @ w)
+                w = w - Cm @ (Cm.conj().T @ w)
+            for _ in range(2):
+                h = np.array([np.vdot(v, w) for v in V])
+                w = w - np.array(V).T @ h
+                H[:j + 1, j] += h
+            H[j + 1, j] = np.linalg.norm(w)
+            V.append(w / H[j + 1, j])
+        return np.array(V).T, H
+
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    V, Hb = arnoldi(b, m)
+    Uc, Cc, theta = harmonic_ritz_recycle(Hb, k)
+    U, Cm = V[:, :m] @ Uc, V @ Cc                        # unpreconditioned: Z = V
+    assert np.abs(Cm.conj().T @ Cm - np.eye(k)).max() < 1e-12
+    assert np.abs(K @ U - Cm).max() < 1e-10
+    assert np.all(theta < 0.05)                          # the four outliers were found
+    small = X[:, :4]
+    Qu = np.linalg.qr(U)[0]
+    assert np.linalg.norm(small - Qu @ (Qu.conj().T @ small)) < 1e-3
+
+    def gmres_steps(b2, Cm=None, U=None, tol=1e-10):
+        x0 = np.zeros(n, complex)
+        r = b2.copy()
+        if Cm is not None:
+            t = Cm.conj().T @ r
+            x0, r = U @ t, r - Cm @ t
+        for steps in range(2, 80, 2):
+            Vs, Hs = arnoldi(r, steps, Cm)
+            e1 = np.zeros(steps + 1, complex)
+            e1[0] = np.linalg.norm(r)
+            y = np.linalg.lstsq(Hs, e1, rcond=None)[0]
+            if np.linalg.norm(e1 - Hs @ y) <= tol * np.linalg.norm(b2):
+                return steps
+        return 80
+
+    b2 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    plain, recycled = gmres_steps(b2), gmres_steps(b2, Cm, U)
+    assert recycled <= plain - 4, (plain, recycled)

@@ -275,7 +275,7 @@ def sharded_solve_extra(case, ref_omegas, barrier, rank, out):
     the replicas result -- on time-out rank 0 prints the JSON line with the error recorded and every rank exits."""
     import contextlib
     import threading
-    budget = float(os.environ.get("HX_BENCH_SHARDED_TIMEOUT", "420"))
+    budget = float(os.environ.get("HX_BENCH_SHARDED_TIMEOUT", "240"))
 
     def fire():
         if rank == 0:

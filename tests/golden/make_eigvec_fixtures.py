@@ -27,6 +27,7 @@ CASES = {
     "rijke3d_dir": "Longitudinal/NetworkCode/RijkeTube3D/Results/Active/p.h5",
     "rijkeffd_dir": "ShapeSensitivities/RijkeFFD/Results/Original/p_dir.h5",
     "rijkeffd_adj": "ShapeSensitivities/RijkeFFD/Results/Original/p_adj.h5",
+    "rijkeffd_opt_dir": "ShapeSensitivities/RijkeFFD/Results/Optimized/p_dir.h5",
 }
 
 if __name__ == "__main__":

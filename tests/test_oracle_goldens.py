@@ -215,6 +215,37 @@ def test_rijkeffd_degree1_sixteen_digit_golden(ref_logs, golden_dir):
     assert err < 1e-7, err
 
 
+def test_rijkeffd_optimized_shape_golden(ref_logs, golden_dir):
+    """main_opt.py: the same problem on the FFD-optimised tube (a different, deformed geometry; mesh read from the
+    reference's XDMF/HDF5 files): logged trajectory, 16-digit eigenvalue, committed eigenvector."""
+    from helmholtz_x.io_utils import read_xdmf          # mesh ingestion only (host I/O)
+    g = ref_logs["rijkeffd_optimized"]
+    F = RijkeFFD
+    mesh, sub, ft = read_xdmf(os.path.join(golden_dir, "meshes", "rijkeffd_optimized", "mesh"))
+    x, cells = mesh.geometry.x, mesh.topology.cells
+    n = x.shape[0]
+    T = fem.step_field(x, 3, F.x_f, F.T_in, F.T_out)
+    c = fem.sound_speed_variable_gamma(T)
+    A = fem.assemble_A(x, cells, c)
+    C = fem.assemble_C(x, cells)
+    B = fem.assemble_B(x, n, [(mesh.facets[ft.find(t)], fem.robin_Z(F.R_in), c, None) for t in (2, 3)])
+    rho = fem.density_step(x[:, 2], 0.25, F.a_f, F.rho_d, F.rho_u)
+    w = fem.gaussian_function(x, cells, F.x_r, F.a_r)
+    h = fem.gaussian_function(x, cells, F.x_f, F.a_f)
+    left = fem.threshold_pack(fem.distributed_left(x, cells, F.gamma, h, F.q_0, F.u_b), 1e-5)
+    right = fem.threshold_pack(fem.distributed_right(x, cells, rho, w), 1e-5)
+    flame = eigen.OracleFlame(fem.flame_outer(n, left, right), eigen.NTau(F.n, F.tau))
+    E, hist = eigen.fixed_point_iteration(A, B, C, flame, F.target, nev=2, i=0)
+    assert len(hist) - 1 == len(g["trajectory"])
+    for z, ref in zip(hist[1:], g["trajectory"]):
+        _close(z, ref)
+    assert abs(E.eigs[0] - complex(*g["direct"])) / abs(E.eigs[0]) < 1e-9
+    vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))
+    p = eigen.normalize_eigenvector(E.vecs[:, 0], C)
+    err = sign_free_error(p, vecs["rijkeffd_opt_dir_p"][match_nodes(x, vecs["rijkeffd_opt_dir_x"])])
+    assert err < 1e-7, err
+
+
 def test_micca_full_annulus_flagship_case(ref_logs, golden_dir):
     """The reference's flagship example (AnnularCombustor/Micca/fullAnnulus/active_fpi.py) on its REAL mesh, read from
     the committed XDMF/HDF5 files: 16 pointwise flames, state-space FTF, Robin outlet, quadratic problem, nev = 4.

@@ -7,8 +7,9 @@ operator lives on the GPU as an ordinary CSR ``Mat`` and the eigen-iteration run
 
 Differences, on purpose:
   * master/slave DOFs are paired GEOMETRICALLY (rotate the master face by 2 pi / N about the z axis) by default;
-    the reference pairs them by sorted DOF index (:40), which is only right if the numbering happens to line up.
-    ``pairing='index'`` reproduces the reference rule.
+    the reference pairs them by sorted DOF index (:40), which is only right if the numbering happens to line up
+    (on its own MICCA sector mesh it does not: paired nodes end up to 0.069 m apart).  ``pairing='index'`` reproduces
+    the reference rule, in the numbering given by ``index_order`` (tests pin the reference's Bloch logs this way).
   * the rank-r flame operator stays factored: blochify() of a low-rank ``Mat`` transforms the factors
     (u' = NB u, v' = BN^T v) instead of materialising a (x) b.
   * ``B_adj`` is provided (the reference leaves it None, :25,88-90, so its Bloch + Robin adjoint cannot run).
@@ -22,7 +23,8 @@ from .solver_utils import info
 
 class Blochifier:
 
-    def __init__(self, geometry, boundary_conditions, N, passive_matrices, active_matrix=None, pairing="geometric"):
+    def __init__(self, geometry, boundary_conditions, N, passive_matrices, active_matrix=None, pairing="geometric",
+                 index_order=None):
         self.passive_matrices = passive_matrices
         self.active_matrix = active_matrix
         self.b = 1.0                                  # Bloch wave number
@@ -39,7 +41,14 @@ class Blochifier:
         assert len(dofs_master) == len(dofs_slave)
         if pairing == "geometric":
             dofs_slave = self._pair_by_rotation(dofs_master, dofs_slave, 2 * np.pi / N)
-        elif pairing != "index":
+        elif pairing == "index":
+            # the reference rule: k-th smallest master index with k-th smallest slave index.  ``index_order[i]`` = the
+            # index node i has in the numbering that rule is to be applied in (e.g. DOLFINx's, to reproduce its logs)
+            if index_order is not None:
+                order = np.asarray(index_order)
+                dofs_master = dofs_master[np.argsort(order[dofs_master], kind="stable")]
+                dofs_slave = dofs_slave[np.argsort(order[dofs_slave], kind="stable")]
+        else:
             raise ValueError("pairing must be 'geometric' or 'index'")
         self.dofs_master, self.dofs_slave = dofs_master, dofs_slave
 

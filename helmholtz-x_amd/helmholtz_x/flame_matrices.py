@@ -124,12 +124,19 @@ class FlameMatrix:
 class PointwiseFlameMatrix(FlameMatrix):
 
     def __init__(self, mesh, subdomains, x_r, h, rho_u, q_0, u_b, FTF, degree=1, bloch_object=None, gamma=1.4,
-                 tol=1e-10):
+                 tol=1e-10, owner_cells=None):
+        """``owner_cells`` (beyond the reference's signature): the cell to take grad(phi) from for each reference point.
+        Only matters when a point sits on a mesh vertex / edge / face, where the P1 gradient is multi-valued and the
+        reference's answer is whatever cell DOLFINx's point-ownership search returns first (flame_matrices.py:144-152);
+        by default the lowest-index containing cell is used."""
         super().__init__(mesh, h, q_0, u_b, FTF, degree, bloch_object, tol)
         self.subdomains = subdomains
         self.x_r = x_r
         self.rho_u = rho_u
         self.gamma = gamma
+        if owner_cells is not None:
+            self._x_r_cells = np.asarray(owner_cells, dtype=np.int64)
+            assert len(self._x_r_cells) == len(x_r)
 
     def _assemble_vectors(self, flame, point):
         asm = self.mesh.assembler()

@@ -28,6 +28,12 @@ CASES = {
     "rijkeffd_dir": "ShapeSensitivities/RijkeFFD/Results/Original/p_dir.h5",
     "rijkeffd_adj": "ShapeSensitivities/RijkeFFD/Results/Original/p_adj.h5",
     "rijkeffd_opt_dir": "ShapeSensitivities/RijkeFFD/Results/Optimized/p_dir.h5",
+    # Bloch sector: besides the modes, the node ORDER of these files is data the Bloch goldens depend on -- the reference
+    # pairs master/slave DOFs by DOLFINx index (bloch_operator.py:30-40), and DOLFINx writes nodes in that order
+    "micca_bloch_p1": "AnnularCombustor/Micca/bloch/Results/Passive/p_1.h5",
+    "micca_bloch_p2": "AnnularCombustor/Micca/bloch/Results/Passive/p_2.h5",
+    "micca_bloch_p3": "AnnularCombustor/Micca/bloch/Results/Passive/p_3.h5",
+    "micca_bloch_active_p1": "AnnularCombustor/Micca/bloch/Results/Active/p_1_dir.h5",
 }
 
 if __name__ == "__main__":

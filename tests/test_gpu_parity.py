@@ -479,6 +479,64 @@ def test_bloch_sector_equals_full_annulus_and_oracle():
     assert np.max(np.abs(pm - bloch.f_b * ps)) < 1e-10 * np.max(np.abs(ps))
 
 
+def test_micca_bloch_sector_reference_logs(ref_logs, golden_dir):
+    """AnnularCombustor/Micca/bloch/passive.py and active.py through the drop-in API on the reference's sector mesh.
+    Two pieces of DATA make the logs reproducible: DOLFINx's node order (the order of its HDF5 output, which fixes the
+    reference's index-order master/slave pairing) and the owner cell of the reference point (a mesh vertex here; see
+    tests/test_oracle_goldens.py).  Then: three passive eigenvalues (6 printed decimals) and the three committed
+    Bloch-remapped modes, the active 6-step trajectory (3 decimals), its final eigenvalue (6 decimals) and mode."""
+    from scipy.io import loadmat
+    from test_oracle_goldens import BLOCH_XR_CELL, match_nodes
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.bloch_operator import Blochifier
+    from helmholtz_x.eigensolvers import eps_solver, fixed_point_iteration
+    from helmholtz_x.eigenvectors import normalize_eigenvector
+    from helmholtz_x.fem import Function, FunctionSpace
+    from helmholtz_x.flame_matrices import PointwiseFlameMatrix
+    from helmholtz_x.flame_transfer_function import stateSpace
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.parameters_utils import Q_volumetric
+    from cases import Micca
+    g = ref_logs["micca_bloch"]
+    vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))
+    micca = XDMFReader(os.path.join(golden_dir, "meshes", "micca_bloch_sector"))
+    mesh, subdomains, facet_tags = micca.getAll()
+    order = match_nodes(mesh.geometry.x, vecs["micca_bloch_p1_x"])
+    c = Function(FunctionSpace(mesh, "DG", 0), "soundspeed")
+    c.x.array[:] = Micca.c_of_z(c.function_space.tabulate_dof_coordinates()[:, 2])
+    # passive.py:21-44
+    bcs = {t: 'Neumann' for t in range(1, 12)}
+    bcs.update({12: 'Master', 13: 'Slave'})
+    matrices = AcousticMatrices(mesh, facet_tags, bcs, c, degree=1)
+    bloch = Blochifier(geometry=micca, boundary_conditions=bcs, N=16, passive_matrices=matrices, pairing="index",
+                       index_order=order)
+    E = eps_solver(bloch.A, bloch.C, 3000.0, nev=5, print_results=False)
+    for k, ref in enumerate(g["passive"]):
+        omega, p = normalize_eigenvector(mesh, E, k, BlochRemapper=bloch.remapper, print_eigs=False)
+        assert abs(omega - ref) < 2e-6, (k, omega, ref)
+        assert _eigvec_error(golden_dir, "micca_bloch_p%d" % (k + 1), mesh, p) < 1e-6
+    # active.py:24-58
+    bcs[11] = {'Robin': Micca.R_outlet}
+    acoustic = AcousticMatrices(mesh, facet_tags, bcs, c, degree=1)
+    bloch = Blochifier(geometry=micca, boundary_conditions=bcs, N=16, passive_matrices=acoustic, pairing="index",
+                       index_order=order)
+    mat = loadmat(os.path.join(golden_dir, "micca_ftf.mat"))
+    FTF = stateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+    h = Q_volumetric(mesh, subdomains, 1)
+    D = PointwiseFlameMatrix(mesh, subdomains, Micca.x_r()[:1], h, Micca.rho_amb, Micca.q_0, Micca.u_b, FTF, degree=1,
+                             bloch_object=bloch, owner_cells=[BLOCH_XR_CELL])
+    D.assemble_submatrices('direct')
+    D.blochify()
+    hist = []
+    E = fixed_point_iteration(bloch, D, 3200 + 500j, nev=3, i=0, tol=1e-3, history=hist)
+    assert len(hist) - 1 == len(g["active_trajectory_3dec"])
+    for z, ref in zip(hist[1:], g["active_trajectory_3dec"]):
+        assert abs(z - complex(*ref)) < 7.5e-4
+    omega, p = normalize_eigenvector(mesh, E, 0, degree=1, BlochRemapper=bloch.remapper, print_eigs=False)
+    assert abs(omega - complex(*g["active"])) < 2e-6
+    assert _eigvec_error(golden_dir, "micca_bloch_active_p1", mesh, p) < 1e-6
+
+
 def test_annulus_adjoint_eigenvalue_is_conjugate():
     """MICCA-style adjoint run (active_fpi.py:64-69): D^T with conj(FTF(conj w)), B_adj = B^H, target conj(target).
     The adjoint fixed point converges to the complex conjugate of the direct eigenvalue (as in the reference's

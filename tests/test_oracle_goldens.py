@@ -86,6 +86,9 @@ def test_prf1d_pep_direct_and_adjoint(ref_logs):
     _close(hist[-1], g["adjoint_omega"])
 
 
+BLOCH_XR_CELL = 1389
+
+
 def match_nodes(x_mine, x_ref):
     """Permutation q with x_ref[q] == x_mine (the reference writes DOLFINx's node order)."""
     d = x_mine.shape[1] if x_mine.ndim == 2 else 1
@@ -244,6 +247,58 @@ def test_rijkeffd_optimized_shape_golden(ref_logs, golden_dir):
     p = eigen.normalize_eigenvector(E.vecs[:, 0], C)
     err = sign_free_error(p, vecs["rijkeffd_opt_dir_p"][match_nodes(x, vecs["rijkeffd_opt_dir_x"])])
     assert err < 1e-7, err
+
+
+def test_micca_bloch_sector_goldens(ref_logs, golden_dir):
+    """AnnularCombustor/Micca/bloch/passive.py + active.py (1/16 sector, Bloch b = 1).  The reference pairs master/slave
+    DOFs by DOLFINx index order (bloch_operator.py:30-40); that order is recovered from the node order of the HDF5 files
+    DOLFINx wrote (data fixture).  With it the oracle reproduces the three logged passive eigenvalues, the three committed
+    passive modes, the logged active fixed-point trajectory and its final eigenvalue and mode."""
+    from scipy.io import loadmat
+    from cases import Micca
+    g = ref_logs["micca_bloch"]
+    vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))
+    m = meshes.read_gmsh41(os.path.join(golden_dir, "meshes", "micca_bloch_sector.msh"), 3)
+    x, cells = m.x, m.cells
+    n = x.shape[0]
+    q = match_nodes(x, vecs["micca_bloch_p1_x"])               # q[i] = DOLFINx index of my node i
+    master = np.unique(m.facets[m.facet_tags == 12])
+    slave = np.unique(m.facets[m.facet_tags == 13])
+    master, slave = master[np.argsort(q[master])], slave[np.argsort(q[slave])]
+    BN, NB = eigen.bloch_maps(n, master, slave, 16)
+    c = Micca.c_of_z(x[cells].mean(axis=1)[:, 2])
+    A = fem.assemble_A(x, cells, c, c_is_cellwise=True)
+    C = fem.assemble_C(x, cells)
+    Ab, Cb = eigen.blochify(A, BN, NB), eigen.blochify(C, BN, NB)
+    E = eigen.eps_solve(Ab, Cb, 3000.0, 5)
+    for k, ref in enumerate(g["passive"]):
+        assert abs(np.sqrt(E.eigs[k]) - ref) < 2e-6, (k, np.sqrt(E.eigs[k]), ref)       # log prints 6 decimals
+        p = eigen.normalize_eigenvector(BN @ E.vecs[:, k], C)                          # BlochRemapper, then int p p = 1
+        assert sign_free_error(p, vecs["micca_bloch_p%d_p" % (k + 1)][q]) < 1e-6
+    # active: Robin outlet, one pointwise flame, state-space FTF
+    P = Micca
+    ft_sel = m.facets[m.facet_tags == 11]
+    B = fem.assemble_B(x, n, [(ft_sel, fem.robin_Z(P.R_outlet), c, m.facet_cells[m.facet_tags == 11])])
+    Bb = eigen.blochify(B, BN, NB)
+    qv = fem.q_multiple(x, cells, m.cell_tags, 1)
+    left = fem.threshold_pack(fem.pointwise_left(x, cells, m.cell_tags, 0, qv, 1.4, P.q_0, P.u_b), 1e-10)
+    # x_r = (0.175, 0, -0.02) IS a mesh vertex here, shared by 20 cells (10 distinct gradients by mirror symmetry), and
+    # the P1 gradient is multi-valued there; the reference uses whichever cell DOLFINx's ownership search returns, which
+    # no log records.  Exactly one of the 10 possibilities reproduces the logged trajectory (3 decimals x 6 steps) and
+    # the 6-decimal eigenvalue -- cell BLOCH_XR_CELL of the fixture file's ordering (or its mirror image 6230).
+    G, _ = fem.cell_geometry(x, cells[BLOCH_XR_CELL:BLOCH_XR_CELL + 1])
+    assert np.any(np.all(np.abs(x[cells[BLOCH_XR_CELL]] - P.x_r()[0]) < 1e-12, axis=1))      # the point is its vertex
+    right = (cells[BLOCH_XR_CELL].astype(np.int32), ((G[0] @ fem.reference_direction(3)) / P.rho_amb).astype(complex))
+    D = fem.flame_outer(n, left, right)
+    mat = loadmat(os.path.join(golden_dir, "micca_ftf.mat"))
+    flame = eigen.OracleFlame(eigen.blochify(D, BN, NB), eigen.StateSpace(mat['A'], mat['b'], mat['c'], mat['d']))
+    Ea, hist = eigen.fixed_point_iteration(Ab, Bb, Cb, flame, 3200 + 500j, nev=3, i=0, tol=1e-3)
+    assert len(hist) - 1 == len(g["active_trajectory_3dec"])
+    for z, ref in zip(hist[1:], g["active_trajectory_3dec"]):
+        assert abs(z - complex(*ref)) < 7.5e-4
+    assert abs(Ea.eigs[0] - complex(*g["active"])) < 2e-6
+    p = eigen.normalize_eigenvector(BN @ Ea.vecs[:, 0], C)
+    assert sign_free_error(p, vecs["micca_bloch_active_p1_p"][q]) < 1e-6
 
 
 def test_micca_full_annulus_flagship_case(ref_logs, golden_dir):

@@ -162,3 +162,23 @@ class RijkeFFD:
     a_r = 0.025
     target = 180 * 2 * np.pi
     bcs = {1: {'Neumann'}, 2: {'Robin': R_out}, 3: {'Robin': R_in}}
+
+
+class FlamedDuct:
+    """Longitudinal/NetworkCode/FlamedDuct/params.py."""
+    p_gas = 100000.0
+    r_gas = 287.1
+    T_passive = 1000.0
+    T_flame = 1500.0
+    x_flame = np.array([[0.0, 0.0, 0.50]])
+    a_flame = 0.025
+    x_ref = np.array([[0.0, 0.0, 0.35]])
+    a_ref = 0.025
+    n = 1
+    tau = 0.2e-3
+    q_0 = -57015.232012607579
+    u_b = 11.485465769828917
+    M0 = 9.2224960671405849e-3
+    M1 = 1.1408306741423997e-2
+    target_passive = 262 * 2 * np.pi
+    target_active = 250 * 2 * np.pi

@@ -249,6 +249,61 @@ def test_rijkeffd_optimized_shape_golden(ref_logs, golden_dir):
     assert err < 1e-7, err
 
 
+def test_flamedduct_choked_boundaries_and_half_gaussian_flame(ref_logs, golden_dir):
+    """Longitudinal/NetworkCode/FlamedDuct (passive.py, active.py) on the reference's mesh (XDMF/HDF5): choked inlet and
+    outlet (reflection coefficients from the facet-averaged gamma), variable-gamma sound speed from a temperature field,
+    ideal-gas density, half-Gaussian heat release.  Passive: the eleven eigenvalues SLEPc printed for nev = 10.
+    Active: the logged 5-step trajectory to 8 decimals."""
+    from cases import FlamedDuct as F
+    from helmholtz_x.io_utils import read_xdmf          # mesh ingestion only (host I/O)
+    g = ref_logs["flamedduct"]
+    mesh, sub, ft = read_xdmf(os.path.join(golden_dir, "meshes", "flamedduct", "mesh"))
+    x, cells = mesh.geometry.x, mesh.topology.cells
+    n = x.shape[0]
+    assert (n, cells.shape[0]) == (33855, 177771)
+    C = fem.assemble_C(x, cells)
+
+    def operators(T):
+        gamma = fem.gamma_of_T(T)
+        c = fem.sound_speed_variable_gamma(T)
+        terms = []
+        for tag, Mach, rule in ((3, F.M0, fem.choked_inlet_R), (8, F.M1, fem.choked_outlet_R)):
+            fac = mesh.facets[ft.find(tag)]
+            terms.append((fac, fem.robin_Z(rule(fem.facet_average(x, fac, gamma), Mach)), c, None))
+        return fem.assemble_A(x, cells, c), fem.assemble_B(x, n, terms), gamma
+
+    # passive.py
+    A, B, _ = operators(np.full(n, F.T_passive, dtype=complex))
+    E = eigen.pep_solve(A, B, C, F.target_passive, 10)
+    ref = np.array([complex(*z) for z in g["passive"]])
+    # same set (order among equidistant pairs is not defined).  The last two printed values, 9203.635 / 9203.729, are a
+    # nearly degenerate pair of transverse duct modes split only by the mesh; their individual values are ill-conditioned
+    # (two independent solvers agree to 1e-3 only), everything else is reproduced to the printed 6 decimals.
+    for lam in E.eigs[:10]:
+        tol = 2e-3 if abs(lam.real - 9203.68) < 0.1 else 5e-6
+        assert np.min(np.abs(ref - lam)) < tol, lam
+    assert abs(E.eigs[0] - ref[0]) < 2e-6
+    # active.py -- verified once (6 minutes: the explicit Gaussian-flame block makes every SuperLU factorisation of
+    # A - D(omega_k) expensive, which is the reference's own cost structure); opt-in so the CPU suite stays short.
+    # The HIP path reproduces the same log in tests/test_gpu_parity.py.
+    if not os.environ.get("HX_SLOW_TESTS"):
+        return
+    T = fem.step_field(x, 3, F.x_flame, F.T_passive, F.T_flame)
+    A, B, gamma = operators(T)
+    rho = F.p_gas / (F.r_gas * T)
+    w = fem.gaussian_function(x, cells, F.x_ref, F.a_ref)
+    h = fem.gaussian_function(x, cells, F.x_flame, F.a_flame)
+    h[x[:, 2] < F.x_flame[0][2]] = 0.0                      # halfGaussianFunction (parameters_utils.py:45-60)
+    h = h / fem.integrate_p1(x, cells, h)
+    left = fem.threshold_pack(fem.distributed_left(x, cells, gamma, h, F.q_0, F.u_b), 1e-5)
+    right = fem.threshold_pack(fem.distributed_right(x, cells, rho, w), 1e-5)
+    flame = eigen.OracleFlame(fem.flame_outer(n, left, right), eigen.NTau(F.n, F.tau))
+    _, hist = eigen.fixed_point_iteration(A, B, C, flame, F.target_active, nev=2, i=0)
+    assert len(hist) - 1 == len(g["active_trajectory"])
+    for z, r in zip(hist[1:], g["active_trajectory"]):
+        _close(z, r)
+
+
 def test_micca_bloch_sector_goldens(ref_logs, golden_dir):
     """AnnularCombustor/Micca/bloch/passive.py + active.py (1/16 sector, Bloch b = 1).  The reference pairs master/slave
     DOFs by DOLFINx index order (bloch_operator.py:30-40); that order is recovered from the node order of the HDF5 files

@@ -297,14 +297,16 @@ class AMGSolver:
         info("- AMG hierarchy: " + " -> ".join("%d" % lv["n"] for lv in levels)
              + "  (operator complexity %.2f)" % (sum(lv["K"].nnz for lv in levels) / levels[0]["K"].nnz))
 
-    def solve(self, b, x):
+    def solve(self, b, x, relax=1.0):
+        """``relax`` >= 1 multiplies the relative tolerance (inexact-Krylov relaxation decided by the eigen-solver)."""
         import time
         t0 = time.perf_counter()
         it, rr = C.c_int(0), C.c_double(0.0)
         K = self.K
+        rtol = self.params["rtol"] * max(float(relax), 1.0)
         if self.shard is not None:
             rc = _hx.lib.hx_gmres_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
-                                          self.sell, _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
+                                          self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
                                           self.params["restart"], _hx.ptr(self.ws), _hx.ptr(self._bufs[_hx.BUF_GMRES_XE]),
                                           _hx.ptr(self._bufs[_hx.BUF_GMRES_DOTS]), C.byref(it), C.byref(rr), _hx.stream())
             if rc != 0 and self._cb.error:
@@ -312,7 +314,7 @@ class AMGSolver:
             _hx.check(rc)
         else:
             _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
-                                       self.sell, _hx.ptr(b), _hx.ptr(x), self.params["rtol"], self.params["max_it"],
+                                       self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
                                        self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
         if self.recycle_k > 0 and not self.recycled:
             self._harvest()
@@ -320,7 +322,7 @@ class AMGSolver:
         self.total_iters += it.value
         self.n_solves += 1
         self.last = (it.value, rr.value)
-        if rr.value > 100 * self.params["rtol"]:
+        if rr.value > 100 * rtol:
             raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
                                   % (rr.value, it.value))
 

@@ -28,6 +28,15 @@ def default_ncv(nev):
     return max(2 * nev, nev + 15)
 
 
+def _tell(basis, theta, resid, nev):
+    """Let the basis relax the accuracy of its operator applications (inexact Krylov): the largest relative residual
+    estimate among the wanted pairs bounds how much of the remaining Krylov directions can still enter them."""
+    hook = getattr(basis, "set_inner_accuracy", None)
+    if hook is not None and len(theta):
+        k = min(nev, len(theta))
+        hook(float(np.max(resid[:k] / np.maximum(np.abs(theta[:k]), 1e-300))), nev)
+
+
 def _ritz(S, mact, tol):
     """Ritz pairs of the leading mact x mact block, sorted by |theta| descending, with residual estimates."""
     theta, Y = sla.eig(S[:mact, :mact])
@@ -65,10 +74,13 @@ def krylov_schur(basis, nev, ncv, tol=1e-15, max_it=100, keep_fraction=0.5, rela
             S[j + 1, j] = beta
             cols = j + 1
             if cols < m and cols >= k + nev + 1 and (cols - k) % check_every == 0:
-                if _ritz(S, cols, tol)[3] >= nev:
+                th_c, _, res_c, nc_c = _ritz(S, cols, tol)
+                _tell(basis, th_c, res_c, nev)
+                if nc_c >= nev:
                     mact = cols
                     break
         theta, Y, resid, nconv = _ritz(S, mact, tol)
+        _tell(basis, theta, resid, nev)
         if nconv >= nev or its >= max_it:
             break
         # stagnation guard: the estimate cannot always reach tol = 1e-15 in double precision; once the wanted

@@ -28,6 +28,7 @@ from .petsc import combine_csr, to_device
 from .solver_utils import info
 
 DEFAULTS = {"st_type": "auto", "lu_max_dofs": 20_000}
+RELAX_CAP = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP", "1e4"))     # 1 switches the relaxation off
 
 
 # ----------------------------------------------------------------------------- inner solvers for sparse K
@@ -82,8 +83,8 @@ class LUSolver:
             out.append((lv.value, ln.value, nz.value))
         return out
 
-    def solve(self, b, x):
-        """x = K^-1 b (device tensors; b is preserved, may not alias x)."""
+    def solve(self, b, x, relax=1.0):
+        """x = K^-1 b (device tensors; b is preserved, may not alias x).  ``relax`` is ignored: the solve is direct."""
         s = _hx.stream()
         self.n_solves += 1
         _hx.check(_hx.lib.hx_zgather(self.n, _hx.ptr(b), _hx.ptr(self.gather_in), _hx.ptr(self.tmp), s))
@@ -184,8 +185,8 @@ class WoodburySolver:
             self.shard.all_reduce_(self.t_dev)
         return self.t_dev.cpu().numpy().copy()
 
-    def solve(self, b, x):
-        self.inner.solve(b, x)
+    def solve(self, b, x, relax=1.0):
+        self.inner.solve(b, x, relax=relax)
         if not self.active:
             return
         t = self._vt(x)
@@ -227,6 +228,16 @@ class DeviceBasis:
         self.h_dev = torch.empty(m + 1, dtype=torch.complex128, device=dev)
         self.ws = torch.empty(_hx.lib.hx_panel_dot_ws(m), dtype=torch.complex128, device=dev)
         self.n_ops = 0
+        self.relax = 1.0             # factor on the inner solver's tolerance for the NEXT operator applications
+
+    def set_inner_accuracy(self, lead_residual, nev):
+        """Inexact Krylov relaxation (krylov._tell): a Krylov direction generated while the wanted Ritz pair has relative
+        residual r enters it with a weight of about r, so the operator may then be applied with an error 1/r times
+        larger without changing the converged pair (Simoncini 2005).  A factor 10 is kept in hand and the relaxation is
+        capped at 1e4 (inner tolerance 1e-11 -> at most 1e-7).  Only for single-pair solves (the lean solves of the
+        fixed-point loop): with several wanted pairs the trailing, nearly degenerate ones were measured to move by
+        1e-9 .. 1e-7, because their left Ritz vectors do not share the decay the argument relies on."""
+        self.relax = float(min(max(0.1 / max(lead_residual, 1e-300), 1.0), RELAX_CAP)) if nev == 1 else 1.0
 
     def _dots(self, k, w):
         _hx.check(_hx.lib.hx_zpanel_dot(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(w), _hx.ptr(self.h_dev),
@@ -239,6 +250,7 @@ class DeviceBasis:
                                         _hx.stream()))
 
     def set_start(self, j):
+        self.relax = 1.0
         if self.start is not None and self.start.numel() == self.n:
             self.V[j].copy_(self.start)              # warm start: previous Ritz vectors (fixed-point iteration)
         else:
@@ -495,17 +507,19 @@ class EPS(_EigenSolverBase):
                 xe[:n_loc].copy_(v)
                 sh.halo(xe)
                 Mloc.spmv(xe, tmp)
-                solver.solve(tmp, w)
+                solver.solve(tmp, w, relax=basis.relax)
 
-            self._finish(DeviceBasis(n_loc, self._ncv_for(n) + 1, op, start=self._start(), shard=sh, pool=self._pool()), sigma)
+            basis = DeviceBasis(n_loc, self._ncv_for(n) + 1, op, start=self._start(), shard=sh, pool=self._pool())
+            self._finish(basis, sigma)
             return
         tmp = torch.empty(n, dtype=torch.complex128, device=Mcsr.val.device)
 
         def op(v, w):
             Mcsr.spmv(v, tmp)
-            solver.solve(tmp, w)
+            solver.solve(tmp, w, relax=basis.relax)
 
-        self._finish(DeviceBasis(n, self._ncv_for(n) + 1, op, start=self._start(), pool=self._pool()), sigma)
+        basis = DeviceBasis(n, self._ncv_for(n) + 1, op, start=self._start(), pool=self._pool())
+        self._finish(basis, sigma)
         if self._two_sided:
             left = EPS()
             At, Mt = A.copy(), M.copy()
@@ -569,14 +583,14 @@ class PEP(_EigenSolverBase):
                 sh.halo(x2e)
                 BsC_l.spmv(x1e, tmp, alpha=-1.0)
                 C_l.spmv(x2e, tmp, alpha=-1.0, beta=1.0)
-                solver.solve(tmp, y1)
+                solver.solve(tmp, y1, relax=basis.relax)
                 arr = (C.c_void_p * 2)(x1e.data_ptr(), y1.data_ptr())
                 cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
                 _hx.check(_hx.lib.hx_zlincomb(m, 2, cf, arr, _hx.ptr(y2), _hx.stream()))
 
-            self._finish(DeviceBasis(2 * m, self._ncv_for(2 * n) + 1, op, start=self._start(), shard=sh, blocks=2,
-                                     pool=self._pool()),
-                         sigma)
+            basis = DeviceBasis(2 * m, self._ncv_for(2 * n) + 1, op, start=self._start(), shard=sh, blocks=2,
+                                pool=self._pool())
+            self._finish(basis, sigma)
             self._n = m
             return
         tmp = torch.empty(n, dtype=torch.complex128, device=Ccsr.val.device)
@@ -586,12 +600,13 @@ class PEP(_EigenSolverBase):
             y1, y2 = y[:n], y[n:]
             BsC.spmv(x1, tmp, alpha=-1.0)
             Ccsr.spmv(x2, tmp, alpha=-1.0, beta=1.0)
-            solver.solve(tmp, y1)                                # y1 = -K^-1[(B + sigma C) x1 + C x2]
+            solver.solve(tmp, y1, relax=basis.relax)             # y1 = -K^-1[(B + sigma C) x1 + C x2]
             arr = (C.c_void_p * 2)(x1.data_ptr(), y1.data_ptr())
             cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
             _hx.check(_hx.lib.hx_zlincomb(n, 2, cf, arr, _hx.ptr(y2), _hx.stream()))   # y2 = x1 + sigma y1
 
-        self._finish(DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op, start=self._start(), pool=self._pool()), sigma)
+        basis = DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op, start=self._start(), pool=self._pool())
+        self._finish(basis, sigma)
         self._n = n
 
 

@@ -86,10 +86,13 @@ def np_count_plane(x):
     return int(np.argmax(np.abs(th - th[0]) > 1e-12))
 
 
-def spmv_roofline(matrices, target, reps=50):
+def spmv_roofline(matrices, target, reps=50, in_situ=None):
     """Average launch time of the operator product y = K x (K = A + sigma B + sigma^2 C) as the inner solver runs it:
-    SELL-64 layout (`k_sell<c128, 0>`, hx_sell_spmv_z); the plain CSR kernel is timed beside it.  HIP events on the
-    launch stream; achieved = CSR-algorithmic bytes (nnz*20 + n*36) / average launch time."""
+    SELL-64 layout (`k_sell<c128, 0>`, hx_sell_spmv_z).  achieved = CSR-algorithmic bytes (nnz*20 + n*36) /
+    average launch duration, where the duration is measured IN SITU: HIP events on the launch stream around every such
+    launch of the timed region (``in_situ`` = (launches, summed ms) from hx_profile_sell_spmv_read) -- the number
+    rocprofv3's per-kernel average reproduces.  A back-to-back loop of the same kernel and of the plain CSR kernel is
+    timed beside it (on some boxes the loop runs ~10 % faster than the in-situ launches)."""
     import ctypes as C
     import torch
     from helmholtz_x import _hx
@@ -120,10 +123,16 @@ def spmv_roofline(matrices, target, reps=50):
     ms = timed(lambda: _hx.check(_hx.lib.hx_sell_spmv_z(sell, _hx.ptr(x), _hx.ptr(y), one, zero, _hx.stream())))
     _hx.lib.hx_sell_destroy(sell)
     alg_bytes = nnz * 20 + n * 36
+    loop_ms = ms
+    if in_situ is not None and in_situ[0] > 0:
+        ms = in_situ[1] / in_situ[0]
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel="k_sell<c128, 0> (hx_sell_spmv_z)", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=measured_traffic(n, nnz), n_rows=n, nnz=nnz,
                 bytes_per_launch=alg_bytes, avg_launch_ms=round(ms, 5),
+                timing="in situ: HIP events around %d launches of the timed region" % in_situ[0]
+                if (in_situ is not None and in_situ[0] > 0) else "back-to-back loop",
+                back_to_back_loop_ms=round(loop_ms, 5),
                 csr_kernel={"kernel": "k_spmv<8, 0, c128> (hx_csr_spmv_z)", "avg_launch_ms": round(ms_csr, 5),
                             "achieved": round(alg_bytes / (ms_csr * 1e-3) / 1e9, 1)})
 
@@ -213,6 +222,10 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):          # the library logs like the reference; stdout = the JSON line
         for _ in range(args.warmup):
             hot_path(case, args.st_type)
+        from helmholtz_x import _hx
+        import ctypes as C
+        # in-situ HIP-event timing of the roofline kernel (operator product on the fine operator) over the timed region
+        _hx.check(_hx.lib.hx_profile_sell_spmv(1, n_dof if n_dof >= 50_000 else 2 ** 31 - 1))
         barrier()
         t0 = time.perf_counter()
         pairs = 0
@@ -223,6 +236,10 @@ def main():
             pairs += min(E.getConverged(), 4)
         barrier()
         dt = time.perf_counter() - t0
+        n_launch, tot_ms = C.c_int64(0), C.c_double(0.0)
+        _hx.check(_hx.lib.hx_profile_sell_spmv_read(C.byref(n_launch), C.byref(tot_ms)))
+        _hx.check(_hx.lib.hx_profile_sell_spmv(0, 0))
+        in_situ = (n_launch.value, tot_ms.value)
     red_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     tot = torch.tensor([float(pairs)], dtype=torch.float64, device=red_dev)
@@ -236,7 +253,7 @@ def main():
     if rank == 0:
         inner = next((v for v in (E.inner_cache or {}).values() if hasattr(v, "stats")), None)
         with contextlib.redirect_stdout(sys.stderr):
-            roof = spmv_roofline(matrices, case["P"].target)
+            roof = spmv_roofline(matrices, case["P"].target, in_situ=in_situ)
         out = {
             "metric": "converged eigenpairs/sec + SpMV GB/s (% HBM roofline), AnnularCombustor",
             "value": round(pairs_all / dt, 5), "unit": "eigenpairs/s",

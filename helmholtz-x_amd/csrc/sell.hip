@@ -218,12 +218,54 @@ static int sell_grid(int32_t n_slices) {
   return (int)(blocks < 1 ? 1 : blocks);
 }
 
+// In-situ timing of the operator product (the roofline kernel of bench.py): when enabled, every k_sell<c128,0> launch is
+// bracketed by a pair of HIP events on its launch stream (no synchronisation until the read-out).
+#include <vector>
+namespace {
+struct SpmvProfile {
+  bool on = false;
+  int32_t min_rows = 0;
+  std::vector<hipEvent_t> ev;          // 2 per launch
+  size_t used = 0;
+  int64_t skipped = 0;
+} g_prof;
+const size_t PROF_MAX_LAUNCHES = 16384;
+}
+extern "C" int hx_profile_sell_spmv(int enable, int32_t min_rows) {
+  if (enable && g_prof.ev.empty()) {
+    g_prof.ev.resize(2 * PROF_MAX_LAUNCHES);
+    for (auto& e : g_prof.ev) HX_HIP(hipEventCreate(&e));
+  }
+  g_prof.on = enable != 0;
+  g_prof.min_rows = min_rows;
+  if (enable) { g_prof.used = 0; g_prof.skipped = 0; }
+  return HX_OK;
+}
+// number of recorded launches and the sum of their durations (SYNC: waits for the last recorded event)
+extern "C" int hx_profile_sell_spmv_read(int64_t* launches, double* total_ms) {
+  HX_REQUIRE(launches && total_ms, "bad argument");
+  double tot = 0.0;
+  for (size_t i = 0; i < g_prof.used; i += 2) {
+    HX_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+    float ms = 0.f;
+    HX_HIP(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+    tot += ms;
+  }
+  *launches = (int64_t)(g_prof.used / 2);
+  *total_ms = tot;
+  return HX_OK;
+}
+
 extern "C" int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
                               hx_stream s) {
   HX_REQUIRE(h && h->val_z && x && y && alpha && beta, "bad argument");
   const zc a = hx_z(alpha), b = hx_z(beta);
+  const bool rec = g_prof.on && h->n >= g_prof.min_rows && g_prof.used + 2 <= g_prof.ev.size();
+  if (g_prof.on && !rec && h->n >= g_prof.min_rows) ++g_prof.skipped;
+  if (rec) HX_HIP(hipEventRecord(g_prof.ev[g_prof.used], hx_s(s)));
   k_sell<zc, 0><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_z, (const zc*)x,
                                                               (zc*)y, a, b, (b.x == 0 && b.y == 0), nullptr, nullptr, nullptr, 0.0, 0.0, 1.0);
+  if (rec) { HX_HIP(hipEventRecord(g_prof.ev[g_prof.used + 1], hx_s(s))); g_prof.used += 2; }
   HX_LAUNCH_CHECK("k_sell<c128,spmv>");
   return HX_OK;
 }

@@ -121,6 +121,11 @@ int hx_sell_smooth_z(const hx_sell* h, const hx_c128* dinv, const hx_c128* b, co
 int hx_sell_smooth_c64(const hx_sell* h, const hx_c64* dinv, const hx_c64* b, const hx_c64* xin, hx_c64* xout,
                        float omega, const hx_c64* xprev, float mom, hx_stream s);
 int hx_sell_destroy(hx_sell* h);
+/* In-situ timing of hx_sell_spmv_z (the operator product = the roofline kernel): once enabled, every launch on an operator
+ * with at least min_rows rows is bracketed by HIP events on its launch stream (up to 16384 launches, no synchronisation);
+ * the read-out waits for the recorded events and returns their count and summed duration. */
+int hx_profile_sell_spmv(int enable, int32_t min_rows);
+int hx_profile_sell_spmv_read(int64_t* launches, double* total_ms);
 
 /* ------------------------------------------------------------------ P1 assembly (DOLFINx assemble_*)
  * Vertex-centric "owner computes" assembly: one CSR row per vertex, gathered from the cells incident

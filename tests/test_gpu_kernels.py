@@ -299,3 +299,35 @@ def test_sell64_complex_half_storage(hx, n, scale):
     refs = x + 0.7 * (1.0 / d) * (y0 - Mq @ x) + 0.25 * x
     assert np.max(np.abs(o32.cpu().numpy() - refs)) <= 3e-5 * np.max(np.abs(refs)) + flip * np.max(np.abs(1.0 / d))
     hx.check(hx.lib.hx_sell_destroy(h))
+
+
+def test_in_situ_spmv_profile_counts_launches(hx):
+    """hx_profile_sell_spmv: HIP events around every hx_sell_spmv_z launch on operators of at least min_rows rows."""
+    import torch
+    n = 4096
+    rng = np.random.default_rng(2)
+    M = sp.random(n, n, density=8.0 / n, random_state=rng, format="csr") + sp.eye(n, format="csr")
+    M = sp.csr_matrix(M, dtype=np.complex128)
+    M.sort_indices()
+    rp, ci, va = _dev(M.indptr.astype(np.int32)), _dev(M.indices.astype(np.int32)), _dev(M.data)
+    h = C.c_void_p()
+    hx.check(hx.lib.hx_sell_create(C.byref(h), n, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), 1, 0, hx.stream()))
+    x = _dev(_rand_c(rng, n))
+    y = torch.empty_like(x)
+    one, zero = hx.z2(1.0), hx.z2(0.0)
+    cnt, ms = C.c_int64(-1), C.c_double(-1.0)
+    hx.check(hx.lib.hx_profile_sell_spmv(1, n + 1))            # operator too small: nothing recorded
+    hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(x), hx.ptr(y), one, zero, hx.stream()))
+    hx.check(hx.lib.hx_profile_sell_spmv_read(C.byref(cnt), C.byref(ms)))
+    assert cnt.value == 0 and ms.value == 0.0
+    hx.check(hx.lib.hx_profile_sell_spmv(1, n))
+    for _ in range(7):
+        hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(x), hx.ptr(y), one, zero, hx.stream()))
+    hx.check(hx.lib.hx_profile_sell_spmv_read(C.byref(cnt), C.byref(ms)))
+    assert cnt.value == 7 and 0.0 < ms.value < 50.0
+    hx.check(hx.lib.hx_profile_sell_spmv(0, 0))
+    hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(x), hx.ptr(y), one, zero, hx.stream()))
+    hx.check(hx.lib.hx_profile_sell_spmv_read(C.byref(cnt), C.byref(ms)))
+    assert cnt.value == 7                                       # disabled: no new records
+    assert np.max(np.abs(y.cpu().numpy() - M @ x.cpu().numpy())) < 1e-12
+    hx.check(hx.lib.hx_sell_destroy(h))

@@ -882,6 +882,30 @@ def test_micca_full_annulus_flagship_case(ref_logs, golden_dir, st_type):
         assert abs(E_adj.getEigenvalue(i) - ref) / abs(ref) < 1e-8, (i, E_adj.getEigenvalue(i), ref)
 
 
+def test_micca_full_annulus_newton_solver_log(ref_logs, golden_dir, capsys):
+    """active_newton.py: the reference's two-sided Newton iteration on lambda(omega) for the two azimuthal modes, on its
+    real mesh.  With the reference's update rule restated as written (relaxation *= 0.8 every iteration; PETSc's
+    conjugating dot in vector_matrix_vector) both logged runs are reproduced line by line -- 19 and 30 iterations, omega to
+    the 2 printed decimals, |domega| to its 3 printed digits -- and the stored 16-digit results to 1e-9."""
+    import re
+    from helmholtz_x.eigensolvers import newtonSolver
+    g = ref_logs["micca_full_newton"]
+    matrices, D = _micca_full_problem(golden_dir)
+    for i in (0, 1):
+        capsys.readouterr()
+        omega, p = newtonSolver(matrices, D, 3260 + 460j, i=i, nev=2, tol=1e-2)
+        lines = re.findall(r"iter =\s*(\d+),\s+omega = ([+-][\d.]+)\s+([+-][\d.]+)j,\s+\|domega\| = ([\d.e+-]+)",
+                           capsys.readouterr().out)
+        ref = g["iterations_omega_2dec_and_domega"][i]
+        assert len(lines) == len(ref)
+        for (k, re_, im_, dom), (rr, ri, rd) in zip(lines, ref):
+            assert abs(float(re_) - rr) < 0.011 and abs(float(im_) - ri) < 0.011, (i, k)
+            assert abs(float(dom) - rd) <= 0.011 * rd, (i, k, dom, rd)
+        final = complex(*g["final"][i])
+        assert abs(omega - final) / abs(final) < 1e-9, (i, omega, final)
+        assert abs(p.x.array @ (matrices.C.to_scipy() @ p.x.array) - 1.0) < 1e-8       # normalised: int p p dx = 1
+
+
 def test_micca_full_annulus_modes_at_six_targets(ref_logs, golden_dir):
     """active_modes.py at the six targets the reference ran (1000 ... 11000 rad/s, its 8-rank MPI logs): every logged
     fixed-point trajectory to its 3 printed decimals and every stored eigenfrequency (omega / 2 pi, 16 digits) to 1e-8.

@@ -765,6 +765,20 @@ extern "C" int hx_host_sa_prolongator(int32_t n, const int32_t* rp, const int32_
   return HX_OK;
 }
 
+// Diagonal of a complex CSR matrix (0 where no diagonal entry is stored); row-parallel.  SciPy's csr_diagonal is a
+// sequential pass (0.1 s at 5 M rows).
+extern "C" int hx_host_csr_diagonal(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, hx_c128* out) {
+  HX_REQUIRE(n > 0 && rp && ci && val && out, "bad argument");
+  parallel_rows(n, [&](int, int32_t i0, int32_t i1) {
+    for (int32_t i = i0; i < i1; ++i) {
+      hx_c128 d = {0.0, 0.0};
+      for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] == i) { d = val[p]; break; }
+      out[i] = d;
+    }
+  });
+  return HX_OK;
+}
+
 // Power iteration for rho(Df^-1 Lf) (Lf CSR with positive diagonal): v <- Df^-1 Lf v / ||.||, `iters` times from the
 // caller's start vector v (overwritten); returns the last norm ratio.  Row-parallel matvec; the norm is summed per
 // row block and combined in block order.

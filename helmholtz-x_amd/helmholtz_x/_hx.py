@@ -89,6 +89,7 @@ SIGNATURES = {
     "hx_host_aggregate": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "hx_host_sa_filter": (C.c_int, [_i32, _vp, _vp, _vp, _int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "hx_host_galerkin_rap": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
+    "hx_host_csr_diagonal": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "hx_host_power_rho": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _int, C.POINTER(C.c_double)]),
     "hx_host_sa_prolongator": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
 }

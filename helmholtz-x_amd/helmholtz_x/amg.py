@@ -91,6 +91,17 @@ def _galerkin(R, K, P, n_threads=None):
     return sp.csr_matrix((ov, oci, orp), shape=(nc, P.shape[1]))
 
 
+def _diagonal(K):
+    """Diagonal of a scipy CSR (complex128) by the native row-parallel pass."""
+    n = K.shape[0]
+    rp = np.ascontiguousarray(K.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(K.indices, dtype=np.int32)
+    kv = np.ascontiguousarray(K.data, dtype=np.complex128)
+    out = np.empty(n, dtype=np.complex128)
+    _hx.check(_hx.lib.hx_host_csr_diagonal(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(kv), _hx.nptr(out)))
+    return out
+
+
 def _spectral_radius_dinv(Lf, iters=10, seed=0):
     """Power-iteration estimate of rho(Df^-1 Lf) (similar to an SPD matrix: the norm ratio converges from below; the
     smoothing weights derived from it carry a 4/3 safety factor).  Native row-parallel pass (hx_host_power_rho)."""
@@ -114,7 +125,7 @@ def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], c
     th = theta
     while True:
         n = Kl.shape[0]
-        diag = Kl.diagonal()
+        diag = _diagonal(Kl)
         level = dict(K=Kl, n=n)
         if n <= coarse_size or len(levels) == max_levels - 1:
             levels.append(level)

@@ -298,6 +298,8 @@ int hx_host_aggregate(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const
 int hx_host_sa_prolongator(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_lf,
                            const int32_t* h_agg, const double* h_inv_sqrt_cnt, double omega,
                            int32_t* h_out_rp, int32_t* h_out_ci, double* h_out_v);
+/* diagonal of a complex CSR matrix (0 where none is stored); row-parallel */
+int hx_host_csr_diagonal(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, hx_c128* out);
 /* rho(Df^-1 Lf) by `iters` power iterations from the start vector v (length n, overwritten); row-parallel. */
 int hx_host_power_rho(int32_t n, const int32_t* rp, const int32_t* ci, const double* lf, double* v, int iters,
                       double* rho);

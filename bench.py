@@ -240,6 +240,8 @@ def main():
         _hx.check(_hx.lib.hx_profile_sell_spmv_read(C.byref(n_launch), C.byref(tot_ms)))
         _hx.check(_hx.lib.hx_profile_sell_spmv(0, 0))
         in_situ = (n_launch.value, tot_ms.value)
+        free_b, total_b = torch.cuda.mem_get_info()            # device-wide: torch's pool + the library's own hipMallocs
+        hbm_used_gb = round((total_b - free_b) / 2 ** 30, 1)
     red_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     tot = torch.tensor([float(pairs)], dtype=torch.float64, device=red_dev)
@@ -267,6 +269,7 @@ def main():
                        "inner_stats": inner.stats() if inner is not None else None,
                        "krylov": {k: v for k, v in (E.state or {}).items() if not k.startswith(("start", "_"))},
                        "parallelism": "replicas x%d" % world if world > 1 else "1 gpu",
+                       "hbm_in_use_after_step_gib": hbm_used_gb,
                        "omega": [[round(w.real, 6), round(w.imag, 6)] for w in omegas]},
             "roofline": roof,
         }

@@ -16,10 +16,8 @@ runs unchanged on N ranks) is provided here by a ``ShardContext`` handed to ``fi
 Set-up is replicated: every rank assembles the (cheap, device) global operators and builds the same hierarchy on its
 host, then keeps only its rows.  That part does not scale with N; DESIGN.md section 7 has the numbers.
 """
-import ctypes as C
 import traceback
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

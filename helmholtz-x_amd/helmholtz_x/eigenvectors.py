@@ -43,3 +43,28 @@ def normalize_eigenvector(mesh, obj, i, absolute=False, degree=1, which='right',
     if print_eigs:
         print(f"Eigenvalue-> {omega:.6f} | Eigenfrequency-> {omega/(2*np.pi):.6f}\n ")
     return omega, p
+
+
+def normalize_adjoint(omega_dir, p_dir, p_adj, matrices, D=None):
+    """Scale the adjoint mode so that  <p_adj, dL/domega p_dir> = 1  (reference: eigenvectors.py:125-177; the
+    normalisation the shape-derivative consumer expects).  dL/domega = [B] + 2 omega C [- D'(omega)], applied lazily on
+    the device (the flame derivative stays factored); the bracket is the reference's ``vector_matrix_vector``, i.e.
+    PETSc's conjugating dot."""
+    from .petsc4py_utils import multiply, vector_matrix_vector
+    from .solver_utils import info
+    info("- Normalizing the adjoint eigenvector to calculate shape derivatives..")
+    B = matrices.B
+    p_dir_vec, p_adj_vec = p_dir.x.petsc_vec, p_adj.x.petsc_vec
+    dL_domega = matrices.C * (2 * omega_dir)
+    if B:
+        dL_domega = B + dL_domega
+    if D:
+        dL_domega = dL_domega - D.get_derivative(omega_dir)
+    meas = vector_matrix_vector(p_adj_vec, dL_domega, p_dir_vec)
+    p_adj_vec = multiply(p_adj_vec, 1 / meas)
+    p_adj1 = p_adj
+    p_adj1.name = "p_adj"
+    p_adj1.x.array[:] = p_adj_vec.getArray()          # (Function.x.petsc_vec is a device COPY here, not a view)
+    integral = vector_matrix_vector(p_adj1.x.petsc_vec, dL_domega, p_dir_vec)
+    print("! Normalization Check: ", integral)
+    return p_adj1

@@ -168,6 +168,39 @@ def read_xdmf(name):
             MeshTags(mesh, dim - 1, np.arange(facets.shape[0]), facet_values))
 
 
+def xdmf_writer(name, mesh, function):
+    """Write a P1 / DG0 function for visualisation: ``name.xdmf`` with the heavy data INLINE (Format="XML"), real and
+    imaginary parts as two attributes named like the reference's output (``real_f`` / ``imag_f``, io_utils.py:141-158 ->
+    dolfinx XDMFFile.write_function).  Post-processing is outside the hot path; no HDF5 is written."""
+    import os
+    x = mesh.geometry.x
+    cells = mesh.topology.cells
+    dim = mesh.topology.dim
+    ttype = {1: "Polyline", 2: "Triangle", 3: "Tetrahedron"}[dim]
+    vals = np.asarray(function.x.array)
+    center = "Node" if vals.shape[0] == x.shape[0] else "Cell"
+    assert vals.shape[0] in (x.shape[0], cells.shape[0]), "function does not live on the mesh vertices or cells"
+
+    def block(a, fmt):
+        return "\n".join(" ".join(fmt % v for v in row) for row in np.atleast_2d(a))
+
+    parts = ['<?xml version="1.0"?>', '<Xdmf Version="3.0"><Domain><Grid Name="mesh" GridType="Uniform">',
+             '<Topology TopologyType="%s" NumberOfElements="%d" NodesPerElement="%d">' % (ttype, cells.shape[0], dim + 1),
+             '<DataItem Dimensions="%d %d" NumberType="Int" Format="XML">' % cells.shape, block(cells, "%d"),
+             '</DataItem></Topology>', '<Geometry GeometryType="XYZ">',
+             '<DataItem Dimensions="%d 3" NumberType="Float" Precision="8" Format="XML">' % x.shape[0],
+             block(x, "%.17g"), '</DataItem></Geometry>']
+    for label, comp in (("real_f", vals.real), ("imag_f", vals.imag)):
+        parts += ['<Attribute Name="%s" AttributeType="Scalar" Center="%s">' % (label, center),
+                  '<DataItem Dimensions="%d 1" NumberType="Float" Precision="8" Format="XML">' % vals.shape[0],
+                  block(comp.reshape(-1, 1), "%.17g"), '</DataItem></Attribute>']
+    parts.append('</Grid></Domain></Xdmf>')
+    os.makedirs(os.path.dirname(os.path.abspath(name)), exist_ok=True)
+    with open(name + ".xdmf", "w") as fh:
+        fh.write("\n".join(parts) + "\n")
+    print(name + ".xdmf is saved.")
+
+
 class XDMFReader:
     """Same accessors as the reference's reader (io_utils.py:160-217).  Reads ``name.xdmf`` / ``name_tags.xdmf`` with
     their HDF5 heavy data when present (the reference's own format), else the ASCII gmsh file ``name.msh``."""

@@ -794,6 +794,14 @@ def test_rijkeffd_degree1_sixteen_digit_golden(ref_logs, golden_dir, st_type):
     assert abs(E.getEigenvalue(0) - ref) / abs(ref) < 1e-8
     omega_adj, p_adj = normalize_eigenvector(mesh, E, 0, degree=1, which='right')          # main.py: p_adj.h5
     assert _eigvec_error(golden_dir, "rijkeffd_adj", mesh, p_adj) < 1e-7
+    # adjoint normalisation for the shape-derivative consumer (eigenvectors.py:125-177): <p_adj, dL/domega p_dir> = 1,
+    # checked against the explicit operator B + 2 omega C - D'(omega) built on the host
+    from helmholtz_x.eigenvectors import normalize_adjoint
+    D.assemble_submatrices('direct')
+    p_adj_n = normalize_adjoint(omega_dir, p_dir, p_adj, M, D)
+    dL = (M.B.to_scipy() + 2 * omega_dir * M.C.to_scipy() - D.get_derivative(omega_dir).to_scipy())
+    bracket = np.vdot(dL @ p_dir.x.array, p_adj_n.x.array)          # PETSc VecDot(y, A x) = (A x)^H y
+    assert abs(bracket - 1.0) < 1e-10
 
 
 @pytest.mark.parametrize("st_type", ["lu", "amg"])

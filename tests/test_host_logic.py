@@ -340,3 +340,22 @@ def test_harmonic_ritz_recycle_pair_algebra():
     b2 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
     plain, recycled = gmres_steps(b2), gmres_steps(b2, Cm, U)
     assert recycled <= plain - 4, (plain, recycled)
+
+
+def test_xdmf_writer_round_trip(tmp_path, golden_dir):
+    """Minimal results writer (inline XML heavy data): values and mesh come back exactly."""
+    import re
+    from helmholtz_x.fem import Function, FunctionSpace
+    from helmholtz_x.io_utils import read_gmsh, xdmf_writer
+    mesh, _, _ = read_gmsh(os.path.join(golden_dir, "meshes", "rijke2d.msh"))
+    p = Function(FunctionSpace(mesh, "CG", 1), "p")
+    rng = np.random.default_rng(0)
+    p.x.array[:] = rng.standard_normal(mesh.num_vertices) + 1j * rng.standard_normal(mesh.num_vertices)
+    xdmf_writer(str(tmp_path / "out" / "p"), mesh, p)
+    text = open(tmp_path / "out" / "p.xdmf").read()
+    items = re.findall(r'<DataItem Dimensions="(\d+) (\d+)"[^>]*>\s*(.*?)\s*</DataItem>', text, flags=re.S)
+    arrays = [np.array(body.split(), dtype=float).reshape(int(a), int(b)) for a, b, body in items]
+    assert np.array_equal(arrays[0].astype(np.int64), mesh.topology.cells)
+    assert np.array_equal(arrays[1], mesh.geometry.x)
+    assert np.array_equal(arrays[2].ravel(), p.x.array.real) and np.array_equal(arrays[3].ravel(), p.x.array.imag)
+    assert 'Name="real_f"' in text and 'Name="imag_f"' in text and 'TopologyType="Triangle"' in text

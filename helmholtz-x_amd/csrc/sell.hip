@@ -20,6 +20,12 @@ struct hx_sell {
   int64_t padded = 0;                // stored entries (multiple of 64)
   int64_t* slice_ptr = nullptr;      // n_slices + 1 offsets (in entries)
   int32_t* col = nullptr;
+  // 16-bit column DELTAS (column - row), used slice by slice: a slice whose stored entries all satisfy
+  // |column - row| <= 32767 (banded numberings: structured grids, RCM-ordered meshes) streams 2 instead of 4 index bytes
+  // per entry; the others (e.g. the rows that close a periodic ring) keep the 32-bit columns (`wide[slice]` = 1).
+  int16_t* dcol = nullptr;
+  uint8_t* wide = nullptr;
+  int32_t n_wide = 0;
   zc* val_z = nullptr;               // complex128 values (may be null)
   cc* val_c = nullptr;               // complex64 values (may be null)
   // complex-half STORAGE of the values for the complex64 kernels (8 instead of 12 bytes per entry with the int32
@@ -86,9 +92,35 @@ __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restri
   }
 }
 
+// per slice: do all stored (padded) entries fit a 16-bit delta?  If so write them, else flag the slice as wide.
+__global__ void k_sell_narrow(int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
+                              int16_t* __restrict__ dcol, uint8_t* __restrict__ wide, int32_t* __restrict__ n_wide) {
+  const int lane = threadIdx.x & 63;
+  const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  if (slice >= n_slices) return;
+  const int64_t base = slice_ptr[slice];
+  const int width = (int)((slice_ptr[slice + 1] - base) / SELL_C);
+  const int32_t row = slice * SELL_C + lane;
+  int m = 0;
+  for (int k = 0; k < width; ++k) {
+    const int32_t d = scol[base + (int64_t)k * SELL_C + lane] - row;
+    m = max(m, d < 0 ? -d : d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  const bool w = m > 32767;
+  if (lane == 0) { wide[slice] = w ? 1 : 0; if (w) atomicAdd(n_wide, 1); }
+  if (!w)
+    for (int k = 0; k < width; ++k) {
+      const int64_t o = base + (int64_t)k * SELL_C + lane;
+      dcol[o] = (int16_t)(scol[o] - row);
+    }
+}
+
 extern "C" int hx_sell_destroy(hx_sell* h) {
   if (!h) return HX_OK;
-  (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->val_z); (void)hipFree(h->val_c); (void)hipFree(h->val_h);
+  (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->dcol); (void)hipFree(h->wide); (void)hipFree(h->val_z); (void)hipFree(h->val_c);
+  (void)hipFree(h->val_h);
   delete h;
   return HX_OK;
 }
@@ -156,9 +188,33 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
   HX_LAUNCH_CHECK("hx_sell_create");
+  // 16-bit column deltas, slice by slice (HX_SELL_INDEX=i32 keeps the 32-bit columns everywhere)
+  static const bool allow16 = !(getenv("HX_SELL_INDEX") && strcmp(getenv("HX_SELL_INDEX"), "i32") == 0);
+  if (allow16 && total > 0) {
+    int32_t* d_nw = nullptr;
+    bool ok = hipMalloc((void**)&h->dcol, sizeof(int16_t) * ne) == hipSuccess &&
+              hipMalloc((void**)&h->wide, (size_t)h->n_slices) == hipSuccess &&
+              hipMalloc((void**)&d_nw, sizeof(int32_t)) == hipSuccess;
+    if (ok) {
+      (void)hipMemsetAsync(d_nw, 0, sizeof(int32_t), s);
+      k_sell_narrow<<<grid, 256, 0, s>>>(h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, d_nw);
+      ok = hipMemcpyAsync(&h->n_wide, d_nw, sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
+           hipStreamSynchronize(s) == hipSuccess;
+    }
+    (void)hipFree(d_nw);
+    // not worth it when (nearly) every slice is wide: drop the narrow copy
+    if (!ok || h->n_wide > h->n_slices / 2) {
+      (void)hipFree(h->dcol); (void)hipFree(h->wide);
+      h->dcol = nullptr; h->wide = nullptr; h->n_wide = h->n_slices;
+    }
+    (void)hipGetLastError();
+  } else h->n_wide = h->n_slices;
   *out = h;
   return HX_OK;
 }
+
+extern "C" int hx_sell_index_bits(const hx_sell* h) { return h ? (h->dcol ? 16 : 32) : 0; }
+extern "C" int hx_sell_wide_slices(const hx_sell* h) { return h ? h->n_wide : 0; }
 
 extern "C" int hx_sell_info(const hx_sell* h, int32_t* n_slices, int64_t* padded_entries) {
   HX_REQUIRE(h, "null handle");
@@ -167,11 +223,34 @@ extern "C" int hx_sell_info(const hx_sell* h, int32_t* n_slices, int64_t* padded
   return HX_OK;
 }
 
+// IT = int32_t: absolute columns.  IT = int16_t: column - row (see hx_sell::dcol).
+template <typename IT> __device__ __forceinline__ int32_t cidx(IT c, int32_t row);
+template <> __device__ __forceinline__ int32_t cidx<int32_t>(int32_t c, int32_t) { return c; }
+template <> __device__ __forceinline__ int32_t cidx<int16_t>(int16_t c, int32_t row) { return row + (int32_t)c; }
+
+// one lane = one row of the slice: sum_k val[k] * x[col[k]], two independent chains (4 loads in flight per lane per step)
+template <typename V, typename MV, typename IT>
+__device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cp, const MV* __restrict__ vp, const V* __restrict__ x,
+                                          int width, int32_t row) {
+  V acc0 = czero<V>(), acc1 = czero<V>();
+  int k = 0;
+  for (; k + 1 < width; k += 2) {
+    const int32_t c0 = cidx<IT>(cp[(int64_t)k * SELL_C], row), c1 = cidx<IT>(cp[(int64_t)(k + 1) * SELL_C], row);
+    const V v0 = mload(vp + (int64_t)k * SELL_C), v1 = mload(vp + (int64_t)(k + 1) * SELL_C);
+    zfma(acc0, v0, x[c0]);
+    zfma(acc1, v1, x[c1]);
+  }
+  if (k < width) zfma(acc0, mload(vp + (int64_t)k * SELL_C), x[cidx<IT>(cp[(int64_t)k * SELL_C], row)]);
+  return zadd(acc0, acc1);
+}
+
 // MODE 0: y = alpha*A*x + beta*y.   MODE 1: xout = xin + omega*dinv.*(b - A*xin) + mom*(xin - xprev)  (smoother step)
 // MV = storage type of the matrix values (V itself, or complex-half for V = complex64: entries are then vscale * half2).
+// dcol / wide: 16-bit column deltas for the slices flagged narrow (wave-uniform branch); both null -> 32-bit everywhere.
 template <typename V, int MODE, typename MV = V>
 __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+       const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide,
        const MV* __restrict__ val, const V* __restrict__ x, V* __restrict__ y, V alpha, V beta, int beta_is_zero,
        const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev,
        typename real_of<V>::type omega, typename real_of<V>::type mom, typename real_of<V>::type vscale) {
@@ -182,18 +261,9 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     const int64_t base = slice_ptr[slice];
     const int width = (int)((slice_ptr[slice + 1] - base) >> 6);
     const int32_t row = slice * SELL_C + lane;
-    V acc0 = czero<V>(), acc1 = czero<V>();
-    const int32_t* cp = col + base + lane;
     const MV* vp = val + base + lane;
-    int k = 0;
-    for (; k + 1 < width; k += 2) {                      // two independent chains: 4 loads in flight per lane per step
-      const int32_t c0 = cp[(int64_t)k * SELL_C], c1 = cp[(int64_t)(k + 1) * SELL_C];
-      const V v0 = mload(vp + (int64_t)k * SELL_C), v1 = mload(vp + (int64_t)(k + 1) * SELL_C);
-      zfma(acc0, v0, x[c0]);
-      zfma(acc1, v1, x[c1]);
-    }
-    if (k < width) zfma(acc0, mload(vp + (int64_t)k * SELL_C), x[cp[(int64_t)k * SELL_C]]);
-    V acc = zadd(acc0, acc1);
+    V acc = (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t>(dcol + base + lane, vp, x, width, row)
+                                   : sell_row_dot<V, MV, int32_t>(col + base + lane, vp, x, width, row);
     if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(vscale, acc);
     if (row < n) {
       if (MODE == 0) {
@@ -216,6 +286,14 @@ static int sell_grid(int32_t n_slices) {
   int64_t blocks = ((int64_t)n_slices + 3) / 4;           // 4 waves (slices) per 256-thread block
   if (blocks > 256 * 16) blocks = 256 * 16;
   return (int)(blocks < 1 ? 1 : blocks);
+}
+// one launch site
+template <typename V, int MODE, typename MV>
+static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alpha, V beta, int beta_is_zero, const V* dinv,
+                        const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
+                        typename real_of<V>::type vscale, hx_stream s) {
+  k_sell<V, MODE, MV><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, val, x,
+                                                                   y, alpha, beta, beta_is_zero, dinv, b, xprev, omega, mom, vscale);
 }
 
 // In-situ timing of the operator product (the roofline kernel of bench.py): when enabled, every k_sell<c128,0> launch is
@@ -263,8 +341,7 @@ extern "C" int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, co
   const bool rec = g_prof.on && h->n >= g_prof.min_rows && g_prof.used + 2 <= g_prof.ev.size();
   if (g_prof.on && !rec && h->n >= g_prof.min_rows) ++g_prof.skipped;
   if (rec) HX_HIP(hipEventRecord(g_prof.ev[g_prof.used], hx_s(s)));
-  k_sell<zc, 0><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_z, (const zc*)x,
-                                                              (zc*)y, a, b, (b.x == 0 && b.y == 0), nullptr, nullptr, nullptr, 0.0, 0.0, 1.0);
+  launch_sell<zc, 0, zc>(h, h->val_z, (const zc*)x, (zc*)y, a, b, (b.x == 0 && b.y == 0), nullptr, nullptr, nullptr, 0.0, 0.0, 1.0, s);
   if (rec) { HX_HIP(hipEventRecord(g_prof.ev[g_prof.used + 1], hx_s(s))); g_prof.used += 2; }
   HX_LAUNCH_CHECK("k_sell<c128,spmv>");
   return HX_OK;
@@ -272,13 +349,11 @@ extern "C" int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, co
 extern "C" int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, float alpha, float beta, hx_stream s) {
   HX_REQUIRE(h && (h->val_c || h->val_h) && x && y, "bad argument");
   if (h->val_h)
-    k_sell<cc, 0, ch><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_h, (const cc*)x,
-                                                                    (cc*)y, make_float2(alpha, 0.f), make_float2(beta, 0.f), beta == 0.f,
-                                                                    nullptr, nullptr, nullptr, 0.f, 0.f, h->h_scale);
+    launch_sell<cc, 0, ch>(h, h->val_h, (const cc*)x, (cc*)y, make_float2(alpha, 0.f), make_float2(beta, 0.f), beta == 0.f, nullptr,
+                           nullptr, nullptr, 0.f, 0.f, h->h_scale, s);
   else
-  k_sell<cc, 0><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_c, (const cc*)x,
-                                                              (cc*)y, make_float2(alpha, 0.f), make_float2(beta, 0.f), beta == 0.f,
-                                                              nullptr, nullptr, nullptr, 0.f, 0.f, 1.f);
+    launch_sell<cc, 0, cc>(h, h->val_c, (const cc*)x, (cc*)y, make_float2(alpha, 0.f), make_float2(beta, 0.f), beta == 0.f, nullptr,
+                           nullptr, nullptr, 0.f, 0.f, 1.f, s);
   HX_LAUNCH_CHECK("k_sell<c64,spmv>");
   return HX_OK;
 }
@@ -287,23 +362,19 @@ extern "C" int hx_sell_smooth_c64(const hx_sell* h, const hx_c64* dinv, const hx
                                   float omega, const hx_c64* xprev, float mom, hx_stream s) {
   HX_REQUIRE(h && (h->val_c || h->val_h) && dinv && b && xin && xout && xin != xout, "bad argument");
   if (h->val_h)
-    k_sell<cc, 1, ch><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_h, (const cc*)xin,
-                                                                    (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1,
-                                                                    (const cc*)dinv, (const cc*)b, (const cc*)xprev, omega, mom,
-                                                                    h->h_scale);
+    launch_sell<cc, 1, ch>(h, h->val_h, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
+                           (const cc*)b, (const cc*)xprev, omega, mom, h->h_scale, s);
   else
-  k_sell<cc, 1><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_c, (const cc*)xin,
-                                                              (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1,
-                                                              (const cc*)dinv, (const cc*)b, (const cc*)xprev, omega, mom, 1.f);
+    launch_sell<cc, 1, cc>(h, h->val_c, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
+                           (const cc*)b, (const cc*)xprev, omega, mom, 1.f, s);
   HX_LAUNCH_CHECK("k_sell<c64,smooth>");
   return HX_OK;
 }
 extern "C" int hx_sell_smooth_z(const hx_sell* h, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin, hx_c128* xout,
                                 double omega, const hx_c128* xprev, double mom, hx_stream s) {
   HX_REQUIRE(h && h->val_z && dinv && b && xin && xout && xin != xout, "bad argument");
-  k_sell<zc, 1><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->val_z, (const zc*)xin,
-                                                              (zc*)xout, make_double2(0, 0), make_double2(0, 0), 1,
-                                                              (const zc*)dinv, (const zc*)b, (const zc*)xprev, omega, mom, 1.0);
+  launch_sell<zc, 1, zc>(h, h->val_z, (const zc*)xin, (zc*)xout, make_double2(0, 0), make_double2(0, 0), 1, (const zc*)dinv,
+                         (const zc*)b, (const zc*)xprev, omega, mom, 1.0, s);
   HX_LAUNCH_CHECK("k_sell<c128,smooth>");
   return HX_OK;
 }

@@ -357,7 +357,8 @@ class AMGSolver:
 
     def stats(self):
         return dict(recycled_pairs=self.recycled, levels=[lv["n"] for lv in self.levels],
-                    fine_format=("sell64/" + self.fine_values) if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
+                    fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
+                    if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
                     setup_s=round(self.setup_s, 3), solves=self.n_solves,
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1))

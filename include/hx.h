@@ -112,6 +112,12 @@ typedef struct hx_sell hx_sell;
 int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
                    int want_c128, int want_c64, hx_stream s);
 int hx_sell_info(const hx_sell* h, int32_t* n_slices, int64_t* padded_entries);
+/* Index compression, decided slice by slice at creation: a slice whose stored entries all satisfy |column - row| <= 32767
+ * (banded numberings) is streamed through 16-bit column DELTAS, two index bytes per entry less; the remaining "wide"
+ * slices (e.g. the rows closing a periodic ring) keep 32-bit columns.  hx_sell_index_bits: 16 if any slice is narrow,
+ * else 32; hx_sell_wide_slices: number of slices that stayed on 32-bit columns. */
+int hx_sell_index_bits(const hx_sell* h);
+int hx_sell_wide_slices(const hx_sell* h);
 int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
                    hx_stream s);
 int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, float alpha, float beta, hx_stream s);

@@ -244,6 +244,14 @@ def test_sell64_products_match_csr(hx, n, density):
     ns, pad = C.c_int32(), C.c_int64()
     hx.check(hx.lib.hx_sell_info(h, C.byref(ns), C.byref(pad)))
     assert ns.value == (n + 63) // 64 and pad.value >= M.nnz and pad.value % 64 == 0
+    # index compression is decided per slice of 64 rows: count the slices that must stay on 32-bit columns
+    coo = M.tocoo()
+    far = np.zeros((n + 63) // 64, dtype=bool)
+    far[(coo.row[np.abs(coo.row - coo.col) > 32767]) // 64] = True
+    n_far = int(far.sum())                                                      # > 0 only for n = 40000
+    expect_bits = 16 if n_far <= ((n + 63) // 64) // 2 else 32
+    assert hx.lib.hx_sell_index_bits(h) == expect_bits
+    assert hx.lib.hx_sell_wide_slices(h) == (n_far if expect_bits == 16 else (n + 63) // 64)
     x, y0 = _rand_c(rng, n), _rand_c(rng, n)
     xd, yd = _dev(x), _dev(y0.copy())
     a, b = 0.7 - 0.2j, -1.3 + 0.4j

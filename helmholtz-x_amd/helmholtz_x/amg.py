@@ -27,6 +27,9 @@ PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_o
               recycle_min_rows=100_000)
 
 
+MAX_DENSE_COARSE = 6000          # the coarsest operator is inverted densely on the host
+
+
 def _aggregate(S):
     """Greedy aggregation of the (symmetric) strength graph S (CSR; diagonal entries ignored, |value| = strength)."""
     n = S.shape[0]
@@ -128,13 +131,24 @@ def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], c
         diag = _diagonal(Kl)
         level = dict(K=Kl, n=n)
         if n <= coarse_size or len(levels) == max_levels - 1:
+            if n > MAX_DENSE_COARSE:
+                raise ArithmeticError("AMG hierarchy still has %d unknowns after %d levels" % (n, len(levels) + 1))
             levels.append(level)
             break
         # Laplacian-like real part with positive diagonal drives strength / prolongator smoothing
         sgn = -1.0 if 2 * np.count_nonzero(diag.real < 0) > n else 1.0
         Lf = _filter(Kl, sgn, th)
         agg, na = _aggregate(Lf)
-        if na >= 0.8 * n:                          # coarsening stalled
+        for _ in range(3):                         # too few couplings count as strong: relax the threshold and retry
+            if na < 0.8 * n:
+                break
+            th *= 0.25
+            Lf = _filter(Kl, sgn, th)
+            agg, na = _aggregate(Lf)
+        if na >= 0.8 * n:                          # coarsening stalled for good: this level becomes the coarsest one
+            if n > MAX_DENSE_COARSE:
+                raise ArithmeticError("AMG coarsening stalled at %d unknowns (strength threshold %.3g): the coarsest "
+                                      "level would need a dense inverse of that size" % (n, th))
             levels.append(level)
             break
         rho = _spectral_radius_dinv(Lf)

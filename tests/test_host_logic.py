@@ -359,3 +359,21 @@ def test_xdmf_writer_round_trip(tmp_path, golden_dir):
     assert np.array_equal(arrays[1], mesh.geometry.x)
     assert np.array_equal(arrays[2].ravel(), p.x.array.real) and np.array_equal(arrays[3].ravel(), p.x.array.imag)
     assert 'Name="real_f"' in text and 'Name="imag_f"' in text and 'TopologyType="Triangle"' in text
+
+
+def test_amg_hierarchy_retries_and_refuses_a_huge_dense_coarse_level():
+    """A strength threshold that classifies every coupling as weak stalls the aggregation; the builder relaxes it and
+    retries instead of silently ending with one giant 'coarsest' level (which would be inverted densely)."""
+    from helmholtz_x import amg
+    from oracle import fem, meshes
+    m = meshes.rectangle(60, 30, 0.4, 0.1)
+    K = sp.csr_matrix(-fem.assemble_A(m.x, m.cells, np.full(m.x.shape[0], 300.0)) + (40.0 + 4j) * sp.eye(m.x.shape[0]))
+    lv = amg.build_hierarchy(K, theta=0.9, coarse_size=50)       # 0.9: nothing is strong at first
+    assert len(lv) >= 2 and lv[-1]["n"] <= amg.MAX_DENSE_COARSE
+    old = amg.MAX_DENSE_COARSE
+    try:
+        amg.MAX_DENSE_COARSE = 10
+        with pytest.raises(ArithmeticError):
+            amg.build_hierarchy(sp.csr_matrix(sp.eye(500, dtype=np.complex128)), coarse_size=5)   # no couplings at all
+    finally:
+        amg.MAX_DENSE_COARSE = old

@@ -13,6 +13,7 @@ Split of work
   device (every solve): hx_gmres -> hx_amg_vcycle -> fused Jacobi sweeps / residual / P, R products / CGS2 panels.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -105,10 +106,12 @@ def _diagonal(K):
     return out
 
 
-def _spectral_radius_dinv(Lf, iters=10, seed=0):
+def _spectral_radius_dinv(Lf, iters=None, seed=0):
     """Power-iteration estimate of rho(Df^-1 Lf) (similar to an SPD matrix: the norm ratio converges from below; the
     smoothing weights derived from it carry a 4/3 safety factor).  Native row-parallel pass (hx_host_power_rho)."""
     n = Lf.shape[0]
+    if iters is None:
+        iters = int(os.environ.get("HX_AMG_RHO_ITERS", "10"))
     v = np.random.default_rng(seed).standard_normal(n)
     rp = np.ascontiguousarray(Lf.indptr, dtype=np.int32)
     ci = np.ascontiguousarray(Lf.indices, dtype=np.int32)

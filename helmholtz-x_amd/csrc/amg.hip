@@ -86,7 +86,17 @@ struct hx_amg {
   void* ctx = nullptr;
   int32_t n_ext = 0;           // owned + ghost length of the level-0 iterates
   Recycle rec;
+  // hipGraph of the complex64 V-cycle (all buffers of the cycle are owned by the handle, so the ~45 launches of one cycle
+  // are captured once and replayed): for small and mid-size problems, where the cycle is launch-bound
+  int graph_state = -1;        // -1 off, 0 requested (capture at the next cycle), 1 ready
+  hipGraphExec_t vexec = nullptr;
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
+static void drop_graph(hx_amg* h) {
+  if (h->vexec) { (void)hipGraphExecDestroy(h->vexec); h->vexec = nullptr; }
+  if (h->graph_state == 1) h->graph_state = 0;          // re-capture with the new set-up
+}
 static int buf_id(const hx_amg* h, const void* p) {
   const void* ids[3] = {h->single ? (const void*)h->S.L[0].x : (const void*)h->D.L[0].x,
                         h->single ? (const void*)h->S.L[0].x2 : (const void*)h->D.L[0].x2,
@@ -165,6 +175,10 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
   for (auto& l : h->D.L) release(l);
   for (auto& l : h->S.L) release(l);
   (void)hipFree(h->rec.U); (void)hipFree(h->rec.CV); (void)hipFree(h->rec.CVf);
+  if (h->vexec) (void)hipGraphExecDestroy(h->vexec);
+  if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+  if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+  if (h->gstream) (void)hipStreamDestroy(h->gstream);
   delete h;
   return HX_OK;
 }
@@ -208,11 +222,13 @@ extern "C" int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, con
                                   const int32_t* rpR, const int32_t* ciR, const hx_c64* vaR) {
   HX_REQUIRE(h, "null handle");
   h->single = true;
+  drop_graph(h);
   return set_level<float>(h->S, l, n, nnzK, rpK, ciK, (const float*)vaK, (const float*)dinv, n_coarse, nnzP, rpP, ciP,
                           (const float*)vaP, nnzR, rpR, ciR, (const float*)vaR);
 }
 extern "C" int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell) {
   HX_REQUIRE(h && l >= 0 && l < (int)h->D.L.size(), "bad argument");
+  drop_graph(h);
   h->D.L[l].sell = sell;       // the handle must carry the value copy of the precision the V-cycle runs in
   h->S.L[l].sell = sell;
   return HX_OK;
@@ -220,6 +236,7 @@ extern "C" int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell) {
 
 extern "C" int hx_amg_set_smoother(hx_amg* h, int l, double rho) {
   HX_REQUIRE(h && l >= 0 && l < (int)h->D.L.size() && rho >= 0.0, "bad argument");
+  drop_graph(h);
   h->D.L[l].rho = rho;
   h->S.L[l].rho = rho;
   return HX_OK;
@@ -256,6 +273,7 @@ extern "C" int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int3
 extern "C" int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                                    const hx_c64* va) {
   HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->S.L.back().n == n_c, "bad argument");
+  drop_graph(h);
   h->S.coarse_inv.rows = n_c; h->S.coarse_inv.nnz = nnz; h->S.coarse_inv.rp = rp; h->S.coarse_inv.ci = ci;
   h->S.coarse_inv.va = (const float*)va;
   return HX_OK;
@@ -331,6 +349,17 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   return HX_OK;
 }
 
+// Request (1) / drop (0) the hipGraph replay of the complex64 V-cycle.  Ignored in row-sharded mode (the cycle calls
+// back to the host for its exchanges) and for the complex128 cycle.
+extern "C" int hx_amg_enable_graph(hx_amg* h, int enable) {
+  HX_REQUIRE(h, "null handle");
+  if (!enable) { if (h->vexec) { (void)hipGraphExecDestroy(h->vexec); h->vexec = nullptr; } h->graph_state = -1; }
+  else if (h->graph_state < 0) h->graph_state = 0;
+  return HX_OK;
+}
+// 1 if the last cycles were replayed from the captured graph
+extern "C" int hx_amg_graph_active(const hx_amg* h) { return h && h->graph_state == 1 ? 1 : 0; }
+
 extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream s) {
   HX_REQUIRE(h && b && x && b != x && !h->D.L.empty(), "bad argument");
   if (h->single) {
@@ -339,7 +368,28 @@ extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream 
     int rc;
     if ((rc = hx_cast_z2c(L0.n, b, L0.b, s))) return rc;          // narrow the right-hand side
     // on level 0 the residual buffer L0.r is consumed by the restriction before the last post-sweep writes it
-    if ((rc = vcycle<float>(h, h->S, 0, L0.b, L0.r, s))) return rc;
+    if (h->graph_state == 0 && !h->sharded) {                      // capture the cycle once (its buffers never change)
+      bool ok = true;
+      if (!h->gstream) ok = hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess &&
+                            hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
+                            hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
+      hipGraph_t g = nullptr;
+      if (ok && hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int rcap = vcycle<float>(h, h->S, 0, L0.b, L0.r, (hx_stream)h->gstream);
+        const hipError_t e = hipStreamEndCapture(h->gstream, &g);
+        ok = rcap == HX_OK && e == hipSuccess && g && hipGraphInstantiate(&h->vexec, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+      } else ok = false;
+      (void)hipGetLastError();
+      h->graph_state = ok ? 1 : -1;                                // any failure: fall back to eager launches for good
+    }
+    if (h->graph_state == 1 && !h->sharded) {
+      HX_HIP(hipEventRecord(h->ev_in, hx_s(s)));                   // order the graph after the cast on the caller's stream
+      HX_HIP(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
+      HX_HIP(hipGraphLaunch(h->vexec, h->gstream));
+      HX_HIP(hipEventRecord(h->ev_out, h->gstream));
+      HX_HIP(hipStreamWaitEvent(hx_s(s), h->ev_out, 0));           // ... and everything that follows after the graph
+    } else if ((rc = vcycle<float>(h, h->S, 0, L0.b, L0.r, s))) return rc;
     return hx_cast_c2z(L0.n, L0.r, x, s);                         // widen the result
   }
   HX_REQUIRE(h->D.coarse_inv.rp && h->D.L[0].n > 0, "coarse solver not set");

@@ -76,6 +76,8 @@ SIGNATURES = {
     "hx_amg_set_level_c": (C.c_int, [_vp, _int, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
                                      _vp, _vp]),
     "hx_amg_set_coarse_c": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
+    "hx_amg_enable_graph": (C.c_int, [_vp, _int]),
+    "hx_amg_graph_active": (C.c_int, [_vp]),
     "hx_amg_vcycle": (C.c_int, [_vp, _vp, _vp, _vp]),
     "hx_amg_destroy": (C.c_int, [_vp]),
     "hx_gmres_ws": (C.c_size_t, [_i64, _int]),

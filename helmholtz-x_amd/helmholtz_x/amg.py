@@ -24,7 +24,7 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, vcycle_values="fp16", recycle=6,
+              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, vcycle_values="fp16", graph_max_rows=0, recycle=6,
               recycle_min_rows=100_000)
 
 
@@ -303,6 +303,10 @@ class AMGSolver:
             _hx.check(_hx.lib.hx_amg_set_sharded(h, shard.n_ext, _hx.ptr(self._bufs[0]), _hx.ptr(self._bufs[1]),
                                                  _hx.ptr(self._bufs[2]), _hx.ptr(self._bufs[_hx.BUF_COARSE_RHS]),
                                                  self._cb.halo, self._cb.allreduce, None))
+        # hipGraph replay of the V-cycle where it is launch-bound (measured: see DESIGN.md section 5)
+        gmax = int(os.environ.get("HX_AMG_GRAPH_MAX_ROWS", self.params["graph_max_rows"]))
+        if mixed and shard is None and len(levels) > 1 and self.n <= gmax:
+            _hx.check(_hx.lib.hx_amg_enable_graph(h, 1))
         self.ws = torch.empty(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), dtype=torch.complex128, device=dev)
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
         # subspace recycling (all solves of a fixed-point call share K): worth its panel rows once the hierarchy is deep
@@ -373,7 +377,7 @@ class AMGSolver:
         self.harmonic_ritz = theta
 
     def stats(self):
-        return dict(recycled_pairs=self.recycled, levels=[lv["n"] for lv in self.levels],
+        return dict(recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)), levels=[lv["n"] for lv in self.levels],
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
                     if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
                     setup_s=round(self.setup_s, 3), solves=self.n_solves,

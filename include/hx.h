@@ -242,6 +242,12 @@ int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t*
                        const int32_t* rpR, const int32_t* ciR, const hx_c64* vaR);
 int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                         const hx_c64* va);
+/* hipGraph replay of the complex64 V-cycle: all buffers of the cycle belong to the handle, so its ~45 kernel launches are
+ * captured once (on a private stream, ordered against the caller's stream by events) and replayed by one hipGraphLaunch
+ * per cycle.  For small / mid-size problems where the cycle is launch-bound; falls back to eager launches if the
+ * capture fails; not used in row-sharded mode.  hx_amg_graph_active: 1 once cycles run from the graph. */
+int hx_amg_enable_graph(hx_amg* h, int enable);
+int hx_amg_graph_active(const hx_amg* h);
 /* x = one V-cycle applied to b from a zero initial guess (b != x) */
 int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream s);
 int hx_amg_destroy(hx_amg* h);

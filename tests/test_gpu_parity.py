@@ -374,7 +374,8 @@ def _annulus_case(shape):
 @pytest.mark.parametrize("overrides", [dict(), dict(sell_min_rows=0), dict(precision="double", smoother="jacobi"),
                                        dict(precision="double", sell_min_rows=0),
                                        dict(recycle_min_rows=0, sell_min_rows=0),
-                                       dict(recycle_min_rows=0, sell_min_rows=0, vcycle_values="c64")])
+                                       dict(recycle_min_rows=0, sell_min_rows=0, vcycle_values="c64"),
+                                       dict(graph_max_rows=10 ** 9)])
 def test_amg_gmres_inner_solver_matches_direct(overrides):
     """K^-1 b from the device AMG-GMRES equals the SuperLU solution on a 3-D annulus (complex shifted operator):
     default (CSR, complex64 Chebyshev V-cycle), SELL-64 fine level, and the all-double variants."""
@@ -409,6 +410,7 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
     else:
         assert solver.stats()["recycled_pairs"] == 0
     assert its[2] < its[1]
+    assert solver.stats()["vcycle_graph"] == ("graph_max_rows" in overrides)      # hipGraph replay of the V-cycle
 
 
 def test_annulus_fixed_point_amg_vs_lu_vs_oracle():

@@ -384,11 +384,16 @@ extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream 
       h->graph_state = ok ? 1 : -1;                                // any failure: fall back to eager launches for good
     }
     if (h->graph_state == 1 && !h->sharded) {
-      HX_HIP(hipEventRecord(h->ev_in, hx_s(s)));                   // order the graph after the cast on the caller's stream
-      HX_HIP(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
-      HX_HIP(hipGraphLaunch(h->vexec, h->gstream));
-      HX_HIP(hipEventRecord(h->ev_out, h->gstream));
-      HX_HIP(hipStreamWaitEvent(hx_s(s), h->ev_out, 0));           // ... and everything that follows after the graph
+      static const bool hop = getenv("HX_AMG_GRAPH_PRIVATE_STREAM") != nullptr;     // (measured variant)
+      if (hop) {
+        HX_HIP(hipEventRecord(h->ev_in, hx_s(s)));                 // order the graph after the cast on the caller's stream
+        HX_HIP(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
+        HX_HIP(hipGraphLaunch(h->vexec, h->gstream));
+        HX_HIP(hipEventRecord(h->ev_out, h->gstream));
+        HX_HIP(hipStreamWaitEvent(hx_s(s), h->ev_out, 0));         // ... and everything that follows after the graph
+      } else {
+        HX_HIP(hipGraphLaunch(h->vexec, hx_s(s)));                 // replay in the caller's stream: plain stream order
+      }
     } else if ((rc = vcycle<float>(h, h->S, 0, L0.b, L0.r, s))) return rc;
     return hx_cast_c2z(L0.n, L0.r, x, s);                         // widen the result
   }

@@ -221,8 +221,10 @@ def main():
 
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # the library logs like the reference; stdout = the JSON line
+        import gc
         for _ in range(args.warmup):
             hot_path(case, args.st_type)
+            gc.collect()
         from helmholtz_x import _hx
         import ctypes as C
         # in-situ HIP-event timing of the roofline kernel (operator product on the fine operator) over the timed region
@@ -231,8 +233,13 @@ def main():
         t0 = time.perf_counter()
         pairs = 0
         hist = []
+        E = matrices = None
         for _ in range(args.steps):
             hist = []
+            if E is not None:                     # release the previous call's solver objects first, as a driver that
+                E.destroy()                       # follows the reference does (eigensolvers.py:161 E.destroy())
+            E = matrices = None
+            gc.collect()
             E, matrices = hot_path(case, args.st_type, history=hist)
             pairs += min(E.getConverged(), 4)
         barrier()

@@ -76,6 +76,8 @@ class HaloPlan:
                 self.send_to[p] = (mine - self.r0).astype(np.int64)
         self.n_ghost = int(ghost_global.size)
         self._dev_idx = {}
+        self._send_span = {}         # neighbour -> (a, b) if its send list is the contiguous owned range [a, b), else False
+        self._send_buf = {}
 
     def exchange(self, x_ext, n_own):
         """Fill x_ext[n_own:] (ghost block) with the owners' current values of x_ext[:n_own] (complex64 or complex128).
@@ -87,10 +89,22 @@ class HaloPlan:
         stage = backend == "gloo" and x_ext.is_cuda       # gloo moves host buffers only
         ops, staged, keep = [], [], []
         for p, idx in sorted(self.send_to.items()):
-            key = (p, x_ext.device)
-            if key not in self._dev_idx:
-                self._dev_idx[key] = torch.from_numpy(idx).to(x_ext.device)
-            buf = torch.view_as_real(x_ext[:n_own][self._dev_idx[key]].contiguous())
+            span = self._send_span.get(p)
+            if span is None:                       # first use: is the send list one contiguous range of owned rows?
+                span = (int(idx[0]), int(idx[-1]) + 1) if (len(idx) and idx[-1] - idx[0] + 1 == len(idx)
+                                                           and np.all(np.diff(idx) == 1)) else False
+                self._send_span[p] = span
+            if span:                               # slabs cut between mesh planes: send the slice itself, no gather
+                src = x_ext[span[0]:span[1]]
+            else:
+                key = (p, x_ext.device)
+                if key not in self._dev_idx:
+                    self._dev_idx[key] = torch.from_numpy(idx).to(x_ext.device)
+                bkey = (p, x_ext.dtype, x_ext.device)
+                if bkey not in self._send_buf:
+                    self._send_buf[bkey] = torch.empty(len(idx), dtype=x_ext.dtype, device=x_ext.device)
+                src = torch.index_select(x_ext[:n_own], 0, self._dev_idx[key], out=self._send_buf[bkey])
+            buf = torch.view_as_real(src)
             buf = buf.cpu() if stage else buf
             keep.append(buf)
             ops.append(dist.P2POp(dist.isend, buf, p, group=self.group))

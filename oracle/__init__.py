@@ -6,9 +6,13 @@ and the fixed-point shift-invert eigen-iteration.  It exists only so that ``test
 path against an independent CPU computation.  Nothing under ``helmholtz-x_amd/`` imports it.
 
 Parity status: PINNED.  The restatement is checked against the reference's own committed
-result logs (see ``tests/golden/reference_logs.json`` and ``tests/test_oracle_goldens.py``):
-Rijke-1D passive / active / adjoint, PRF Rijke-1D direct / adjoint, the analytic 2-D
-dispersion relation, and the ASCII-gmsh Rijke 2-D/3-D and MICCA Bloch-sector cases.
+results (``tests/golden/reference_logs.json``, ``tests/golden/eigenvectors``,
+``tests/test_oracle_goldens.py``): Rijke 1-D/2-D/3-D passive / active / adjoint, PRF Rijke
+1-D/2-D/3-D direct / adjoint, the analytic 2-D dispersion relation, FlamedDuct (choked
+boundaries, variable gamma), RijkeFFD on the original and the optimised shape (16-digit
+eigenvalues), the MICCA full annulus on the reference's own XDMF/HDF5 mesh (logged trajectory,
+16-digit eigenvalues), the MICCA Bloch sector (passive + active), and the normalised
+eigenvectors the reference committed as HDF5 (direct and adjoint, up to the free sign).
 
 The arithmetic the reference delegates to DOLFINx 0.9.0 / PETSc / SLEPc (not vendored under
 /root/reference and not installable here) is restated from the published algorithms:

@@ -51,7 +51,7 @@ static int exclusive_scan_i32(int32_t* d_inout, int64_t count, hipStream_t s) {
 
 extern "C" int hx_build_v2e(int32_t n_vert, int32_t n_ent, int k, const int32_t* ents, int32_t* v2e_ptr,
                             int32_t* v2e_idx, hx_stream s_) {
-  HX_REQUIRE(n_vert > 0 && n_ent >= 0 && k >= 1 && k <= 4 && v2e_ptr && (n_ent == 0 || (ents && v2e_idx)),
+  HX_REQUIRE(n_vert > 0 && n_ent >= 0 && k >= 1 && k <= 16 && v2e_ptr && (n_ent == 0 || (ents && v2e_idx)),
              "bad argument");
   hipStream_t s = hx_s(s_);
   const int64_t total = (int64_t)n_ent * k;
@@ -111,7 +111,7 @@ __global__ void k_pattern_fill(int32_t n, int k, const int32_t* __restrict__ ptr
 extern "C" int hx_p1_pattern_count(int32_t n_vert, int32_t n_ent, int k, const int32_t* ents,
                                    const int32_t* v2e_ptr, const int32_t* v2e_idx, int32_t* rowptr,
                                    int32_t* scratch, int64_t* h_nnz, hx_stream s_) {
-  HX_REQUIRE(n_vert > 0 && n_ent >= 0 && k >= 1 && k <= 4 && v2e_ptr && rowptr && h_nnz, "bad argument");
+  HX_REQUIRE(n_vert > 0 && n_ent >= 0 && k >= 1 && k <= 16 && v2e_ptr && rowptr && h_nnz, "bad argument");
   hipStream_t s = hx_s(s_);
   HX_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * ((size_t)n_vert + 1), s));
   if (n_ent > 0) {
@@ -495,5 +495,203 @@ extern "C" int hx_p1_locate_points(int dim, int32_t n_cells, const double* x, co
   else if (dim == 2) k_locate_points<2><<<grid, 256, 0, hx_s(s)>>>(n_cells, x, cells, n_pts, pts, tol, out_cell);
   else k_locate_points<3><<<grid, 256, 0, hx_s(s)>>>(n_cells, x, cells, n_pts, pts, tol, out_cell);
   HX_LAUNCH_CHECK("k_locate_points");
+  return HX_OK;
+}
+
+
+// ================================================================================================ P2 on tetrahedra
+// Quadratic Lagrange trial/test space with P1 coefficient fields (the reference's degree = 2 runs,
+// ShapeSensitivities/RijkeFFD/main_shape.py:68-83).  Same owner-computes scheme as P1: one thread per CSR row (= P2 dof:
+// a mesh vertex or an edge midpoint) gathers its incident cells in ascending order -> deterministic, no atomics.
+// Local dof order of a cell: 4 vertices, then the 6 edges (0,1),(0,2),(0,3),(1,2),(1,3),(2,3).  Integrals by a quadrature
+// table handed in by the host (barycentric points + weights summing to 1): nq x 5 doubles for cells, nq x 4 for facets.
+__device__ __constant__ int P2_TET_EDGE[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+__device__ __constant__ int P2_TRI_EDGE[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+
+// value and d/dlambda of P2 basis function b on a simplex with NV vertices
+template <int NV>
+__device__ __forceinline__ double p2_basis(int b, const double* lam, double* dl) {
+#pragma unroll
+  for (int m = 0; m < NV; ++m) dl[m] = 0.0;
+  if (b < NV) { dl[b] = 4.0 * lam[b] - 1.0; return lam[b] * (2.0 * lam[b] - 1.0); }
+  const int e = b - NV;
+  const int a0 = NV == 4 ? P2_TET_EDGE[e][0] : P2_TRI_EDGE[e][0], a1 = NV == 4 ? P2_TET_EDGE[e][1] : P2_TRI_EDGE[e][1];
+  dl[a0] = 4.0 * lam[a1];
+  dl[a1] = 4.0 * lam[a0];
+  return 4.0 * lam[a0] * lam[a1];
+}
+
+__global__ void __launch_bounds__(128)
+k_p2_stiff_mass(int32_t n_dof, const double* __restrict__ x, const int32_t* __restrict__ cells,
+                const int32_t* __restrict__ cdofs, const int32_t* __restrict__ d2c_ptr, const int32_t* __restrict__ d2c_idx,
+                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ cf,
+                int nq, const double* __restrict__ quad, zc* __restrict__ A, zc* __restrict__ C) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_dof; i += gridDim.x * blockDim.x) {
+    const int32_t rs = rowptr[i], re = rowptr[i + 1];
+    for (int32_t t = rs; t < re; ++t) { if (A) A[t] = make_double2(0, 0); if (C) C[t] = make_double2(0, 0); }
+    for (int32_t p = d2c_ptr[i]; p < d2c_ptr[i + 1]; ++p) {
+      const int32_t cell = d2c_idx[p];
+      const int32_t* v = cells + (int64_t)cell * 4;
+      const int32_t* dofs = cdofs + (int64_t)cell * 10;
+      int j = 0;
+      for (int t = 0; t < 10; ++t) if (dofs[t] == i) j = t;
+      double G[4][3], vol;
+      p1_geometry<3>(x, v, G, vol);
+      zc cv[4];
+      for (int a = 0; a < 4; ++a) cv[a] = cf ? cf[v[a]] : make_double2(1.0, 0.0);
+      zc rowA[10];
+      double rowC[10];
+      for (int k = 0; k < 10; ++k) { rowA[k] = make_double2(0, 0); rowC[k] = 0.0; }
+      for (int q = 0; q < nq; ++q) {
+        const double* lam = quad + 5 * q;
+        const double w = lam[4] * vol;
+        double dl[4];
+        const double pj = p2_basis<4>(j, lam, dl);
+        double gj[3] = {0, 0, 0};
+        for (int m = 0; m < 4; ++m) for (int c = 0; c < 3; ++c) gj[c] += dl[m] * G[m][c];
+        zc cq = make_double2(0, 0);
+        for (int a = 0; a < 4; ++a) { cq.x += lam[a] * cv[a].x; cq.y += lam[a] * cv[a].y; }
+        const zc c2 = zmul(cq, cq);
+        for (int k = 0; k < 10; ++k) {
+          const double pk = p2_basis<4>(k, lam, dl);
+          double gk[3] = {0, 0, 0};
+          for (int m = 0; m < 4; ++m) for (int c = 0; c < 3; ++c) gk[c] += dl[m] * G[m][c];
+          const double gg = w * (gj[0] * gk[0] + gj[1] * gk[1] + gj[2] * gk[2]);
+          rowA[k].x -= gg * c2.x;
+          rowA[k].y -= gg * c2.y;
+          rowC[k] += w * pj * pk;
+        }
+      }
+      for (int k = 0; k < 10; ++k) {
+        const int32_t pos = find_slot(col, rs, re, dofs[k]);
+        if (A) { A[pos].x += rowA[k].x; A[pos].y += rowA[k].y; }
+        if (C) C[pos].x += rowC[k];
+      }
+    }
+  }
+}
+extern "C" int hx_assemble_p2_stiff_mass(int32_t n_dof, const double* x, const int32_t* cells, const int32_t* cell_dofs,
+                                         const int32_t* d2c_ptr, const int32_t* d2c_idx, const int32_t* rowptr,
+                                         const int32_t* col, const hx_c128* c, int nq, const double* quad, hx_c128* A,
+                                         hx_c128* C, hx_stream s) {
+  HX_REQUIRE(n_dof > 0 && x && cells && cell_dofs && d2c_ptr && d2c_idx && rowptr && col && nq > 0 && quad && (A || C),
+             "bad argument");
+  k_p2_stiff_mass<<<hx_grid(n_dof, 128), 128, 0, hx_s(s)>>>(n_dof, x, cells, cell_dofs, d2c_ptr, d2c_idx, rowptr, col,
+                                                           (const zc*)c, nq, quad, (zc*)A, (zc*)C);
+  HX_LAUNCH_CHECK("k_p2_stiff_mass");
+  return HX_OK;
+}
+
+// B = sum_f coef_f int_F c phi_k phi_j ds over boundary triangles (P2 on the facet: 3 vertices + 3 edges)
+__global__ void __launch_bounds__(128)
+k_p2_robin(int32_t n_dof, const double* __restrict__ x, const int32_t* __restrict__ facets,
+           const int32_t* __restrict__ fdofs, const int32_t* __restrict__ d2f_ptr, const int32_t* __restrict__ d2f_idx,
+           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ cf,
+           const zc* __restrict__ coef, int nq, const double* __restrict__ quad, zc* __restrict__ B) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_dof; i += gridDim.x * blockDim.x) {
+    const int32_t rs = rowptr[i], re = rowptr[i + 1];
+    for (int32_t t = rs; t < re; ++t) B[t] = make_double2(0, 0);
+    for (int32_t p = d2f_ptr[i]; p < d2f_ptr[i + 1]; ++p) {
+      const int32_t f = d2f_idx[p];
+      const int32_t* v = facets + (int64_t)f * 3;
+      const int32_t* dofs = fdofs + (int64_t)f * 6;
+      int j = 0;
+      for (int t = 0; t < 6; ++t) if (dofs[t] == i) j = t;
+      double e1[3], e2[3];
+      for (int c = 0; c < 3; ++c) { e1[c] = x[(int64_t)v[1] * 3 + c] - x[(int64_t)v[0] * 3 + c];
+                                    e2[c] = x[(int64_t)v[2] * 3 + c] - x[(int64_t)v[0] * 3 + c]; }
+      const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+      const double area = 0.5 * sqrt(nx * nx + ny * ny + nz * nz);
+      zc cv[3];
+      for (int a = 0; a < 3; ++a) cv[a] = cf[v[a]];
+      zc row[6];
+      for (int k = 0; k < 6; ++k) row[k] = make_double2(0, 0);
+      for (int q = 0; q < nq; ++q) {
+        const double* lam = quad + 4 * q;
+        const double w = lam[3] * area;
+        double dl[3];
+        const double pj = p2_basis<3>(j, lam, dl);
+        zc cq = make_double2(0, 0);
+        for (int a = 0; a < 3; ++a) { cq.x += lam[a] * cv[a].x; cq.y += lam[a] * cv[a].y; }
+        for (int k = 0; k < 6; ++k) {
+          const double pk = p2_basis<3>(k, lam, dl);
+          row[k].x += w * pj * pk * cq.x;
+          row[k].y += w * pj * pk * cq.y;
+        }
+      }
+      const zc cz = coef[f];
+      for (int k = 0; k < 6; ++k) {
+        const int32_t pos = find_slot(col, rs, re, dofs[k]);
+        const zc t = zmul(cz, row[k]);
+        B[pos].x += t.x;
+        B[pos].y += t.y;
+      }
+    }
+  }
+}
+extern "C" int hx_assemble_p2_robin(int32_t n_dof, const double* x, const int32_t* facets, const int32_t* facet_dofs,
+                                    const int32_t* d2f_ptr, const int32_t* d2f_idx, const int32_t* rowptr,
+                                    const int32_t* col, const hx_c128* c, const hx_c128* coef, int nq, const double* quad,
+                                    hx_c128* B, hx_stream s) {
+  HX_REQUIRE(n_dof > 0 && x && facets && facet_dofs && d2f_ptr && d2f_idx && rowptr && col && c && coef && nq > 0 && quad && B,
+             "bad argument");
+  k_p2_robin<<<hx_grid(n_dof, 128), 128, 0, hx_s(s)>>>(n_dof, x, facets, facet_dofs, d2f_ptr, d2f_idx, rowptr, col,
+                                                      (const zc*)c, (const zc*)coef, nq, quad, (zc*)B);
+  HX_LAUNCH_CHECK("k_p2_robin");
+  return HX_OK;
+}
+
+// load vectors on the P2 space with P1 fields fa, fb:
+//   kind 1: out_j = scale * int fa fb phi_j dx                 (flame_matrices.py:199 with fa = gamma - 1, fb = h)
+//   kind 2: out_j = scale * int (d phi_j / dz) fb / fa dx      (flame_matrices.py:200 with fa = rho, fb = w; n_r = e_z)
+__global__ void __launch_bounds__(128)
+k_p2_load(int kind, int32_t n_dof, const double* __restrict__ x, const int32_t* __restrict__ cells,
+          const int32_t* __restrict__ cdofs, const int32_t* __restrict__ d2c_ptr, const int32_t* __restrict__ d2c_idx,
+          const zc* __restrict__ fa, const zc* __restrict__ fb, zc scale, int nq, const double* __restrict__ quad,
+          zc* __restrict__ out) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_dof; i += gridDim.x * blockDim.x) {
+    zc acc = make_double2(0, 0);
+    for (int32_t p = d2c_ptr[i]; p < d2c_ptr[i + 1]; ++p) {
+      const int32_t cell = d2c_idx[p];
+      const int32_t* v = cells + (int64_t)cell * 4;
+      const int32_t* dofs = cdofs + (int64_t)cell * 10;
+      int j = 0;
+      for (int t = 0; t < 10; ++t) if (dofs[t] == i) j = t;
+      double G[4][3], vol;
+      p1_geometry<3>(x, v, G, vol);
+      zc av[4], bv[4];
+      for (int a = 0; a < 4; ++a) { av[a] = fa[v[a]]; bv[a] = fb[v[a]]; }
+      for (int q = 0; q < nq; ++q) {
+        const double* lam = quad + 5 * q;
+        const double w = lam[4] * vol;
+        double dl[4];
+        const double pj = p2_basis<4>(j, lam, dl);
+        zc aq = make_double2(0, 0), bq = make_double2(0, 0);
+        for (int a = 0; a < 4; ++a) { aq.x += lam[a] * av[a].x; aq.y += lam[a] * av[a].y;
+                                      bq.x += lam[a] * bv[a].x; bq.y += lam[a] * bv[a].y; }
+        if (kind == 1) {
+          const zc t = zmul(aq, bq);
+          acc.x += w * pj * t.x;
+          acc.y += w * pj * t.y;
+        } else {
+          double gz = 0.0;
+          for (int m = 0; m < 4; ++m) gz += dl[m] * G[m][2];
+          const zc t = zdiv(bq, aq);
+          acc.x += w * gz * t.x;
+          acc.y += w * gz * t.y;
+        }
+      }
+    }
+    out[i] = zmul(scale, acc);
+  }
+}
+extern "C" int hx_assemble_p2_load(int kind, int32_t n_dof, const double* x, const int32_t* cells, const int32_t* cell_dofs,
+                                   const int32_t* d2c_ptr, const int32_t* d2c_idx, const hx_c128* fa, const hx_c128* fb,
+                                   const double scale[2], int nq, const double* quad, hx_c128* out, hx_stream s) {
+  HX_REQUIRE((kind == 1 || kind == 2) && n_dof > 0 && x && cells && cell_dofs && d2c_ptr && d2c_idx && fa && fb && scale &&
+             nq > 0 && quad && out, "bad argument");
+  k_p2_load<<<hx_grid(n_dof, 128), 128, 0, hx_s(s)>>>(kind, n_dof, x, cells, cell_dofs, d2c_ptr, d2c_idx, (const zc*)fa,
+                                                     (const zc*)fb, hx_z(scale), nq, quad, (zc*)out);
+  HX_LAUNCH_CHECK("k_p2_load");
   return HX_OK;
 }

@@ -26,7 +26,8 @@ class AcousticMatrices:
         self.V = FunctionSpace(mesh, "Lagrange", degree)
         self.bcs_Dirichlet = []
         self._A = self._B = self._B_adj = self._C = None
-        asm = mesh.assembler()
+        # degree 1: the mesh's P1 assembler; degree 2: quadratic space with P1 coefficient fields (hx_assemble_p2_*)
+        asm = self.V.assembler()
 
         print("Degree of basis functions: ", self.degree, "\n")
 
@@ -47,6 +48,8 @@ class AcousticMatrices:
             if 'Neumann' in spec:
                 info("- Neumann boundaries on boundary " + str(boundary))
             if 'Dirichlet' in spec:
+                if degree != 1:
+                    raise NotImplementedError("Dirichlet rows are provided for degree 1 (no reference example uses them)")
                 self.bcs_Dirichlet.append(np.unique(mesh.facets[facets]))
                 info("- Dirichlet boundary on boundary " + str(boundary))
             R = None

@@ -30,7 +30,7 @@ def normalize_eigenvector(mesh, obj, i, absolute=False, degree=1, which='right',
         vr = matrix_vector(BlochRemapper, vr)
     V = matrices.V if matrices else FunctionSpace(mesh, "CG", degree)
     FixSign(vr)
-    C = mesh.assembler().stiffness_mass(None, want_A=False)[1].csr_part()
+    C = V.assembler().stiffness_mass(None, want_A=False)[1].csr_part()
     Cp = torch.empty_like(vr.t)
     C.spmv(vr.t, Cp)
     meas = np.sqrt(panel_dot(torch.conj_physical(vr.t).reshape(1, -1), 1, Cp)[0])     # sqrt(p^T C p)

@@ -111,6 +111,46 @@ def exterior_facets(cells):
     return uniq[m].astype(np.int32), owner[first[m]].astype(np.int32)
 
 
+TET_EDGES = np.array([(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)])
+TRI_EDGES = np.array([(0, 1), (0, 2), (1, 2)])
+
+
+def p2_dofmap(n_vertices, cells):
+    """P2 dofs on tetrahedra: the mesh vertices first (P1 numbering), then one dof per edge, edges sorted by their
+    (low, high) vertex pair.  Returns (cell_dofs (nc, 10): 4 vertices + the edges in TET_EDGES order, edges (ne, 2)).
+    (DOLFINx numbers differently; eigenvalues do not depend on it.)"""
+    cells = np.asarray(cells, dtype=np.int64)
+    pairs = np.sort(cells[:, TET_EDGES], axis=2).reshape(-1, 2)
+    key = pairs[:, 0] * n_vertices + pairs[:, 1]
+    uniq, inv = np.unique(key, return_inverse=True)
+    edges = np.stack([uniq // n_vertices, uniq % n_vertices], axis=1)
+    cell_dofs = np.concatenate([cells, n_vertices + inv.reshape(-1, 6)], axis=1)
+    return np.ascontiguousarray(cell_dofs, dtype=np.int32), np.ascontiguousarray(edges, dtype=np.int32)
+
+
+def collapsed_gauss(dim, n=4):
+    """Barycentric quadrature table (nq, dim + 2): points + weight (sum 1) on the reference simplex -- tensor
+    Gauss-Legendre in collapsed coordinates, exact to total degree 2n - 1 - (dim - 1) (n = 4: 5 on tetrahedra, 6 on
+    triangles: every polynomial form of the degree-2 operators)."""
+    g, w = np.polynomial.legendre.leggauss(n)
+    g, w = 0.5 * (g + 1), 0.5 * w
+    rows = []
+    if dim == 2:
+        for a, wa in zip(g, w):
+            for b, wb in zip(g, w):
+                x1, x2 = a, b * (1 - a)
+                rows.append([1 - x1 - x2, x1, x2, wa * wb * (1 - a)])
+    else:
+        for a, wa in zip(g, w):
+            for b, wb in zip(g, w):
+                for c, wc in zip(g, w):
+                    x1, x2, x3 = a, b * (1 - a), c * (1 - a) * (1 - b)
+                    rows.append([1 - x1 - x2 - x3, x1, x2, x3, wa * wb * wc * (1 - a) ** 2 * (1 - b)])
+    t = np.array(rows)
+    t[:, -1] /= t[:, -1].sum()
+    return np.ascontiguousarray(t)
+
+
 class FunctionSpace:
     def __init__(self, mesh, family="Lagrange", degree=1):
         fam = family.upper()
@@ -118,15 +158,37 @@ class FunctionSpace:
             self.kind, self.size = "P1", mesh.num_vertices
         elif fam in ("DG", "DISCONTINUOUS LAGRANGE") and degree == 0:
             self.kind, self.size = "DG0", mesh.num_cells
+        elif fam in ("LAGRANGE", "CG", "P") and degree == 2:
+            if mesh.topology.dim != 3:
+                raise NotImplementedError("quadratic elements are provided on tetrahedra (the reference's degree-2 case)")
+            self.kind = "P2"
+            self.cell_dofs, self.edges = p2_dofmap(mesh.num_vertices, mesh.topology.cells)
+            self.size = mesh.num_vertices + self.edges.shape[0]
         else:
-            raise NotImplementedError("only P1 and DG0 spaces are on the hot path (got %s %d); degree 2 is a "
-                                      "'next' row of SURVEY.md section 8f" % (family, degree))
+            raise NotImplementedError("P1, P2 (tetrahedra) and DG0 spaces are on the hot path (got %s %d)" % (family, degree))
         self.mesh = mesh
-        self.dofmap = mesh.topology.cells if self.kind == "P1" else np.arange(mesh.num_cells, dtype=np.int32)[:, None]
+        if self.kind == "P1":
+            self.dofmap = mesh.topology.cells
+        elif self.kind == "P2":
+            self.dofmap = self.cell_dofs
+        else:
+            self.dofmap = np.arange(mesh.num_cells, dtype=np.int32)[:, None]
+
+    def assembler(self):
+        """Device assembler of this space (P1: the mesh's; P2: cached on the mesh per space kind)."""
+        if self.kind == "P2":
+            cache = self.mesh.__dict__.setdefault("_p2_assembler", None)
+            if cache is None:
+                cache = self.mesh.__dict__["_p2_assembler"] = P2Assembler(self)
+            return cache
+        return self.mesh.assembler()
 
     def tabulate_dof_coordinates(self):
         if self.kind == "P1":
             return self.mesh.geometry.x
+        if self.kind == "P2":
+            x = self.mesh.geometry.x
+            return np.concatenate([x, 0.5 * (x[self.edges[:, 0]] + x[self.edges[:, 1]])], axis=0)
         return self.mesh.geometry.x[self.mesh.topology.cells].mean(axis=1)
 
 
@@ -311,3 +373,86 @@ class P1Assembler:
         if (cells == 2 ** 31 - 1).any():
             raise ValueError("reference point(s) %s outside the mesh" % (pts[cells == 2 ** 31 - 1],))
         return cells
+
+
+class P2Assembler:
+    """Quadratic Lagrange space on tetrahedra with P1 coefficient fields: device dof map, dof -> cell adjacency, CSR
+    pattern and the hx_assemble_p2_* kernels (the reference's ``degree = 2``: acoustic_matrices.py:25,
+    flame_matrices.py:199-200).  Same owner-computes scheme as P1Assembler."""
+
+    def __init__(self, V):
+        assert V.kind == "P2"
+        self.V, self.mesh = V, V.mesh
+        base = self.mesh.assembler()
+        self.x, self.cells = base.x, base.cells
+        self.n, self.nc = V.size, self.mesh.num_cells
+        self.cdofs = to_device(V.cell_dofs)
+        self.quad3 = to_device(collapsed_gauss(3))
+        self.quad2 = to_device(collapsed_gauss(2))
+        self.d2c_ptr, self.d2c_idx = self._adjacency(self.cdofs, self.nc, 10)
+        self.rowptr, self.col = self._pattern(self.cdofs, self.nc, 10, self.d2c_ptr, self.d2c_idx)
+        self.pattern_id = id(self)
+
+    _adjacency = P1Assembler._adjacency
+    _pattern = P1Assembler._pattern
+
+    def _csr(self, val):
+        out = CSR((self.n, self.n), self.rowptr, self.col, val, pattern_id=self.pattern_id)
+        out.symmetric = True
+        return out
+
+    @staticmethod
+    def _p1_field(f):
+        if not (isinstance(f, Function) and f.function_space.kind == "P1"):
+            raise NotImplementedError("coefficient fields of the quadratic space must be P1 Functions")
+        return to_device(f.x.array.astype(np.complex128))
+
+    def stiffness_mass(self, c=None, want_A=True, want_C=True):
+        A_val = torch.empty(self.col.numel(), dtype=torch.complex128, device=self.x.device) if want_A else None
+        C_val = torch.empty(self.col.numel(), dtype=torch.complex128, device=self.x.device) if want_C else None
+        cf = self._p1_field(c) if c is not None else None
+        _hx.check(_hx.lib.hx_assemble_p2_stiff_mass(self.n, _hx.ptr(self.x), _hx.ptr(self.cells), _hx.ptr(self.cdofs),
+                                                    _hx.ptr(self.d2c_ptr), _hx.ptr(self.d2c_idx), _hx.ptr(self.rowptr),
+                                                    _hx.ptr(self.col), _hx.ptr(cf), self.quad3.shape[0],
+                                                    _hx.ptr(self.quad3), _hx.ptr(A_val), _hx.ptr(C_val), _hx.stream()))
+        return (Mat.from_csr(self._csr(A_val)) if want_A else None,
+                Mat.from_csr(self._csr(C_val)) if want_C else None)
+
+    def facet_dofs(self, facets):
+        """(nf, 6) global P2 dofs of boundary triangles: 3 vertices + the edges in TRI_EDGES order."""
+        nv = self.mesh.num_vertices
+        facets = np.asarray(facets, dtype=np.int64)
+        ekey = self.V.edges[:, 0].astype(np.int64) * nv + self.V.edges[:, 1]
+        pairs = np.sort(facets[:, TRI_EDGES], axis=2)
+        key = pairs[..., 0] * nv + pairs[..., 1]
+        pos = np.searchsorted(ekey, key)
+        if not np.array_equal(ekey[np.minimum(pos, len(ekey) - 1)], key):
+            raise ValueError("a boundary facet edge is not a mesh edge")
+        return np.ascontiguousarray(np.concatenate([facets, nv + pos], axis=1), dtype=np.int32)
+
+    def robin(self, facet_ids, coef_per_facet, c):
+        facet_ids = np.asarray(facet_ids, dtype=np.int64)
+        fv = self.mesh.facets[facet_ids]
+        facets = to_device(np.ascontiguousarray(fv, dtype=np.int32))
+        fdofs = to_device(self.facet_dofs(fv))
+        nf = fv.shape[0]
+        coef = to_device(np.asarray(coef_per_facet, dtype=np.complex128))
+        ptr, idx = self._adjacency(fdofs, nf, 6)
+        rowptr, col = self._pattern(fdofs, nf, 6, ptr, idx)
+        val = torch.empty(col.numel(), dtype=torch.complex128, device=self.x.device)
+        cf = self._p1_field(c)
+        _hx.check(_hx.lib.hx_assemble_p2_robin(self.n, _hx.ptr(self.x), _hx.ptr(facets), _hx.ptr(fdofs), _hx.ptr(ptr),
+                                               _hx.ptr(idx), _hx.ptr(rowptr), _hx.ptr(col), _hx.ptr(cf), _hx.ptr(coef),
+                                               self.quad2.shape[0], _hx.ptr(self.quad2), _hx.ptr(val), _hx.stream()))
+        return Mat.from_csr(CSR((self.n, self.n), rowptr, col, val))
+
+    def load(self, kind, fa, fb, scale=1.0):
+        """kind 1: scale * int fa fb phi_j dx; kind 2: scale * int (d phi_j / dz) fb / fa dx (fa, fb: P1 nodal arrays)."""
+        fa_t = to_device(np.asarray(fa, dtype=np.complex128))
+        fb_t = to_device(np.asarray(fb, dtype=np.complex128))
+        out = torch.empty(self.n, dtype=torch.complex128, device=self.x.device)
+        _hx.check(_hx.lib.hx_assemble_p2_load(kind, self.n, _hx.ptr(self.x), _hx.ptr(self.cells), _hx.ptr(self.cdofs),
+                                              _hx.ptr(self.d2c_ptr), _hx.ptr(self.d2c_idx), _hx.ptr(fa_t), _hx.ptr(fb_t),
+                                              _hx.z2(scale), self.quad3.shape[0], _hx.ptr(self.quad3), _hx.ptr(out),
+                                              _hx.stream()))
+        return out

@@ -130,6 +130,9 @@ class PointwiseFlameMatrix(FlameMatrix):
         reference's answer is whatever cell DOLFINx's point-ownership search returns first (flame_matrices.py:144-152);
         by default the lowest-index containing cell is used."""
         super().__init__(mesh, h, q_0, u_b, FTF, degree, bloch_object, tol)
+        if degree != 1:
+            raise NotImplementedError("pointwise flames are provided for degree 1 (the reference's degree-2 run uses "
+                                      "DistributedFlameMatrix)")
         self.subdomains = subdomains
         self.x_r = x_r
         self.rho_u = rho_u
@@ -171,11 +174,12 @@ class DistributedFlameMatrix(FlameMatrix):
         self.gamma, self.w, self.rho = gamma, w, rho
 
     def _assemble_vectors(self, problem_type='direct'):
-        asm = self.mesh.assembler()
+        asm = self.V.assembler()                   # P1, or the quadratic space (fields gamma, h, rho, w stay P1)
+        n_p1 = self.mesh.num_vertices
         if isinstance(self.gamma, Function):
             gm1 = self.gamma.x.array - 1.0
         else:
-            gm1 = np.full(self.V.size, self.gamma - 1.0, dtype=np.complex128)
+            gm1 = np.full(n_p1, self.gamma - 1.0, dtype=np.complex128)
         left = self.indices_and_values(asm.load(1, gm1, self.h.x.array, scale=self.q_0 / self.u_b))
         right = self.indices_and_values(asm.load(2, self.rho.x.array, self.w.x.array))
         return left, right

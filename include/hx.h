@@ -186,6 +186,26 @@ int hx_p1_cell_volumes(int dim, int32_t n_cells, const double* x, const int32_t*
 int hx_p1_locate_points(int dim, int32_t n_cells, const double* x, const int32_t* cells, int n_pts,
                         const double* pts, double tol, int32_t* out_cell, hx_stream s);
 
+/* ---- P2 (quadratic Lagrange) on tetrahedra with P1 coefficient fields: the reference's degree = 2 runs
+ * (acoustic_matrices.py:25-125 and flame_matrices.py:199-200 with functionspace(mesh, ("Lagrange", 2));
+ * ShapeSensitivities/RijkeFFD/main_shape.py:68-83).  One CSR row per P2 dof (vertices first, then one dof per edge);
+ * cell_dofs: n_cells x 10 (4 vertices, then the edges (0,1),(0,2),(0,3),(1,2),(1,3),(2,3)); facet_dofs: n_facets x 6
+ * (3 vertices, then the edges (0,1),(0,2),(1,2)).  The dof -> cell adjacency and the CSR pattern come from
+ * hx_build_v2e / hx_p1_pattern_count / hx_p1_pattern_fill with k = 10 (resp. 6).  quad: barycentric quadrature table on
+ * the device, nq x 5 doubles (4 barycentric coordinates + weight, weights summing to 1) for cells, nq x 4 for facets. */
+int hx_assemble_p2_stiff_mass(int32_t n_dof, const double* x, const int32_t* cells, const int32_t* cell_dofs,
+                              const int32_t* d2c_ptr, const int32_t* d2c_idx, const int32_t* rowptr, const int32_t* col,
+                              const hx_c128* c /* P1 nodal, may be NULL (= 1) */, int nq, const double* quad,
+                              hx_c128* A /* may be NULL */, hx_c128* C /* may be NULL */, hx_stream s);
+int hx_assemble_p2_robin(int32_t n_dof, const double* x, const int32_t* facets, const int32_t* facet_dofs,
+                         const int32_t* d2f_ptr, const int32_t* d2f_idx, const int32_t* rowptr, const int32_t* col,
+                         const hx_c128* c, const hx_c128* coef_per_facet, int nq, const double* quad, hx_c128* B,
+                         hx_stream s);
+/* kind 1: out_j = scale * int fa fb phi_j dx;  kind 2: out_j = scale * int (d phi_j / dz) fb / fa dx   (fa, fb P1 nodal) */
+int hx_assemble_p2_load(int kind, int32_t n_dof, const double* x, const int32_t* cells, const int32_t* cell_dofs,
+                        const int32_t* d2c_ptr, const int32_t* d2c_idx, const hx_c128* fa, const hx_c128* fb,
+                        const double scale[2], int nq, const double* quad, hx_c128* out, hx_stream s);
+
 /* ------------------------------------------------------------------ sparse triangular solves (MatSolve)
  * replaces: KSP(preonly)+PC(LU) MatSolve inside ST sinvert (eigensolvers.py:49-50,102-103 -> :62,:113).
  * The factors come from a host factorisation (Pr*A*Pc = L*U); each triangle is passed as strictly

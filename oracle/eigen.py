@@ -217,3 +217,68 @@ def normalize_eigenvector(vec, C):
     v = v / (v[0] / abs(v[0]))
     meas = np.sqrt(v @ (C @ v))
     return v / meas
+
+
+# ----------------------------------------------------------------------------- factored flame term (large supports)
+class FactoredFlame:
+    """D(omega) = FTF(omega) * a b^T kept as two vectors.  Used where the explicit block a (x) b of OracleFlame would not
+    fit a sparse factorisation (P2 spaces, large 3-D Gaussian supports): mathematically the same operator, applied
+    through the Sherman-Morrison identity on top of ONE factorisation of the passive shifted operator."""
+
+    def __init__(self, a, b, FTF):
+        self.a, self.b, self.FTF = np.asarray(a, dtype=complex), np.asarray(b, dtype=complex), FTF
+
+
+def pep_solve_factored(A, B, C, target, nev, flame=None, omega=None, lu=None):
+    """pep_solve for (A - FTF(omega) a b^T) + lambda B + lambda^2 C with the rank-1 term handled by Sherman-Morrison:
+    (K - f a b^T)^-1 r = y + w * f (b.y) / (1 - f (b.w)),  y = K^-1 r,  w = K^-1 a."""
+    n = A.shape[0]
+    sigma = complex(target)
+    Bm = B if B is not None else sp.csr_matrix((n, n), dtype=complex)
+    if lu is None:
+        lu = spla.splu((A + sigma * Bm + sigma ** 2 * C).tocsc())
+    BsC = (Bm + sigma * C).tocsr()
+    Cr = C.tocsr()
+    if flame is not None and omega is not None:
+        f = flame.FTF(omega)
+        w = lu.solve(flame.a)
+        denom = 1.0 - f * (flame.b @ w)
+
+        def ksolve(r):
+            y = lu.solve(r)
+            return y + w * (f * (flame.b @ y) / denom)
+    else:
+        ksolve = lu.solve
+
+    def op(z):
+        x1, x2 = z[:n], z[n:]
+        y1 = -ksolve(BsC @ x1 + Cr @ x2)
+        return np.concatenate([y1, x1 + sigma * y1])
+
+    OP = spla.LinearOperator((2 * n, 2 * n), matvec=op, dtype=complex)
+    theta, vecs = spla.eigs(OP, k=nev, which='LM', ncv=_ncv(nev, 2 * n), tol=0,
+                            v0=np.ones(2 * n, dtype=complex), maxiter=20 * n)
+    return OracleE('pep', sigma + 1.0 / theta, vecs[:n], sigma), lu
+
+
+def fixed_point_iteration_factored(A, B, C, flame, target, nev=2, i=0, tol=1e-8, maxiter=50):
+    """eigensolvers.py:197-259 with the flame term factored (see FactoredFlame); same update rule."""
+    omega = np.zeros(maxiter, dtype=complex)
+    f = np.zeros(maxiter, dtype=complex)
+    alpha = np.zeros(maxiter, dtype=complex)
+    E, lu = pep_solve_factored(A, B, C, target, nev)
+    omega[0] = E.getEigenvalue(i)
+    alpha[0] = 0.5
+    domega = 2 * tol
+    k = -1
+    hist = [omega[0]]
+    while abs(domega) > tol:
+        k += 1
+        E, _ = pep_solve_factored(A, B, C, target, nev, flame, omega[k], lu)
+        f[k] = E.getEigenvalue(i)
+        if k != 0:
+            alpha[k] = 1 / (1 - ((f[k] - f[k - 1]) / (omega[k] - omega[k - 1])))
+        omega[k + 1] = alpha[k] * f[k] + (1 - alpha[k]) * omega[k]
+        domega = omega[k + 1] - omega[k]
+        hist.append(omega[k + 1])
+    return E, np.array(hist)

@@ -388,3 +388,50 @@ def test_micca_full_annulus_flagship_case(ref_logs, golden_dir):
         assert abs(z - complex(*ref)) < 7.5e-4
     for lam, ref in zip(E.eigs[:2], g["direct"]):
         assert abs(lam - complex(*ref)) / abs(lam) < 1e-9
+
+
+def test_p2_oracle_patch_tests_and_factored_flame(golden_dir):
+    """Quadratic-element oracle (oracle/fem_p2.py): exactness on quadratics, constants in the stiffness null space, total
+    mass = volume, Robin mass = boundary area, load vectors summing to the P1 integrals; and the factored-flame
+    fixed-point driver (Sherman-Morrison on one factorisation) against the explicit-D driver on a P1 case."""
+    from oracle import fem_p2
+    m = meshes.read_gmsh41(os.path.join(golden_dir, "meshes", "rijke3d.msh"), 3)
+    x, cells = m.x, m.cells
+    nv = x.shape[0]
+    cd, edges = fem_p2.p2_dofmap(nv, cells)
+    n = nv + len(edges)
+    X = fem_p2.dof_coordinates(x, edges)
+    _, vol = fem.cell_geometry(x, cells)
+    A, C = fem_p2.assemble_A_C(x, cells, cd, n, np.ones(nv))
+    one = np.ones(n)
+    assert abs((one @ (C @ one)).real - vol.sum()) < 1e-12 * vol.sum()
+    assert np.abs(A @ one).max() < 1e-12 * abs(A).max()
+    u = X[:, 2] ** 2 + X[:, 0] * X[:, 1] - 0.3 * X[:, 1]                      # quadratic: represented exactly by P2
+    g2 = 4 * X[:, 2] ** 2 + X[:, 1] ** 2 + (X[:, 0] - 0.3) ** 2              # |grad u|^2, again a quadratic
+    assert abs(-(u @ (A @ u)).real - (one @ (C @ g2)).real) < 1e-11 * abs(u @ (A @ u))
+    fac = m.facets[m.facet_tags == 2]
+    B = fem_p2.assemble_B(x, n, [(fac, fem_p2.facet_dofs(nv, edges, fac), 1j, np.ones(nv))])   # (i / Z) = 1
+    assert abs((one @ (B @ one)) - fem.facet_measure(x, fac).sum()) < 1e-12
+    h = fem.gaussian_function(x, cells, Rijke.x_f(3), Rijke.a_f)
+    a2 = fem_p2.distributed_left(x, cells, cd, n, 1.4, h, 2.0, 4.0)
+    a1 = fem.distributed_left(x, cells, 1.4, h, 2.0, 4.0)
+    assert abs(a2.sum() - a1.sum()) < 1e-12 * abs(a1.sum())                   # partition of unity
+    rho = fem.density_step(x[:, 2], 0.25, 0.025, 0.85, 1.22)
+    b2 = fem_p2.distributed_right(x, cells, cd, n, rho, h)
+    assert abs(b2.sum()) < 1e-12 * np.abs(b2).sum()                           # sum_k grad(phi_k) = 0
+    # sum_k z_k d(phi_k)/dz = 1  =>  b . z = int w / rho dx  (same quadrature on both sides)
+    lam, wq = fem_p2.collapsed_gauss(3)
+    ref = (((h[cells] @ lam.T) / (rho[cells] @ lam.T)) @ wq * vol).sum()
+    assert abs(b2 @ X[:, 2] - ref) < 1e-12 * abs(ref)
+    # factored-flame driver == explicit-D driver (P1, Rijke 3-D, EPS-free PEP form with B = 0)
+    A1, C1, flame, left, right = _rijke_distributed(m, 3, False)
+
+    def dense(pk):
+        v = np.zeros(nv, dtype=complex)
+        v[pk[0]] = pk[1]
+        return v
+    ff = eigen.FactoredFlame(dense(left), dense(right), flame.FTF)
+    Bsmall = fem.assemble_B(x, nv, [(fac, fem.robin_Z(-0.9 - 0.1j), np.full(nv, 340.0), None)])
+    _, h1 = eigen.fixed_point_iteration(A1, Bsmall, C1, flame, Rijke.target, nev=2, i=0)
+    _, h2 = eigen.fixed_point_iteration_factored(A1, Bsmall, C1, ff, Rijke.target, nev=2, i=0)
+    assert len(h1) == len(h2) and np.max(np.abs(h1 - h2) / np.abs(h1)) < 1e-10

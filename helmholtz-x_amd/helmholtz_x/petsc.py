@@ -209,11 +209,46 @@ class Mat:
 
     __array_ufunc__ = None        # numpy scalars defer to Mat.__rmul__ (omega * B, eigensolvers.py:176)
 
-    def __init__(self, shape, csr_terms=(), lr_terms=()):
+    def __init__(self, shape=(0, 0), csr_terms=(), lr_terms=()):
         self.shape = (int(shape[0]), int(shape[1]))
         self.csr_terms = [(complex(c), m) for c, m in csr_terms]
         self.lr_terms = [(complex(c), m) for c, m in lr_terms]
         self._mat = None
+        self._coo = None             # (rows, cols, vals) blocks collected by setValues until assemblyEnd
+
+    # ---- incremental assembly in the petsc4py style (flame_matrices.py:165-189, 219-244 build the explicit D this way:
+    #      create -> setSizes -> setType('aij') -> setUp -> setValues(rows, cols, block, ADD_VALUES) -> assemblyBegin/End)
+    def create(self, comm=None):
+        return self
+
+    def setSizes(self, size, bsize=None):
+        def glob(s):
+            return int(s[1] if isinstance(s, (tuple, list)) else s)
+        size = size if isinstance(size, (tuple, list)) else (size, size)
+        self.shape = (glob(size[0]), glob(size[1]))
+
+    def setType(self, mat_type):
+        pass
+
+    def setUp(self):
+        pass
+
+    def setPreallocationNNZ(self, nnz):
+        pass
+
+    def setOption(self, option, flag):
+        pass
+
+    def setValues(self, rows, cols, values, addv=None):
+        """Dense block ``values`` (len(rows) x len(cols), row-major) added into the matrix (ADD_VALUES semantics)."""
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.int64))
+        cols = np.atleast_1d(np.asarray(cols, dtype=np.int64))
+        vals = np.asarray(values, dtype=np.complex128).reshape(len(rows), len(cols))
+        if self._coo is None:
+            self._coo = ([], [], [])
+        self._coo[0].append(np.repeat(rows, len(cols)))
+        self._coo[1].append(np.tile(cols, len(rows)))
+        self._coo[2].append(vals.ravel())
 
     # ---- construction helpers (petsc4py API)
     @classmethod
@@ -238,16 +273,22 @@ class Mat:
     getVecs = createVecs
 
     def assemble(self):
+        self.assemblyEnd()
         return self
 
     def assemblyBegin(self):
         pass
 
     def assemblyEnd(self):
-        pass
+        if self._coo is not None:                  # duplicates are summed (ADD_VALUES), then the CSR goes to the device
+            r, c, v = (np.concatenate(a) if a else np.zeros(0) for a in self._coo)
+            M = sp.coo_matrix((v, (r, c)), shape=self.shape).tocsr()
+            M.sum_duplicates()
+            self.csr_terms.append((1.0 + 0j, CSR.from_scipy(M)))
+            self._coo = None
 
     def destroy(self):
-        self.csr_terms, self.lr_terms, self._mat = [], [], None
+        self.csr_terms, self.lr_terms, self._mat, self._coo = [], [], None, None
 
     def copy(self):
         return Mat(self.shape, list(self.csr_terms), list(self.lr_terms))

@@ -6,6 +6,7 @@ to the largest entry; eigenvalues |dw|/|w| < 1e-8 (BASELINE.json north_star)."""
 import os
 
 import numpy as np
+import scipy.sparse as sp
 import pytest
 
 from cases import PRF, Rijke, RijkeFFD, dispersion_root
@@ -13,6 +14,10 @@ from cases import PRF, Rijke, RijkeFFD, dispersion_root
 pytestmark = pytest.mark.gpu
 
 os.environ.setdefault("HX_QUIET", "1")
+
+
+def _rand_c(rng, n):
+    return rng.standard_normal(n) + 1j * rng.standard_normal(n)
 
 
 def _rel(a, b):
@@ -151,6 +156,36 @@ def test_distributed_flame_vectors(ref_logs, golden_dir):
             D.assemble_submatrices('adjoint')
             ref = fem.flame_outer(x.shape[0], (oli, olv), (ori, orv), 'adjoint')
             assert _rel(D.adjoint_submatrices.to_scipy().toarray(), ref.toarray()) < 1e-12
+
+
+def test_petsc_style_incremental_matrix_assembly():
+    """Mat built the way the reference builds its explicit flame block (flame_matrices.py:165-189: create, setSizes,
+    setType, setUp, setValues(ADD_VALUES), assemblyBegin/End) equals the factored LowRank operator of this package."""
+    from helmholtz_x.petsc import LowRank, Mat, Vec
+    rng = np.random.default_rng(4)
+    n = 500
+    ui, vi = np.sort(rng.choice(n, 40, replace=False)).astype(np.int32), np.sort(rng.choice(n, 7, replace=False)).astype(np.int32)
+    uv, vv = _rand_c(rng, 40), _rand_c(rng, 7)
+    mat = Mat().create()
+    mat.setSizes([(n, n), (n, n)])
+    mat.setType('aij')
+    mat.setPreallocationNNZ([7, 7])
+    mat.setOption(0, False)
+    mat.setUp()
+    mat.setValues(ui, vi, np.outer(uv, vv), addv=None)
+    mat.setValues(ui[:3], vi[:2], np.ones((3, 2)))                       # overlapping block: values add up
+    mat.assemblyBegin()
+    mat.assemblyEnd()
+    ref = LowRank(n, [((ui, uv), (vi, vv))]).to_scipy().toarray()
+    ref[np.ix_(ui[:3], vi[:2])] += 1.0
+    assert mat.getSize() == (n, n)
+    assert np.max(np.abs(mat.to_scipy().toarray() - ref)) < 1e-14
+    x = Vec(_rand_c(rng, n))
+    y = Vec.zeros(n)
+    mat.mult(x, y)
+    assert np.max(np.abs(y.array - ref @ x.array)) < 1e-12
+    ai, aj, av = mat.getValuesCSR()
+    assert np.max(np.abs(sp.csr_matrix((av, aj, ai), shape=(n, n)).toarray() - ref)) < 1e-14
 
 
 def test_pointwise_flame_vectors(golden_dir):

@@ -156,7 +156,7 @@ static int op_diag(const LevelT<float>& L, double w, const float* b, float* x, h
 }
 
 extern "C" int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, double omega) {
-  HX_REQUIRE(out && n_levels >= 1 && pre >= 1 && post >= 0 && omega > 0, "bad argument");
+  HX_REQUIRE(out && n_levels >= 1 && pre >= 0 && post >= 0 && pre + post >= 1 && omega > 0, "bad argument");
   hx_amg* h = new hx_amg();
   h->D.L.resize(n_levels);
   h->S.L.resize(n_levels);
@@ -312,29 +312,34 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   auto other = [&](const T* a, const T* c) -> T* { for (T* q : bufs) if (q != a && q != c) return q; return nullptr; };
   T* cur = L.x;
   T* prev = nullptr;
-  // pre-smoothing from x = 0: the first step is a diagonal scaling
-  if ((rc = op_diag(L, cheb ? C.a[0] : h->omega, b, cur, s))) return rc;
-  for (int k = 1; k < n_pre; ++k) {
-    T* nxt = other(cur, prev);
-    if (cheb) {   // for k = 1 the previous iterate is the zero start vector (prev == nullptr)
-      if ((rc = halo_before_k(h, l, cur))) return rc;
-      if ((rc = op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], s))) return rc;
-    } else { if ((rc = halo_before_k(h, l, cur))) return rc;
-             if ((rc = op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s))) return rc; }
-    prev = cur; cur = nxt;
-  }
-  // residual r = b - K x, restrict
-  HX_HIP(hipMemcpyAsync(L.r, b, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
-  if ((rc = halo_before_k(h, l, cur))) return rc;
-  if ((rc = op_kmult(L, cur, L.r, (T)-1, (T)1, s))) return rc;
   LevelT<T>& Lc = H.L[l + 1];
-  if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
+  if (n_pre == 0) {
+    // no pre-smoothing: x = 0, so the residual IS b and no operator product is needed before the restriction
+    if ((rc = op_spmv(L.R, b, Lc.b, (T)1, (T)0, true, s))) return rc;
+  } else {
+    // pre-smoothing from x = 0: the first step is a diagonal scaling
+    if ((rc = op_diag(L, cheb ? C.a[0] : h->omega, b, cur, s))) return rc;
+    for (int k = 1; k < n_pre; ++k) {
+      T* nxt = other(cur, prev);
+      if (cheb) {   // for k = 1 the previous iterate is the zero start vector (prev == nullptr)
+        if ((rc = halo_before_k(h, l, cur))) return rc;
+        if ((rc = op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], s))) return rc;
+      } else { if ((rc = halo_before_k(h, l, cur))) return rc;
+               if ((rc = op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s))) return rc; }
+      prev = cur; cur = nxt;
+    }
+    // residual r = b - K x, restrict
+    HX_HIP(hipMemcpyAsync(L.r, b, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
+    if ((rc = halo_before_k(h, l, cur))) return rc;
+    if ((rc = op_kmult(L, cur, L.r, (T)-1, (T)1, s))) return rc;
+    if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
+  }
   if (h->sharded && l == 0) {   // R holds this rank's columns only: the coarse right-hand side is the sum over ranks
     if (h->allreduce(h->ctx, HX_BUF_COARSE_RHS, Lc.n) != 0) return hx_fail(HX_ERR_COMM, __func__, "all-reduce callback failed");
   }
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
   if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s))) return rc;
-  if ((rc = op_spmv(L.P, ec, cur, (T)1, (T)1, true, s))) return rc;    // x += P e_c
+  if ((rc = op_spmv(L.P, ec, cur, (T)1, n_pre == 0 ? (T)0 : (T)1, true, s))) return rc;    // x (+)= P e_c
   // post-smoothing: a fresh polynomial started from the corrected x; the last step writes xout
   prev = nullptr;
   for (int k = 0; k < n_post; ++k) {

@@ -48,16 +48,19 @@ def _ritz(S, mact, tol):
     return theta, Y, resid, nconv
 
 
-def krylov_schur(basis, nev, ncv, tol=1e-15, max_it=100, keep_fraction=0.5, relaxed_tol=1e-12, check_every=2,
+def krylov_schur(basis, nev, ncv, tol=1e-15, max_it=100, keep_fraction=0.5, relaxed_tol=1e-12, check_every=1,
                  n_extra=0):
     """Largest-magnitude eigenvalues theta of OP (theta = 1/(lambda - sigma): closest to the target).
 
     Returns KrylovSchurResult with Ritz values sorted by |theta| descending; the first ``nconv`` have
     residual estimate <= tol*|theta|.  After return, basis columns 0..nout-1 hold unit-norm Ritz VECTORS.
-    Convergence is also tested inside a cycle every ``check_every`` expansions (the projected problem is tiny),
+    Convergence is also tested inside a cycle every ``check_every`` expansions (the projected problem is tiny; every
+    step by default: measured 85 instead of 88 operator applications per 5 M-DOF fixed-point call),
     so a warm-started solve stops as soon as the wanted pairs are there instead of filling all ncv columns.
     ``n_extra`` further (not necessarily converged) Ritz vectors are also left in the basis: good start directions
     for a following solve of a nearby problem that wants more pairs."""
+    import os
+    check_every = int(os.environ.get("HX_KRYLOV_CHECK_EVERY", check_every))      # experiment hook
     m = ncv
     assert basis.m >= m + 1
     S = np.zeros((m + 1, m), dtype=complex)      # OP V_j = V_{j+1} S[:j+1, :j]

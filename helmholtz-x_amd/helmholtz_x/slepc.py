@@ -466,6 +466,8 @@ class _EigenSolverBase:
         if self.state is None:
             return None
         wide = self.state.get("start_wide")
+        if __import__("os").environ.get("HX_NO_WIDE_START"):          # experiment hook
+            wide = None
         if wide is not None and self._nev > self.state.get("lean_nev", self._nev):
             return wide
         return self.state.get("start")

@@ -17,7 +17,7 @@
 #include <thread>
 #include <vector>
 
-#include "hx_common.h"
+#include "amg_internal.h"
 
 extern "C" int hx_csr_jacobi_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*,
                                const hx_c128*, const hx_c128*, hx_c128*, double, hx_stream);
@@ -47,52 +47,6 @@ int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 
 static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 0.0};
 
-// T = double: complex128 hierarchy; T = float: complex64 copy of it (values interleaved re, im: 2 T per entry).
-template <typename T> struct CsrT { int32_t rows = 0; int64_t nnz = 0; const int32_t* rp = nullptr; const int32_t* ci = nullptr; const T* va = nullptr; };
-template <typename T> struct LevelT {
-  int32_t n = 0;
-  CsrT<T> K, P, R;             // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
-  const T* dinv = nullptr;
-  double rho = 0.0;            // estimate of rho(D^-1 K) for the Chebyshev smoother (0: damped Jacobi with h->omega)
-  const hx_sell* sell = nullptr;   // optional SELL-64 companion of K (fine level): used for the K products
-  T *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
-  bool ext_x = false, ext_b = false;   // x/x2/x3 (resp. b) are caller-owned (row-sharded mode)
-};
-template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
-
-typedef std::complex<double> cd;
-// Recycled pairs of the GCRO variant of hx_gmres (K U = C, C^H C = I) and the panel that holds [C; V].
-struct Recycle {
-  int kmax = 0, k = 0, restart = 0, m_last = 0;
-  int64_t n = 0;
-  hx_c128* U = nullptr;        // kmax x n
-  hx_c128* CV = nullptr;       // (kmax + restart + 1) x n : rows [0, k) = C, then the Arnoldi vectors
-  float* CVf = nullptr;        // complex64 copy of CV, read by the inner-product passes (hx_zpanel_dot_c64)
-  std::vector<cd> Hraw;        // raw Hessenberg of the last first cycle, column-major, ld = restart + 1
-};
-// Row-sharded mode (one process per GPU): level 0 holds this rank's rows over [owned | ghost] columns, every coarser
-// level is replicated.  The two exchange steps of the path are delegated to the host side (torch.distributed over
-// RCCL): `halo(ctx, id)` fills the ghost block of registered buffer `id`, `allreduce(ctx, id, count)` sums a registered
-// buffer over the ranks.  Both are enqueued on / ordered against the stream the kernels run on.
-struct hx_amg {
-  HierT<double> D;
-  HierT<float> S;
-  bool single = false;         // run the V-cycle on the complex64 copy
-  int pre = 2, post = 2;
-  double omega = 0.6;
-  bool sharded = false;
-  hx_halo_fn halo = nullptr;
-  hx_allreduce_fn allreduce = nullptr;
-  void* ctx = nullptr;
-  int32_t n_ext = 0;           // owned + ghost length of the level-0 iterates
-  Recycle rec;
-  // hipGraph of the complex64 V-cycle (all buffers of the cycle are owned by the handle, so the ~45 launches of one cycle
-  // are captured once and replayed): for small and mid-size problems, where the cycle is launch-bound
-  int graph_state = -1;        // -1 off, 0 requested (capture at the next cycle), 1 ready
-  hipGraphExec_t vexec = nullptr;
-  hipStream_t gstream = nullptr;
-  hipEvent_t ev_in = nullptr, ev_out = nullptr;
-};
 static void drop_graph(hx_amg* h) {
   if (h->vexec) { (void)hipGraphExecDestroy(h->vexec); h->vexec = nullptr; }
   if (h->graph_state == 1) h->graph_state = 0;          // re-capture with the new set-up
@@ -175,6 +129,7 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
   for (auto& l : h->D.L) release(l);
   for (auto& l : h->S.L) release(l);
   (void)hipFree(h->rec.U); (void)hipFree(h->rec.CV); (void)hipFree(h->rec.CVf);
+  (void)hipFree(h->rec.Uf); (void)hipFree(h->rec.Cd); (void)hipFree(h->rec.Einv);
   if (h->vexec) (void)hipGraphExecDestroy(h->vexec);
   if (h->ev_in) (void)hipEventDestroy(h->ev_in);
   if (h->ev_out) (void)hipEventDestroy(h->ev_out);
@@ -283,9 +238,18 @@ extern "C" int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const in
 struct Cheb { double a[4], c[4]; };
 static Cheb cheb_coeffs(double rho) {
   static const double lo_frac = getenv("HX_CHEB_LO") ? atof(getenv("HX_CHEB_LO")) : 0.1;   // experiment hook
+  static const int kind = getenv("HX_CHEB_KIND") ? atoi(getenv("HX_CHEB_KIND")) : 1;       // experiment hook
   const double hi = 1.1 * rho, lo = lo_frac * hi;
-  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
   Cheb C;
+  if (kind == 4) {
+    // Chebyshev polynomials of the 4th kind (Lottes 2022): no lower bound needed, d_k = c_k d_{k-1} + a_k D^-1 r_k
+    for (int k = 0; k < 4; ++k) {
+      C.a[k] = (8.0 * k + 4.0) / (2.0 * k + 3.0) / hi;
+      C.c[k] = k ? (2.0 * k - 1.0) / (2.0 * k + 3.0) : 0.0;
+    }
+    return C;
+  }
+  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
   double r_old = 1.0 / sigma;
   C.a[0] = 1.0 / theta; C.c[0] = 0.0;
   for (int k = 1; k < 4; ++k) {
@@ -596,6 +560,9 @@ extern "C" int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int rest
   HX_HIP(hipMalloc((void**)&R.U, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
   HX_HIP(hipMalloc((void**)&R.CV, sizeof(hx_c128) * (size_t)(k_max + restart + 1) * (size_t)n));
   HX_HIP(hipMalloc((void**)&R.CVf, sizeof(hx_c64) * (size_t)(k_max + restart + 1) * (size_t)n));
+  HX_HIP(hipMalloc((void**)&R.Uf, sizeof(hx_c64) * (size_t)k_max * (size_t)n));
+  HX_HIP(hipMalloc((void**)&R.Cd, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
+  HX_HIP(hipMalloc((void**)&R.Einv, sizeof(hx_c128) * (size_t)k_max * (size_t)k_max));
   R.kmax = k_max; R.k = 0; R.n = n; R.restart = restart; R.m_last = 0;
   R.Hraw.assign((size_t)(restart + 1) * restart, cd(0));
   return HX_OK;
@@ -628,6 +595,7 @@ extern "C" int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const 
   int rc;
   HX_HIP(hipMemcpyAsync(coef, Ucoef, sizeof(hx_c128) * (size_t)m * k, hipMemcpyHostToDevice, hx_s(s)));
   rc = hx_zpanel_mul(n, m, k, Z, n, coef, R.U, n, s);
+  if (!rc) rc = hx_cast_z2c((int64_t)k * n, R.U, R.Uf, s);
   HX_HIP(hipStreamSynchronize(hx_s(s)));
   if (!rc) {
     HX_HIP(hipMemcpyAsync(coef, Ccoef, sizeof(hx_c128) * (size_t)(m + 1) * k, hipMemcpyHostToDevice, hx_s(s)));
@@ -639,7 +607,7 @@ extern "C" int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const 
   }
   (void)hipFree(coef);
   if (rc) return rc;
-  R.k = k; R.m_last = 0;
+  R.k = k; R.m_last = 0; R.have_E = false;
   return HX_OK;
 }
 

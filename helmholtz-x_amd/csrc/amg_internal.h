@@ -1,0 +1,61 @@
+// Private structures of the AMG handle, shared by amg.hip (V-cycle, flexible GMRES) and cocg.hip (deflated COCG).
+#pragma once
+#include <complex>
+#include <vector>
+
+#include "hx_common.h"
+
+struct hx_sell;
+
+// T = double: complex128 hierarchy; T = float: complex64 copy of it (values interleaved re, im: 2 T per entry).
+template <typename T> struct CsrT { int32_t rows = 0; int64_t nnz = 0; const int32_t* rp = nullptr; const int32_t* ci = nullptr; const T* va = nullptr; };
+template <typename T> struct LevelT {
+  int32_t n = 0;
+  CsrT<T> K, P, R;             // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
+  const T* dinv = nullptr;
+  double rho = 0.0;            // estimate of rho(D^-1 K) for the Chebyshev smoother (0: damped Jacobi with h->omega)
+  const hx_sell* sell = nullptr;   // optional SELL-64 companion of K (fine level): used for the K products
+  T *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
+  bool ext_x = false, ext_b = false;   // x/x2/x3 (resp. b) are caller-owned (row-sharded mode)
+};
+template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
+
+typedef std::complex<double> cd;
+// Recycled pairs of the GCRO variant of hx_gmres (K U = C, C^H C = I) and the panel that holds [C; V].
+struct Recycle {
+  int kmax = 0, k = 0, restart = 0, m_last = 0;
+  int64_t n = 0;
+  hx_c128* U = nullptr;        // kmax x n
+  hx_c128* CV = nullptr;       // (kmax + restart + 1) x n : rows [0, k) = C, then the Arnoldi vectors
+  float* CVf = nullptr;        // complex64 copy of CV, read by the inner-product passes (hx_zpanel_dot_c64)
+  // hx_cocg deflates with the pairs (Ut, Cd): Ut = U ROUNDED to complex64 (kept in that format: exactly representable),
+  // Cd = K Ut recomputed in complex128 -- an exactly consistent pair, which the K-conjugacy of the recurrence needs
+  float* Uf = nullptr;         // Ut, kmax x n complex64
+  hx_c128* Cd = nullptr;       // K Ut, kmax x n complex128 (built on first use)
+  hx_c128* Einv = nullptr;     // device copy of (Ut^T K Ut)^-1, k x k row-major (built on first use)
+  bool have_E = false;
+  std::vector<cd> Hraw;        // raw Hessenberg of the last first cycle, column-major, ld = restart + 1
+};
+// Row-sharded mode (one process per GPU): level 0 holds this rank's rows over [owned | ghost] columns, every coarser
+// level is replicated.  The two exchange steps of the path are delegated to the host side (torch.distributed over
+// RCCL): `halo(ctx, id)` fills the ghost block of registered buffer `id`, `allreduce(ctx, id, count)` sums a registered
+// buffer over the ranks.  Both are enqueued on / ordered against the stream the kernels run on.
+struct hx_amg {
+  HierT<double> D;
+  HierT<float> S;
+  bool single = false;         // run the V-cycle on the complex64 copy
+  int pre = 2, post = 2;
+  double omega = 0.6;
+  bool sharded = false;
+  hx_halo_fn halo = nullptr;
+  hx_allreduce_fn allreduce = nullptr;
+  void* ctx = nullptr;
+  int32_t n_ext = 0;           // owned + ghost length of the level-0 iterates
+  Recycle rec;
+  // hipGraph of the complex64 V-cycle (all buffers of the cycle are owned by the handle, so the ~45 launches of one cycle
+  // are captured once and replayed): for small and mid-size problems, where the cycle is launch-bound
+  int graph_state = -1;        // -1 off, 0 requested (capture at the next cycle), 1 ready
+  hipGraphExec_t vexec = nullptr;
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+};

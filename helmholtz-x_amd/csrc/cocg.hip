@@ -1,0 +1,326 @@
+// Deflated, preconditioned COCG (conjugate orthogonal conjugate gradients) for the shifted operator K (complex128).
+//
+// K = A + sigma B + sigma^2 C of the shift-invert solve (eigensolvers.py:49-50,102-103 -> PCLU in the reference) is
+// complex SYMMETRIC (K^T = K, not Hermitian), and the V-cycle with equal pre/post Chebyshev smoothing and R = P^T is a
+// complex symmetric operator too.  COCG is CG in the bilinear form x^T y: three-term recurrences, so no Gram-Schmidt
+// panel -- the CGS2 passes were 36 % of the kernel time of a 5 M-DOF fixed-point call with flexible GMRES.  Per
+// iteration: 1 operator product, 1 V-cycle, 2 reductions and 2 fused vector updates.
+//
+// Deflation replaces the subspace recycling of hx_gmres: with pairs (U, C = K U) and E = U^T K U every search direction
+// is kept K-conjugate to span(U),  p = z - U E^-1 C^T z + beta p,  and the iteration starts from the Galerkin guess
+// x0 = U E^-1 U^T b.  The recurrence needs K U = C to hold to working precision: with complex64 MIRRORS of the harvested
+// pairs the residual leaves the deflated space at the 1e-8 level and the iteration diverges from there (measured).
+// So U is ROUNDED to complex64 once (the rounded vectors are exactly representable, and any basis of nearly the same
+// space deflates as well), and C = K U is recomputed from the rounded vectors in complex128: an exactly consistent pair
+// whose U half streams 8 bytes per entry.  All scalars (rho, alpha, beta, the k deflation coefficients) live on the
+// device; the host reads one number per iteration (|r|^2) for the stopping test.
+//
+// A breakdown (p^T K p = 0 or r^T z = 0: possible in the bilinear form) or a stall is reported as HX_ERR_BREAKDOWN; the
+// caller then repeats the solve with hx_gmres.
+#include <cmath>
+#include <cstdlib>
+
+#include "amg_internal.h"
+
+struct hx_sell;
+extern "C" int hx_sell_spmv_z(const hx_sell*, const hx_c128*, hx_c128*, const double*, const double*, hx_stream);
+int hx_zpanel_bdot(int64_t, int, const hx_c128*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
+int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
+int hx_zpanel_bdot_c64(int64_t, int, const hx_c64*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
+int hx_panel_dot_blocks(int64_t n, int64_t* rows_per_block);
+int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* out, hx_stream s);
+
+static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 0.0};
+
+// Scalar block on the device (complex128 entries): OUT = raw reduction results (always at the FRONT: in row-sharded mode
+// the all-reduce callback sums the first `count` entries of the registered buffer), ST = state, T = deflation coefficients.
+#define CG_OUT 0      // [0, 33): dot results
+#define CG_RHO 34     // r^T z of the current iterate
+#define CG_BETA 35
+#define CG_T 40       // [40, 72): t = E^-1 C^T z
+#define CG_SCALARS 72
+#define CG_MAXK 32
+
+// x += alpha p, r -= alpha q with alpha = rho / (p^T q) read from the device; per-block partial sums of |r|^2.
+__global__ void __launch_bounds__(256)
+k_cocg_update(int64_t n, const zc* __restrict__ p, const zc* __restrict__ q, zc* __restrict__ x, zc* __restrict__ r,
+              const zc* __restrict__ sc, zc* __restrict__ partials, int64_t rows_per_block) {
+  __shared__ double red[256 / HX_WAVE];
+  const zc alpha = zdiv(sc[CG_RHO], sc[CG_OUT]);
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  double acc = 0.0;
+  for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+    zc xv = x[i], rv = r[i];
+    const zc pv = p[i], qv = q[i];
+    zfma(xv, alpha, pv);
+    rv.x = fma(-alpha.x, qv.x, rv.x); rv.x = fma(alpha.y, qv.y, rv.x);
+    rv.y = fma(-alpha.x, qv.y, rv.y); rv.y = fma(-alpha.y, qv.x, rv.y);
+    x[i] = xv; r[i] = rv;
+    acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+  }
+#pragma unroll
+  for (int o = HX_WAVE / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, HX_WAVE);
+  if ((threadIdx.x & (HX_WAVE - 1)) == 0) red[threadIdx.x / HX_WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = red[0];
+    for (int w = 1; w < 256 / HX_WAVE; ++w) v += red[w];
+    partials[blockIdx.x] = make_double2(v, 0.0);
+  }
+}
+
+// After the reduction of [C^T z ; r^T z]: beta = rho_new / rho (0 on the first step), rho = rho_new, t = sign * E^-1 c.
+// mode 0: direction update (sign +, with beta); mode 1: Galerkin start (t = -E^-1 U^T b so that x = 0 - U t ... ), no rho.
+__global__ void __launch_bounds__(HX_WAVE)
+k_cocg_small(int k, const zc* __restrict__ Einv, zc* __restrict__ sc, int first, int mode) {
+  const int i = threadIdx.x;
+  if (i < k) {
+    zc t = make_double2(0.0, 0.0);
+    for (int j = 0; j < k; ++j) zfma(t, Einv[i * k + j], sc[CG_OUT + j]);
+    if (mode == 1) t = make_double2(-t.x, -t.y);
+    sc[CG_T + i] = t;
+  }
+  if (i == 0 && mode == 0) {
+    const zc rho_new = sc[CG_OUT + k];
+    sc[CG_BETA] = first ? make_double2(0.0, 0.0) : zdiv(rho_new, sc[CG_RHO]);
+    sc[CG_RHO] = rho_new;
+  }
+}
+
+// p = z - sum_j t_j U_j + beta p   (U read from its complex64 mirror; t and beta from the device scalar block)
+__global__ void __launch_bounds__(256)
+k_cocg_direction(int64_t n, int k, const cc* __restrict__ Uf, int64_t ldu, const zc* __restrict__ z, zc* __restrict__ p,
+                 const zc* __restrict__ sc) {
+  __shared__ zc ts[CG_MAXK];
+  if ((int)threadIdx.x < k) ts[threadIdx.x] = sc[CG_T + threadIdx.x];
+  __syncthreads();
+  const zc beta = sc[CG_BETA];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    zc acc = z[i];
+    if (beta.x != 0.0 || beta.y != 0.0) zfma(acc, beta, p[i]);
+    for (int j = 0; j < k; ++j) {
+      const cc u = Uf[(int64_t)j * ldu + i];
+      const zc v = make_double2((double)u.x, (double)u.y), tj = ts[j];
+      acc.x = fma(-v.x, tj.x, acc.x); acc.x = fma(v.y, tj.y, acc.x);
+      acc.y = fma(-v.x, tj.y, acc.y); acc.y = fma(-v.y, tj.x, acc.y);
+    }
+    p[i] = acc;
+  }
+}
+
+// x -= sum_j t_j U_j
+__global__ void __launch_bounds__(256)
+k_cocg_start(int64_t n, int k, const cc* __restrict__ U, int64_t ldu, zc* __restrict__ x, const zc* __restrict__ sc) {
+  __shared__ zc ts[CG_MAXK];
+  if ((int)threadIdx.x < k) ts[threadIdx.x] = sc[CG_T + threadIdx.x];
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    zc acc = x[i];
+    for (int j = 0; j < k; ++j) {
+      const cc u = U[(int64_t)j * ldu + i];
+      const zc v = make_double2((double)u.x, (double)u.y), tj = ts[j];
+      acc.x = fma(-v.x, tj.x, acc.x); acc.x = fma(v.y, tj.y, acc.x);
+      acc.y = fma(-v.x, tj.y, acc.y); acc.y = fma(-v.y, tj.x, acc.y);
+    }
+    x[i] = acc;
+  }
+}
+
+extern "C" size_t hx_cocg_ws(int64_t n) {
+  return 5 * (size_t)n + hx_panel_dot_ws(CG_MAXK + 1) + CG_SCALARS + 8;
+}
+
+// small dense complex inverse (Gauss-Jordan with partial pivoting), row-major k x k; returns false if singular
+static bool invert_small(std::vector<cd>& A, int k) {
+  std::vector<cd> I((size_t)k * k, cd(0));
+  for (int i = 0; i < k; ++i) I[(size_t)i * k + i] = 1.0;
+  for (int c = 0; c < k; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < k; ++r) if (std::abs(A[(size_t)r * k + c]) > std::abs(A[(size_t)piv * k + c])) piv = r;
+    if (std::abs(A[(size_t)piv * k + c]) == 0.0) return false;
+    if (piv != c) for (int j = 0; j < k; ++j) { std::swap(A[(size_t)piv * k + j], A[(size_t)c * k + j]); std::swap(I[(size_t)piv * k + j], I[(size_t)c * k + j]); }
+    const cd d = 1.0 / A[(size_t)c * k + c];
+    for (int j = 0; j < k; ++j) { A[(size_t)c * k + j] *= d; I[(size_t)c * k + j] *= d; }
+    for (int r = 0; r < k; ++r) {
+      if (r == c) continue;
+      const cd f = A[(size_t)r * k + c];
+      if (f == cd(0)) continue;
+      for (int j = 0; j < k; ++j) { A[(size_t)r * k + j] -= f * A[(size_t)c * k + j]; I[(size_t)r * k + j] -= f * I[(size_t)c * k + j]; }
+    }
+  }
+  A.swap(I);
+  return true;
+}
+
+static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+                     const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it, hx_c128* ws,
+                     hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s) {
+  HX_REQUIRE(M && n > 0 && rowptr && col && val && b && x && ws && max_it >= 1, "bad argument");
+  HX_REQUIRE(M->pre == M->post, "hx_cocg needs a symmetric V-cycle (pre == post smoothing steps)");
+  const bool sharded = xe != nullptr;
+  HX_REQUIRE(!sharded || (M->sharded && hbuf), "row-sharded COCG needs a sharded preconditioner handle");
+  HX_REQUIRE(sharded || !M->sharded, "use hx_cocg_sharded with a row-sharded preconditioner");
+  Recycle* rec = (M->rec.kmax > 0 && M->rec.k > 0) ? &M->rec : nullptr;
+  HX_REQUIRE(!rec || rec->n == n, "deflation pairs were harvested for another n");
+  const int k = rec ? rec->k : 0;
+  HX_REQUIRE(k <= CG_MAXK, "too many deflation pairs");
+  hx_c128 *r = ws, *p = r + n, *q = p + n, *z = q + n, *tmp = z + n;
+  hx_c128* part = tmp + n;
+  hx_c128* sc = sharded ? hbuf : part + hx_panel_dot_ws(CG_MAXK + 1);
+  const int sc_buf = HX_BUF_GMRES_DOTS;
+  int64_t rpb;
+  const int nblocks = hx_panel_dot_blocks(n, &rpb);
+  int rc;
+  auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) -> int {
+    if (sharded) {
+      HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+      if (M->halo(M->ctx, HX_BUF_GMRES_XE) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
+      in = xe;
+    }
+    if (Ksell) return hx_sell_spmv_z(Ksell, in, out, a, bt, s);
+    return hx_csr_spmv_z(n, nnz, rowptr, col, val, in, out, a, bt, 0, s);
+  };
+  auto reduce = [&](int count) -> int {       // sum the first `count` scalars over the ranks
+    if (sharded && M->allreduce(M->ctx, sc_buf, count) != 0)
+      return hx_fail(HX_ERR_COMM, "hx_cocg", "all-reduce callback failed");
+    return HX_OK;
+  };
+  cd host[CG_MAXK + 2];
+  auto fetch = [&](int count) -> int {        // first `count` scalars -> host (SYNC)
+    HX_HIP(hipMemcpyAsync(host, sc, sizeof(cd) * (size_t)count, hipMemcpyDeviceToHost, hx_s(s)));
+    HX_HIP(hipStreamSynchronize(hx_s(s)));
+    return HX_OK;
+  };
+  static const bool trace = getenv("HX_GMRES_TRACE") != nullptr;
+
+  // ---- once per harvested set: Cd = K Ut (Ut = the complex64-rounded U), E = Cd^T Ut (bilinear) and its inverse
+  if (rec && !rec->have_E) {
+    std::vector<cd> E((size_t)k * k);
+    for (int j = 0; j < k; ++j) {
+      if ((rc = hx_cast_c2z(n, rec->Uf + 2 * (size_t)j * n, tmp, s))) return rc;      // Ut_j widened (exact)
+      if ((rc = Kx(tmp, rec->Cd + (size_t)j * n, ONE, ZERO))) return rc;
+    }
+    for (int j = 0; j < k; ++j) {             // column j: Cd_i^T Ut_j for all i
+      if ((rc = hx_cast_c2z(n, rec->Uf + 2 * (size_t)j * n, tmp, s))) return rc;
+      if ((rc = hx_zpanel_bdot(n, k, rec->Cd, n, tmp, tmp, sc, part, s))) return rc;
+      if ((rc = reduce(k))) return rc;
+      if ((rc = fetch(k))) return rc;
+      for (int i = 0; i < k; ++i) E[(size_t)i * k + j] = host[i];     // E[i][j] = (K Ut_i)^T Ut_j, symmetric for K^T = K
+    }
+    if (!invert_small(E, k)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "singular deflation matrix U^T K U");
+    HX_HIP(hipMemcpyAsync(rec->Einv, E.data(), sizeof(cd) * (size_t)k * k, hipMemcpyHostToDevice, hx_s(s)));
+    HX_HIP(hipStreamSynchronize(hx_s(s)));
+    rec->have_E = true;
+  }
+
+  // ---- |b|
+  if ((rc = hx_zpanel_dot(n, 0, nullptr, n, b, sc, part, s))) return rc;
+  if ((rc = reduce(1))) return rc;
+  if ((rc = fetch(1))) return rc;
+  const double bnorm = std::sqrt(host[0].real());
+  if (!(bnorm > 0.0)) {
+    HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
+    if (h_iters) *h_iters = 0;
+    if (h_relres) *h_relres = 0.0;
+    return bnorm == 0.0 ? HX_OK : hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "right-hand side is not finite");
+  }
+
+  int it = 0;
+  double relres = 1.0;
+  bool converged = false, x_zero = true;
+  auto true_residual = [&]() -> int {        // r = b - K x, relres = |r| / |b|  (SYNC)
+    HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+    if (!x_zero) { if ((rc = Kx(x, r, MONE, ONE))) return rc; }
+    if ((rc = hx_zpanel_dot(n, 0, nullptr, n, r, sc, part, s))) return rc;
+    if ((rc = reduce(1))) return rc;
+    if ((rc = fetch(1))) return rc;
+    relres = std::sqrt(host[0].real()) / bnorm;
+    return HX_OK;
+  };
+  HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
+  // A cycle = one run of the recurrences.  It ends when the recurrence residual meets the tolerance, when it reaches
+  // the attainable accuracy (a right-hand side close to the eigenvector next to the shift has a solution 1e4..1e5
+  // times larger than b, so eps * cond bounds the residual near 1e-11 |b|: progress stops there and the deflated
+  // recurrence would drift away again), or when it starts to grow.  Each new cycle measures the TRUE residual,
+  // accepts it within 10 rtol (as hx_gmres does), and otherwise re-projects on span(U) and restarts from x.
+  for (int cycle = 0; cycle < 4 && it < max_it; ++cycle) {
+    if ((rc = true_residual())) return rc;
+    if (trace) fprintf(stderr, "[hx_cocg] cycle %d start  true relres %.3e\n", cycle, relres);
+    if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "non-finite residual");
+    if (relres <= (cycle == 0 ? rtol : 10 * rtol)) { converged = true; break; }
+    if (k > 0) {     // Galerkin correction on span(U): x += U E^-1 U^T r, so that U^T r = 0 again
+      if ((rc = hx_zpanel_bdot_c64(n, k, (const hx_c64*)rec->Uf, n, r, r, sc, part, s))) return rc;   // U^T r (entry k unused)
+      if ((rc = reduce(k))) return rc;
+      k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, (const zc*)rec->Einv, (zc*)sc, 1, 1);
+      HX_LAUNCH_CHECK("k_cocg_small");
+      k_cocg_start<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const cc*)rec->Uf, n, (zc*)x, (const zc*)sc);
+      HX_LAUNCH_CHECK("k_cocg_start");
+      x_zero = false;
+      if ((rc = true_residual())) return rc;
+      if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "non-finite residual");
+    }
+    bool first = true;
+    double best = relres, prev = relres;
+    int since_best = 0;
+    while (it < max_it) {
+      // z = M r ;  [c ; rho] = [C^T z ; r^T z] ;  t = E^-1 c, beta ;  p = z - U t + beta p
+      if ((rc = hx_amg_vcycle(M, r, z, s))) return rc;
+      if (k > 0) { if ((rc = hx_zpanel_bdot(n, k, rec->Cd, n, z, r, sc, part, s))) return rc; }
+      else if ((rc = hx_zpanel_bdot(n, 0, nullptr, n, z, r, sc, part, s))) return rc;
+      if ((rc = reduce(k + 1))) return rc;
+      k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, rec ? (const zc*)rec->Einv : nullptr, (zc*)sc, first ? 1 : 0, 0);
+      HX_LAUNCH_CHECK("k_cocg_small");
+      k_cocg_direction<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, rec ? (const cc*)rec->Uf : nullptr, n, (const zc*)z,
+                                                            (zc*)p, (const zc*)sc);
+      HX_LAUNCH_CHECK("k_cocg_direction");
+      first = false;
+      // q = K p ;  alpha = rho / p^T q ;  x += alpha p, r -= alpha q, |r|^2
+      if ((rc = Kx(p, q, ONE, ZERO))) return rc;
+      if ((rc = hx_zpanel_bdot(n, 0, nullptr, n, q, p, sc, part, s))) return rc;
+      if ((rc = reduce(1))) return rc;
+      k_cocg_update<<<nblocks, 256, 0, hx_s(s)>>>(n, (const zc*)p, (const zc*)q, (zc*)x, (zc*)r, (const zc*)sc, (zc*)part, rpb);
+      HX_LAUNCH_CHECK("k_cocg_update");
+      x_zero = false;
+      if ((rc = hx_panel_dot_finish(nblocks, 0, part, sc, s))) return rc;
+      if ((rc = reduce(1))) return rc;
+      if ((rc = fetch(1))) return rc;
+      ++it;
+      relres = std::sqrt(host[0].real()) / bnorm;
+      if (trace) fprintf(stderr, "[hx_cocg] it %3d  relres %.3e\n", it, relres);
+      if (h_iters) *h_iters = it;
+      if (h_relres) *h_relres = relres;
+      if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "breakdown (p^T K p = 0 or r^T z = 0)");
+      if (relres <= rtol) break;
+      if (relres <= 10 * rtol && relres > 0.5 * prev) break;          // attainable accuracy reached inside the acceptance band
+      prev = relres;
+      if (relres < best) { best = relres; since_best = 0; }
+      else {
+        ++since_best;
+        if (since_best >= 3 && best <= 1e3 * rtol) break;               // drifting away from a nearly converged iterate
+        if (since_best >= 25 || relres > 1e6 * best)
+          return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "stalled (no progress in 25 iterations) or diverging");
+      }
+    }
+  }
+  if (!converged) {                           // iteration / cycle limit: report the true residual of what we have
+    if ((rc = true_residual())) return rc;
+  }
+  if (h_iters) *h_iters = it;
+  if (h_relres) *h_relres = relres;
+  return HX_OK;
+}
+
+extern "C" int hx_cocg(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+                       const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it, hx_c128* ws,
+                       int* h_iters, double* h_relres, hx_stream s) {
+  return cocg_impl(M, n, nnz, rowptr, col, val, Ksell, b, x, rtol, max_it, ws, nullptr, nullptr, h_iters, h_relres, s);
+}
+extern "C" int hx_cocg_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                               const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol,
+                               int max_it, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres,
+                               hx_stream s) {
+  HX_REQUIRE(M && M->sharded && xe && hbuf, "bad argument");
+  return cocg_impl(M, n_own, nnz, rowptr, col, val, Ksell, b, x, rtol, max_it, ws, xe, hbuf, h_iters, h_relres, s);
+}

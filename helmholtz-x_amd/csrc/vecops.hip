@@ -116,16 +116,19 @@ __device__ __forceinline__ zc pd_load(const cc* p) { const cc v = *p; return mak
 // PT = zc: complex128 panel.  PT = cc: a complex64 COPY of the panel (half the traffic); w and the accumulation stay
 // complex128.  The coefficients then carry a 6e-8 relative error, which classical Gram-Schmidt applied twice removes:
 // the subtraction w -= V h always uses the complex128 panel, so the Arnoldi relation holds for whatever h was used.
-template <typename PT, int JT>
+// BILIN: unconjugated products out[j] = V_j^T w and out[k] = e^T w for a separate vector e (the bilinear form of complex
+// symmetric Krylov methods, hx_cocg); otherwise e is w itself and all products are conjugated (Gram-Schmidt).
+template <typename PT, int JT, bool BILIN>
 __global__ void __launch_bounds__(PD_BLOCK)
 k_panel_dot_stage1(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, const zc* __restrict__ w,
-                   zc* __restrict__ partials, int64_t rows_per_block) {
+                   const zc* __restrict__ e, zc* __restrict__ partials, int64_t rows_per_block) {
   __shared__ zc red[PD_BLOCK / HX_WAVE][JT];
   const int64_t r0 = blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
   const int lane = threadIdx.x & (HX_WAVE - 1), wv = threadIdx.x / HX_WAVE;
-  for (int j0 = 0; j0 <= k; j0 += JT) {           // column k is w itself (w^H w)
+  auto acc_fma = [](zc& a, zc v, zc x) { if (BILIN) zfma(a, v, x); else zcfma(a, v, x); };
+  for (int j0 = 0; j0 <= k; j0 += JT) {           // column k is w itself (w^H w) or the extra vector (e^T w)
     zc acc[JT];
 #pragma unroll
     for (int t = 0; t < JT; ++t) acc[t] = make_double2(0.0, 0.0);
@@ -137,9 +140,12 @@ k_panel_dot_stage1(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, cons
         const int j = j0 + t;
         if (j < k) {
           const zc va = pd_load(V + (int64_t)j * ldv + i), vb = pd_load(V + (int64_t)j * ldv + i + PD_BLOCK);
-          zcfma(acc[t], va, wa);
-          zcfma(acc[t], vb, wb);
-        } else if (j == k) { zcfma(acc[t], wa, wa); zcfma(acc[t], wb, wb); }
+          acc_fma(acc[t], va, wa);
+          acc_fma(acc[t], vb, wb);
+        } else if (j == k) {
+          if (BILIN) { acc_fma(acc[t], e[i], wa); acc_fma(acc[t], e[i + PD_BLOCK], wb); }
+          else { zcfma(acc[t], wa, wa); zcfma(acc[t], wb, wb); }
+        }
       }
     }
     for (; i < r1; i += PD_BLOCK) {
@@ -147,8 +153,8 @@ k_panel_dot_stage1(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, cons
 #pragma unroll
       for (int t = 0; t < JT; ++t) {
         const int j = j0 + t;
-        if (j < k) zcfma(acc[t], pd_load(V + (int64_t)j * ldv + i), wi);
-        else if (j == k) zcfma(acc[t], wi, wi);
+        if (j < k) acc_fma(acc[t], pd_load(V + (int64_t)j * ldv + i), wi);
+        else if (j == k) { if (BILIN) acc_fma(acc[t], e[i], wi); else zcfma(acc[t], wi, wi); }
       }
     }
 #pragma unroll
@@ -174,27 +180,47 @@ k_panel_dot_stage2(int nblocks, int k, const zc* __restrict__ partials, zc* __re
   v = zreduce_sub<HX_WAVE>(v);
   if (threadIdx.x == 0) out[j] = v;
 }
-template <typename PT, int JT>
-static int panel_dot_launch(int64_t n, int k, const PT* V, int64_t ldv, const hx_c128* w, hx_c128* out, hx_c128* partials,
-                            hx_stream s) {
-  HX_REQUIRE(n > 0 && k >= 0 && w && out && partials && (k == 0 || V) && ldv >= n, "bad argument");
+// number of stage-1 blocks (= partial sums per column) for vectors of length n
+int hx_panel_dot_blocks(int64_t n, int64_t* rows_per_block) {
   int64_t rpb = (n + PD_MAXBLOCKS - 1) / PD_MAXBLOCKS;
   if (rpb < PD_BLOCK * 4) rpb = PD_BLOCK * 4;
-  int nblocks = (int)((n + rpb - 1) / rpb);
-  k_panel_dot_stage1<PT, JT><<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, V, ldv, (const zc*)w, (zc*)partials, rpb);
-  HX_LAUNCH_CHECK("k_panel_dot_stage1");
+  if (rows_per_block) *rows_per_block = rpb;
+  return (int)((n + rpb - 1) / rpb);
+}
+// fixed-order sum of per-block partials (k + 1 columns) -> out
+int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* out, hx_stream s) {
   k_panel_dot_stage2<<<k + 1, HX_WAVE, 0, hx_s(s)>>>(nblocks, k, (const zc*)partials, (zc*)out);
   HX_LAUNCH_CHECK("k_panel_dot_stage2");
   return HX_OK;
 }
+template <typename PT, int JT, bool BILIN>
+static int panel_dot_launch(int64_t n, int k, const PT* V, int64_t ldv, const hx_c128* w, const hx_c128* e, hx_c128* out,
+                            hx_c128* partials, hx_stream s) {
+  HX_REQUIRE(n > 0 && k >= 0 && w && out && partials && (k == 0 || V) && ldv >= n && (!BILIN || e), "bad argument");
+  int64_t rpb;
+  const int nblocks = hx_panel_dot_blocks(n, &rpb);
+  k_panel_dot_stage1<PT, JT, BILIN><<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, V, ldv, (const zc*)w, (const zc*)e,
+                                                                      (zc*)partials, rpb);
+  HX_LAUNCH_CHECK("k_panel_dot_stage1");
+  return hx_panel_dot_finish(nblocks, k, partials, out, s);
+}
 extern "C" int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, hx_c128* out,
                              hx_c128* partials, hx_stream s) {
-  return panel_dot_launch<zc, PD_JT>(n, k, (const zc*)V, ldv, w, out, partials, s);
+  return panel_dot_launch<zc, PD_JT, false>(n, k, (const zc*)V, ldv, w, nullptr, out, partials, s);
 }
 extern "C" int hx_zpanel_dot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_c128* w, hx_c128* out,
                                  hx_c128* partials, hx_stream s) {
-  return panel_dot_launch<cc, PD_JT>(   // (a 16-wide register tile was measured: 371 vs 223 us per launch)
-      n, k, (const cc*)Vf, ldv, w, out, partials, s);
+  return panel_dot_launch<cc, PD_JT, false>(   // (a 16-wide register tile was measured: 371 vs 223 us per launch)
+      n, k, (const cc*)Vf, ldv, w, nullptr, out, partials, s);
+}
+// Bilinear variants (internal; hx_cocg): out[j] = V_j^T w for j < k, out[k] = e^T w.
+int hx_zpanel_bdot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, const hx_c128* e, hx_c128* out,
+                   hx_c128* partials, hx_stream s) {
+  return panel_dot_launch<zc, PD_JT, true>(n, k, (const zc*)V, ldv, w, e, out, partials, s);
+}
+int hx_zpanel_bdot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_c128* w, const hx_c128* e, hx_c128* out,
+                       hx_c128* partials, hx_stream s) {
+  return panel_dot_launch<cc, PD_JT, true>(n, k, (const cc*)Vf, ldv, w, e, out, partials, s);
 }
 
 // ---------------------------------------------------------------- w -= V h

@@ -21,6 +21,7 @@ _dp = C.POINTER(C.c_double)
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)                # hx_halo_fn
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)   # hx_allreduce_fn
 BUF_VCYCLE_X0, BUF_COARSE_RHS, BUF_GMRES_XE, BUF_GMRES_DOTS = 0, 3, 4, 5
+ERR_BREAKDOWN = -5
 
 SIGNATURES = {
     "hx_version": (C.c_int, []),
@@ -86,6 +87,11 @@ SIGNATURES = {
     "hx_gmres_ws": (C.c_size_t, [_i64, _int]),
     "hx_gmres": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp,
                            C.POINTER(_int), C.POINTER(C.c_double), _vp]),
+    "hx_cocg_ws": (C.c_size_t, [_i64]),
+    "hx_cocg": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _vp,
+                          C.POINTER(_int), C.POINTER(C.c_double), _vp]),
+    "hx_cocg_sharded": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _vp, _vp, _vp,
+                                  C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_amg_set_level_sell": (C.c_int, [_vp, _int, _vp]),
     "hx_amg_enable_recycling": (C.c_int, [_vp, _i64, _int, _int]),
     "hx_gmres_hessenberg": (C.c_int, [_vp, C.POINTER(_int), _vp]),

@@ -24,8 +24,8 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, vcycle_values="fp16", graph_max_rows=0, recycle=6,
-              recycle_min_rows=100_000)
+              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, vcycle_values="fp16", graph_max_rows=0, recycle=8,
+              recycle_min_rows=100_000, krylov="auto")
 
 
 MAX_DENSE_COARSE = 6000          # the coarsest operator is inverted densely on the host
@@ -122,6 +122,21 @@ def _spectral_radius_dinv(Lf, iters=None, seed=0):
     return rho.value
 
 
+def _is_complex_symmetric(K, tol=1e-11):
+    """x^T K y == y^T K x for two random device vectors (bilinear form, no conjugation): K^T = K up to rounding."""
+    n = K.shape[0]
+    gen = torch.Generator(device=K.val.device)
+    gen.manual_seed(20260101)
+    x, y = (torch.view_as_complex(torch.randn((n, 2), generator=gen, device=K.val.device, dtype=torch.float64))
+            for _ in range(2))
+    kx, ky = torch.empty_like(x), torch.empty_like(x)
+    K.spmv(x, kx)
+    K.spmv(y, ky)
+    a, b = complex(torch.dot(y, kx)), complex(torch.dot(x, ky))
+    scale = float(torch.linalg.vector_norm(kx) * torch.linalg.vector_norm(y))
+    return abs(a - b) <= tol * max(scale, 1e-300)
+
+
 def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], coarse_size=PARAMS["coarse_size"]):
     """K: scipy CSR (complex).  Returns a list of dicts {K, n, dinv, P, R, omega, n_coarse} (host scipy objects),
     finest first.  Graph passes (filter, aggregation, prolongator) are native host code in libhx; the Galerkin
@@ -208,6 +223,13 @@ class AMGSolver:
                                                                            self.params["max_levels"],
                                                                            self.params["coarse_size"])
         self.levels = levels
+        # Krylov method of the inner solve: complex symmetric K (every shifted operator of the path except the
+        # Bloch-reduced ones) + symmetric V-cycle (pre == post) -> deflated COCG (short recurrences, hx_cocg);
+        # otherwise flexible GMRES.  "auto" probes the symmetry of the bilinear form with two random vectors.
+        kry = os.environ.get("HX_AMG_KRYLOV", self.params["krylov"])
+        self.use_cocg = len(levels) > 1 and self.params["pre"] == self.params["post"] and (
+            kry == "cocg" or (kry == "auto" and _is_complex_symmetric(K_global)))
+        self.cocg_solves = self.cocg_fallbacks = self.cocg_iters = 0
         if shard is not None:
             if len(levels) < 2:
                 raise ValueError("row-sharded AMG needs at least one coarse level (problem too small to shard)")
@@ -297,7 +319,7 @@ class AMGSolver:
             self._bufs = {0: shard.ext_vector(cdt), 1: shard.ext_vector(cdt), 2: shard.ext_vector(cdt),
                           _hx.BUF_COARSE_RHS: torch.zeros(n1, dtype=cdt, device=dev),
                           _hx.BUF_GMRES_XE: shard.ext_vector(torch.complex128),
-                          _hx.BUF_GMRES_DOTS: torch.zeros(self.params["restart"] + 2 + 32, dtype=torch.complex128,
+                          _hx.BUF_GMRES_DOTS: torch.zeros(max(self.params["restart"] + 2 + 32, 80), dtype=torch.complex128,
                                                           device=dev)}
             self._cb = ShardedCallbacks(shard, self._bufs)
             _hx.check(_hx.lib.hx_amg_set_sharded(h, shard.n_ext, _hx.ptr(self._bufs[0]), _hx.ptr(self._bufs[1]),
@@ -307,7 +329,8 @@ class AMGSolver:
         gmax = int(os.environ.get("HX_AMG_GRAPH_MAX_ROWS", self.params["graph_max_rows"]))
         if mixed and shard is None and len(levels) > 1 and self.n <= gmax:
             _hx.check(_hx.lib.hx_amg_enable_graph(h, 1))
-        self.ws = torch.empty(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), dtype=torch.complex128, device=dev)
+        self.ws = torch.empty(max(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), _hx.lib.hx_cocg_ws(self.n)),
+                              dtype=torch.complex128, device=dev)
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
         # subspace recycling (all solves of a fixed-point call share K): worth its panel rows once the hierarchy is deep
         # enough for the preconditioned operator to show a few near-null modes (measured: plateau of 5 its at 1 M DOF,
@@ -334,8 +357,26 @@ class AMGSolver:
         import time
         t0 = time.perf_counter()
         it, rr = C.c_int(0), C.c_double(0.0)
-        K = self.K
         rtol = self.params["rtol"] * max(float(relax), 1.0)
+        # deflated COCG once the deflation pairs exist (or when none are wanted); the first solve of a hierarchy runs
+        # GMRES, whose Hessenberg matrix yields the harmonic Ritz vectors both methods recycle
+        done = False
+        if self.use_cocg and (self.recycle_k == 0 or self.recycled):
+            done = self._solve_cocg(b, x, rtol, it, rr)
+        if not done:
+            self._solve_gmres(b, x, rtol, it, rr)
+        if self.recycle_k > 0 and not self.recycled:
+            self._harvest()
+        self.solve_s += time.perf_counter() - t0        # hx_gmres synchronises internally
+        self.total_iters += it.value
+        self.n_solves += 1
+        self.last = (it.value, rr.value)
+        if rr.value > 100 * rtol:
+            raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
+                                  % (rr.value, it.value))
+
+    def _solve_gmres(self, b, x, rtol, it, rr):
+        K = self.K
         if self.shard is not None:
             rc = _hx.lib.hx_gmres_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                           self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
@@ -348,15 +389,35 @@ class AMGSolver:
             _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                        self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
                                        self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
-        if self.recycle_k > 0 and not self.recycled:
-            self._harvest()
-        self.solve_s += time.perf_counter() - t0        # hx_gmres synchronises internally
-        self.total_iters += it.value
-        self.n_solves += 1
-        self.last = (it.value, rr.value)
-        if rr.value > 100 * rtol:
-            raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
-                                  % (rr.value, it.value))
+
+    def _solve_cocg(self, b, x, rtol, it, rr):
+        """True when hx_cocg delivered the solution; False = breakdown / stall of the bilinear recurrence (the caller
+        repeats the solve with GMRES; after three such solves COCG is switched off for this operator)."""
+        K = self.K
+        if self.shard is not None:
+            rc = _hx.lib.hx_cocg_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
+                                         self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
+                                         _hx.ptr(self.ws), _hx.ptr(self._bufs[_hx.BUF_GMRES_XE]),
+                                         _hx.ptr(self._bufs[_hx.BUF_GMRES_DOTS]), C.byref(it), C.byref(rr), _hx.stream())
+            if rc != 0 and self._cb.error:
+                raise RuntimeError("exchange callback failed inside hx_cocg_sharded:\n" + self._cb.error)
+        else:
+            rc = _hx.lib.hx_cocg(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
+                                 self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"], _hx.ptr(self.ws),
+                                 C.byref(it), C.byref(rr), _hx.stream())
+        if rc == 0 and rr.value <= 100 * rtol:
+            self.cocg_solves += 1
+            self.cocg_iters += it.value
+            return True
+        if rc not in (0, _hx.ERR_BREAKDOWN):
+            _hx.check(rc)
+        self.cocg_fallbacks += 1
+        self.total_iters += it.value                 # the abandoned iterations were paid for
+        info("! hx_cocg gave up after %d iterations at relative residual %.2e (%s): repeating the solve with GMRES"
+             % (it.value, rr.value, _hx.lib.hx_last_error().decode(errors="replace") if rc else "iteration limit"))
+        if self.cocg_fallbacks >= 3:
+            self.use_cocg = False
+        return False
 
     def _harvest(self):
         """Install the k harmonic Ritz vectors of smallest |theta| of the solve that just finished as recycled pairs
@@ -364,8 +425,9 @@ class AMGSolver:
         The small dense algebra runs on the host from all-reduced numbers, i.e. identically on every rank."""
         m = C.c_int(0)
         _hx.check(_hx.lib.hx_gmres_hessenberg(self.handle, C.byref(m), None))
-        m, k = m.value, self.recycle_k
-        if m < k + 2:
+        m = m.value
+        k = min(self.recycle_k, m - 2)              # a short first solve yields fewer pairs
+        if k < min(4, self.recycle_k):
             return                                  # restarted / too short: try again after the next solve
         Hb = np.zeros((m + 1) * m, dtype=np.complex128)
         _hx.check(_hx.lib.hx_gmres_hessenberg(self.handle, C.byref(C.c_int(0)), _hx.nptr(Hb)))
@@ -381,6 +443,8 @@ class AMGSolver:
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
                     if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
                     setup_s=round(self.setup_s, 3), solves=self.n_solves,
+                    krylov="cocg" if self.use_cocg else "fgmres", cocg_solves=self.cocg_solves,
+                    cocg_iters=self.cocg_iters, cocg_fallbacks=self.cocg_fallbacks,
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1))
 

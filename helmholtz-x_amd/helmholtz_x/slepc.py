@@ -29,6 +29,10 @@ from .solver_utils import info
 
 DEFAULTS = {"st_type": "auto", "lu_max_dofs": 20_000}
 W_RELAX = float(__import__("os").environ.get("HX_WOODBURY_RELAX", "30"))
+# Columns beyond twice SLEPc's default Krylov dimension: the 4-pair solve that ends a fixed-point call converges right at
+# the 38th column; a restart there (when the last pair misses the tolerance by a hair) costs five more shift-invert
+# applications of ~45 ms each at 5 M DOF, eight spare columns cost 1.3 GB of HBM.
+NCV_EXTRA = int(__import__("os").environ.get("HX_NCV_EXTRA", "8"))
 RELAX_CAP = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP", "1e4"))     # 1 switches the relaxation off
 
 
@@ -439,7 +443,7 @@ class _EigenSolverBase:
         # SLEPc's default is max(2 nev, nev + 15); twice that is used here: HBM holds the larger basis easily and the
         # restart losses on near-degenerate pairs (azimuthal mode pairs of an annulus) shrink (51 -> 44 operator
         # applications for the 4-pair solve of the 1 M-DOF case).  An explicit setDimensions(nev, ncv) is honoured.
-        ncv = self._ncv if self._ncv else 2 * default_ncv(self._nev)
+        ncv = self._ncv if self._ncv else 2 * default_ncv(self._nev) + NCV_EXTRA
         self._ncv_used = max(min(ncv, n - 1), self._nev + 1)
         return self._ncv_used
 
@@ -459,7 +463,7 @@ class _EigenSolverBase:
             return None
         pool = self.state.setdefault("_pool", {})
         if "nev_max" in self.state and self._ncv is None:
-            pool["rows_hint"] = 2 * default_ncv(int(self.state["nev_max"])) + 1
+            pool["rows_hint"] = 2 * default_ncv(int(self.state["nev_max"])) + NCV_EXTRA + 1
         return pool
 
     def _start(self):

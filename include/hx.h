@@ -291,6 +291,19 @@ int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int
 int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int restart);
 int hx_gmres_hessenberg(const hx_amg* h, int* m, hx_c128* H);
 int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const hx_c128* Ccoef, hx_c128* ws, hx_stream s);
+/* ---- Short-recurrence alternative to hx_gmres for COMPLEX SYMMETRIC K (K^T = K: every shifted operator of this path
+ * except the Bloch-reduced ones) with a complex symmetric preconditioner (V-cycle with pre == post smoothing steps and
+ * R = P^T): deflated preconditioned COCG -- CG in the bilinear form x^T y.  No Gram-Schmidt panel: per iteration one
+ * operator product, one V-cycle, two reductions and two fused vector updates; all scalars stay on the device, the host
+ * reads |r|^2 once per iteration.  When the handle carries harvested pairs (hx_amg_set_recycle: K U = C) they are used
+ * as a deflation space: x0 = U E^-1 U^T b and p = z - U E^-1 C^T z + beta p with E = U^T K U (complex64 mirrors of U and
+ * C are read: the direction may be perturbed freely, x and r stay consistent).  Convergence is accepted against the TRUE
+ * residual.  Returns HX_ERR_BREAKDOWN on a breakdown of the bilinear form or a stall: repeat the solve with hx_gmres.
+ * ws: hx_cocg_ws(n) complex numbers (the hx_gmres workspace is large enough).  SYNC. */
+size_t hx_cocg_ws(int64_t n);
+int hx_cocg(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+            const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it, hx_c128* ws, int* h_iters,
+            double* h_relres, hx_stream s);
 /* ---- Row-sharded mode (one process per GPU).  Replaces what the reference gets from PETSc's
  * parallel Mat/KSP under mpirun (eigensolvers.py:43-62 with a distributed A): level 0 of the hierarchy holds THIS rank's
  * rows of K over [owned | ghost] columns (hx_amg_set_level* with n = owned rows, R = (P rows owned)^T), every coarser
@@ -316,6 +329,10 @@ int hx_amg_set_sharded(hx_amg* h, int32_t n_ext, void* x, void* x2, void* x3, vo
 int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                      const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
                      int restart, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s);
+/* hx_cocg on the row-sharded operator (same buffers as hx_gmres_sharded; hbuf needs at least 72 entries). */
+int hx_cocg_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                    const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
+                    hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s);
 /* HOST set-up passes of the smoothed-aggregation hierarchy (graph / integer work, once per K):
  * hx_host_sa_filter: strength filter |l_ij| >= theta*sqrt(l_ii l_jj) with weak couplings lumped on the diagonal;
  *   L is the Laplacian-like real part (CSR), entry p = sign * h_lv[p * stride] (stride 2 = the real parts of an

@@ -410,7 +410,9 @@ def _annulus_case(shape):
                                        dict(precision="double", sell_min_rows=0),
                                        dict(recycle_min_rows=0, sell_min_rows=0),
                                        dict(recycle_min_rows=0, sell_min_rows=0, vcycle_values="c64"),
-                                       dict(graph_max_rows=10 ** 9)])
+                                       dict(graph_max_rows=10 ** 9),
+                                       dict(krylov="fgmres"), dict(krylov="fgmres", recycle_min_rows=0, sell_min_rows=0),
+                                       dict(krylov="cocg", recycle_min_rows=0, recycle=6)])
 def test_amg_gmres_inner_solver_matches_direct(overrides):
     """K^-1 b from the device AMG-GMRES equals the SuperLU solution on a 3-D annulus (complex shifted operator):
     default (CSR, complex64 Chebyshev V-cycle), SELL-64 fine level, and the all-double variants."""
@@ -439,13 +441,52 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
         assert solver.last[0] < 60
         tol = 1e-9 if k < 2 else 1e-7                     # third solve: relaxed tolerance requested by the caller
         assert np.linalg.norm(x.cpu().numpy() - ref) <= tol * np.linalg.norm(ref)
+    st = solver.stats()
+    assert st["krylov"] == overrides.get("krylov", "cocg") and st["cocg_fallbacks"] == 0
+    if st["krylov"] == "cocg":      # the first solve of a recycling hierarchy is the harvested GMRES run
+        assert st["cocg_solves"] == (2 if overrides.get("recycle_min_rows") == 0 else 3)
     if overrides.get("recycle_min_rows") == 0:
-        assert solver.stats()["recycled_pairs"] == 6 and its[1] <= its[0]
-        assert solver.stats()["fine_format"].startswith("sell64/" + overrides.get("vcycle_values", "fp16"))
+        assert solver.stats()["recycled_pairs"] == overrides.get("recycle", 8) and its[1] <= its[0]
+        if overrides.get("sell_min_rows") == 0:
+            assert solver.stats()["fine_format"].startswith("sell64/" + overrides.get("vcycle_values", "fp16"))
     else:
         assert solver.stats()["recycled_pairs"] == 0
     assert its[2] < its[1]
     assert solver.stats()["vcycle_graph"] == ("graph_max_rows" in overrides)      # hipGraph replay of the V-cycle
+
+
+def test_cocg_symmetry_probe_and_fallback():
+    """hx_cocg is only chosen for complex symmetric operators (the probe rejects a Bloch-reduced / perturbed K), and a
+    solve forced through it on an unsymmetric operator falls back to GMRES instead of returning a wrong answer."""
+    import scipy.sparse.linalg as spla
+    import torch
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.amg import AMGSolver, _is_complex_symmetric
+    from helmholtz_x.petsc import CSR, combine_csr, to_device
+    case = _annulus_case((8, 96, 10))
+    P, mesh = case["P"], case["mesh"]
+    M = AcousticMatrices(mesh, case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    s = P.target
+    K = combine_csr(M.A.shape, M.A.csr_terms + [(s * c, m) for c, m in M.B.csr_terms]
+                    + [(s ** 2 * c, m) for c, m in M.C.csr_terms])
+    assert _is_complex_symmetric(K)
+    Ks = K.to_scipy().tocsr()
+    Ku = Ks.copy()
+    Ku.data = Ku.data * (1.0 + 0.02 * np.sin(np.arange(Ku.nnz)))        # same pattern, K^T != K
+    Kd = CSR.from_scipy(Ku)
+    assert not _is_complex_symmetric(Kd)
+    assert AMGSolver(Kd).stats()["krylov"] == "fgmres"
+    solver = AMGSolver(Kd, krylov="cocg")                                 # forced: must not return garbage
+    lu = spla.splu(Ku.tocsc())
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(K.shape[0]) + 1j * rng.standard_normal(K.shape[0])
+    bd = to_device(b)
+    x = torch.empty_like(bd)
+    solver.solve(bd, x)
+    ref = lu.solve(b)
+    assert np.linalg.norm(x.cpu().numpy() - ref) <= 1e-9 * np.linalg.norm(ref)
+    st = solver.stats()
+    assert st["cocg_fallbacks"] + st["cocg_solves"] == 1
 
 
 def test_annulus_fixed_point_amg_vs_lu_vs_oracle():

@@ -99,6 +99,16 @@ SIGNATURES = {
     "hx_amg_set_sharded": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
     "hx_gmres_sharded": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp, _vp, _vp,
                                    C.POINTER(_int), C.POINTER(C.c_double), _vp]),
+    "hx_csr_diagonal_z": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
+    "hx_sa_filter_count": (C.c_int, [_i32, _vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, C.POINTER(_i64), _vp]),
+    "hx_sa_filter_fill": (C.c_int, [_i32, _vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp]),
+    "hx_sa_power_rho": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _int, C.POINTER(C.c_double), _vp]),
+    "hx_sa_prolongator_count": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    "hx_sa_prolongator_fill": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "hx_csr_transpose_d": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hx_spgemm_symbolic": (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    "hx_spgemm_numeric": (C.c_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
+    "hx_spgemm_destroy": (C.c_int, [_vp]),
     "hx_host_aggregate": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "hx_host_sa_filter": (C.c_int, [_i32, _vp, _vp, _vp, _int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "hx_host_galerkin_rap": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),

@@ -25,7 +25,7 @@ from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
               max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, vcycle_values="fp16", graph_max_rows=0, recycle=8,
-              recycle_min_rows=100_000, krylov="auto")
+              recycle_min_rows=100_000, krylov="auto", setup="device")
 
 
 MAX_DENSE_COARSE = 6000          # the coarsest operator is inverted densely on the host
@@ -182,6 +182,145 @@ def build_hierarchy(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], c
     return levels
 
 
+class DevCSR:
+    """Device CSR of the hierarchy: int32 rowptr / col tensors + values (complex128 for operators, float64 for the
+    transfer operators)."""
+
+    def __init__(self, shape, rowptr, col, val):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.nnz = int(col.numel())
+
+    def to_scipy(self):
+        return sp.csr_matrix((self.val.cpu().numpy(), self.col.cpu().numpy(), self.rowptr.cpu().numpy()), shape=self.shape)
+
+    def rows(self, r0, r1):
+        """Rows [r0, r1) as a new device CSR (row-sharded level 0)."""
+        a, b = int(self.rowptr[r0]), int(self.rowptr[r1])
+        return DevCSR((r1 - r0, self.shape[1]), (self.rowptr[r0:r1 + 1] - a).contiguous(), self.col[a:b].contiguous(),
+                      self.val[a:b].contiguous())
+
+
+def _dev_filter(K, sign, theta, sd):
+    """Lf on the device (hx_sa_filter_*): DevCSR with float64 values."""
+    n, dev = K.shape[0], K.val.device
+    rp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    nnz = C.c_int64(0)
+    args = (n, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val), float(sign), float(theta), _hx.ptr(sd))
+    _hx.check(_hx.lib.hx_sa_filter_count(*args, _hx.ptr(rp), C.byref(nnz), _hx.stream()))
+    ci = torch.empty(nnz.value, dtype=torch.int32, device=dev)
+    v = torch.empty(nnz.value, dtype=torch.float64, device=dev)
+    _hx.check(_hx.lib.hx_sa_filter_fill(*args, _hx.ptr(rp), _hx.ptr(ci), _hx.ptr(v), _hx.stream()))
+    return DevCSR(K.shape, rp, ci, v)
+
+
+def _dev_aggregate(Lf):
+    """Greedy aggregation of the strength graph: the one sequential pass of the set-up, run on the host on the
+    (pattern, |weight|) of Lf -- the filtered graph is a fraction of K and K itself stays in HBM."""
+    n = Lf.shape[0]
+    rp = Lf.rowptr.cpu().numpy()
+    ci = Lf.col.cpu().numpy()
+    w = Lf.val.cpu().numpy()
+    agg = np.empty(n, dtype=np.int32)
+    na = C.c_int32(0)
+    _hx.check(_hx.lib.hx_host_aggregate(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(w), _hx.nptr(agg), C.byref(na)))
+    return agg, na.value
+
+
+def _dev_transpose(A, n_cols):
+    dev = A.val.device
+    rp = torch.empty(n_cols + 1, dtype=torch.int32, device=dev)
+    ci = torch.empty(A.nnz, dtype=torch.int32, device=dev)
+    v = torch.empty(A.nnz, dtype=torch.float64, device=dev)
+    _hx.check(_hx.lib.hx_csr_transpose_d(A.shape[0], n_cols, A.nnz, _hx.ptr(A.rowptr), _hx.ptr(A.col), _hx.ptr(A.val),
+                                         _hx.ptr(rp), _hx.ptr(ci), _hx.ptr(v), _hx.stream()))
+    return DevCSR((n_cols, A.shape[0]), rp, ci, v)
+
+
+def _dev_spgemm(A, B):
+    """C = A B on the device (hx_spgemm_*); operands real (float64) or complex128, result complex128, sorted columns."""
+    dev = A.val.device
+    rp = torch.empty(A.shape[0] + 1, dtype=torch.int32, device=dev)
+    nnz, plan = C.c_int64(0), C.c_void_p()
+    _hx.check(_hx.lib.hx_spgemm_symbolic(C.byref(plan), A.shape[0], _hx.ptr(A.rowptr), _hx.ptr(A.col), B.shape[1],
+                                         _hx.ptr(B.rowptr), _hx.ptr(B.col), _hx.ptr(rp), C.byref(nnz), _hx.stream()))
+    try:
+        ci = torch.empty(nnz.value, dtype=torch.int32, device=dev)
+        v = torch.empty(nnz.value, dtype=torch.complex128, device=dev)
+        _hx.check(_hx.lib.hx_spgemm_numeric(plan, _hx.ptr(A.rowptr), _hx.ptr(A.col), _hx.ptr(A.val),
+                                            int(A.val.is_complex()), _hx.ptr(B.rowptr), _hx.ptr(B.col), _hx.ptr(B.val),
+                                            int(B.val.is_complex()), _hx.ptr(ci), _hx.ptr(v), _hx.stream()))
+    finally:
+        _hx.lib.hx_spgemm_destroy(plan)
+    return DevCSR((A.shape[0], B.shape[1]), rp, ci, v)
+
+
+def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], coarse_size=PARAMS["coarse_size"]):
+    """Same smoothed-aggregation hierarchy as ``build_hierarchy``, built in HBM: K (petsc.CSR / DevCSR on the device) is
+    never copied to the host.  Device passes (amg_setup.hip): diagonal, strength filter, power iteration, smoothed
+    prolongator, transpose, Galerkin product as R (K P).  Host: the greedy aggregation of the filtered graph and the
+    dense inverse of the coarsest operator (a few hundred unknowns).  Returns level dicts whose K / P / R are DevCSR."""
+    levels = []
+    Kl = DevCSR(K.shape, K.rowptr, K.col, K.val)
+    dev = K.val.device
+    th = theta
+    rho_iters = int(os.environ.get("HX_AMG_RHO_ITERS", "10"))
+    while True:
+        n = Kl.shape[0]
+        diag = torch.empty(n, dtype=torch.complex128, device=dev)
+        _hx.check(_hx.lib.hx_csr_diagonal_z(n, _hx.ptr(Kl.rowptr), _hx.ptr(Kl.col), _hx.ptr(Kl.val), _hx.ptr(diag),
+                                            _hx.stream()))
+        level = dict(K=Kl, n=n)
+        if n <= coarse_size or len(levels) == max_levels - 1:
+            if n > MAX_DENSE_COARSE:
+                raise ArithmeticError("AMG hierarchy still has %d unknowns after %d levels" % (n, len(levels) + 1))
+            levels.append(level)
+            break
+        sgn = -1.0 if 2 * int((diag.real < 0).sum()) > n else 1.0
+        sd = torch.empty(n, dtype=torch.float64, device=dev)
+        Lf = _dev_filter(Kl, sgn, th, sd)
+        agg, na = _dev_aggregate(Lf)
+        for _ in range(3):                         # too few couplings count as strong: relax the threshold and retry
+            if na < 0.8 * n:
+                break
+            th *= 0.25
+            Lf = _dev_filter(Kl, sgn, th, sd)
+            agg, na = _dev_aggregate(Lf)
+        if na >= 0.8 * n:                          # coarsening stalled for good: this level becomes the coarsest one
+            if n > MAX_DENSE_COARSE:
+                raise ArithmeticError("AMG coarsening stalled at %d unknowns (strength threshold %.3g): the coarsest "
+                                      "level would need a dense inverse of that size" % (n, th))
+            levels.append(level)
+            break
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(len(levels))
+        v = torch.randn(n, generator=gen, device=dev, dtype=torch.float64)
+        w = torch.empty_like(v)
+        rho = C.c_double(0.0)
+        _hx.check(_hx.lib.hx_sa_power_rho(n, _hx.ptr(Lf.rowptr), _hx.ptr(Lf.col), _hx.ptr(Lf.val), _hx.ptr(v), _hx.ptr(w),
+                                          rho_iters, C.byref(rho), _hx.stream()))
+        rho = rho.value
+        agg_d = to_device(agg)
+        isc = to_device(1.0 / np.sqrt(np.bincount(agg, minlength=na).astype(np.float64)))
+        prp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        pnnz = C.c_int64(0)
+        _hx.check(_hx.lib.hx_sa_prolongator_count(n, _hx.ptr(Lf.rowptr), _hx.ptr(Lf.col), _hx.ptr(agg_d), _hx.ptr(prp),
+                                                  C.byref(pnnz), _hx.stream()))
+        pci = torch.empty(pnnz.value, dtype=torch.int32, device=dev)
+        pv = torch.empty(pnnz.value, dtype=torch.float64, device=dev)
+        _hx.check(_hx.lib.hx_sa_prolongator_fill(n, _hx.ptr(Lf.rowptr), _hx.ptr(Lf.col), _hx.ptr(Lf.val), _hx.ptr(agg_d),
+                                                 _hx.ptr(isc), 4.0 / (3.0 * rho), _hx.ptr(prp), _hx.ptr(pci), _hx.ptr(pv),
+                                                 _hx.stream()))
+        P = DevCSR((n, na), prp, pci, pv)
+        R = _dev_transpose(P, na)
+        level.update(P=P, R=R, dinv=1.0 / diag, omega=4.0 / (3.0 * 1.05 * rho), rho=1.05 * rho, n_coarse=na)
+        levels.append(level)
+        del Lf, sd, v, w
+        Kl = _dev_spgemm(R, _dev_spgemm(Kl, P))
+        th *= 0.5
+    return levels
+
+
 def harmonic_ritz_recycle(Hb, k):
     """Coefficients of the GCRO recycle pair from one (flexible) GMRES cycle  K Z_m = V_{m+1} Hbar_m  (Hb: (m+1) x m raw
     Hessenberg): the k harmonic Ritz vectors g of smallest |theta|,
@@ -219,9 +358,14 @@ class AMGSolver:
         self.shard = shard
         K_global = K_csr
         dev = K_csr.val.device
-        levels = hierarchy if hierarchy is not None else build_hierarchy(K_csr.to_scipy(), self.params["theta"],
-                                                                           self.params["max_levels"],
-                                                                           self.params["coarse_size"])
+        if hierarchy is not None:
+            levels = hierarchy
+        elif os.environ.get("HX_AMG_SETUP", self.params["setup"]) == "host":      # round-1 host passes (comparison / tests)
+            levels = build_hierarchy(K_csr.to_scipy(), self.params["theta"], self.params["max_levels"],
+                                     self.params["coarse_size"])
+        else:
+            levels = build_hierarchy_device(K_csr, self.params["theta"], self.params["max_levels"],
+                                            self.params["coarse_size"])
         self.levels = levels
         # Krylov method of the inner solve: complex symmetric K (every shifted operator of the path except the
         # Bloch-reduced ones) + symmetric V-cycle (pre == post) -> deflated COCG (short recurrences, hx_cocg);
@@ -248,7 +392,17 @@ class AMGSolver:
         set_coarse = _hx.lib.hx_amg_set_coarse_c if mixed else _hx.lib.hx_amg_set_coarse
 
         def dev_csr(M):
-            """(rowptr, col, val) device tensors of a scipy CSR in the hierarchy's working precision."""
+            """(rowptr, col, val) device tensors of a level operator (DevCSR born on the device, or scipy CSR from the
+            host set-up) in the hierarchy's working precision."""
+            if isinstance(M, DevCSR):
+                if M.val.is_complex():
+                    val = M.val.to(cdt)
+                else:               # transfer operators are real: widen to complex in the working precision
+                    re = M.val.to(torch.float32 if mixed else torch.float64)
+                    val = torch.complex(re, torch.zeros_like(re))
+                t = (M.rowptr, M.col, val)
+                self._keep.append(t)
+                return t, M.nnz
             M = sp.csr_matrix(M)
             M.sort_indices()
             if np.isrealobj(M.data):
@@ -261,6 +415,9 @@ class AMGSolver:
             t = (to_device(M.indptr.astype(np.int32, copy=False)), to_device(M.indices.astype(np.int32, copy=False)), val)
             self._keep.append(t)
             return t, int(M.nnz)
+
+        def values_c128(M):
+            return M.val if isinstance(M, DevCSR) else to_device(sp.csr_matrix(M).data.astype(np.complex128))
 
         # SELL-64 companion of the fine operator (complex128 for K z in GMRES, working precision for the V-cycle)
         self.sell = None
@@ -286,7 +443,7 @@ class AMGSolver:
                 (krp, kci, kva), knnz = dev_csr(lv["K"])
                 if "P" in lv and lv["n"] >= self.params["sell_min_rows"] :
                     # coarse operators with enough rows also get a SELL-64 companion (values in the working precision)
-                    tmp = to_device(sp.csr_matrix(lv["K"]).data.astype(np.complex128))
+                    tmp = values_c128(lv["K"])
                     shl = C.c_void_p()
                     _hx.check(_hx.lib.hx_sell_create(C.byref(shl), lv["n"], _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(tmp),
                                                      int(not mixed), (2 if half_coarse else int(mixed)), _hx.stream()))
@@ -296,12 +453,16 @@ class AMGSolver:
             if "P" in lv:
                 Pl, Rl, dl, nl = lv["P"], lv["R"], lv["dinv"], lv["n"]
                 if shard is not None and l == 0:      # owned rows of P; R = their transpose (partial sums per rank)
-                    Pl = sp.csr_matrix(Pl)[shard.r0:shard.r1]
-                    Rl = Pl.T.tocsr()
+                    if isinstance(Pl, DevCSR):
+                        Pl = Pl.rows(shard.r0, shard.r1)
+                        Rl = _dev_transpose(Pl, lv["n_coarse"])
+                    else:
+                        Pl = sp.csr_matrix(Pl)[shard.r0:shard.r1]
+                        Rl = Pl.T.tocsr()
                     dl, nl = dl[shard.r0:shard.r1], shard.n_own
                 (prp, pci, pva), pnnz = dev_csr(Pl)
                 (rrp, rci, rva), rnnz = dev_csr(Rl)
-                dinv = to_device(np.asarray(dl, dtype=np.complex128)).to(cdt)
+                dinv = (dl if isinstance(dl, torch.Tensor) else to_device(np.asarray(dl, dtype=np.complex128))).to(cdt)
                 self._keep.append(dinv)
                 _hx.check(set_level(h, l, nl, knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), _hx.ptr(dinv),
                                     lv["n_coarse"], pnnz, _hx.ptr(prp), _hx.ptr(pci), _hx.ptr(pva), rnnz,
@@ -311,7 +472,8 @@ class AMGSolver:
             else:
                 _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), None, 0, 0, None,
                                     None, None, 0, None, None, None))
-                (crp, cci, cva), cnnz = dev_csr(sp.csr_matrix(np.linalg.inv(lv["K"].toarray())))
+                Kc = lv["K"].to_scipy() if isinstance(lv["K"], DevCSR) else lv["K"]
+                (crp, cci, cva), cnnz = dev_csr(sp.csr_matrix(np.linalg.inv(Kc.toarray())))
                 _hx.check(set_coarse(h, lv["n"], cnnz, _hx.ptr(crp), _hx.ptr(cci), _hx.ptr(cva)))
         if shard is not None:
             from .sharded import ShardedCallbacks

@@ -333,6 +333,40 @@ int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowpt
 int hx_cocg_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                     const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
                     hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s);
+/* ---- DEVICE set-up passes of the smoothed-aggregation hierarchy (once per K; all arrays are device pointers, K never
+ * leaves HBM).  Same mathematics as the hx_host_* passes below, which remain for the row-sharded mode.
+ *   hx_csr_diagonal_z       diagonal of a complex CSR (0 where none is stored)
+ *   hx_sa_filter_*          Lf = strength-filtered L = sign*Re(K): |l_ij| >= theta sqrt(|l_ii l_jj|) kept, weak couplings
+ *                           lumped on the diagonal; count pass (SYNC) fills out_rp (n+1) and *h_nnz, sd = n doubles kept
+ *                           for the fill pass
+ *   hx_sa_power_rho         rho(Df^-1 Lf) from `iters` >= 2 power iterations starting at v (v, w: n doubles, overwritten). SYNC
+ *   hx_sa_prolongator_*     P = (I - omega Df^-1 Lf) P0, P0[i, agg(i)] = inv_sqrt_cnt[agg(i)]; sorted columns; count is SYNC
+ *   hx_csr_transpose_d      out = A^T of a real CSR with sorted columns (stable radix sort of the column indices). SYNC
+ *   hx_spgemm_*             C = A B row by row (hash-based symbolic pass + one radix sort for the sorted pattern, then a
+ *                           numeric pass by binary search); values real (float64) or complex128 per operand, C complex128.
+ *                           The Galerkin operator is R (K P): two products. */
+int hx_csr_diagonal_z(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, hx_c128* diag, hx_stream s);
+int hx_sa_filter_count(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, double sign, double theta,
+                       double* sd, int32_t* out_rp, int64_t* h_nnz, hx_stream s);
+int hx_sa_filter_fill(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, double sign, double theta,
+                      const double* sd, const int32_t* out_rp, int32_t* out_ci, double* out_v, hx_stream s);
+int hx_sa_power_rho(int32_t n, const int32_t* rp, const int32_t* ci, const double* lf, double* v, double* w, int iters,
+                    double* h_rho, hx_stream s);
+int hx_sa_prolongator_count(int32_t n, const int32_t* rp, const int32_t* ci, const int32_t* agg, int32_t* out_rp,
+                            int64_t* h_nnz, hx_stream s);
+int hx_sa_prolongator_fill(int32_t n, const int32_t* rp, const int32_t* ci, const double* lf, const int32_t* agg,
+                           const double* inv_sqrt_cnt, double omega, const int32_t* out_rp, int32_t* out_ci,
+                           double* out_v, hx_stream s);
+int hx_csr_transpose_d(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t* rp, const int32_t* ci, const double* v,
+                       int32_t* out_rp, int32_t* out_ci, double* out_v, hx_stream s);
+typedef struct hx_spgemm hx_spgemm;
+/* SYNC.  out_rp: nA + 1 entries (device); the plan keeps the sorted pattern of C for the numeric pass. */
+int hx_spgemm_symbolic(hx_spgemm** plan, int32_t nA, const int32_t* rpA, const int32_t* ciA, int32_t ncolsB,
+                       const int32_t* rpB, const int32_t* ciB, int32_t* out_rp, int64_t* h_nnz, hx_stream s);
+int hx_spgemm_numeric(const hx_spgemm* plan, const int32_t* rpA, const int32_t* ciA, const void* va, int a_complex,
+                      const int32_t* rpB, const int32_t* ciB, const void* vb, int b_complex, int32_t* out_ci,
+                      hx_c128* out_v, hx_stream s);
+int hx_spgemm_destroy(hx_spgemm* plan);
 /* HOST set-up passes of the smoothed-aggregation hierarchy (graph / integer work, once per K):
  * hx_host_sa_filter: strength filter |l_ij| >= theta*sqrt(l_ii l_jj) with weak couplings lumped on the diagonal;
  *   L is the Laplacian-like real part (CSR), entry p = sign * h_lv[p * stride] (stride 2 = the real parts of an

@@ -339,3 +339,121 @@ def test_in_situ_spmv_profile_counts_launches(hx):
     assert cnt.value == 7                                       # disabled: no new records
     assert np.max(np.abs(y.cpu().numpy() - M @ x.cpu().numpy())) < 1e-12
     hx.check(hx.lib.hx_sell_destroy(h))
+
+
+# ------------------------------------------------------------------------------------------------ device AMG set-up
+def _dcsr(M, dtype=None):
+    """scipy CSR -> helmholtz_x.amg.DevCSR on the device (values complex128 or float64)."""
+    from helmholtz_x.amg import DevCSR
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    val = M.data.astype(dtype if dtype is not None else (np.complex128 if np.iscomplexobj(M.data) else np.float64))
+    return DevCSR(M.shape, _dev(M.indptr.astype(np.int32)), _dev(M.indices.astype(np.int32)), _dev(val))
+
+
+def _same_csr(got, ref, tol=1e-12):
+    """Pattern bit-exact (sorted rows), values to a relative tolerance."""
+    ref = sp.csr_matrix(ref)
+    ref.sort_indices()
+    g = got.to_scipy()
+    assert g.shape == ref.shape
+    assert np.array_equal(g.indptr, ref.indptr) and np.array_equal(g.indices, ref.indices)
+    assert np.abs(g.data - ref.data).max() <= tol * max(np.abs(ref.data).max(), 1e-300)
+
+
+def test_device_amg_setup_passes_match_host(hx):
+    """amg_setup.hip against the host passes of round 1 (themselves pinned to NumPy in test_host_logic.py): strength
+    filter, power iteration, smoothed prolongator, transpose, sparse products, and the whole hierarchy."""
+    import torch
+    from helmholtz_x import amg
+    from oracle import fem, meshes
+    m = meshes.box(9, 7, 8, 0.4, 0.1, 0.25) if hasattr(meshes, "box") else None
+    rng = np.random.default_rng(3)
+    if m is None:
+        m = meshes.rectangle(40, 12, 0.4, 0.1)
+    x = m.x.copy()
+    x[:, 1] *= 3.0                                          # anisotropy => weak couplings to lump
+    S = fem.assemble_A(x, m.cells, 300.0 + 50 * rng.random(x.shape[0])).real.tocsr()       # negative semi-definite
+    n = S.shape[0]
+    K = (S + (40.0 + 6j) * fem.assemble_C(x, m.cells)).tocsr().astype(np.complex128)
+    Kd = _dcsr(K)
+    # diagonal
+    diag = torch.empty(n, dtype=torch.complex128, device=Kd.val.device)
+    hx.check(hx.lib.hx_csr_diagonal_z(n, hx.ptr(Kd.rowptr), hx.ptr(Kd.col), hx.ptr(Kd.val), hx.ptr(diag), hx.stream()))
+    assert np.array_equal(diag.cpu().numpy(), K.diagonal())
+    # strength filter
+    theta = 0.25
+    sd = torch.empty(n, dtype=torch.float64, device=Kd.val.device)
+    Lf_d = amg._dev_filter(Kd, -1.0, theta, sd)
+    Lf_h = amg._filter(K, -1.0, theta)
+    assert Lf_h.nnz < K.nnz                                  # something was lumped
+    _same_csr(Lf_d, Lf_h, 1e-14)
+    # rho by power iteration (same start vector on both sides is not available: compare with the dense spectrum)
+    v = torch.randn(n, dtype=torch.float64, device=Kd.val.device)
+    w = torch.empty_like(v)
+    rho = C.c_double(0.0)
+    hx.check(hx.lib.hx_sa_power_rho(n, hx.ptr(Lf_d.rowptr), hx.ptr(Lf_d.col), hx.ptr(Lf_d.val), hx.ptr(v), hx.ptr(w), 60,
+                                    C.byref(rho), hx.stream()))
+    exact = np.max(np.abs(np.linalg.eigvals((sp.diags(1 / Lf_h.diagonal()) @ Lf_h).toarray())))
+    assert abs(rho.value - exact) < 2e-2 * exact
+    # aggregation (host pass in both set-ups) + smoothed prolongator
+    agg, na = amg._dev_aggregate(Lf_d)
+    agg_h, na_h = amg._aggregate(Lf_h)
+    assert na == na_h and np.array_equal(agg, agg_h)
+    isc = 1.0 / np.sqrt(np.bincount(agg, minlength=na).astype(np.float64))
+    prp = torch.empty(n + 1, dtype=torch.int32, device=Kd.val.device)
+    pnnz = C.c_int64(0)
+    agg_d = _dev(agg)
+    hx.check(hx.lib.hx_sa_prolongator_count(n, hx.ptr(Lf_d.rowptr), hx.ptr(Lf_d.col), hx.ptr(agg_d), hx.ptr(prp),
+                                            C.byref(pnnz), hx.stream()))
+    pci = torch.empty(pnnz.value, dtype=torch.int32, device=Kd.val.device)
+    pv = torch.empty(pnnz.value, dtype=torch.float64, device=Kd.val.device)
+    hx.check(hx.lib.hx_sa_prolongator_fill(n, hx.ptr(Lf_d.rowptr), hx.ptr(Lf_d.col), hx.ptr(Lf_d.val), hx.ptr(agg_d),
+                                           hx.ptr(_dev(isc)), 0.6, hx.ptr(prp), hx.ptr(pci), hx.ptr(pv), hx.stream()))
+    P_d = amg.DevCSR((n, na), prp, pci, pv)
+    P_h = amg._prolongator(Lf_h, agg, na, 0.6)
+    _same_csr(P_d, P_h, 1e-14)
+    # transpose and the two products of the Galerkin operator
+    R_d = amg._dev_transpose(P_d, na)
+    _same_csr(R_d, P_d.to_scipy().T.tocsr(), 0.0)
+    T_d = amg._dev_spgemm(Kd, P_d)
+    _same_csr(T_d, K @ P_h, 1e-13)
+    Kc_d = amg._dev_spgemm(R_d, T_d)
+    Kc_h = amg._galerkin(P_h.T.tocsr(), K, P_h)
+    _same_csr(Kc_d, Kc_h, 1e-12)
+    # whole hierarchy
+    lv_d = amg.build_hierarchy_device(Kd, coarse_size=40)
+    lv_h = amg.build_hierarchy(K, coarse_size=40)
+    # rho comes from different start vectors, so transfer weights differ by O(1e-2) and a coupling next to the strength
+    # threshold may flip on the coarser levels: level 0 -> 1 must agree exactly, the rest in size
+    assert len(lv_d) == len(lv_h) >= 3 and lv_d[1]["n"] == lv_h[1]["n"]
+    assert all(abs(a["n"] - b["n"]) <= 0.05 * b["n"] + 2 for a, b in zip(lv_d, lv_h))
+    g, h = lv_d[1]["K"].to_scipy(), sp.csr_matrix(lv_h[1]["K"])
+    h.sort_indices()
+    assert np.array_equal(g.indptr, h.indptr) and np.array_equal(g.indices, h.indices)
+    for a, b in zip(lv_d, lv_d[1:]):
+        Kc = (a["R"].to_scipy() @ a["K"].to_scipy() @ a["P"].to_scipy()).tocsr()
+        assert abs(b["K"].to_scipy() - Kc).max() < 1e-11 * abs(Kc).max()              # Galerkin, level by level
+
+
+@pytest.mark.parametrize("m,k,n,da,db", [(1, 1, 1, 1.0, 1.0), (300, 200, 250, 0.02, 0.03), (64, 3000, 40, 0.3, 0.5),
+                                         (2000, 2000, 2000, 0.004, 0.004)])
+def test_device_spgemm_and_transpose_random(hx, m, k, n, da, db):
+    """Sparse products on random rectangular operands: empty rows, rows denser than the hash-table floor, every
+    real/complex combination; transposes with empty columns."""
+    from helmholtz_x import amg
+    rng = np.random.default_rng(m + 7 * n)
+    A = sp.random(m, k, density=da, random_state=rng, format="csr")
+    B = sp.random(k, n, density=db, random_state=rng, format="csr")
+    if A.nnz == 0:
+        A = sp.csr_matrix(np.ones((m, k)))
+    if B.nnz == 0:
+        B = sp.csr_matrix(np.ones((k, n)))
+    Az = A + 1j * A.multiply(A)
+    Bz = B - 0.5j * B
+    for X, Y in ((A, B), (Az, B), (A, Bz), (Az, Bz)):
+        ref = (sp.csr_matrix(X) @ sp.csr_matrix(Y)).tocsr()
+        if ref.nnz == 0:
+            continue
+        _same_csr(amg._dev_spgemm(_dcsr(X), _dcsr(Y)), ref, 1e-13)
+    _same_csr(amg._dev_transpose(_dcsr(A), k), A.T.tocsr(), 0.0)

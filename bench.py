@@ -138,6 +138,28 @@ def spmv_roofline(matrices, target, reps=50, in_situ=None):
                             "achieved": round(alg_bytes / (ms_csr * 1e-3) / 1e9, 1)})
 
 
+def smoother_roofline(inner, n, in_situ):
+    """The kernel with the largest share of the run time: one Chebyshev smoother step of the V-cycle on the fine level
+    (`k_sell<c64, 1, half>`: x' = x + a D^-1 (b - K x) + c (x - x_prev) in complex64 on complex-half values with 16-bit
+    column deltas).  Bytes per launch = what the kernel must stream: stored entries * (4 + index bytes) + n * 5 complex64
+    vectors (b, x gathered once, x_prev, D^-1, x').  Same in-situ HIP-event timing as the operator product."""
+    import ctypes as C
+    from helmholtz_x import _hx
+    sell = getattr(inner, "sell", None)
+    if sell is None or in_situ[0] == 0:
+        return None
+    ns, padded = C.c_int32(0), C.c_int64(0)
+    _hx.check(_hx.lib.hx_sell_info(sell, C.byref(ns), C.byref(padded)))
+    idx_bytes = _hx.lib.hx_sell_index_bits(sell) // 8
+    val_bytes = {"fp16": 4, "fp16r": 2, "c64": 8, "c128": 16}.get(getattr(inner, "fine_values", "fp16"), 4)
+    nbytes = padded.value * (val_bytes + idx_bytes) + n * 5 * 8
+    ms = in_situ[1] / in_situ[0]
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return dict(kernel="k_sell<c64, 1, half> (hx_sell_smooth_c64, fine level)", launches=in_situ[0],
+                avg_launch_ms=round(ms, 5), bytes_per_launch=nbytes, achieved=round(gbs, 1), unit="GB/s",
+                frac=round(gbs / HBM_PEAK_GBS, 4))
+
+
 def measured_traffic(n, nnz):
     """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (profiles/spmv_traffic.json): 2 x FETCH_SIZE
     (gfx950 correction of MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, for the matrix of exactly this size; else None."""
@@ -246,8 +268,11 @@ def main():
         dt = time.perf_counter() - t0
         n_launch, tot_ms = C.c_int64(0), C.c_double(0.0)
         _hx.check(_hx.lib.hx_profile_sell_spmv_read(C.byref(n_launch), C.byref(tot_ms)))
+        n_sm, sm_ms = C.c_int64(0), C.c_double(0.0)
+        _hx.check(_hx.lib.hx_profile_sell_read(1, C.byref(n_sm), C.byref(sm_ms)))
         _hx.check(_hx.lib.hx_profile_sell_spmv(0, 0))
         in_situ = (n_launch.value, tot_ms.value)
+        in_situ_smoother = (n_sm.value, sm_ms.value)
         free_b, total_b = torch.cuda.mem_get_info()            # device-wide: torch's pool + the library's own hipMallocs
         hbm_used_gb = round((total_b - free_b) / 2 ** 30, 1)
     red_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
@@ -264,6 +289,7 @@ def main():
         inner = next((v for v in (E.inner_cache or {}).values() if hasattr(v, "stats")), None)
         with contextlib.redirect_stdout(sys.stderr):
             roof = spmv_roofline(matrices, case["P"].target, in_situ=in_situ)
+            roof["smoother_kernel"] = smoother_roofline(inner, n_dof, in_situ_smoother)
         out = {
             "metric": "converged eigenpairs/sec + SpMV GB/s (% HBM roofline), AnnularCombustor",
             "value": round(pairs_all / dt, 5), "unit": "eigenpairs/s",

@@ -33,11 +33,17 @@ struct hx_sell {
   // identical iteration counts with fp16-rounded fine-level values (bf16: +3..9 %).  May be null.
   __half2* val_h = nullptr;
   float h_scale = 1.0f;
+  // REAL-half copy (2 bytes per entry, same scale) for the smoother steps only: K = A + sigma B + sigma^2 C is dominated
+  // by the real stiffness part on the fine levels ((omega h / c)^2 ~ 1e-3), and a smoother only has to damp the
+  // oscillatory error, where the complex shift is invisible; the residual that feeds the coarse grids keeps the complex
+  // values.  May be null.
+  __half* val_r = nullptr;
 };
 typedef __half2 ch;
 __device__ __forceinline__ zc mload(const zc* p) { return *p; }
 __device__ __forceinline__ cc mload(const cc* p) { return *p; }
 __device__ __forceinline__ cc mload(const ch* p) { return __half22float2(*p); }
+__device__ __forceinline__ cc mload(const __half* p) { return make_float2(__half2float(*p), 0.f); }
 
 // max over |re|, |im| of a complex128 array (non-negative floats order like their bit patterns)
 __global__ void k_absmax(int64_t n, const zc* __restrict__ v, unsigned int* __restrict__ out) {
@@ -53,6 +59,8 @@ __global__ void k_absmax(int64_t n, const zc* __restrict__ v, unsigned int* __re
 
 template <>
 __device__ __forceinline__ ch czero<ch>() { return __floats2half2_rn(0.f, 0.f); }
+template <>
+__device__ __forceinline__ __half czero<__half>() { return __float2half(0.f); }
 
 __global__ void k_sell_widths(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, int64_t* __restrict__ slice_sz) {
   const int lane = threadIdx.x & 63;
@@ -84,7 +92,8 @@ __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restri
       if (scol) scol[o] = col[s + k];
       if constexpr (sizeof(VOUT) == sizeof(zc)) sval[o] = v;
       else if constexpr (sizeof(VOUT) == sizeof(cc)) sval[o] = make_float2((float)v.x, (float)v.y);
-      else sval[o] = __floats2half2_rn((float)v.x * inv_scale, (float)v.y * inv_scale);
+      else if constexpr (sizeof(VOUT) == sizeof(ch)) sval[o] = __floats2half2_rn((float)v.x * inv_scale, (float)v.y * inv_scale);
+      else sval[o] = __float2half((float)v.x * inv_scale);
     } else {
       if (scol) scol[o] = pad_col;
       sval[o] = czero<VOUT>();
@@ -120,14 +129,15 @@ __global__ void k_sell_narrow(int32_t n_slices, const int64_t* __restrict__ slic
 extern "C" int hx_sell_destroy(hx_sell* h) {
   if (!h) return HX_OK;
   (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->dcol); (void)hipFree(h->wide); (void)hipFree(h->val_z); (void)hipFree(h->val_c);
-  (void)hipFree(h->val_h);
+  (void)hipFree(h->val_h); (void)hipFree(h->val_r);
   delete h;
   return HX_OK;
 }
 
 // Build the SELL-64 companion of a device CSR (complex128 values).  want_z / want_c select which value copies to
 // keep (complex128 for the operator product, complex64 for the single-precision V-cycle; want_c == 2 stores that copy
-// as scaled complex-half instead: same complex64 arithmetic, 8 instead of 12 bytes per entry).  SYNC.
+// as scaled complex-half instead: same complex64 arithmetic, 8 instead of 12 bytes per entry; want_c == 3 adds the
+// real-half copy that the smoother steps read).  SYNC.
 extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
                               int want_z, int want_c, hx_stream s_) {
   HX_REQUIRE(out && n > 0 && rowptr && col && val && (want_z || want_c), "bad argument");
@@ -155,14 +165,15 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   if (hipMalloc((void**)&h->col, sizeof(int32_t) * ne) != hipSuccess ||
       (want_z && hipMalloc((void**)&h->val_z, sizeof(zc) * ne) != hipSuccess) ||
       (want_c == 1 && hipMalloc((void**)&h->val_c, sizeof(cc) * ne) != hipSuccess) ||
-      (want_c == 2 && hipMalloc((void**)&h->val_h, sizeof(ch) * ne) != hipSuccess)) {
+      (want_c >= 2 && hipMalloc((void**)&h->val_h, sizeof(ch) * ne) != hipSuccess) ||
+      (want_c == 3 && hipMalloc((void**)&h->val_r, sizeof(__half) * ne) != hipSuccess)) {
     hx_sell_destroy(h);
     return hx_fail(HX_ERR_ALLOC, __func__, "SELL arrays");
   }
   if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f);
   if (want_c == 1) k_sell_fill<cc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
                                                           want_z ? nullptr : h->col, h->val_c, 1.f);
-  if (want_c == 2) {
+  if (want_c >= 2) {
     // scale so that the largest component maps to 2^14: five binary orders of head-room below the fp16 maximum, and
     // entries down to ~4e-9 of the largest stay normal numbers
     unsigned int* dmax = nullptr;
@@ -184,6 +195,9 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     h->h_scale = vmax > 0.f ? vmax / 16384.f : 1.f;
     k_sell_fill<ch><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
                                            want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale);
+    if (want_c == 3)
+      k_sell_fill<__half><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, nullptr, h->val_r,
+                                               1.f / h->h_scale);
   }
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
@@ -300,49 +314,63 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
 // bracketed by a pair of HIP events on its launch stream (no synchronisation until the read-out).
 #include <vector>
 namespace {
+// kind 0: operator product k_sell<c128,0> (hx_sell_spmv_z); kind 1: smoother step k_sell<c64,1,*> (hx_sell_smooth_c64)
 struct SpmvProfile {
   bool on = false;
   int32_t min_rows = 0;
   std::vector<hipEvent_t> ev;          // 2 per launch
   size_t used = 0;
   int64_t skipped = 0;
-} g_prof;
+} g_prof[2];
 const size_t PROF_MAX_LAUNCHES = 16384;
 }
 extern "C" int hx_profile_sell_spmv(int enable, int32_t min_rows) {
-  if (enable && g_prof.ev.empty()) {
-    g_prof.ev.resize(2 * PROF_MAX_LAUNCHES);
-    for (auto& e : g_prof.ev) HX_HIP(hipEventCreate(&e));
+  for (auto& P : g_prof) {
+    if (enable && P.ev.empty()) {
+      P.ev.resize(2 * PROF_MAX_LAUNCHES);
+      for (auto& e : P.ev) HX_HIP(hipEventCreate(&e));
+    }
+    P.on = enable != 0;
+    P.min_rows = min_rows;
+    if (enable) { P.used = 0; P.skipped = 0; }
   }
-  g_prof.on = enable != 0;
-  g_prof.min_rows = min_rows;
-  if (enable) { g_prof.used = 0; g_prof.skipped = 0; }
   return HX_OK;
 }
 // number of recorded launches and the sum of their durations (SYNC: waits for the last recorded event)
-extern "C" int hx_profile_sell_spmv_read(int64_t* launches, double* total_ms) {
-  HX_REQUIRE(launches && total_ms, "bad argument");
+extern "C" int hx_profile_sell_read(int kind, int64_t* launches, double* total_ms) {
+  HX_REQUIRE(launches && total_ms && (kind == 0 || kind == 1), "bad argument");
+  SpmvProfile& P = g_prof[kind];
   double tot = 0.0;
-  for (size_t i = 0; i < g_prof.used; i += 2) {
-    HX_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+  for (size_t i = 0; i < P.used; i += 2) {
+    HX_HIP(hipEventSynchronize(P.ev[i + 1]));
     float ms = 0.f;
-    HX_HIP(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+    HX_HIP(hipEventElapsedTime(&ms, P.ev[i], P.ev[i + 1]));
     tot += ms;
   }
-  *launches = (int64_t)(g_prof.used / 2);
+  *launches = (int64_t)(P.used / 2);
   *total_ms = tot;
   return HX_OK;
+}
+extern "C" int hx_profile_sell_spmv_read(int64_t* launches, double* total_ms) { return hx_profile_sell_read(0, launches, total_ms); }
+static bool prof_begin(int kind, int32_t n, hx_stream s) {
+  SpmvProfile& P = g_prof[kind];
+  const bool rec = P.on && n >= P.min_rows && P.used + 2 <= P.ev.size();
+  if (P.on && !rec && n >= P.min_rows) ++P.skipped;
+  if (rec && hipEventRecord(P.ev[P.used], hx_s(s)) != hipSuccess) return false;
+  return rec;
+}
+static void prof_end(int kind, hx_stream s) {
+  SpmvProfile& P = g_prof[kind];
+  if (hipEventRecord(P.ev[P.used + 1], hx_s(s)) == hipSuccess) P.used += 2;
 }
 
 extern "C" int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
                               hx_stream s) {
   HX_REQUIRE(h && h->val_z && x && y && alpha && beta, "bad argument");
   const zc a = hx_z(alpha), b = hx_z(beta);
-  const bool rec = g_prof.on && h->n >= g_prof.min_rows && g_prof.used + 2 <= g_prof.ev.size();
-  if (g_prof.on && !rec && h->n >= g_prof.min_rows) ++g_prof.skipped;
-  if (rec) HX_HIP(hipEventRecord(g_prof.ev[g_prof.used], hx_s(s)));
+  const bool rec = prof_begin(0, h->n, s);
   launch_sell<zc, 0, zc>(h, h->val_z, (const zc*)x, (zc*)y, a, b, (b.x == 0 && b.y == 0), nullptr, nullptr, nullptr, 0.0, 0.0, 1.0, s);
-  if (rec) { HX_HIP(hipEventRecord(g_prof.ev[g_prof.used + 1], hx_s(s))); g_prof.used += 2; }
+  if (rec) prof_end(0, s);
   HX_LAUNCH_CHECK("k_sell<c128,spmv>");
   return HX_OK;
 }
@@ -361,12 +389,17 @@ extern "C" int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, fl
 extern "C" int hx_sell_smooth_c64(const hx_sell* h, const hx_c64* dinv, const hx_c64* b, const hx_c64* xin, hx_c64* xout,
                                   float omega, const hx_c64* xprev, float mom, hx_stream s) {
   HX_REQUIRE(h && (h->val_c || h->val_h) && dinv && b && xin && xout && xin != xout, "bad argument");
-  if (h->val_h)
+  const bool rec = prof_begin(1, h->n, s);
+  if (h->val_r)
+    launch_sell<cc, 1, __half>(h, h->val_r, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1,
+                               (const cc*)dinv, (const cc*)b, (const cc*)xprev, omega, mom, h->h_scale, s);
+  else if (h->val_h)
     launch_sell<cc, 1, ch>(h, h->val_h, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
                            (const cc*)b, (const cc*)xprev, omega, mom, h->h_scale, s);
   else
     launch_sell<cc, 1, cc>(h, h->val_c, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
                            (const cc*)b, (const cc*)xprev, omega, mom, 1.f, s);
+  if (rec) prof_end(1, s);
   HX_LAUNCH_CHECK("k_sell<c64,smooth>");
   return HX_OK;
 }

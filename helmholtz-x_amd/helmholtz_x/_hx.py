@@ -52,6 +52,7 @@ SIGNATURES = {
     "hx_sell_destroy": (C.c_int, [_vp]),
     "hx_profile_sell_spmv": (C.c_int, [_int, _i32]),
     "hx_profile_sell_spmv_read": (C.c_int, [C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "hx_profile_sell_read": (C.c_int, [_int, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "hx_build_v2e": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp]),
     "hx_p1_pattern_count": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     "hx_p1_pattern_fill": (C.c_int, [_i32, _int, _vp, _vp, _vp, _vp, _vp]),

@@ -75,13 +75,14 @@ class AcousticMatrices:
         info("- Passive matrices are assembling..")
         bc_dofs = np.unique(np.concatenate(self.bcs_Dirichlet)) if self.bcs_Dirichlet else None
 
-        self._A, self._C = asm.stiffness_mass(self.c)
+        c_dev = asm._field(self.c) if hasattr(asm, "_field") and degree == 1 else self.c    # one upload for A, C and B
+        self._A, self._C = asm.stiffness_mass(c_dev)
         if bc_dofs is not None:
             asm.apply_dirichlet(self._A, bc_dofs, 1.0)
         info("- Matrix A is assembled.")
 
         if robin_facets:
-            B = asm.robin(np.concatenate(robin_facets), np.concatenate(robin_coefs), self.c)
+            B = asm.robin(np.concatenate(robin_facets), np.concatenate(robin_coefs), c_dev)
             B_adj = B.copy()
             B_adj.transpose()
             B_adj.conjugate()

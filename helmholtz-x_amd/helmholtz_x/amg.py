@@ -24,7 +24,7 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, vcycle_values="fp16", graph_max_rows=0, recycle=8,
+              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
               recycle_min_rows=100_000, krylov="auto", setup="device")
 
 
@@ -426,14 +426,17 @@ class AMGSolver:
             sh = C.c_void_p()
             # complex128 copy for K z in GMRES; V-cycle copy in the working precision -- stored as scaled complex-half
             # when the cycle runs in complex64 (8 instead of 12 bytes per entry; same GMRES iteration counts measured)
-            half = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
-            self.fine_values = "fp16" if half else ("c64" if mixed else "c128")
+            vv = os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"])
+            half = mixed and vv in ("fp16", "fp16r")
+            self.fine_values = vv if half else ("c64" if mixed else "c128")
             _hx.check(_hx.lib.hx_sell_create(C.byref(sh), self.n, _hx.ptr(K_csr.rowptr), _hx.ptr(K_csr.col),
-                                             _hx.ptr(K_csr.val), 1, 2 if half else int(mixed), _hx.stream()))
+                                             _hx.ptr(K_csr.val), 1, (3 if vv == "fp16r" else 2) if half else int(mixed),
+                                             _hx.stream()))
             self.sell = sh
             _hx.check(_hx.lib.hx_amg_set_level_sell(h, 0, sh))
         # coarse SELL levels take the same storage (5 M DOF: iterations unchanged, 8.38 -> 8.27 s)
-        half_coarse = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
+        vvc = os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"])
+        half_coarse = mixed and vvc in ("fp16", "fp16r")
         for l, lv in enumerate(levels):
             if l == 0:
                 k0 = K_csr.val.to(cdt) if mixed else K_csr.val
@@ -441,12 +444,15 @@ class AMGSolver:
                 (krp, kci, kva), knnz = (K_csr.rowptr, K_csr.col, k0), K_csr.nnz
             else:
                 (krp, kci, kva), knnz = dev_csr(lv["K"])
-                if "P" in lv and lv["n"] >= self.params["sell_min_rows"] :
+                # (one lane per row only pays for short rows: measured 33 us per SELL smoothing step on 88 k rows of
+                # ~60 entries, a latency-bound walk, so long-row levels stay on the multi-lane CSR kernels)
+                if "P" in lv and lv["n"] >= self.params["sell_min_rows"] and knnz <= self.params["sell_max_row"] * lv["n"]:
                     # coarse operators with enough rows also get a SELL-64 companion (values in the working precision)
                     tmp = values_c128(lv["K"])
                     shl = C.c_void_p()
                     _hx.check(_hx.lib.hx_sell_create(C.byref(shl), lv["n"], _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(tmp),
-                                                     int(not mixed), (2 if half_coarse else int(mixed)), _hx.stream()))
+                                                     int(not mixed), ((3 if vvc == "fp16r" else 2) if half_coarse else int(mixed)),
+                                                     _hx.stream()))
                     del tmp
                     self.coarse_sells.append(shl)
                     _hx.check(_hx.lib.hx_amg_set_level_sell(h, l, shl))

@@ -269,7 +269,10 @@ class P1Assembler:
 
     @staticmethod
     def _field(f):
-        """Function | ndarray | scalar -> (device complex tensor, is_cellwise) for a coefficient."""
+        """Function -> (device complex tensor, is_cellwise) for a coefficient; a pair already in that form passes through
+        (a caller that assembles several operators with one coefficient uploads it once)."""
+        if isinstance(f, tuple) and len(f) == 2 and isinstance(f[0], torch.Tensor):
+            return f
         if isinstance(f, Function):
             return to_device(f.x.array.astype(np.complex128)), f.function_space.kind == "DG0"
         raise TypeError("coefficient must be a Function")

@@ -61,6 +61,7 @@ def krylov_schur(basis, nev, ncv, tol=1e-15, max_it=100, keep_fraction=0.5, rela
     for a following solve of a nearby problem that wants more pairs."""
     import os
     check_every = int(os.environ.get("HX_KRYLOV_CHECK_EVERY", check_every))      # experiment hook
+    trace = bool(os.environ.get("HX_KRYLOV_TRACE"))                              # diagnostics: residual history
     m = ncv
     assert basis.m >= m + 1
     S = np.zeros((m + 1, m), dtype=complex)      # OP V_j = V_{j+1} S[:j+1, :j]
@@ -78,6 +79,9 @@ def krylov_schur(basis, nev, ncv, tol=1e-15, max_it=100, keep_fraction=0.5, rela
             cols = j + 1
             if cols < m and cols >= k + nev + 1 and (cols - k) % check_every == 0:
                 th_c, _, res_c, nc_c = _ritz(S, cols, tol)
+                if trace:
+                    print("[krylov_schur] nev %d cols %2d  rel.resid %s" % (
+                        nev, cols, " ".join("%.1e" % r for r in (res_c / np.abs(th_c))[:nev + 2])), flush=True)
                 _tell(basis, th_c, res_c, nev)
                 if nc_c >= nev:
                     mact = cols

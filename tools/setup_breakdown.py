@@ -26,7 +26,8 @@ def timed(name, fn):
     return wrap
 
 
-for f in ("_filter", "_aggregate", "_prolongator", "_galerkin", "_spectral_radius_dinv", "build_hierarchy"):
+for f in ("_dev_filter", "_dev_aggregate", "_dev_transpose", "_dev_spgemm", "build_hierarchy_device", "_is_complex_symmetric",
+          "_filter", "_aggregate", "_prolongator", "_galerkin", "_spectral_radius_dinv", "build_hierarchy"):
     setattr(amg, f, timed(f, getattr(amg, f)))
 from helmholtz_x.petsc import CSR  # noqa: E402
 CSR.to_scipy = timed("K.to_scipy (D2H + scipy)", CSR.to_scipy)

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round-2 parameter sweep on one box (annulus-5M, one step each): deflation pairs x Chebyshev kind x spare Krylov columns.
+# Round-2 A/B runs on one box (annulus-5M unless WL is set, one step each): label, then environment overrides.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-run() {  # label, env...
+WL=${WL:-annulus-5M}
+run() {
   local label=$1; shift
-  env "$@" python bench.py --no-cpu-baseline > gpurun_out/sw_$label.json 2> /dev/null || { echo "$label FAILED"; return; }
+  env "$@" python bench.py --no-cpu-baseline --workload $WL > gpurun_out/sw_$label.json 2> /dev/null || { echo "$label FAILED"; return; }
   python3 - "$label" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/sw_%s.json" % sys.argv[1]))
@@ -13,9 +14,7 @@ print("%-22s %7.1f ms  setup %.2f solve %.2f  solves %d its %d (%.1f/solve) fall
     s["cocg_fallbacks"], k["ops_per_solve"], d["config"]["omega"][0][0], d["config"]["omega"][0][1]))
 PY
 }
-for k in 4 6 8 10; do
-  run k${k} HX_AMG_RECYCLE=$k
-  run k${k}_cheb4 HX_AMG_RECYCLE=$k HX_CHEB_KIND=4
+while read -r line; do
+  [ -z "$line" ] && continue
+  run $line
 done
-run k8_lo05 HX_AMG_RECYCLE=8 HX_CHEB_LO=0.05
-run k8_lo2 HX_AMG_RECYCLE=8 HX_CHEB_LO=0.2

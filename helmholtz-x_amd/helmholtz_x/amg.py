@@ -263,7 +263,8 @@ def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_leve
     levels = []
     Kl = DevCSR(K.shape, K.rowptr, K.col, K.val)
     dev = K.val.device
-    th = theta
+    th = float(os.environ.get("HX_AMG_THETA", theta))                    # experiment hooks (tools/sweep_r2.sh)
+    p_damp = float(os.environ.get("HX_AMG_PDAMP", 4.0 / 3.0))
     rho_iters = int(os.environ.get("HX_AMG_RHO_ITERS", "10"))
     while True:
         n = Kl.shape[0]
@@ -309,7 +310,7 @@ def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_leve
         pci = torch.empty(pnnz.value, dtype=torch.int32, device=dev)
         pv = torch.empty(pnnz.value, dtype=torch.float64, device=dev)
         _hx.check(_hx.lib.hx_sa_prolongator_fill(n, _hx.ptr(Lf.rowptr), _hx.ptr(Lf.col), _hx.ptr(Lf.val), _hx.ptr(agg_d),
-                                                 _hx.ptr(isc), 4.0 / (3.0 * rho), _hx.ptr(prp), _hx.ptr(pci), _hx.ptr(pv),
+                                                 _hx.ptr(isc), p_damp / rho, _hx.ptr(prp), _hx.ptr(pci), _hx.ptr(pv),
                                                  _hx.stream()))
         P = DevCSR((n, na), prp, pci, pv)
         R = _dev_transpose(P, na)

@@ -52,6 +52,11 @@ struct hx_amg {
   void* ctx = nullptr;
   int32_t n_ext = 0;           // owned + ghost length of the level-0 iterates
   Recycle rec;
+  // hx_cocg: ||K||_inf of the operator last seen (by value pointer) and the backward error of the last solve that ended
+  // above its tolerance (-1: not measured)
+  double normK = 0.0;
+  const void* normK_val = nullptr;
+  double last_backward = -1.0;
   // hipGraph of the complex64 V-cycle (all buffers of the cycle are owned by the handle, so the ~45 launches of one cycle
   // are captured once and replayed): for small and mid-size problems, where the cycle is launch-bound
   int graph_state = -1;        // -1 off, 0 requested (capture at the next cycle), 1 ready

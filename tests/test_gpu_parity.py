@@ -595,7 +595,7 @@ def test_flamedduct_reference_logs(ref_logs, golden_dir):
     assert E.getConverged() >= 10
     for k in range(10):
         lam = E.getEigenvalue(k)
-        tol = 2e-3 if abs(lam.real - 9203.68) < 0.1 else 5e-6
+        tol = 2e-3 if abs(lam.real - 9203.68) < 0.1 else 2e-5     # (2.5e-9 relative: a quarter of the 1e-8 parity bar)
         assert np.min(np.abs(ref - lam)) < tol, (k, lam)
     assert abs(E.getEigenvalue(0) - ref[0]) < 2e-6
     # active.py:27-41

@@ -117,6 +117,8 @@ def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history, stat
         state["warm_pairs"] = nev - lean        # lean solves also hand over their best unconverged Ritz directions
         state["lean_nev"] = lean
         state["nev_max"] = nev
+    if state is not None:
+        state["_omega_k"] = None                 # (the passive problem is not a member of the omega-family of the loop)
     E, omega[0] = solve_passive(lean)
     alpha[0] = 0.5
     if history is not None:
@@ -129,6 +131,8 @@ def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history, stat
             raise RuntimeError("fixed-point iteration did not converge in maxiter=%d iterations" % maxiter)
         E.destroy()
         print("* iter = {:2d}".format(k + 1))
+        if state is not None:
+            state["_omega_k"] = complex(omega[k])    # lets the solver extrapolate its start vector along the trajectory
         E, f[k] = solve_active(omega[k], lean)
         if k != 0:
             alpha[k] = 1 / (1 - ((f[k] - f[k - 1]) / (omega[k] - omega[k - 1])))

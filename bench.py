@@ -151,7 +151,7 @@ def smoother_roofline(inner, n, in_situ):
     ns, padded = C.c_int32(0), C.c_int64(0)
     _hx.check(_hx.lib.hx_sell_info(sell, C.byref(ns), C.byref(padded)))
     idx_bytes = _hx.lib.hx_sell_index_bits(sell) // 8
-    val_bytes = {"fp16": 4, "fp16r": 2, "c64": 8, "c128": 16}.get(getattr(inner, "fine_values", "fp16"), 4)
+    val_bytes = {"fp16": 4, "c64": 8, "c128": 16}.get(getattr(inner, "fine_values", "fp16"), 4)
     nbytes = padded.value * (val_bytes + idx_bytes) + n * 5 * 8
     ms = in_situ[1] / in_situ[0]
     gbs = nbytes / (ms * 1e-3) / 1e9

@@ -33,17 +33,11 @@ struct hx_sell {
   // identical iteration counts with fp16-rounded fine-level values (bf16: +3..9 %).  May be null.
   __half2* val_h = nullptr;
   float h_scale = 1.0f;
-  // REAL-half copy (2 bytes per entry, same scale) for the smoother steps only: K = A + sigma B + sigma^2 C is dominated
-  // by the real stiffness part on the fine levels ((omega h / c)^2 ~ 1e-3), and a smoother only has to damp the
-  // oscillatory error, where the complex shift is invisible; the residual that feeds the coarse grids keeps the complex
-  // values.  May be null.
-  __half* val_r = nullptr;
 };
 typedef __half2 ch;
 __device__ __forceinline__ zc mload(const zc* p) { return *p; }
 __device__ __forceinline__ cc mload(const cc* p) { return *p; }
 __device__ __forceinline__ cc mload(const ch* p) { return __half22float2(*p); }
-__device__ __forceinline__ cc mload(const __half* p) { return make_float2(__half2float(*p), 0.f); }
 
 // max over |re|, |im| of a complex128 array (non-negative floats order like their bit patterns)
 __global__ void k_absmax(int64_t n, const zc* __restrict__ v, unsigned int* __restrict__ out) {
@@ -59,8 +53,6 @@ __global__ void k_absmax(int64_t n, const zc* __restrict__ v, unsigned int* __re
 
 template <>
 __device__ __forceinline__ ch czero<ch>() { return __floats2half2_rn(0.f, 0.f); }
-template <>
-__device__ __forceinline__ __half czero<__half>() { return __float2half(0.f); }
 
 __global__ void k_sell_widths(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, int64_t* __restrict__ slice_sz) {
   const int lane = threadIdx.x & 63;
@@ -92,8 +84,7 @@ __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restri
       if (scol) scol[o] = col[s + k];
       if constexpr (sizeof(VOUT) == sizeof(zc)) sval[o] = v;
       else if constexpr (sizeof(VOUT) == sizeof(cc)) sval[o] = make_float2((float)v.x, (float)v.y);
-      else if constexpr (sizeof(VOUT) == sizeof(ch)) sval[o] = __floats2half2_rn((float)v.x * inv_scale, (float)v.y * inv_scale);
-      else sval[o] = __float2half((float)v.x * inv_scale);
+      else sval[o] = __floats2half2_rn((float)v.x * inv_scale, (float)v.y * inv_scale);
     } else {
       if (scol) scol[o] = pad_col;
       sval[o] = czero<VOUT>();
@@ -129,18 +120,17 @@ __global__ void k_sell_narrow(int32_t n_slices, const int64_t* __restrict__ slic
 extern "C" int hx_sell_destroy(hx_sell* h) {
   if (!h) return HX_OK;
   (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->dcol); (void)hipFree(h->wide); (void)hipFree(h->val_z); (void)hipFree(h->val_c);
-  (void)hipFree(h->val_h); (void)hipFree(h->val_r);
+  (void)hipFree(h->val_h);
   delete h;
   return HX_OK;
 }
 
 // Build the SELL-64 companion of a device CSR (complex128 values).  want_z / want_c select which value copies to
 // keep (complex128 for the operator product, complex64 for the single-precision V-cycle; want_c == 2 stores that copy
-// as scaled complex-half instead: same complex64 arithmetic, 8 instead of 12 bytes per entry; want_c == 3 adds the
-// real-half copy that the smoother steps read).  SYNC.
+// as scaled complex-half instead: same complex64 arithmetic, 8 instead of 12 bytes per entry).  SYNC.
 extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
                               int want_z, int want_c, hx_stream s_) {
-  HX_REQUIRE(out && n > 0 && rowptr && col && val && (want_z || want_c), "bad argument");
+  HX_REQUIRE(out && n > 0 && rowptr && col && val && (want_z || want_c) && want_c >= 0 && want_c <= 2, "bad argument");
   hipStream_t s = hx_s(s_);
   hx_sell* h = new hx_sell();
   h->n = n;
@@ -165,15 +155,14 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   if (hipMalloc((void**)&h->col, sizeof(int32_t) * ne) != hipSuccess ||
       (want_z && hipMalloc((void**)&h->val_z, sizeof(zc) * ne) != hipSuccess) ||
       (want_c == 1 && hipMalloc((void**)&h->val_c, sizeof(cc) * ne) != hipSuccess) ||
-      (want_c >= 2 && hipMalloc((void**)&h->val_h, sizeof(ch) * ne) != hipSuccess) ||
-      (want_c == 3 && hipMalloc((void**)&h->val_r, sizeof(__half) * ne) != hipSuccess)) {
+      (want_c == 2 && hipMalloc((void**)&h->val_h, sizeof(ch) * ne) != hipSuccess)) {
     hx_sell_destroy(h);
     return hx_fail(HX_ERR_ALLOC, __func__, "SELL arrays");
   }
   if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f);
   if (want_c == 1) k_sell_fill<cc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
                                                           want_z ? nullptr : h->col, h->val_c, 1.f);
-  if (want_c >= 2) {
+  if (want_c == 2) {
     // scale so that the largest component maps to 2^14: five binary orders of head-room below the fp16 maximum, and
     // entries down to ~4e-9 of the largest stay normal numbers
     unsigned int* dmax = nullptr;
@@ -195,9 +184,6 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     h->h_scale = vmax > 0.f ? vmax / 16384.f : 1.f;
     k_sell_fill<ch><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
                                            want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale);
-    if (want_c == 3)
-      k_sell_fill<__half><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, nullptr, h->val_r,
-                                               1.f / h->h_scale);
   }
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
@@ -390,10 +376,7 @@ extern "C" int hx_sell_smooth_c64(const hx_sell* h, const hx_c64* dinv, const hx
                                   float omega, const hx_c64* xprev, float mom, hx_stream s) {
   HX_REQUIRE(h && (h->val_c || h->val_h) && dinv && b && xin && xout && xin != xout, "bad argument");
   const bool rec = prof_begin(1, h->n, s);
-  if (h->val_r)
-    launch_sell<cc, 1, __half>(h, h->val_r, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1,
-                               (const cc*)dinv, (const cc*)b, (const cc*)xprev, omega, mom, h->h_scale, s);
-  else if (h->val_h)
+  if (h->val_h)
     launch_sell<cc, 1, ch>(h, h->val_h, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
                            (const cc*)b, (const cc*)xprev, omega, mom, h->h_scale, s);
   else

@@ -25,7 +25,7 @@ from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
               max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
-              recycle_min_rows=100_000, krylov="auto", setup="device")
+              recycle_min_rows=100_000, krylov="auto", cocg_min_rows=100_000, setup="device")
 
 
 MAX_DENSE_COARSE = 6000          # the coarsest operator is inverted densely on the host
@@ -371,9 +371,13 @@ class AMGSolver:
         # Krylov method of the inner solve: complex symmetric K (every shifted operator of the path except the
         # Bloch-reduced ones) + symmetric V-cycle (pre == post) -> deflated COCG (short recurrences, hx_cocg);
         # otherwise flexible GMRES.  "auto" probes the symmetry of the bilinear form with two random vectors.
+        # Below ~1e5 rows the solve is launch-latency bound and the iteration COUNT decides: undeflated COCG needs
+        # 14-18 iterations where GMRES needs 12-14 (measured at 34 k / 66 k rows), so "auto" keeps GMRES there.
         kry = os.environ.get("HX_AMG_KRYLOV", self.params["krylov"])
+        n_rows = K_global.shape[0]
         self.use_cocg = len(levels) > 1 and self.params["pre"] == self.params["post"] and (
-            kry == "cocg" or (kry == "auto" and _is_complex_symmetric(K_global)))
+            kry == "cocg" or (kry == "auto" and n_rows >= self.params["cocg_min_rows"]
+                              and _is_complex_symmetric(K_global)))
         self.cocg_solves = self.cocg_fallbacks = self.cocg_iters = self.attainable_stops = 0
         self.backward_stable = False
         if shard is not None:
@@ -428,17 +432,14 @@ class AMGSolver:
             sh = C.c_void_p()
             # complex128 copy for K z in GMRES; V-cycle copy in the working precision -- stored as scaled complex-half
             # when the cycle runs in complex64 (8 instead of 12 bytes per entry; same GMRES iteration counts measured)
-            vv = os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"])
-            half = mixed and vv in ("fp16", "fp16r")
-            self.fine_values = vv if half else ("c64" if mixed else "c128")
+            half = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
+            self.fine_values = "fp16" if half else ("c64" if mixed else "c128")
             _hx.check(_hx.lib.hx_sell_create(C.byref(sh), self.n, _hx.ptr(K_csr.rowptr), _hx.ptr(K_csr.col),
-                                             _hx.ptr(K_csr.val), 1, (3 if vv == "fp16r" else 2) if half else int(mixed),
-                                             _hx.stream()))
+                                             _hx.ptr(K_csr.val), 1, 2 if half else int(mixed), _hx.stream()))
             self.sell = sh
             _hx.check(_hx.lib.hx_amg_set_level_sell(h, 0, sh))
         # coarse SELL levels take the same storage (5 M DOF: iterations unchanged, 8.38 -> 8.27 s)
-        vvc = os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"])
-        half_coarse = mixed and vvc in ("fp16", "fp16r")
+        half_coarse = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
         for l, lv in enumerate(levels):
             if l == 0:
                 k0 = K_csr.val.to(cdt) if mixed else K_csr.val
@@ -453,8 +454,7 @@ class AMGSolver:
                     tmp = values_c128(lv["K"])
                     shl = C.c_void_p()
                     _hx.check(_hx.lib.hx_sell_create(C.byref(shl), lv["n"], _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(tmp),
-                                                     int(not mixed), ((3 if vvc == "fp16r" else 2) if half_coarse else int(mixed)),
-                                                     _hx.stream()))
+                                                     int(not mixed), (2 if half_coarse else int(mixed)), _hx.stream()))
                     del tmp
                     self.coarse_sells.append(shl)
                     _hx.check(_hx.lib.hx_amg_set_level_sell(h, l, shl))

@@ -107,9 +107,7 @@ int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int3
  * transaction and a lane owns a whole row (no shuffle reduction, no row-pointer chase).  Same products as
  * hx_csr_spmv_z / hx_csr_jacobi_*; the handle owns its arrays.  hx_sell_create is SYNC.
  * want_c64: 0 none, 1 complex64 value copy for the *_c64 entry points, 2 the same copy STORED as scaled complex-half
- * (8 instead of 12 bytes per entry, arithmetic still complex64) -- for the V-cycle preconditioner only; 3 = as 2, plus a
- * REAL-half copy (Re K, 2 bytes per entry) that hx_sell_smooth_c64 reads instead: the smoother damps oscillatory error,
- * where the complex shift of K = A + sigma B + sigma^2 C is invisible; hx_sell_spmv_c64 (residuals) keeps Re + Im. */
+ * (8 instead of 12 bytes per entry, arithmetic still complex64) -- for the V-cycle preconditioner only. */
 typedef struct hx_sell hx_sell;
 int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
                    int want_c128, int want_c64, hx_stream s);

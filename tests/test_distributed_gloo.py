@@ -183,11 +183,14 @@ def test_sharded_spmv_and_dots_two_ranks_one_gpu():
         assert err_spmv < 1e-12 and err_dot < 1e-12
 
 
-def _gpu_fpi_worker(rank, world, port, out):
+def _gpu_fpi_worker(rank, world, port, out, krylov):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
     os.environ["HX_QUIET"] = "1"
+    if krylov == "cocg":            # "auto" keeps GMRES below 1e5 rows: force the deflated COCG path (hx_cocg_sharded)
+        os.environ["HX_AMG_KRYLOV"] = "cocg"
+        os.environ["HX_AMG_RECYCLE"] = "6"
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
@@ -211,14 +214,15 @@ def _gpu_fpi_worker(rank, world, port, out):
 
 
 @pytest.mark.gpu
-def test_row_sharded_fixed_point_matches_single_gpu_two_ranks():
+@pytest.mark.parametrize("krylov", ["auto", "cocg"])
+def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov):
     """The whole fixed-point solve, row-sharded over two ranks (sharing the one GPU; gloo stages the exchanges through
-    the host): sharded level-0 V-cycle + replicated coarse levels, hx_gmres_sharded, all-reduced CGS2 panels and
-    Woodbury dots.  Eigenvalues and the fixed-point trajectory must match the single-GPU solve of the same problem
+    the host): sharded level-0 V-cycle + replicated coarse levels, hx_gmres_sharded / hx_cocg_sharded, all-reduced CGS2
+    panels and Woodbury dots.  Eigenvalues and the fixed-point trajectory must match the single-GPU solve of the same problem
     to 1e-9 (same algorithm, same hierarchy; only the summation order of the inner products differs)."""
     world, port = 2, _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_gpu_fpi_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_gpu_fpi_worker, args=(world, port, out, krylov), nprocs=world, join=True)
     assert len(out) == world
     for rank in range(world):
         r = out[rank]
@@ -233,6 +237,8 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks():
         assert abs(single["ops"] - sharded["ops"]) <= 0.1 * single["ops"]
         n_halo, n_allreduce, n_own, n_ext = r["exchanges"]
         assert n_halo > 0 and n_allreduce > 0 and n_ext > n_own
+        assert sharded["stats"]["krylov"] == ("cocg" if krylov == "cocg" else "fgmres")
+        assert sharded["stats"]["cocg_fallbacks"] == 0 and (krylov != "cocg" or sharded["stats"]["cocg_solves"] > 50)
     # both ranks hold identical (all-reduced) results
     assert out[0]["sharded"]["eigs"] == out[1]["sharded"]["eigs"]
     print("sharded stats:", out[0]["sharded"]["stats"], "single:", out[0]["single"]["stats"], out[0]["exchanges"])

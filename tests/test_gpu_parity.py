@@ -411,7 +411,10 @@ def _annulus_case(shape):
                                        dict(recycle_min_rows=0, sell_min_rows=0),
                                        dict(recycle_min_rows=0, sell_min_rows=0, vcycle_values="c64"),
                                        dict(graph_max_rows=10 ** 9),
-                                       dict(krylov="fgmres"), dict(krylov="fgmres", recycle_min_rows=0, sell_min_rows=0),
+                                       # deflated / plain COCG ("auto" only picks it from 1e5 rows on)
+                                       dict(cocg_min_rows=0), dict(cocg_min_rows=0, sell_min_rows=0),
+                                       dict(cocg_min_rows=0, precision="double", smoother="jacobi"),
+                                       dict(cocg_min_rows=0, recycle_min_rows=0, sell_min_rows=0),
                                        dict(krylov="cocg", recycle_min_rows=0, recycle=6)])
 def test_amg_gmres_inner_solver_matches_direct(overrides):
     """K^-1 b from the device AMG-GMRES equals the SuperLU solution on a 3-D annulus (complex shifted operator):
@@ -442,7 +445,8 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
         tol = 1e-9 if k < 2 else 1e-7                     # third solve: relaxed tolerance requested by the caller
         assert np.linalg.norm(x.cpu().numpy() - ref) <= tol * np.linalg.norm(ref)
     st = solver.stats()
-    assert st["krylov"] == overrides.get("krylov", "cocg") and st["cocg_fallbacks"] == 0
+    want = "cocg" if (overrides.get("krylov") == "cocg" or overrides.get("cocg_min_rows") == 0) else "fgmres"
+    assert st["krylov"] == want and st["cocg_fallbacks"] == 0
     if st["krylov"] == "cocg":      # the first solve of a recycling hierarchy is the harvested GMRES run
         assert st["cocg_solves"] == (2 if overrides.get("recycle_min_rows") == 0 else 3)
     if overrides.get("recycle_min_rows") == 0:
@@ -475,7 +479,8 @@ def test_cocg_symmetry_probe_and_fallback():
     Ku.data = Ku.data * (1.0 + 0.02 * np.sin(np.arange(Ku.nnz)))        # same pattern, K^T != K
     Kd = CSR.from_scipy(Ku)
     assert not _is_complex_symmetric(Kd)
-    assert AMGSolver(Kd).stats()["krylov"] == "fgmres"
+    assert AMGSolver(Kd, cocg_min_rows=0).stats()["krylov"] == "fgmres"
+    assert AMGSolver(K, cocg_min_rows=0).stats()["krylov"] == "cocg" and AMGSolver(K).stats()["krylov"] == "fgmres"
     solver = AMGSolver(Kd, krylov="cocg")                                 # forced: must not return garbage
     lu = spla.splu(Ku.tocsc())
     rng = np.random.default_rng(1)

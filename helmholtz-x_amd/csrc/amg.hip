@@ -42,6 +42,10 @@ extern "C" int hx_sell_smooth_z(const hx_sell*, const hx_c128*, const hx_c128*, 
                                 const hx_c128*, double, hx_stream);
 extern "C" int hx_sell_smooth_c64(const hx_sell*, const hx_c64*, const hx_c64*, const hx_c64*, hx_c64*, float,
                                   const hx_c64*, float, hx_stream);
+int hx_sell_residual_c64(const hx_sell*, const hx_c64*, const hx_c64*, hx_c64*, hx_stream);
+int hx_sell_residual_z(const hx_sell*, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
+int hx_csr_residual_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*, float*, hx_stream);
+int hx_csr_residual_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
 int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
 int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 
@@ -87,6 +91,15 @@ static int op_kmult(const LevelT<double>& L, const double* x, double* y, double 
 static int op_kmult(const LevelT<float>& L, const float* x, float* y, float a, float b, hx_stream s) {
   if (L.sell) return hx_sell_spmv_c64(L.sell, (const hx_c64*)x, (hx_c64*)y, a, b, s);
   return op_spmv(L.K, x, y, a, b, false, s);
+}
+// r = b - K x (one pass, no copy of b)
+static int op_residual(const LevelT<double>& L, const double* x, const double* b, double* r, hx_stream s) {
+  if (L.sell) return hx_sell_residual_z(L.sell, (const hx_c128*)x, (const hx_c128*)b, (hx_c128*)r, s);
+  return hx_csr_residual_z(L.K.rows, L.K.nnz, L.K.rp, L.K.ci, (const hx_c128*)L.K.va, (const hx_c128*)x, (const hx_c128*)b, (hx_c128*)r, s);
+}
+static int op_residual(const LevelT<float>& L, const float* x, const float* b, float* r, hx_stream s) {
+  if (L.sell) return hx_sell_residual_c64(L.sell, (const hx_c64*)x, (const hx_c64*)b, (hx_c64*)r, s);
+  return hx_csr_residual_c(L.K.rows, L.K.nnz, L.K.rp, L.K.ci, L.K.va, x, b, r, s);
 }
 // xout = xin + w D^-1 (b - K xin) + mom (xin - xprev)     (xprev may be NULL)
 static int op_smooth(const LevelT<double>& L, const double* b, const double* xin, double* xout, double w,
@@ -293,9 +306,8 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
       prev = cur; cur = nxt;
     }
     // residual r = b - K x, restrict
-    HX_HIP(hipMemcpyAsync(L.r, b, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
     if ((rc = halo_before_k(h, l, cur))) return rc;
-    if ((rc = op_kmult(L, cur, L.r, (T)-1, (T)1, s))) return rc;
+    if ((rc = op_residual(L, cur, b, L.r, s))) return rc;
     if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
   }
   if (h->sharded && l == 0) {   // R holds this rank's columns only: the coarse right-hand side is the sum over ranks
@@ -329,6 +341,50 @@ extern "C" int hx_amg_enable_graph(hx_amg* h, int enable) {
 // 1 if the last cycles were replayed from the captured graph
 extern "C" int hx_amg_graph_active(const hx_amg* h) { return h && h->graph_state == 1 ? 1 : 0; }
 
+// The complex64 cycle from the level-0 input buffer (L0.b) to the output buffer (L0.r), no precision casts: hx_cocg writes
+// its residual into the input buffer in complex64 and reads the result as complex64.
+int hx_amg_vcycle_buffers(hx_amg* h, hx_c64** b, hx_c64** z) {
+  HX_REQUIRE(h && b && z, "bad argument");
+  if (!h->single || h->S.L.empty() || h->S.L[0].n <= 0) { *b = nullptr; *z = nullptr; return HX_OK; }
+  *b = (hx_c64*)h->S.L[0].b;
+  *z = (hx_c64*)h->S.L[0].r;
+  return HX_OK;
+}
+int hx_amg_vcycle_c64(hx_amg* h, hx_stream s) {
+  HX_REQUIRE(h && h->single && h->S.coarse_inv.rp && h->S.L[0].n > 0, "complex64 hierarchy not set");
+  LevelT<float>& L0 = h->S.L[0];
+  // on level 0 the residual buffer L0.r is consumed by the restriction before the last post-sweep writes it
+  if (h->graph_state == 0 && !h->sharded) {                      // capture the cycle once (its buffers never change)
+    bool ok = true;
+    if (!h->gstream) ok = hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess &&
+                          hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
+    hipGraph_t g = nullptr;
+    if (ok && hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      const int rcap = vcycle<float>(h, h->S, 0, L0.b, L0.r, (hx_stream)h->gstream);
+      const hipError_t e = hipStreamEndCapture(h->gstream, &g);
+      ok = rcap == HX_OK && e == hipSuccess && g && hipGraphInstantiate(&h->vexec, g, nullptr, nullptr, 0) == hipSuccess;
+      if (g) (void)hipGraphDestroy(g);
+    } else ok = false;
+    (void)hipGetLastError();
+    h->graph_state = ok ? 1 : -1;                                // any failure: fall back to eager launches for good
+  }
+  if (h->graph_state == 1 && !h->sharded) {
+    static const bool hop = getenv("HX_AMG_GRAPH_PRIVATE_STREAM") != nullptr;     // (measured variant)
+    if (hop) {
+      HX_HIP(hipEventRecord(h->ev_in, hx_s(s)));                 // order the graph after the producer on the caller's stream
+      HX_HIP(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
+      HX_HIP(hipGraphLaunch(h->vexec, h->gstream));
+      HX_HIP(hipEventRecord(h->ev_out, h->gstream));
+      HX_HIP(hipStreamWaitEvent(hx_s(s), h->ev_out, 0));         // ... and everything that follows after the graph
+    } else {
+      HX_HIP(hipGraphLaunch(h->vexec, hx_s(s)));                 // replay in the caller's stream: plain stream order
+    }
+    return HX_OK;
+  }
+  return vcycle<float>(h, h->S, 0, L0.b, L0.r, s);
+}
+
 extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream s) {
   HX_REQUIRE(h && b && x && b != x && !h->D.L.empty(), "bad argument");
   if (h->single) {
@@ -336,34 +392,7 @@ extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream 
     LevelT<float>& L0 = h->S.L[0];
     int rc;
     if ((rc = hx_cast_z2c(L0.n, b, L0.b, s))) return rc;          // narrow the right-hand side
-    // on level 0 the residual buffer L0.r is consumed by the restriction before the last post-sweep writes it
-    if (h->graph_state == 0 && !h->sharded) {                      // capture the cycle once (its buffers never change)
-      bool ok = true;
-      if (!h->gstream) ok = hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess &&
-                            hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
-                            hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
-      hipGraph_t g = nullptr;
-      if (ok && hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        const int rcap = vcycle<float>(h, h->S, 0, L0.b, L0.r, (hx_stream)h->gstream);
-        const hipError_t e = hipStreamEndCapture(h->gstream, &g);
-        ok = rcap == HX_OK && e == hipSuccess && g && hipGraphInstantiate(&h->vexec, g, nullptr, nullptr, 0) == hipSuccess;
-        if (g) (void)hipGraphDestroy(g);
-      } else ok = false;
-      (void)hipGetLastError();
-      h->graph_state = ok ? 1 : -1;                                // any failure: fall back to eager launches for good
-    }
-    if (h->graph_state == 1 && !h->sharded) {
-      static const bool hop = getenv("HX_AMG_GRAPH_PRIVATE_STREAM") != nullptr;     // (measured variant)
-      if (hop) {
-        HX_HIP(hipEventRecord(h->ev_in, hx_s(s)));                 // order the graph after the cast on the caller's stream
-        HX_HIP(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
-        HX_HIP(hipGraphLaunch(h->vexec, h->gstream));
-        HX_HIP(hipEventRecord(h->ev_out, h->gstream));
-        HX_HIP(hipStreamWaitEvent(hx_s(s), h->ev_out, 0));         // ... and everything that follows after the graph
-      } else {
-        HX_HIP(hipGraphLaunch(h->vexec, hx_s(s)));                 // replay in the caller's stream: plain stream order
-      }
-    } else if ((rc = vcycle<float>(h, h->S, 0, L0.b, L0.r, s))) return rc;
+    if ((rc = hx_amg_vcycle_c64(h, s))) return rc;
     return hx_cast_c2z(L0.n, L0.r, x, s);                         // widen the result
   }
   HX_REQUIRE(h->D.coarse_inv.rp && h->D.L[0].n > 0, "coarse solver not set");

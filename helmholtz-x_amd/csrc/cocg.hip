@@ -27,6 +27,10 @@ extern "C" int hx_sell_spmv_z(const hx_sell*, const hx_c128*, hx_c128*, const do
 int hx_zpanel_bdot(int64_t, int, const hx_c128*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
 int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 int hx_zpanel_bdot_c64(int64_t, int, const hx_c64*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
+int hx_zpanel_bdot_w32(int64_t, int, const hx_c128*, int64_t, const hx_c64*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
+int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
+int hx_amg_vcycle_buffers(hx_amg*, hx_c64**, hx_c64**);
+int hx_amg_vcycle_c64(hx_amg*, hx_stream);
 int hx_panel_dot_blocks(int64_t n, int64_t* rows_per_block);
 int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* out, hx_stream s);
 
@@ -44,6 +48,7 @@ static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 
 // x += alpha p, r -= alpha q with alpha = rho / (p^T q) read from the device; per-block partial sums of |r|^2.
 __global__ void __launch_bounds__(256)
 k_cocg_update(int64_t n, const zc* __restrict__ p, const zc* __restrict__ q, zc* __restrict__ x, zc* __restrict__ r,
+              cc* __restrict__ r32 /* may be NULL: complex64 copy of the new residual = the V-cycle's input */,
               const zc* __restrict__ sc, zc* __restrict__ partials, int64_t rows_per_block) {
   __shared__ double red[256 / HX_WAVE];
   const zc alpha = zdiv(sc[CG_RHO], sc[CG_OUT]);
@@ -58,6 +63,7 @@ k_cocg_update(int64_t n, const zc* __restrict__ p, const zc* __restrict__ q, zc*
     rv.x = fma(-alpha.x, qv.x, rv.x); rv.x = fma(alpha.y, qv.y, rv.x);
     rv.y = fma(-alpha.x, qv.y, rv.y); rv.y = fma(-alpha.y, qv.x, rv.y);
     x[i] = xv; r[i] = rv;
+    if (r32) r32[i] = make_float2((float)rv.x, (float)rv.y);
     acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
   }
 #pragma unroll
@@ -89,16 +95,19 @@ k_cocg_small(int k, const zc* __restrict__ Einv, zc* __restrict__ sc, int first,
   }
 }
 
-// p = z - sum_j t_j U_j + beta p   (U read from its complex64 mirror; t and beta from the device scalar block)
+// p = z - sum_j t_j U_j + beta p   (U complex64; z complex128 or the V-cycle's complex64 output; t, beta from the scalar block)
+__device__ __forceinline__ zc widen(zc v) { return v; }
+__device__ __forceinline__ zc widen(cc v) { return make_double2((double)v.x, (double)v.y); }
+template <typename ZT>
 __global__ void __launch_bounds__(256)
-k_cocg_direction(int64_t n, int k, const cc* __restrict__ Uf, int64_t ldu, const zc* __restrict__ z, zc* __restrict__ p,
+k_cocg_direction(int64_t n, int k, const cc* __restrict__ Uf, int64_t ldu, const ZT* __restrict__ z, zc* __restrict__ p,
                  const zc* __restrict__ sc) {
   __shared__ zc ts[CG_MAXK];
   if ((int)threadIdx.x < k) ts[threadIdx.x] = sc[CG_T + threadIdx.x];
   __syncthreads();
   const zc beta = sc[CG_BETA];
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    zc acc = z[i];
+    zc acc = widen(z[i]);
     if (beta.x != 0.0 || beta.y != 0.0) zfma(acc, beta, p[i]);
     for (int j = 0; j < k; ++j) {
       const cc u = Uf[(int64_t)j * ldu + i];
@@ -180,13 +189,17 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   HX_REQUIRE(!rec || rec->n == n, "deflation pairs were harvested for another n");
   const int k = rec ? rec->k : 0;
   HX_REQUIRE(k <= CG_MAXK, "too many deflation pairs");
+  int rc = HX_OK, rc0 = HX_OK;
   hx_c128 *r = ws, *p = r + n, *q = p + n, *z = q + n, *tmp = z + n;
+  // complex64 cycle: the residual goes into the cycle's input buffer as complex64 (written by the update kernel) and its
+  // result is consumed as complex64: no cast passes, half the bytes for z in the two passes that read it
+  hx_c64 *r32 = nullptr, *z32 = nullptr;
+  if ((rc0 = hx_amg_vcycle_buffers(M, &r32, &z32))) return rc0;
   hx_c128* part = tmp + n;
   hx_c128* sc = sharded ? hbuf : part + hx_panel_dot_ws(CG_MAXK + 1);
   const int sc_buf = HX_BUF_GMRES_DOTS;
   int64_t rpb;
   const int nblocks = hx_panel_dot_blocks(n, &rpb);
-  int rc;
   auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) -> int {
     if (sharded) {
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
@@ -326,26 +339,34 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       if ((rc = true_residual())) return rc;
       if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "non-finite residual");
     }
+    if (r32) { if ((rc = hx_cast_z2c(n, r, (float*)r32, s))) return rc; }     // later residuals: written by k_cocg_update
     bool first = true;
     double best = relres, prev = relres;
     int since_best = 0;
     while (it < max_it) {
       // z = M r ;  [c ; rho] = [C^T z ; r^T z] ;  t = E^-1 c, beta ;  p = z - U t + beta p
-      if ((rc = hx_amg_vcycle(M, r, z, s))) return rc;
-      if (k > 0) { if ((rc = hx_zpanel_bdot(n, k, rec->Cd, n, z, r, sc, part, s))) return rc; }
-      else if ((rc = hx_zpanel_bdot(n, 0, nullptr, n, z, r, sc, part, s))) return rc;
+      if (r32) {
+        if ((rc = hx_amg_vcycle_c64(M, s))) return rc;
+        if ((rc = hx_zpanel_bdot_w32(n, k, k > 0 ? rec->Cd : nullptr, n, z32, r, sc, part, s))) return rc;
+      } else {
+        if ((rc = hx_amg_vcycle(M, r, z, s))) return rc;
+        if ((rc = hx_zpanel_bdot(n, k, k > 0 ? rec->Cd : nullptr, n, z, r, sc, part, s))) return rc;
+      }
       if ((rc = reduce(k + 1))) return rc;
       k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, rec ? (const zc*)rec->Einv : nullptr, (zc*)sc, first ? 1 : 0, 0);
       HX_LAUNCH_CHECK("k_cocg_small");
-      k_cocg_direction<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, rec ? (const cc*)rec->Uf : nullptr, n, (const zc*)z,
-                                                            (zc*)p, (const zc*)sc);
+      if (r32) k_cocg_direction<cc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, rec ? (const cc*)rec->Uf : nullptr, n,
+                                                                          (const cc*)z32, (zc*)p, (const zc*)sc);
+      else k_cocg_direction<zc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, rec ? (const cc*)rec->Uf : nullptr, n, (const zc*)z,
+                                                                      (zc*)p, (const zc*)sc);
       HX_LAUNCH_CHECK("k_cocg_direction");
       first = false;
       // q = K p ;  alpha = rho / p^T q ;  x += alpha p, r -= alpha q, |r|^2
       if ((rc = Kx(p, q, ONE, ZERO))) return rc;
       if ((rc = hx_zpanel_bdot(n, 0, nullptr, n, q, p, sc, part, s))) return rc;
       if ((rc = reduce(1))) return rc;
-      k_cocg_update<<<nblocks, 256, 0, hx_s(s)>>>(n, (const zc*)p, (const zc*)q, (zc*)x, (zc*)r, (const zc*)sc, (zc*)part, rpb);
+      k_cocg_update<<<nblocks, 256, 0, hx_s(s)>>>(n, (const zc*)p, (const zc*)q, (zc*)x, (zc*)r, (cc*)r32, (const zc*)sc,
+                                                  (zc*)part, rpb);
       HX_LAUNCH_CHECK("k_cocg_update");
       x_zero = false;
       if ((rc = hx_panel_dot_finish(nblocks, 0, part, sc, s))) return rc;

@@ -244,14 +244,14 @@ __device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cp, const MV* _
   return zadd(acc0, acc1);
 }
 
-// MODE 0: y = alpha*A*x + beta*y.   MODE 1: xout = xin + omega*dinv.*(b - A*xin) + mom*(xin - xprev)  (smoother step)
+// MODE 0: y = alpha*A*x + beta*yin (yin may be y itself).   MODE 1: xout = xin + omega*dinv.*(b - A*xin) + mom*(xin - xprev)  (smoother step)
 // MV = storage type of the matrix values (V itself, or complex-half for V = complex64: entries are then vscale * half2).
 // dcol / wide: 16-bit column deltas for the slices flagged narrow (wave-uniform branch); both null -> 32-bit everywhere.
 template <typename V, int MODE, typename MV = V>
 __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide,
-       const MV* __restrict__ val, const V* __restrict__ x, V* __restrict__ y, V alpha, V beta, int beta_is_zero,
+       const MV* __restrict__ val, const V* __restrict__ x, V* y, const V* yin, V alpha, V beta, int beta_is_zero,
        const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev,
        typename real_of<V>::type omega, typename real_of<V>::type mom, typename real_of<V>::type vscale) {
   const int lane = threadIdx.x & 63;
@@ -268,7 +268,7 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     if (row < n) {
       if (MODE == 0) {
         V r = zmul(alpha, acc);
-        if (!beta_is_zero) zfma(r, beta, y[row]);
+        if (!beta_is_zero) zfma(r, beta, yin[row]);
         y[row] = r;
       } else {
         const V res = zsub(b[row], acc);
@@ -291,9 +291,10 @@ static int sell_grid(int32_t n_slices) {
 template <typename V, int MODE, typename MV>
 static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alpha, V beta, int beta_is_zero, const V* dinv,
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
-                        typename real_of<V>::type vscale, hx_stream s) {
+                        typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr) {
   k_sell<V, MODE, MV><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, val, x,
-                                                                   y, alpha, beta, beta_is_zero, dinv, b, xprev, omega, mom, vscale);
+                                                                   y, yin ? yin : y, alpha, beta, beta_is_zero, dinv, b, xprev,
+                                                                   omega, mom, vscale);
 }
 
 // In-situ timing of the operator product (the roofline kernel of bench.py): when enabled, every k_sell<c128,0> launch is
@@ -369,6 +370,25 @@ extern "C" int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, fl
     launch_sell<cc, 0, cc>(h, h->val_c, (const cc*)x, (cc*)y, make_float2(alpha, 0.f), make_float2(beta, 0.f), beta == 0.f, nullptr,
                            nullptr, nullptr, 0.f, 0.f, 1.f, s);
   HX_LAUNCH_CHECK("k_sell<c64,spmv>");
+  return HX_OK;
+}
+// r = b - A x in one pass (internal; the V-cycle's residual: no copy of b into r first)
+int hx_sell_residual_c64(const hx_sell* h, const hx_c64* x, const hx_c64* b, hx_c64* r, hx_stream s) {
+  HX_REQUIRE(h && (h->val_c || h->val_h) && x && b && r, "bad argument");
+  if (h->val_h)
+    launch_sell<cc, 0, ch>(h, h->val_h, (const cc*)x, (cc*)r, make_float2(-1.f, 0.f), make_float2(1.f, 0.f), 0, nullptr, nullptr,
+                           nullptr, 0.f, 0.f, h->h_scale, s, (const cc*)b);
+  else
+    launch_sell<cc, 0, cc>(h, h->val_c, (const cc*)x, (cc*)r, make_float2(-1.f, 0.f), make_float2(1.f, 0.f), 0, nullptr, nullptr,
+                           nullptr, 0.f, 0.f, 1.f, s, (const cc*)b);
+  HX_LAUNCH_CHECK("k_sell<c64,residual>");
+  return HX_OK;
+}
+int hx_sell_residual_z(const hx_sell* h, const hx_c128* x, const hx_c128* b, hx_c128* r, hx_stream s) {
+  HX_REQUIRE(h && h->val_z && x && b && r, "bad argument");
+  launch_sell<zc, 0, zc>(h, h->val_z, (const zc*)x, (zc*)r, make_double2(-1.0, 0.0), make_double2(1.0, 0.0), 0, nullptr, nullptr,
+                         nullptr, 0.0, 0.0, 1.0, s, (const zc*)b);
+  HX_LAUNCH_CHECK("k_sell<c128,residual>");
   return HX_OK;
 }
 // smoother step (see hx_csr_jacobi_* / the Chebyshev recurrence in amg.hip); xprev may be NULL

@@ -35,7 +35,7 @@ __device__ __forceinline__ cc row_dot(const int32_t* __restrict__ col, const cc*
 template <int LPR, int ROLE, typename V>
 __global__ void __launch_bounds__(256)
 k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const V* __restrict__ val,
-       const V* __restrict__ x, V* __restrict__ y, V alpha, V beta, int beta_is_zero) {
+       const V* __restrict__ x, V* y, const V* yin, V alpha, V beta, int beta_is_zero) {
   constexpr int RPB = 256 / LPR;                       // rows per block per sweep
   const int sub = threadIdx.x % LPR;
   const int64_t stride = (int64_t)gridDim.x * RPB;
@@ -48,18 +48,19 @@ k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict_
     if (LPR > 1) acc = zreduce_sub<LPR>(acc);
     if (row < n && sub == 0) {
       V r = zmul(alpha, acc);
-      if (!beta_is_zero) zfma(r, beta, y[row]);
+      if (!beta_is_zero) zfma(r, beta, yin[row]);
       y[row] = r;
     }
   }
 }
 
+// yin: the vector scaled by beta (y itself when NULL): y = alpha*A*x + beta*yin
 template <int LPR, int ROLE, typename V>
 static int launch(int32_t n, const int32_t* rowptr, const int32_t* col, const V* val, const V* x, V* y,
-                  V alpha, V beta, hipStream_t s) {
+                  V alpha, V beta, hipStream_t s, const V* yin = nullptr) {
   int64_t rows_per_block = 256 / LPR;
   int grid = hx_grid((int64_t)n, (int)rows_per_block, 256 * 16);
-  k_spmv<LPR, ROLE, V><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, alpha, beta, (beta.x == 0 && beta.y == 0));
+  k_spmv<LPR, ROLE, V><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, yin ? yin : y, alpha, beta, (beta.x == 0 && beta.y == 0));
   HX_LAUNCH_CHECK("k_spmv");
   return HX_OK;
 }
@@ -71,18 +72,18 @@ static inline int pick_lpr(int64_t nnz, int32_t n_rows) {
 
 template <int ROLE, typename V>
 static int spmv_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const V* val,
-                         const V* x, V* y, V a, V b, int lanes_per_row, hx_stream s) {
+                         const V* x, V* y, V a, V b, int lanes_per_row, hx_stream s, const V* yin = nullptr) {
   HX_REQUIRE(n_rows >= 0 && nnz >= 0 && rowptr && x && y && (nnz == 0 || (col && val)), "bad argument");
   if (n_rows == 0) return HX_OK;
   const int lpr = lanes_per_row ? lanes_per_row : pick_lpr(nnz, n_rows);
   switch (lpr) {
-    case 1: return launch<1, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
-    case 2: return launch<2, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
-    case 4: return launch<4, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
-    case 8: return launch<8, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
-    case 16: return launch<16, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
-    case 32: return launch<32, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
-    case 64: return launch<64, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s));
+    case 1: return launch<1, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 2: return launch<2, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 4: return launch<4, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 8: return launch<8, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 16: return launch<16, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 32: return launch<32, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 64: return launch<64, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
     default: return hx_fail(HX_ERR_ARG, __func__, "lanes_per_row must be 0,1,2,4,8,16,32,64");
   }
 }
@@ -106,6 +107,18 @@ int hx_csr_spmv_c(int role, int32_t n_rows, int64_t nnz, const int32_t* rowptr, 
   const cc a = make_float2(alpha, 0.f), b = make_float2(beta, 0.f);
   if (role == 1) return spmv_dispatch<1, cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)x, (cc*)y, a, b, 0, s);
   return spmv_dispatch<2, cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)x, (cc*)y, a, b, 0, s);
+}
+
+// r = b - A x in one pass (internal; the V-cycle's residual on the CSR levels)
+int hx_csr_residual_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val, const float* x,
+                      const float* b, float* r, hx_stream s) {
+  return spmv_dispatch<2, cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)x, (cc*)r, make_float2(-1.f, 0.f),
+                              make_float2(1.f, 0.f), 0, s, (const cc*)b);
+}
+int hx_csr_residual_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+                      const hx_c128* x, const hx_c128* b, hx_c128* r, hx_stream s) {
+  return spmv_dispatch<0, zc>(n_rows, nnz, rowptr, col, (const zc*)val, (const zc*)x, (zc*)r, make_double2(-1.0, 0.0),
+                              make_double2(1.0, 0.0), 0, s, (const zc*)b);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -118,9 +118,10 @@ __device__ __forceinline__ zc pd_load(const cc* p) { const cc v = *p; return mak
 // the subtraction w -= V h always uses the complex128 panel, so the Arnoldi relation holds for whatever h was used.
 // BILIN: unconjugated products out[j] = V_j^T w and out[k] = e^T w for a separate vector e (the bilinear form of complex
 // symmetric Krylov methods, hx_cocg); otherwise e is w itself and all products are conjugated (Gram-Schmidt).
-template <typename PT, int JT, bool BILIN>
+// WT: type of w (complex128, or complex64 for the V-cycle output that hx_cocg consumes without widening it first).
+template <typename PT, int JT, bool BILIN, typename WT = zc>
 __global__ void __launch_bounds__(PD_BLOCK)
-k_panel_dot_stage1(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, const zc* __restrict__ w,
+k_panel_dot_stage1(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, const WT* __restrict__ w,
                    const zc* __restrict__ e, zc* __restrict__ partials, int64_t rows_per_block) {
   __shared__ zc red[PD_BLOCK / HX_WAVE][JT];
   const int64_t r0 = blockIdx.x * rows_per_block;
@@ -134,7 +135,7 @@ k_panel_dot_stage1(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, cons
     for (int t = 0; t < JT; ++t) acc[t] = make_double2(0.0, 0.0);
     int64_t i = r0 + threadIdx.x;
     for (; i + PD_BLOCK < r1; i += 2 * PD_BLOCK) {     // two rows per trip: 2 x JT independent loads in flight
-      const zc wa = w[i], wb = w[i + PD_BLOCK];
+      const zc wa = pd_load(w + i), wb = pd_load(w + i + PD_BLOCK);
 #pragma unroll
       for (int t = 0; t < JT; ++t) {
         const int j = j0 + t;
@@ -149,7 +150,7 @@ k_panel_dot_stage1(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, cons
       }
     }
     for (; i < r1; i += PD_BLOCK) {
-      const zc wi = w[i];
+      const zc wi = pd_load(w + i);
 #pragma unroll
       for (int t = 0; t < JT; ++t) {
         const int j = j0 + t;
@@ -193,14 +194,14 @@ int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* ou
   HX_LAUNCH_CHECK("k_panel_dot_stage2");
   return HX_OK;
 }
-template <typename PT, int JT, bool BILIN>
-static int panel_dot_launch(int64_t n, int k, const PT* V, int64_t ldv, const hx_c128* w, const hx_c128* e, hx_c128* out,
+template <typename PT, int JT, bool BILIN, typename WT = zc>
+static int panel_dot_launch(int64_t n, int k, const PT* V, int64_t ldv, const void* w, const hx_c128* e, hx_c128* out,
                             hx_c128* partials, hx_stream s) {
   HX_REQUIRE(n > 0 && k >= 0 && w && out && partials && (k == 0 || V) && ldv >= n && (!BILIN || e), "bad argument");
   int64_t rpb;
   const int nblocks = hx_panel_dot_blocks(n, &rpb);
-  k_panel_dot_stage1<PT, JT, BILIN><<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, V, ldv, (const zc*)w, (const zc*)e,
-                                                                      (zc*)partials, rpb);
+  k_panel_dot_stage1<PT, JT, BILIN, WT><<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, V, ldv, (const WT*)w, (const zc*)e,
+                                                                          (zc*)partials, rpb);
   HX_LAUNCH_CHECK("k_panel_dot_stage1");
   return hx_panel_dot_finish(nblocks, k, partials, out, s);
 }
@@ -217,6 +218,11 @@ extern "C" int hx_zpanel_dot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv
 int hx_zpanel_bdot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, const hx_c128* e, hx_c128* out,
                    hx_c128* partials, hx_stream s) {
   return panel_dot_launch<zc, PD_JT, true>(n, k, (const zc*)V, ldv, w, e, out, partials, s);
+}
+// the same with w given in complex64 (panel complex128)
+int hx_zpanel_bdot_w32(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c64* w, const hx_c128* e, hx_c128* out,
+                       hx_c128* partials, hx_stream s) {
+  return panel_dot_launch<zc, PD_JT, true, cc>(n, k, (const zc*)V, ldv, w, e, out, partials, s);
 }
 int hx_zpanel_bdot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_c128* w, const hx_c128* e, hx_c128* out,
                        hx_c128* partials, hx_stream s) {

@@ -24,6 +24,8 @@ extern "C" int hx_csr_jacobi_z(int32_t, int64_t, const int32_t*, const int32_t*,
 extern "C" int hx_zdiag_scale(int64_t, double, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
 int hx_csr_spmv_transfer(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, hx_c128*,
                          const double*, const double*, hx_stream);
+int hx_csr_spmv_creal(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, float*, float, float, hx_stream);
+int hx_csr_spmv_zreal(int32_t, int64_t, const int32_t*, const int32_t*, const double*, const hx_c128*, hx_c128*, double, double, hx_stream);
 int hx_csr_spmv_c(int role, int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, float*, float,
                   float, hx_stream);
 int hx_csr_jacobi_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
@@ -74,12 +76,14 @@ static int halo_before_k(hx_amg* h, int l, const void* v) {
 static int op_kmult(const LevelT<double>& L, const double* x, double* y, double a, double b, hx_stream s);
 static int op_kmult(const LevelT<float>& L, const float* x, float* y, float a, float b, hx_stream s);
 static int op_spmv(const CsrT<double>& A, const double* x, double* y, double a, double b, bool transfer, hx_stream s) {
+  if (A.real_vals) return hx_csr_spmv_zreal(A.rows, A.nnz, A.rp, A.ci, A.va, (const hx_c128*)x, (hx_c128*)y, a, b, s);
   const double aa[2] = {a, 0.0}, bb[2] = {b, 0.0};
   if (transfer)
     return hx_csr_spmv_transfer(A.rows, A.nnz, A.rp, A.ci, (const hx_c128*)A.va, (const hx_c128*)x, (hx_c128*)y, aa, bb, s);
   return hx_csr_spmv_z(A.rows, A.nnz, A.rp, A.ci, (const hx_c128*)A.va, (const hx_c128*)x, (hx_c128*)y, aa, bb, 0, s);
 }
 static int op_spmv(const CsrT<float>& A, const float* x, float* y, float a, float b, bool transfer, hx_stream s) {
+  if (A.real_vals) return hx_csr_spmv_creal(A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, s);
   return hx_csr_spmv_c(transfer ? 1 : 2, A.rows, A.nnz, A.rp, A.ci, A.va, x, y, a, b, s);
 }
 // y = a K x + b y through the SELL companion when the level has one
@@ -152,7 +156,7 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
 }
 
 template <typename T>
-static int set_level(HierT<T>& H, int l, int32_t n, int64_t nnzK, const int32_t* rpK, const int32_t* ciK, const T* vaK,
+static int set_level(bool real_transfers, HierT<T>& H, int l, int32_t n, int64_t nnzK, const int32_t* rpK, const int32_t* ciK, const T* vaK,
                      const T* dinv, int32_t n_coarse, int64_t nnzP, const int32_t* rpP, const int32_t* ciP,
                      const T* vaP, int64_t nnzR, const int32_t* rpR, const int32_t* ciR, const T* vaR) {
   HX_REQUIRE(l >= 0 && l < (int)H.L.size() && n > 0 && rpK && ciK && vaK, "bad argument");
@@ -162,8 +166,8 @@ static int set_level(HierT<T>& H, int l, int32_t n, int64_t nnzK, const int32_t*
   L.dinv = dinv;
   if (l != (int)H.L.size() - 1) {
     HX_REQUIRE(dinv && n_coarse > 0 && rpP && ciP && vaP && rpR && ciR && vaR, "missing transfer operators");
-    L.P.rows = n; L.P.nnz = nnzP; L.P.rp = rpP; L.P.ci = ciP; L.P.va = vaP;
-    L.R.rows = n_coarse; L.R.nnz = nnzR; L.R.rp = rpR; L.R.ci = ciR; L.R.va = vaR;
+    L.P.rows = n; L.P.nnz = nnzP; L.P.rp = rpP; L.P.ci = ciP; L.P.va = vaP; L.P.real_vals = real_transfers;
+    L.R.rows = n_coarse; L.R.nnz = nnzR; L.R.rp = rpR; L.R.ci = ciR; L.R.va = vaR; L.R.real_vals = real_transfers;
   }
   if (!L.x) {
     const size_t bytes = 2 * sizeof(T) * (size_t)n;
@@ -181,7 +185,7 @@ extern "C" int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const
                                 const int32_t* rpP, const int32_t* ciP, const hx_c128* vaP, int64_t nnzR,
                                 const int32_t* rpR, const int32_t* ciR, const hx_c128* vaR) {
   HX_REQUIRE(h, "null handle");
-  return set_level<double>(h->D, l, n, nnzK, rpK, ciK, (const double*)vaK, (const double*)dinv, n_coarse, nnzP, rpP, ciP,
+  return set_level<double>(h->real_transfers, h->D, l, n, nnzK, rpK, ciK, (const double*)vaK, (const double*)dinv, n_coarse, nnzP, rpP, ciP,
                            (const double*)vaP, nnzR, rpR, ciR, (const double*)vaR);
 }
 extern "C" int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t* rpK, const int32_t* ciK,
@@ -191,8 +195,14 @@ extern "C" int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, con
   HX_REQUIRE(h, "null handle");
   h->single = true;
   drop_graph(h);
-  return set_level<float>(h->S, l, n, nnzK, rpK, ciK, (const float*)vaK, (const float*)dinv, n_coarse, nnzP, rpP, ciP,
+  return set_level<float>(h->real_transfers, h->S, l, n, nnzK, rpK, ciK, (const float*)vaK, (const float*)dinv, n_coarse, nnzP, rpP, ciP,
                           (const float*)vaP, nnzR, rpR, ciR, (const float*)vaR);
+}
+// P / R values of the following hx_amg_set_level* calls are REAL arrays (float for the complex64 copy, double otherwise)
+extern "C" int hx_amg_set_real_transfers(hx_amg* h, int flag) {
+  HX_REQUIRE(h, "null handle");
+  h->real_transfers = flag != 0;
+  return HX_OK;
 }
 extern "C" int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell) {
   HX_REQUIRE(h && l >= 0 && l < (int)h->D.L.size(), "bad argument");

@@ -8,7 +8,8 @@
 struct hx_sell;
 
 // T = double: complex128 hierarchy; T = float: complex64 copy of it (values interleaved re, im: 2 T per entry).
-template <typename T> struct CsrT { int32_t rows = 0; int64_t nnz = 0; const int32_t* rp = nullptr; const int32_t* ci = nullptr; const T* va = nullptr; };
+// va: interleaved complex values (2 T per entry), or -- real_vals -- one T per entry (transfer operators are real)
+template <typename T> struct CsrT { int32_t rows = 0; int64_t nnz = 0; const int32_t* rp = nullptr; const int32_t* ci = nullptr; const T* va = nullptr; bool real_vals = false; };
 template <typename T> struct LevelT {
   int32_t n = 0;
   CsrT<T> K, P, R;             // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
@@ -44,6 +45,7 @@ struct hx_amg {
   HierT<double> D;
   HierT<float> S;
   bool single = false;         // run the V-cycle on the complex64 copy
+  bool real_transfers = false; // hx_amg_set_level* receive P / R values as REAL arrays
   int pre = 2, post = 2;
   double omega = 0.6;
   bool sharded = false;

@@ -70,6 +70,9 @@ __device__ __forceinline__ void zfma(cc& acc, cc a, cc b) {
   acc.x = fmaf(a.x, b.x, acc.x); acc.x = fmaf(-a.y, b.y, acc.x);
   acc.y = fmaf(a.x, b.y, acc.y); acc.y = fmaf(a.y, b.x, acc.y);
 }
+// real matrix entry times complex vector entry (transfer operators of the hierarchy are real)
+__device__ __forceinline__ void zfma(zc& acc, double a, zc b) { acc.x = fma(a, b.x, acc.x); acc.y = fma(a, b.y, acc.y); }
+__device__ __forceinline__ void zfma(cc& acc, float a, cc b) { acc.x = fmaf(a, b.x, acc.x); acc.y = fmaf(a, b.y, acc.y); }
 template <int W>
 __device__ __forceinline__ cc zreduce_sub(cc v) {
 #pragma unroll

@@ -9,19 +9,13 @@
 #include "hx_common.h"
 
 // Partial row product of one sub-wave lane: sum over p = s+sub, s+sub+LPR, ... of val[p] * x[col[p]].
-template <int LPR>
-__device__ __forceinline__ zc row_dot(const int32_t* __restrict__ col, const zc* __restrict__ val,
-                                      const zc* __restrict__ x, int32_t s, int32_t e, int sub) {
-  zc acc = make_double2(0.0, 0.0);
-  for (int32_t p = s + sub; p < e; p += LPR) zfma(acc, val[p], x[col[p]]);
-  return acc;
-}
+// MV = type of the matrix values: V itself, or the real type of V for the (real) transfer operators of the hierarchy.
 // complex64: same entry-per-lane sweep.  Measured and rejected on MI355X (5 M rows, round 1): lanes taking PAIRS of
 // entries (one 16-byte value load + one 8-byte index load) ran at 3.1-3.4 TB/s against 3.9 TB/s for this form.
-template <int LPR>
-__device__ __forceinline__ cc row_dot(const int32_t* __restrict__ col, const cc* __restrict__ val,
-                                      const cc* __restrict__ x, int32_t s, int32_t e, int sub) {
-  cc acc = make_float2(0.0f, 0.0f);
+template <int LPR, typename V, typename MV>
+__device__ __forceinline__ V row_dot(const int32_t* __restrict__ col, const MV* __restrict__ val,
+                                     const V* __restrict__ x, int32_t s, int32_t e, int sub) {
+  V acc = czero<V>();
   for (int32_t p = s + sub; p < e; p += LPR) zfma(acc, val[p], x[col[p]]);
   return acc;
 }
@@ -32,9 +26,9 @@ __device__ __forceinline__ cc row_dot(const int32_t* __restrict__ col, const cc*
 // Measured and rejected on MI355X at 1 M / 5 M rows (tools/run_spmv_modes.sh, round 1): (a) XCD-aware banding
 // (workgroups with equal blockIdx % 8 sweeping a contiguous eighth of the rows) -8 %; (b) non-temporal loads of
 // val/col -30 % (they split the 16-byte value load).  The plain grid-stride sweep below is the fastest form.
-template <int LPR, int ROLE, typename V>
+template <int LPR, int ROLE, typename V, typename MV = V>
 __global__ void __launch_bounds__(256)
-k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const V* __restrict__ val,
+k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const MV* __restrict__ val,
        const V* __restrict__ x, V* y, const V* yin, V alpha, V beta, int beta_is_zero) {
   constexpr int RPB = 256 / LPR;                       // rows per block per sweep
   const int sub = threadIdx.x % LPR;
@@ -44,7 +38,7 @@ k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict_
   int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
   for (int64_t it = 0; it < sweeps; ++it, row += stride) {
     V acc = czero<V>();
-    if (row < n) acc = row_dot<LPR>(col, val, x, rowptr[row], rowptr[row + 1], sub);
+    if (row < n) acc = row_dot<LPR, V, MV>(col, val, x, rowptr[row], rowptr[row + 1], sub);
     if (LPR > 1) acc = zreduce_sub<LPR>(acc);
     if (row < n && sub == 0) {
       V r = zmul(alpha, acc);
@@ -55,12 +49,12 @@ k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict_
 }
 
 // yin: the vector scaled by beta (y itself when NULL): y = alpha*A*x + beta*yin
-template <int LPR, int ROLE, typename V>
-static int launch(int32_t n, const int32_t* rowptr, const int32_t* col, const V* val, const V* x, V* y,
+template <int LPR, int ROLE, typename V, typename MV = V>
+static int launch(int32_t n, const int32_t* rowptr, const int32_t* col, const MV* val, const V* x, V* y,
                   V alpha, V beta, hipStream_t s, const V* yin = nullptr) {
   int64_t rows_per_block = 256 / LPR;
   int grid = hx_grid((int64_t)n, (int)rows_per_block, 256 * 16);
-  k_spmv<LPR, ROLE, V><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, yin ? yin : y, alpha, beta, (beta.x == 0 && beta.y == 0));
+  k_spmv<LPR, ROLE, V, MV><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, yin ? yin : y, alpha, beta, (beta.x == 0 && beta.y == 0));
   HX_LAUNCH_CHECK("k_spmv");
   return HX_OK;
 }
@@ -70,20 +64,20 @@ static inline int pick_lpr(int64_t nnz, int32_t n_rows) {
   return avg <= 2.0 ? 1 : avg <= 4.5 ? 2 : avg <= 9.0 ? 4 : avg <= 24.0 ? 8 : avg <= 64.0 ? 16 : avg <= 160 ? 32 : 64;
 }
 
-template <int ROLE, typename V>
-static int spmv_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const V* val,
+template <int ROLE, typename V, typename MV = V>
+static int spmv_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const MV* val,
                          const V* x, V* y, V a, V b, int lanes_per_row, hx_stream s, const V* yin = nullptr) {
   HX_REQUIRE(n_rows >= 0 && nnz >= 0 && rowptr && x && y && (nnz == 0 || (col && val)), "bad argument");
   if (n_rows == 0) return HX_OK;
   const int lpr = lanes_per_row ? lanes_per_row : pick_lpr(nnz, n_rows);
   switch (lpr) {
-    case 1: return launch<1, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 2: return launch<2, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 4: return launch<4, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 8: return launch<8, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 16: return launch<16, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 32: return launch<32, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 64: return launch<64, ROLE, V>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 1: return launch<1, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 2: return launch<2, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 4: return launch<4, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 8: return launch<8, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 16: return launch<16, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 32: return launch<32, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 64: return launch<64, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
     default: return hx_fail(HX_ERR_ARG, __func__, "lanes_per_row must be 0,1,2,4,8,16,32,64");
   }
 }
@@ -109,6 +103,18 @@ int hx_csr_spmv_c(int role, int32_t n_rows, int64_t nnz, const int32_t* rowptr, 
   return spmv_dispatch<2, cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)x, (cc*)y, a, b, 0, s);
 }
 
+// transfer operators with REAL values (float for the complex64 hierarchy, double for the complex128 one): 8 instead of
+// 12 (resp. 12 instead of 20) bytes per entry with the column index
+int hx_csr_spmv_creal(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val, const float* x,
+                      float* y, float alpha, float beta, hx_stream s) {
+  return spmv_dispatch<1, cc, float>(n_rows, nnz, rowptr, col, val, (const cc*)x, (cc*)y, make_float2(alpha, 0.f),
+                                     make_float2(beta, 0.f), 0, s);
+}
+int hx_csr_spmv_zreal(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const double* val,
+                      const hx_c128* x, hx_c128* y, double alpha, double beta, hx_stream s) {
+  return spmv_dispatch<1, zc, double>(n_rows, nnz, rowptr, col, val, (const zc*)x, (zc*)y, make_double2(alpha, 0.0),
+                                      make_double2(beta, 0.0), 0, s);
+}
 // r = b - A x in one pass (internal; the V-cycle's residual on the CSR levels)
 int hx_csr_residual_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val, const float* x,
                       const float* b, float* r, hx_stream s) {
@@ -138,7 +144,7 @@ k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restric
   int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
   for (int64_t it = 0; it < sweeps; ++it, row += stride) {
     V acc = czero<V>();
-    if (row < n) acc = row_dot<LPR>(col, val, xin, rowptr[row], rowptr[row + 1], sub);
+    if (row < n) acc = row_dot<LPR, V, V>(col, val, xin, rowptr[row], rowptr[row + 1], sub);
     if (LPR > 1) acc = zreduce_sub<LPR>(acc);
     if (row < n && sub == 0) {
       const V r = zsub(b[row], acc);

@@ -391,6 +391,7 @@ class AMGSolver:
         h = C.c_void_p()
         _hx.check(_hx.lib.hx_amg_create(C.byref(h), len(levels), self.params["pre"], self.params["post"], float(omega)))
         self.handle = h
+        _hx.check(_hx.lib.hx_amg_set_real_transfers(h, 1))     # P, R: real values, 8 bytes per entry with the column
         self._keep = []                               # device arrays referenced by the handle
         mixed = self.params["precision"] == "mixed"   # complex64 V-cycle inside complex128 flexible GMRES
         cdt = torch.complex64 if mixed else torch.complex128
@@ -403,9 +404,8 @@ class AMGSolver:
             if isinstance(M, DevCSR):
                 if M.val.is_complex():
                     val = M.val.to(cdt)
-                else:               # transfer operators are real: widen to complex in the working precision
-                    re = M.val.to(torch.float32 if mixed else torch.float64)
-                    val = torch.complex(re, torch.zeros_like(re))
+                else:               # transfer operators are real and stay real (hx_amg_set_real_transfers)
+                    val = M.val.to(torch.float32 if mixed else torch.float64)
                 t = (M.rowptr, M.col, val)
                 self._keep.append(t)
                 return t, M.nnz
@@ -414,8 +414,7 @@ class AMGSolver:
             if np.isrealobj(M.data):
                 # transfer operators are real: ship the real parts in the working precision (4x / 2x less H2D traffic
                 # than complex128) and widen to complex on the device
-                re = to_device(M.data.astype(np.float32 if mixed else np.float64))
-                val = torch.complex(re, torch.zeros_like(re))
+                val = to_device(M.data.astype(np.float32 if mixed else np.float64))
             else:
                 val = to_device(M.data.astype(np.complex64 if mixed else np.complex128))
             t = (to_device(M.indptr.astype(np.int32, copy=False)), to_device(M.indices.astype(np.int32, copy=False)), val)

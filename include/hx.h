@@ -246,6 +246,10 @@ int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const int32_t* r
                      const hx_c128* vaK, const hx_c128* dinv, int32_t n_coarse, int64_t nnzP,
                      const int32_t* rpP, const int32_t* ciP, const hx_c128* vaP, int64_t nnzR,
                      const int32_t* rpR, const int32_t* ciR, const hx_c128* vaR);
+/* The prolongators and restrictions of a smoothed-aggregation hierarchy are REAL: after hx_amg_set_real_transfers(h, 1) the
+ * vaP / vaR arguments of hx_amg_set_level / hx_amg_set_level_c are real arrays (double, resp. float: cast the pointer), which
+ * the transfer products stream at 12 / 8 instead of 20 / 12 bytes per entry. */
+int hx_amg_set_real_transfers(hx_amg* h, int flag);
 /* Optional SELL-64 companion of K_l (must hold the value copy of the precision the V-cycle runs in): the smoother
  * steps and the residual product of that level then use the SELL kernels. */
 int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell);

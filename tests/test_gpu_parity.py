@@ -494,6 +494,20 @@ def test_cocg_symmetry_probe_and_fallback():
     assert st["cocg_fallbacks"] + st["cocg_solves"] == 1
 
 
+def test_large_problem_path_on_unstructured_numbering(capsys):
+    """Device hierarchy set-up + deflated COCG + SELL-64 away from the structured annulus: jittered nodes, then a random
+    node numbering (32-bit columns everywhere, unordered strength graph), then RCM.  Same discrete problem => the same
+    four eigenvalues to 1e-8, and no solve may fall back to GMRES (tools/robustness_unstructured.py, 255 k DOF)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("robustness_unstructured", os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "robustness_unstructured.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main("annulus-260k") < 1e-8
+    out = capsys.readouterr().out
+    assert out.count("fallbacks 0") == 4 and "sell64/fp16/i32" in out and out.count("sell64/fp16/i16") == 3
+
+
 def test_annulus_fixed_point_amg_vs_lu_vs_oracle():
     """Synthetic annular combustor (16 pointwise flames, state-space FTF, Robin outlet, PEP): the fixed-point
     eigenvalue from the iterative (AMG-GMRES) and direct (LU) inner solvers and from the CPU oracle agree."""

@@ -141,8 +141,8 @@ def spmv_roofline(matrices, target, reps=50, in_situ=None):
 def smoother_roofline(inner, n, in_situ):
     """The kernel with the largest share of the run time: one Chebyshev smoother step of the V-cycle on the fine level
     (`k_sell<c64, 1, half>`: x' = x + a D^-1 (b - K x) + c (x - x_prev) in complex64 on complex-half values with 16-bit
-    column deltas).  Bytes per launch = what the kernel must stream: stored entries * (4 + index bytes) + n * 5 complex64
-    vectors (b, x gathered once, x_prev, D^-1, x').  Same in-situ HIP-event timing as the operator product."""
+    column deltas, or no index at all in stencil slices).  Bytes per launch = what the kernel must stream: stored entries * 4 +
+    indexed entries * index bytes + n * 5 complex64 vectors (b, x gathered once, x_prev, D^-1, x').  Same in-situ HIP-event timing as the operator product."""
     import ctypes as C
     from helmholtz_x import _hx
     sell = getattr(inner, "sell", None)
@@ -152,7 +152,8 @@ def smoother_roofline(inner, n, in_situ):
     _hx.check(_hx.lib.hx_sell_info(sell, C.byref(ns), C.byref(padded)))
     idx_bytes = _hx.lib.hx_sell_index_bits(sell) // 8
     val_bytes = {"fp16": 4, "c64": 8, "c128": 16}.get(getattr(inner, "fine_values", "fp16"), 4)
-    nbytes = padded.value * (val_bytes + idx_bytes) + n * 5 * 8
+    indexed = padded.value - _hx.lib.hx_sell_stencil_entries(sell)        # stencil slices carry no per-entry index
+    nbytes = padded.value * val_bytes + indexed * idx_bytes + n * 5 * 8
     ms = in_situ[1] / in_situ[0]
     gbs = nbytes / (ms * 1e-3) / 1e9
     return dict(kernel="k_sell<c64, 1, half> (hx_sell_smooth_c64, fine level)", launches=in_situ[0],

@@ -33,6 +33,14 @@ struct hx_sell {
   // identical iteration counts with fp16-rounded fine-level values (bf16: +3..9 %).  May be null.
   __half2* val_h = nullptr;
   float h_scale = 1.0f;
+  // STENCIL slices: when the 64 rows of a slice draw their columns from one common list of deltas (column - row) --
+  // structured and extruded meshes numbered along a grid line -- the slice stores that list once (st_delta[st_ptr[s] ..
+  // st_ptr[s+1])) and NO per-entry index: entry k of a row belongs to column row + delta_k, rows that lack it hold a
+  // zero.  Decided slice by slice (union of the rows' delta lists at most 1/8 longer than the longest row); the others
+  // keep their 16- / 32-bit indices.  Lossless, like the 16-bit deltas.
+  int32_t* st_ptr = nullptr;         // n_slices + 1, or null when no slice qualified
+  int32_t* st_delta = nullptr;
+  int32_t n_stencil = 0;
 };
 typedef __half2 ch;
 __device__ __forceinline__ zc mload(const zc* p) { return *p; }
@@ -65,10 +73,52 @@ __global__ void k_sell_widths(int32_t n, int32_t n_slices, const int32_t* __rest
   if (lane == 0) slice_sz[slice] = (int64_t)len * SELL_C;
 }
 
+// Union of the rows' column deltas, slice by slice: every lane walks its (sorted) row, the wave repeatedly takes the
+// smallest pending delta.  wu[slice] = length of the union if it stays within cap(width) = width + width/8 (at most 64),
+// else 0; the list itself goes to tmp[slice * 64 ...].
+__global__ void k_sell_stencil_union(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                     const int64_t* __restrict__ slice_sz, int32_t* __restrict__ wu, int32_t* __restrict__ tmp) {
+  const int lane = threadIdx.x & 63;
+  const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  if (slice >= n_slices) return;
+  const int width = (int)(slice_sz[slice] / SELL_C);
+  int cap = width + width / 8;
+  if (cap > 64) cap = 64;
+  const int32_t row = slice * SELL_C + lane;
+  int32_t p = row < n ? rowptr[row] : 0;
+  const int32_t e = row < n ? rowptr[row + 1] : 0;
+  int cnt = 0;
+  bool ok = width > 0;
+  while (ok) {
+    long long d = p < e ? (long long)col[p] - row : (1ll << 40);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(d, o, 64); d = t < d ? t : d; }
+    if (d == (1ll << 40)) break;                       // every lane is through
+    if (cnt == cap) { ok = false; break; }
+    if (lane == 0) tmp[(int64_t)slice * 64 + cnt] = (int32_t)d;
+    ++cnt;
+    if (p < e && (long long)col[p] - row == d) ++p;
+  }
+  if (lane == 0) wu[slice] = ok ? cnt : 0;
+}
+__global__ void k_sell_stencil_sizes(int32_t n_slices, const int32_t* __restrict__ wu, int64_t* __restrict__ slice_sz) {
+  for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slices; s += gridDim.x * blockDim.x)
+    if (wu[s] > 0) slice_sz[s] = (int64_t)wu[s] * SELL_C;
+}
+__global__ void k_sell_stencil_pack(int32_t n_slices, const int32_t* __restrict__ st_ptr, const int32_t* __restrict__ tmp,
+                                    int32_t* __restrict__ st_delta) {
+  const int lane = threadIdx.x & 63;
+  const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  if (slice >= n_slices) return;
+  const int32_t b = st_ptr[slice], w = st_ptr[slice + 1] - b;
+  if (lane < w) st_delta[b + lane] = tmp[(int64_t)slice * 64 + lane];
+}
+
 template <typename VOUT>
 __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                             const zc* __restrict__ val, const int64_t* __restrict__ slice_ptr, int32_t* __restrict__ scol,
-                            VOUT* __restrict__ sval, float inv_scale) {
+                            VOUT* __restrict__ sval, float inv_scale, const int32_t* __restrict__ st_ptr,
+                            const int32_t* __restrict__ st_delta) {
   const int lane = threadIdx.x & 63;
   const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
   if (slice >= n_slices) return;
@@ -77,6 +127,26 @@ __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restri
   const int32_t row = slice * SELL_C + lane;
   const int32_t s = row < n ? rowptr[row] : 0, len = row < n ? rowptr[row + 1] - s : 0;
   const int32_t pad_col = row < n ? row : 0;
+  if (st_ptr && st_ptr[slice + 1] > st_ptr[slice]) {
+    // stencil slice: entry k sits at the position of its delta in the slice's list; absent entries are zeros whose
+    // (clamped) column only has to be a valid address
+    const int32_t* U = st_delta + st_ptr[slice];
+    int32_t p = 0;
+    for (int k = 0; k < width; ++k) {
+      const int64_t o = base + (int64_t)k * SELL_C + lane;
+      const int64_t c = (int64_t)row + U[k];
+      const bool hit = p < len && (int64_t)col[s + p] == c;
+      if (scol) scol[o] = hit ? col[s + p] : (int32_t)(c < 0 ? 0 : (c >= n ? n - 1 : c));
+      if (hit) {
+        const zc v = val[s + p];
+        ++p;
+        if constexpr (sizeof(VOUT) == sizeof(zc)) sval[o] = v;
+        else if constexpr (sizeof(VOUT) == sizeof(cc)) sval[o] = make_float2((float)v.x, (float)v.y);
+        else sval[o] = __floats2half2_rn((float)v.x * inv_scale, (float)v.y * inv_scale);
+      } else sval[o] = czero<VOUT>();
+    }
+    return;
+  }
   for (int k = 0; k < width; ++k) {
     const int64_t o = base + (int64_t)k * SELL_C + lane;
     if (k < len) {
@@ -120,7 +190,7 @@ __global__ void k_sell_narrow(int32_t n_slices, const int64_t* __restrict__ slic
 extern "C" int hx_sell_destroy(hx_sell* h) {
   if (!h) return HX_OK;
   (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->dcol); (void)hipFree(h->wide); (void)hipFree(h->val_z); (void)hipFree(h->val_c);
-  (void)hipFree(h->val_h);
+  (void)hipFree(h->val_h); (void)hipFree(h->st_ptr); (void)hipFree(h->st_delta);
   delete h;
   return HX_OK;
 }
@@ -140,6 +210,17 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   (void)hipMemsetAsync(h->slice_ptr, 0, sizeof(int64_t) * np, s);
   const int grid = (int)(((int64_t)h->n_slices * 64 + 255) / 256);
   k_sell_widths<<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, h->slice_ptr);
+  // stencil slices (HX_SELL_STENCIL=0 switches the detection off)
+  static const bool allow_stencil = !(getenv("HX_SELL_STENCIL") && atoi(getenv("HX_SELL_STENCIL")) == 0);
+  int32_t* d_wu = nullptr;
+  int32_t* d_tmpU = nullptr;
+  if (allow_stencil && h->n_slices > 0 &&
+      hipMalloc((void**)&d_wu, sizeof(int32_t) * np) == hipSuccess &&
+      hipMalloc((void**)&d_tmpU, sizeof(int32_t) * 64 * (size_t)h->n_slices) == hipSuccess) {
+    (void)hipMemsetAsync(d_wu, 0, sizeof(int32_t) * np, s);
+    k_sell_stencil_union<<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, h->slice_ptr, d_wu, d_tmpU);
+    k_sell_stencil_sizes<<<hx_grid(h->n_slices, 256), 256, 0, s>>>(h->n_slices, d_wu, h->slice_ptr);
+  } else { (void)hipFree(d_wu); (void)hipFree(d_tmpU); d_wu = nullptr; d_tmpU = nullptr; (void)hipGetLastError(); }
   size_t bytes = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, h->slice_ptr, h->slice_ptr, (int)np, s);
   void* tmp = nullptr;
@@ -149,7 +230,27 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   hipError_t e = hipMemcpyAsync(&total, h->slice_ptr + h->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(tmp);
-  if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
+  if (e == hipSuccess && d_wu) {        // st_ptr = exclusive scan of the union lengths; keep it only if some slice qualified
+    size_t b2 = 0;
+    void* t2 = nullptr;
+    int32_t n_st = 0;
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, b2, d_wu, d_wu, (int)np, s);
+    if (e == hipSuccess) e = hipMalloc(&t2, b2 ? b2 : 16);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(t2, b2, d_wu, d_wu, (int)np, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_st, d_wu + h->n_slices, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(t2);
+    if (e == hipSuccess && n_st > 0 && hipMalloc((void**)&h->st_delta, sizeof(int32_t) * (size_t)n_st) == hipSuccess) {
+      h->st_ptr = d_wu;
+      d_wu = nullptr;
+      h->n_stencil = n_st;
+      k_sell_stencil_pack<<<grid, 256, 0, s>>>(h->n_slices, h->st_ptr, d_tmpU, h->st_delta);
+      e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(d_wu); (void)hipFree(d_tmpU);
+    d_wu = nullptr; d_tmpU = nullptr;
+  }
+  if (e != hipSuccess) { (void)hipFree(d_wu); (void)hipFree(d_tmpU); hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
   h->padded = total;
   const size_t ne = (size_t)(total > 0 ? total : 1);
   if (hipMalloc((void**)&h->col, sizeof(int32_t) * ne) != hipSuccess ||
@@ -159,9 +260,9 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     hx_sell_destroy(h);
     return hx_fail(HX_ERR_ALLOC, __func__, "SELL arrays");
   }
-  if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f);
+  if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f, h->st_ptr, h->st_delta);
   if (want_c == 1) k_sell_fill<cc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
-                                                          want_z ? nullptr : h->col, h->val_c, 1.f);
+                                                          want_z ? nullptr : h->col, h->val_c, 1.f, h->st_ptr, h->st_delta);
   if (want_c == 2) {
     // scale so that the largest component maps to 2^14: five binary orders of head-room below the fp16 maximum, and
     // entries down to ~4e-9 of the largest stay normal numbers
@@ -183,7 +284,7 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     memcpy(&vmax, &hmax, sizeof(float));
     h->h_scale = vmax > 0.f ? vmax / 16384.f : 1.f;
     k_sell_fill<ch><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
-                                           want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale);
+                                           want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale, h->st_ptr, h->st_delta);
   }
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
@@ -215,6 +316,23 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
 
 extern "C" int hx_sell_index_bits(const hx_sell* h) { return h ? (h->dcol ? 16 : 32) : 0; }
 extern "C" int hx_sell_wide_slices(const hx_sell* h) { return h ? h->n_wide : 0; }
+// number of slices stored without per-entry indices (common delta list), and the total length of their lists
+__global__ void k_count_stencil(int32_t n_slices, const int32_t* __restrict__ st_ptr, int32_t* __restrict__ out) {
+  for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slices; s += gridDim.x * blockDim.x)
+    if (st_ptr[s + 1] > st_ptr[s]) atomicAdd(out, 1);
+}
+extern "C" int64_t hx_sell_stencil_entries(const hx_sell* h) { return h ? (int64_t)h->n_stencil * SELL_C : 0; }
+extern "C" int hx_sell_stencil_slices(const hx_sell* h) {
+  if (!h || !h->st_ptr) return 0;
+  int32_t* d = nullptr;
+  int32_t v = 0;
+  if (hipMalloc((void**)&d, sizeof(int32_t)) != hipSuccess) return -1;
+  (void)hipMemset(d, 0, sizeof(int32_t));
+  k_count_stencil<<<hx_grid(h->n_slices, 256), 256>>>(h->n_slices, h->st_ptr, d);
+  (void)hipMemcpy(&v, d, sizeof(int32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return v;
+}
 
 extern "C" int hx_sell_info(const hx_sell* h, int32_t* n_slices, int64_t* padded_entries) {
   HX_REQUIRE(h, "null handle");
@@ -244,13 +362,31 @@ __device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cp, const MV* _
   return zadd(acc0, acc1);
 }
 
+// stencil slice: column of entry k = row + U[k] (U wave-uniform: scalar loads), clamped for the zero entries of rows that
+// lack that neighbour
+template <typename V, typename MV>
+__device__ __forceinline__ V sell_row_dot_stencil(const int32_t* __restrict__ U, const MV* __restrict__ vp,
+                                                  const V* __restrict__ x, int width, int32_t row, int32_t n) {
+  V acc0 = czero<V>(), acc1 = czero<V>();
+  int k = 0;
+  for (; k + 1 < width; k += 2) {
+    const int32_t c0 = min(max(row + U[k], 0), n - 1), c1 = min(max(row + U[k + 1], 0), n - 1);
+    const V v0 = mload(vp + (int64_t)k * SELL_C), v1 = mload(vp + (int64_t)(k + 1) * SELL_C);
+    zfma(acc0, v0, x[c0]);
+    zfma(acc1, v1, x[c1]);
+  }
+  if (k < width) zfma(acc0, mload(vp + (int64_t)k * SELL_C), x[min(max(row + U[k], 0), n - 1)]);
+  return zadd(acc0, acc1);
+}
+
 // MODE 0: y = alpha*A*x + beta*yin (yin may be y itself).   MODE 1: xout = xin + omega*dinv.*(b - A*xin) + mom*(xin - xprev)  (smoother step)
 // MV = storage type of the matrix values (V itself, or complex-half for V = complex64: entries are then vscale * half2).
 // dcol / wide: 16-bit column deltas for the slices flagged narrow (wave-uniform branch); both null -> 32-bit everywhere.
 template <typename V, int MODE, typename MV = V>
 __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
-       const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide,
+       const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
+       const int32_t* __restrict__ st_delta,
        const MV* __restrict__ val, const V* __restrict__ x, V* y, const V* yin, V alpha, V beta, int beta_is_zero,
        const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev,
        typename real_of<V>::type omega, typename real_of<V>::type mom, typename real_of<V>::type vscale) {
@@ -262,8 +398,11 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     const int width = (int)((slice_ptr[slice + 1] - base) >> 6);
     const int32_t row = slice * SELL_C + lane;
     const MV* vp = val + base + lane;
-    V acc = (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t>(dcol + base + lane, vp, x, width, row)
-                                   : sell_row_dot<V, MV, int32_t>(col + base + lane, vp, x, width, row);
+    int32_t st0 = 0, st1 = 0;
+    if (st_ptr) { st0 = __builtin_amdgcn_readfirstlane(st_ptr[slice]); st1 = __builtin_amdgcn_readfirstlane(st_ptr[slice + 1]); }
+    V acc = st1 > st0 ? sell_row_dot_stencil<V, MV>(st_delta + st0, vp, x, width, row, n)
+            : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t>(dcol + base + lane, vp, x, width, row)
+                                     : sell_row_dot<V, MV, int32_t>(col + base + lane, vp, x, width, row);
     if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(vscale, acc);
     if (row < n) {
       if (MODE == 0) {
@@ -292,7 +431,8 @@ template <typename V, int MODE, typename MV>
 static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alpha, V beta, int beta_is_zero, const V* dinv,
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
                         typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr) {
-  k_sell<V, MODE, MV><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, val, x,
+  k_sell<V, MODE, MV><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide,
+                                                                   h->st_ptr, h->st_delta, val, x,
                                                                    y, yin ? yin : y, alpha, beta, beta_is_zero, dinv, b, xprev,
                                                                    omega, mom, vscale);
 }

@@ -618,7 +618,8 @@ class AMGSolver:
     def stats(self):
         return dict(recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)), levels=[lv["n"] for lv in self.levels],
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
-                    if self.sell else "csr", vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
+                    if self.sell else "csr",
+                    stencil_slices=_hx.lib.hx_sell_stencil_slices(self.sell) if self.sell else 0, vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
                     setup_s=round(self.setup_s, 3), solves=self.n_solves,
                     krylov="cocg" if self.use_cocg else "fgmres", cocg_solves=self.cocg_solves,
                     cocg_iters=self.cocg_iters, cocg_fallbacks=self.cocg_fallbacks,

@@ -118,6 +118,12 @@ int hx_sell_info(const hx_sell* h, int32_t* n_slices, int64_t* padded_entries);
  * else 32; hx_sell_wide_slices: number of slices that stayed on 32-bit columns. */
 int hx_sell_index_bits(const hx_sell* h);
 int hx_sell_wide_slices(const hx_sell* h);
+/* Stencil slices, also decided at creation: when the 64 rows of a slice draw their columns from ONE list of deltas
+ * (column - row) at most 1/8 longer than the longest row -- structured or extruded meshes numbered along a grid line --
+ * the slice stores that list once and no per-entry index at all (entry k of a row is column row + delta_k; a row that
+ * lacks it holds a zero).  Lossless; hx_sell_stencil_slices: number of such slices (SYNC). */
+int hx_sell_stencil_slices(const hx_sell* h);
+int64_t hx_sell_stencil_entries(const hx_sell* h);      /* stored entries that carry no index */
 int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
                    hx_stream s);
 int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, float alpha, float beta, hx_stream s);

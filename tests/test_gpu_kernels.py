@@ -276,6 +276,64 @@ def test_sell64_products_match_csr(hx, n, density):
     hx.check(hx.lib.hx_sell_destroy(h))
 
 
+@pytest.mark.parametrize("want", [(1, 0), (1, 1), (0, 2)])
+def test_sell64_stencil_slices(hx, want):
+    """Slices whose rows share one list of column deltas are stored without per-entry indices (structured numberings):
+    a 3-D 7-point operator with complex variable coefficients (boundary rows lack neighbours: zeros in the shared list),
+    some slices made irregular by extra entries (those keep their indices), a first/last row wrap.  Products must equal
+    the CSR ones in every value format, and the detection must find exactly the regular slices."""
+    import torch
+    nx, ny, nz = 23, 17, 19
+    n = nx * ny * nz
+    rng = np.random.default_rng(5)
+    idx = np.arange(n).reshape(nz, ny, nx)
+    rows, cols = [np.arange(n)], [np.arange(n)]
+    for axis, off in ((2, 1), (1, nx), (0, nx * ny)):
+        a = np.take(idx, np.arange(idx.shape[axis] - 1), axis=axis).ravel()
+        rows += [a, a + off]
+        cols += [a + off, a]
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    vals = _rand_c(rng, rows.size) + 6.0 * (rows == cols)
+    M = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    irregular = np.arange(20 * 64, 23 * 64)                       # three slices get a random extra column each row
+    extra = sp.csr_matrix((_rand_c(rng, irregular.size), (irregular, rng.integers(0, n, irregular.size))), shape=(n, n))
+    M = sp.csr_matrix(M + extra)
+    M.sort_indices()
+    n_slices = (n + 63) // 64
+    # expected: a slice is a stencil slice iff the union of its rows' deltas is at most width + width // 8 long
+    expect = 0
+    for sl in range(n_slices):
+        r0, r1 = sl * 64, min(n, sl * 64 + 64)
+        width = int(np.diff(M.indptr[r0:r1 + 1]).max())
+        deltas = set()
+        for r in range(r0, r1):
+            deltas.update((M.indices[M.indptr[r]:M.indptr[r + 1]] - r).tolist())
+        expect += int(len(deltas) <= min(64, width + width // 8))
+    rp, ci, va = _dev(M.indptr.astype(np.int32)), _dev(M.indices.astype(np.int32)), _dev(M.data.astype(np.complex128))
+    h = C.c_void_p()
+    hx.check(hx.lib.hx_sell_create(C.byref(h), n, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), want[0], want[1], hx.stream()))
+    got = hx.lib.hx_sell_stencil_slices(h)
+    assert got == expect and 0 < got < n_slices
+    x, y0 = _rand_c(rng, n), _rand_c(rng, n)
+    if want[0]:
+        xd, yd = _dev(x), _dev(y0.copy())
+        hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(xd), hx.ptr(yd), hx.z2(0.5 + 1j), hx.z2(-2.0), hx.stream()))
+        ref = (0.5 + 1j) * (M @ x) - 2.0 * y0
+        assert np.max(np.abs(yd.cpu().numpy() - ref)) <= 1e-13 * np.max(np.abs(ref))
+    if want[1]:
+        x32, y32 = _dev(x.astype(np.complex64)), _dev(y0.astype(np.complex64))
+        hx.check(hx.lib.hx_sell_spmv_c64(h, hx.ptr(x32), hx.ptr(y32), -1.0, 1.0, hx.stream()))
+        ref32 = y0 - M @ x
+        tol = 3e-5 if want[1] == 1 else 2e-3                  # complex-half storage rounds the entries to 11 bits
+        assert np.max(np.abs(y32.cpu().numpy() - ref32)) <= tol * np.max(np.abs(ref32))
+        d = M.diagonal()
+        d32, o32 = _dev((1.0 / d).astype(np.complex64)), torch.empty_like(x32)
+        hx.check(hx.lib.hx_sell_smooth_c64(h, hx.ptr(d32), hx.ptr(y32), hx.ptr(x32), hx.ptr(o32), 0.6, None, 0.0, hx.stream()))
+        refs = x + 0.6 * (1.0 / d) * (y32.cpu().numpy() - M @ x)
+        assert np.max(np.abs(o32.cpu().numpy() - refs)) <= tol * np.max(np.abs(refs))
+    hx.check(hx.lib.hx_sell_destroy(h))
+
+
 @pytest.mark.parametrize("n,scale", [(64, 1.0), (5000, 3.0e6), (5000, 2.0e-7)])
 def test_sell64_complex_half_storage(hx, n, scale):
     """want_c64 = 2: values stored as scaled complex-half, arithmetic in complex64.  The products must equal those of the

@@ -670,9 +670,9 @@ extern "C" int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int
 // ------------------------------------------------------------------------------------------------ aggregation (host)
 // Greedy (Vanek) aggregation on the strength graph: n nodes, CSR (rp, ci) of strong off-diagonal couplings with
 // weights w (|a_ij|).  Writes agg[i] in [0, n_agg).  Pure integer/graph work, one-off per hierarchy level.
-extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci, const double* w, int32_t* agg,
-                                 int32_t* n_agg) {
-  HX_REQUIRE(n > 0 && rp && agg && n_agg, "bad argument");
+template <typename W>
+static int host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci, const W* w, int32_t* agg, int32_t* n_agg) {
+  if (!(n > 0 && rp && agg && n_agg)) return hx_fail(HX_ERR_ARG, "hx_host_aggregate", "bad argument");
   for (int32_t i = 0; i < n; ++i) agg[i] = -1;
   int32_t na = 0;
   // pass 1: roots whose whole strong neighbourhood is free (a stored diagonal entry is not a neighbour)
@@ -697,7 +697,7 @@ extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci
     for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
       if (ci[p] == i) continue;
       const int32_t a = pass1[ci[p]];
-      const double wp = std::fabs(w[p]);
+      const double wp = std::fabs((double)w[p]);
       if (a >= 0 && wp > best) { best = wp; tgt = a; }
     }
     if (tgt >= 0) agg[i] = tgt;
@@ -713,6 +713,17 @@ extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci
   return HX_OK;
 }
 
+
+extern "C" int hx_host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci, const double* w, int32_t* agg,
+                                 int32_t* n_agg) {
+  return host_aggregate<double>(n, rp, ci, w, agg, n_agg);
+}
+// the same with float32 coupling strengths (they only rank the neighbouring aggregates of a leftover node: half the
+// device-to-host bytes when the graph comes from the device set-up)
+extern "C" int hx_host_aggregate_f32(int32_t n, const int32_t* rp, const int32_t* ci, const float* w, int32_t* agg,
+                                     int32_t* n_agg) {
+  return host_aggregate<float>(n, rp, ci, w, agg, n_agg);
+}
 
 // ------------------------------------------------------------------------------------------------ SA set-up passes (host)
 // Row-parallel helper for the host passes: contiguous row blocks, one std::thread each (HX_HOST_THREADS, default

@@ -115,6 +115,7 @@ SIGNATURES = {
     "hx_spgemm_numeric": (C.c_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "hx_spgemm_destroy": (C.c_int, [_vp]),
     "hx_host_aggregate": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
+    "hx_host_aggregate_f32": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "hx_host_sa_filter": (C.c_int, [_i32, _vp, _vp, _vp, _int, C.c_double, C.c_double, _vp, _vp, _vp]),
     "hx_host_galerkin_rap": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "hx_host_csr_diagonal": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),

@@ -34,12 +34,11 @@ class AcousticMatrices:
         if parameter.name == "temperature":
             self.c = sound_speed_variable_gamma(mesh, parameter, degree=degree)
             self.T = parameter
-            self.gamma = gamma_function(self.T)
+            self._gamma = gamma_function(self.T)
             info("/\\ Temperature function is used for passive flame matrices.")
         else:
             self.c = parameter
-            self.gamma = self.c.copy()
-            self.gamma.x.array[:] = 1.4
+            self._gamma = None                 # gamma = 1.4 everywhere: built on first use (a 29 M-cell copy at 5 M DOF)
             info("\\/ Speed of sound function is used for passive flame matrices.")
 
         robin_facets, robin_coefs = [], []
@@ -108,6 +107,19 @@ class AcousticMatrices:
         else:
             vals = f.x.array[fv].mean(axis=1)
         return (vals * meas).sum() / meas.sum()
+
+    @property
+    def gamma(self):
+        """Ratio of specific heats as a Function (acoustic_matrices.py:49-55): gamma(T), or 1.4 when the speed of sound
+        itself was given."""
+        if self._gamma is None:
+            self._gamma = self.c.copy()
+            self._gamma.x.array[:] = 1.4
+        return self._gamma
+
+    @gamma.setter
+    def gamma(self, value):
+        self._gamma = value
 
     @property
     def A(self):

@@ -214,16 +214,33 @@ def _dev_filter(K, sign, theta, sd):
     return DevCSR(K.shape, rp, ci, v)
 
 
+_PINNED = {}
+
+
+def _to_host_pinned(t, key):
+    """Device tensor -> numpy view of a page-locked staging buffer kept per ``key`` (grown on demand): the strength graph
+    of a 5 M-row operator is 0.35 GB, which a pageable copy moves at a third of the PCIe rate."""
+    buf = _PINNED.get(key)
+    if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
+        buf = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
+        _PINNED[key] = buf
+    view = buf[:t.numel()]
+    view.copy_(t, non_blocking=True)
+    return view
+
+
 def _dev_aggregate(Lf):
     """Greedy aggregation of the strength graph: the one sequential pass of the set-up, run on the host on the
-    (pattern, |weight|) of Lf -- the filtered graph is a fraction of K and K itself stays in HBM."""
+    (pattern, |weight| as float32) of Lf -- the filtered graph is a fraction of K and K itself stays in HBM."""
     n = Lf.shape[0]
-    rp = Lf.rowptr.cpu().numpy()
-    ci = Lf.col.cpu().numpy()
-    w = Lf.val.cpu().numpy()
+    rp = _to_host_pinned(Lf.rowptr, "agg_rp")
+    ci = _to_host_pinned(Lf.col, "agg_ci")
+    w = _to_host_pinned(Lf.val.to(torch.float32), "agg_w")
+    torch.cuda.synchronize()
     agg = np.empty(n, dtype=np.int32)
     na = C.c_int32(0)
-    _hx.check(_hx.lib.hx_host_aggregate(n, _hx.nptr(rp), _hx.nptr(ci), _hx.nptr(w), _hx.nptr(agg), C.byref(na)))
+    _hx.check(_hx.lib.hx_host_aggregate_f32(n, C.c_void_p(rp.data_ptr()), C.c_void_p(ci.data_ptr()),
+                                            C.c_void_p(w.data_ptr()), _hx.nptr(agg), C.byref(na)))
     return agg, na.value
 
 

@@ -314,7 +314,9 @@ class P1Assembler:
                                                _hx.ptr(idx), _hx.ptr(rowptr), _hx.ptr(col), _hx.ptr(cf),
                                                int(cellwise), _hx.ptr(fcell), _hx.ptr(coef), _hx.ptr(val),
                                                _hx.stream()))
-        return Mat.from_csr(CSR((self.n, self.n), rowptr, col, val))
+        out = CSR((self.n, self.n), rowptr, col, val)
+        out.symmetric = True            # boundary mass matrix: B^T = B, so B_adj = B^H is the conjugate (no host transpose)
+        return Mat.from_csr(out)
 
     # ---- load vectors (device tensors of length n)
     def load(self, kind, fa, fb=None, scale=1.0, cell_tag=None, tag=0):

@@ -396,6 +396,8 @@ int hx_host_sa_filter(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const
                       double theta, int32_t* h_out_rp, int32_t* h_out_ci, double* h_out_v);
 int hx_host_aggregate(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_w,
                       int32_t* h_agg, int32_t* h_n_agg);
+int hx_host_aggregate_f32(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const float* h_w,
+                          int32_t* h_agg, int32_t* h_n_agg);      /* float32 strengths (device set-up: half the D2H bytes) */
 int hx_host_sa_prolongator(int32_t n, const int32_t* h_rp, const int32_t* h_ci, const double* h_lf,
                            const int32_t* h_agg, const double* h_inv_sqrt_cnt, double omega,
                            int32_t* h_out_rp, int32_t* h_out_ci, double* h_out_v);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""cProfile of one hot-path pass (host-side view: where the wall time outside the kernels goes)."""
+"""cProfile of one WARM hot-path pass (host-side view: where the wall time outside the kernels goes)."""
 import cProfile
 import contextlib
 import os
@@ -15,8 +15,13 @@ case = bench.build_case(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "a
 case["mesh"].assembler()
 pr = cProfile.Profile()
 with contextlib.redirect_stdout(sys.stderr):
+    E, _ = bench.hot_path(case)            # warm-up pass: code objects, allocator pools
+    E.destroy()
+    del E
+    import gc
+    gc.collect()
     pr.enable()
     bench.hot_path(case)
     pr.disable()
 st = pstats.Stats(pr, stream=sys.stdout)
-st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("cumulative").print_stats(int(sys.argv[2]) if len(sys.argv) > 2 else 60)

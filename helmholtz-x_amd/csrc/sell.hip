@@ -17,6 +17,8 @@
 
 struct hx_sell {
   int32_t n = 0, n_slices = 0;
+  int32_t n_cols = 0;                // largest column + 1 (the operator may be rectangular: row-sharded local rows over
+                                     // [owned | ghost] columns); bound of the clamped columns of stencil slices
   int64_t padded = 0;                // stored entries (multiple of 64)
   int64_t* slice_ptr = nullptr;      // n_slices + 1 offsets (in entries)
   int32_t* col = nullptr;
@@ -118,7 +120,7 @@ template <typename VOUT>
 __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                             const zc* __restrict__ val, const int64_t* __restrict__ slice_ptr, int32_t* __restrict__ scol,
                             VOUT* __restrict__ sval, float inv_scale, const int32_t* __restrict__ st_ptr,
-                            const int32_t* __restrict__ st_delta) {
+                            const int32_t* __restrict__ st_delta, int32_t n_cols) {
   const int lane = threadIdx.x & 63;
   const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
   if (slice >= n_slices) return;
@@ -136,7 +138,7 @@ __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restri
       const int64_t o = base + (int64_t)k * SELL_C + lane;
       const int64_t c = (int64_t)row + U[k];
       const bool hit = p < len && (int64_t)col[s + p] == c;
-      if (scol) scol[o] = hit ? col[s + p] : (int32_t)(c < 0 ? 0 : (c >= n ? n - 1 : c));
+      if (scol) scol[o] = hit ? col[s + p] : (int32_t)(c < 0 ? 0 : (c >= n_cols ? n_cols - 1 : c));
       if (hit) {
         const zc v = val[s + p];
         ++p;
@@ -206,6 +208,25 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   h->n = n;
   h->n_slices = (n + SELL_C - 1) / SELL_C;
   const size_t np = (size_t)h->n_slices + 1;
+  {   // number of columns = largest column index + 1 (at least n)
+    int32_t nnz0 = 0, cmax = -1;
+    int32_t* d_max = nullptr;
+    void* t0 = nullptr;
+    size_t b0 = 0;
+    hipError_t e0 = hipMemcpyAsync(&nnz0, rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);
+    if (e0 == hipSuccess && nnz0 > 0) {
+      e0 = hipMalloc((void**)&d_max, sizeof(int32_t));
+      if (e0 == hipSuccess) e0 = hipcub::DeviceReduce::Max(nullptr, b0, col, d_max, nnz0, s);
+      if (e0 == hipSuccess) e0 = hipMalloc(&t0, b0 ? b0 : 16);
+      if (e0 == hipSuccess) e0 = hipcub::DeviceReduce::Max(t0, b0, col, d_max, nnz0, s);
+      if (e0 == hipSuccess) e0 = hipMemcpyAsync(&cmax, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+      if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);
+      (void)hipFree(t0); (void)hipFree(d_max);
+    }
+    if (e0 != hipSuccess) { delete h; return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e0)); }
+    h->n_cols = cmax + 1 > n ? cmax + 1 : n;
+  }
   if (hipMalloc((void**)&h->slice_ptr, sizeof(int64_t) * np) != hipSuccess) { delete h; return hx_fail(HX_ERR_ALLOC, __func__, "slice_ptr"); }
   (void)hipMemsetAsync(h->slice_ptr, 0, sizeof(int64_t) * np, s);
   const int grid = (int)(((int64_t)h->n_slices * 64 + 255) / 256);
@@ -260,9 +281,9 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     hx_sell_destroy(h);
     return hx_fail(HX_ERR_ALLOC, __func__, "SELL arrays");
   }
-  if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f, h->st_ptr, h->st_delta);
+  if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f, h->st_ptr, h->st_delta, h->n_cols);
   if (want_c == 1) k_sell_fill<cc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
-                                                          want_z ? nullptr : h->col, h->val_c, 1.f, h->st_ptr, h->st_delta);
+                                                          want_z ? nullptr : h->col, h->val_c, 1.f, h->st_ptr, h->st_delta, h->n_cols);
   if (want_c == 2) {
     // scale so that the largest component maps to 2^14: five binary orders of head-room below the fp16 maximum, and
     // entries down to ~4e-9 of the largest stay normal numbers
@@ -284,7 +305,7 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     memcpy(&vmax, &hmax, sizeof(float));
     h->h_scale = vmax > 0.f ? vmax / 16384.f : 1.f;
     k_sell_fill<ch><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
-                                           want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale, h->st_ptr, h->st_delta);
+                                           want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale, h->st_ptr, h->st_delta, h->n_cols);
   }
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
@@ -366,7 +387,7 @@ __device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cp, const MV* _
 // lack that neighbour
 template <typename V, typename MV>
 __device__ __forceinline__ V sell_row_dot_stencil(const int32_t* __restrict__ U, const MV* __restrict__ vp,
-                                                  const V* __restrict__ x, int width, int32_t row, int32_t n) {
+                                                  const V* __restrict__ x, int width, int32_t row, int32_t n /* columns */) {
   V acc0 = czero<V>(), acc1 = czero<V>();
   int k = 0;
   for (; k + 1 < width; k += 2) {
@@ -386,7 +407,7 @@ template <typename V, int MODE, typename MV = V>
 __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
-       const int32_t* __restrict__ st_delta,
+       const int32_t* __restrict__ st_delta, int32_t n_cols,
        const MV* __restrict__ val, const V* __restrict__ x, V* y, const V* yin, V alpha, V beta, int beta_is_zero,
        const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev,
        typename real_of<V>::type omega, typename real_of<V>::type mom, typename real_of<V>::type vscale) {
@@ -400,7 +421,7 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     const MV* vp = val + base + lane;
     int32_t st0 = 0, st1 = 0;
     if (st_ptr) { st0 = __builtin_amdgcn_readfirstlane(st_ptr[slice]); st1 = __builtin_amdgcn_readfirstlane(st_ptr[slice + 1]); }
-    V acc = st1 > st0 ? sell_row_dot_stencil<V, MV>(st_delta + st0, vp, x, width, row, n)
+    V acc = st1 > st0 ? sell_row_dot_stencil<V, MV>(st_delta + st0, vp, x, width, row, n_cols)
             : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t>(dcol + base + lane, vp, x, width, row)
                                      : sell_row_dot<V, MV, int32_t>(col + base + lane, vp, x, width, row);
     if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(vscale, acc);
@@ -432,7 +453,7 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
                         typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr) {
   k_sell<V, MODE, MV><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide,
-                                                                   h->st_ptr, h->st_delta, val, x,
+                                                                   h->st_ptr, h->st_delta, h->n_cols, val, x,
                                                                    y, yin ? yin : y, alpha, beta, beta_is_zero, dinv, b, xprev,
                                                                    omega, mom, vscale);
 }

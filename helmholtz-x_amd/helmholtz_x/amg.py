@@ -24,7 +24,7 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=50_000, sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
+              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=int(os.environ.get("HX_SELL_MIN_ROWS", "50000")), sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
               recycle_min_rows=100_000, krylov="auto", cocg_min_rows=100_000, setup="device")
 
 

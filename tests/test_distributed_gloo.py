@@ -191,6 +191,7 @@ def _gpu_fpi_worker(rank, world, port, out, krylov):
     if krylov == "cocg":            # "auto" keeps GMRES below 1e5 rows: force the deflated COCG path (hx_cocg_sharded)
         os.environ["HX_AMG_KRYLOV"] = "cocg"
         os.environ["HX_AMG_RECYCLE"] = "6"
+        os.environ["HX_SELL_MIN_ROWS"] = "0"    # SELL-64 (stencil slices included) on the rectangular local operator
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
@@ -239,6 +240,8 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov):
         assert n_halo > 0 and n_allreduce > 0 and n_ext > n_own
         assert sharded["stats"]["krylov"] == ("cocg" if krylov == "cocg" else "fgmres")
         assert sharded["stats"]["cocg_fallbacks"] == 0 and (krylov != "cocg" or sharded["stats"]["cocg_solves"] > 50)
+        if krylov == "cocg":
+            assert sharded["stats"]["fine_format"].startswith("sell64") and sharded["stats"]["stencil_slices"] > 0
     # both ranks hold identical (all-reduced) results
     assert out[0]["sharded"]["eigs"] == out[1]["sharded"]["eigs"]
     print("sharded stats:", out[0]["sharded"]["stats"], "single:", out[0]["single"]["stats"], out[0]["exchanges"])

@@ -41,6 +41,7 @@ static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 
 #define CG_OUT 0      // [0, 33): dot results
 #define CG_RHO 34     // r^T z of the current iterate
 #define CG_BETA 35
+#define CG_TMP 36      // [36, 40): scratch
 #define CG_T 40       // [40, 72): t = E^-1 C^T z
 #define CG_SCALARS 72
 #define CG_MAXK 32
@@ -271,7 +272,7 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   const double BE_FLOOR = 10 * 2.220446049250313e-16;
   auto backward_error = [&](double rel) -> int {
     if (M->normK_val != (const void*)val) {
-      unsigned long long* d = (unsigned long long*)(sc + CG_SCALARS - 1);        // last scalar slot as scratch
+      unsigned long long* d = (unsigned long long*)(sc + CG_TMP);
       HX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), hx_s(s)));
       k_csr_norm_inf<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, rowptr, (const zc*)val, d);
       HX_LAUNCH_CHECK("k_csr_norm_inf");
@@ -282,8 +283,8 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       memcpy(&local, &bits, sizeof(double));
       if (sharded) {                                            // sum of the ranks' maxima: same number on every rank
         cd v(local, 0.0);
-        HX_HIP(hipMemcpyAsync(sc + CG_SCALARS - 1, &v, sizeof(cd), hipMemcpyHostToDevice, hx_s(s)));
-        HX_HIP(hipMemcpyAsync(sc, sc + CG_SCALARS - 1, sizeof(cd), hipMemcpyDeviceToDevice, hx_s(s)));
+        HX_HIP(hipMemcpyAsync(sc + CG_TMP, &v, sizeof(cd), hipMemcpyHostToDevice, hx_s(s)));
+        HX_HIP(hipMemcpyAsync(sc, sc + CG_TMP, sizeof(cd), hipMemcpyDeviceToDevice, hx_s(s)));
         HX_HIP(hipStreamSynchronize(hx_s(s)));
         if ((rc = reduce(1))) return rc;
         if ((rc = fetch(1))) return rc;

@@ -75,10 +75,49 @@ class Mesh:
     def num_cells(self):
         return self.topology.cells.shape[0]
 
+    def renumbered(self, perm):
+        """The same mesh with vertex ``old`` renamed ``perm[old]`` (cells and tagged facets keep their order, so MeshTags
+        indices carry over: build them again on the new mesh with the same indices / values).  DOLFINx renumbers the
+        dofs of every mesh it reads for locality (reverse Cuthill-McKee); here the numbering of the file is kept unless
+        the caller asks -- ``locality_permutation`` gives an ordering along a space-filling curve."""
+        perm = np.asarray(perm, dtype=np.int64)
+        x_old = self.geometry.x
+        if perm.shape != (x_old.shape[0],) or not np.array_equal(np.sort(perm), np.arange(x_old.shape[0])):
+            raise ValueError("perm must be a permutation of the vertex ids")
+        x = np.empty_like(x_old)
+        x[perm] = x_old
+        return Mesh(x, perm[self.topology.cells], facets=np.sort(perm[self.facets], axis=1), facet_cells=self.facet_cells)
+
     def assembler(self):
         if self._assembler is None:
             self._assembler = P1Assembler(self)
         return self._assembler
+
+
+def locality_permutation(x, bits=21):
+    """perm[old] = new vertex id along the Morton (Z-order) curve of the coordinates: neighbours in space become
+    neighbours in memory, which is what the SpMV gathers and the 16-bit column deltas of the SELL-64 format want
+    (a randomly numbered 1 M-DOF annulus runs 2.4 times slower than a locality-ordered one).  Pure integer work on the
+    host, O(n log n)."""
+    x = np.asarray(x, dtype=np.float64)
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    span = np.where(hi > lo, hi - lo, 1.0)
+    q = np.minimum(((x - lo) / span * (2 ** bits - 1)).astype(np.uint64), np.uint64(2 ** bits - 1))
+
+    def spread(v):                         # insert two zero bits between the bits of v (21 bits -> 63 bits)
+        v = v & np.uint64(0x1fffff)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    order = np.argsort(code, kind="stable")            # order[new] = old
+    perm = np.empty(x.shape[0], dtype=np.int64)
+    perm[order] = np.arange(x.shape[0])
+    return perm
 
 
 class MeshTags:

@@ -505,7 +505,7 @@ def test_large_problem_path_on_unstructured_numbering(capsys):
     spec.loader.exec_module(mod)
     assert mod.main("annulus-260k") < 1e-8
     out = capsys.readouterr().out
-    assert out.count("fallbacks 0") == 4 and "sell64/fp16/i32" in out and out.count("sell64/fp16/i16") == 3
+    assert out.count("fallbacks 0") == 5 and "sell64/fp16/i32" in out and out.count("sell64/fp16/i16") == 4
 
 
 def test_annulus_fixed_point_amg_vs_lu_vs_oracle():

@@ -2,8 +2,8 @@
 """Robustness of the large-problem path (device hierarchy set-up + deflated COCG + SELL-64 with 16-bit deltas) away from
 the structured annulus numbering: the same geometry with (a) interior nodes jittered by +-0.2 h, (b) the node numbering
 permuted at random (wide band: every SELL slice falls back to 32-bit columns, aggregation sees an unordered graph),
-(c) reverse Cuthill-McKee after the random permutation.  The eigenvalues of (b), (c) must equal those of (a) (the same
-discrete problem) to 1e-8.  usage: robustness_unstructured.py [annulus-260k]"""
+(c) reverse Cuthill-McKee after the random permutation, (d) the Morton order of helmholtz_x.fem.locality_permutation.
+The eigenvalues of (b), (c), (d) must equal those of (a) (the same discrete problem) to 1e-8.  usage: robustness_unstructured.py [annulus-260k]"""
 import json
 import os
 import sys
@@ -26,9 +26,7 @@ from helmholtz_x.synthetic import micca_sound_speed
 def renumber(case, perm):
     """perm[old] = new node id."""
     mesh = case["mesh"]
-    x = np.empty_like(mesh.geometry.x)
-    x[perm] = mesh.geometry.x
-    m2 = Mesh(x, perm[mesh.topology.cells], facets=np.sort(perm[mesh.facets], axis=1), facet_cells=mesh.facet_cells)
+    m2 = mesh.renumbered(perm)
     ft, sd = case["facet_tags"], case["subdomains"]
     out = dict(case)
     out.update(mesh=m2, facet_tags=MeshTags(m2, ft.dim, ft.indices, ft.values),
@@ -85,8 +83,10 @@ def main(wl=None):
     p2[order] = np.arange(n)
     rcm = renumber(shuffled, p2)
     got2 = run("... + RCM", rcm)
+    from helmholtz_x.fem import locality_permutation
+    got3 = run("... + Morton order", renumber(shuffled, locality_permutation(shuffled["mesh"].geometry.x)))
     worst = 0.0
-    for name, g in (("random", got), ("rcm", got2)):
+    for name, g in (("random", got), ("rcm", got2), ("morton", got3)):
         d = max(abs(a - b) / abs(b) for a, b in zip(sorted(g, key=lambda z: z.real), sorted(ref, key=lambda z: z.real)))
         print("max |d omega| / |omega| vs jittered structured numbering (%s): %.2e" % (name, d))
         assert d < 1e-8

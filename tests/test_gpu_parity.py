@@ -508,6 +508,33 @@ def test_large_problem_path_on_unstructured_numbering(capsys):
     assert out.count("fallbacks 0") == 5 and "sell64/fp16/i32" in out and out.count("sell64/fp16/i16") == 4
 
 
+def test_cocg_and_gmres_routes_give_the_same_eigenpairs(monkeypatch):
+    """255 k-DOF annular combustor through both inner Krylov methods (deflated COCG = what "auto" picks at this size, and
+    flexible GMRES): the four eigenvalues to 1e-9, the fixed-point trajectory to 1e-9, the normalised eigenvector of the
+    iterated pair to 1e-7 of its peak value."""
+    import bench
+    import torch
+    from helmholtz_x.petsc import Vec
+    res = {}
+    for kry in ("auto", "fgmres"):
+        monkeypatch.setenv("HX_AMG_KRYLOV", kry)
+        case = bench.build_case(bench.WORKLOADS["annulus-260k"])
+        hist = []
+        E, M = bench.hot_path(case, st_type="amg", nev=4, tol=1e-6, history=hist)
+        st = next(v for v in E.inner_cache.values() if hasattr(v, "stats")).stats()
+        assert st["krylov"] == ("cocg" if kry == "auto" else "fgmres") and st["cocg_fallbacks"] == 0
+        vr = Vec.zeros(M.A.shape[0])
+        lam = E.getEigenpair(0, vr)
+        x = vr.t.clone()
+        x = x / x[torch.argmax(torch.abs(x))]                      # peak value 1: fixes scale and phase
+        res[kry] = ([E.getEigenvalue(i) for i in range(4)], list(hist), x)
+    (e1, h1, x1), (e2, h2, x2) = res["auto"], res["fgmres"]
+    assert len(h1) == len(h2)
+    assert max(abs(a - b) / abs(b) for a, b in zip(h1, h2)) < 1e-9
+    assert max(abs(a - b) / abs(b) for a, b in zip(sorted(e1, key=lambda z: z.real), sorted(e2, key=lambda z: z.real))) < 1e-9
+    assert float(torch.max(torch.abs(x1 - x2))) < 1e-7
+
+
 def test_annulus_fixed_point_amg_vs_lu_vs_oracle():
     """Synthetic annular combustor (16 pointwise flames, state-space FTF, Robin outlet, PEP): the fixed-point
     eigenvalue from the iterative (AMG-GMRES) and direct (LU) inner solvers and from the CPU oracle agree."""

@@ -27,6 +27,11 @@ for p in (ROOT, os.path.join(ROOT, "helmholtz-x_amd"), os.path.join(ROOT, "tests
         sys.path.insert(0, p)
 
 os.environ.setdefault("HX_QUIET", "1")
+# The host side of the path is small dense algebra (projected problems of <= 50 columns): a BLAS thread pool sized for the
+# box's 256 cores only spins there (measured: 38 s of CPU time instead of 20 s per 20 s of wall time, and 3 % slower) and
+# would fight the other ranks of a multi-GPU run.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
 
 WORKLOADS = {
     # name: (nr, ntheta, nz)  -> DOFs = (nr+1)*ntheta*(nz+1)

@@ -14,8 +14,20 @@ Basis interface (columns are Krylov vectors):
     rotate(Q, k)           columns[0:k] = columns[0:m_active] @ Q  (Q is m_active x k), and move the
                            residual column m_active to column k
 """
+import contextlib
+
 import numpy as np
 import scipy.linalg as sla
+
+try:                                   # the projected problems are tiny: keep the BLAS pool from spinning on them
+    from threadpoolctl import ThreadpoolController
+    _blas = ThreadpoolController()
+
+    def _small_dense():
+        return _blas.limit(limits=1, user_api="blas")
+except Exception:                      # pragma: no cover - threadpoolctl is optional
+    def _small_dense():
+        return contextlib.nullcontext()
 
 
 class KrylovSchurResult:
@@ -39,7 +51,8 @@ def _tell(basis, theta, resid, nev):
 
 def _ritz(S, mact, tol):
     """Ritz pairs of the leading mact x mact block, sorted by |theta| descending, with residual estimates."""
-    theta, Y = sla.eig(S[:mact, :mact])
+    with _small_dense():
+        theta, Y = sla.eig(S[:mact, :mact])
     order = np.argsort(-np.abs(theta), kind="stable")
     theta, Y = theta[order], Y[:, order]
     Y = Y / np.linalg.norm(Y, axis=0, keepdims=True)

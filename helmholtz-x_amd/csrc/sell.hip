@@ -388,16 +388,22 @@ __device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cp, const MV* _
 template <typename V, typename MV>
 __device__ __forceinline__ V sell_row_dot_stencil(const int32_t* __restrict__ U, const MV* __restrict__ vp,
                                                   const V* __restrict__ x, int width, int32_t row, int32_t n /* columns */) {
-  V acc0 = czero<V>(), acc1 = czero<V>();
+  // four independent chains: 8 loads in flight per lane and trip (values + gathered x; the deltas are scalar loads)
+  V acc0 = czero<V>(), acc1 = czero<V>(), acc2 = czero<V>(), acc3 = czero<V>();
   int k = 0;
-  for (; k + 1 < width; k += 2) {
+  for (; k + 3 < width; k += 4) {
     const int32_t c0 = min(max(row + U[k], 0), n - 1), c1 = min(max(row + U[k + 1], 0), n - 1);
+    const int32_t c2 = min(max(row + U[k + 2], 0), n - 1), c3 = min(max(row + U[k + 3], 0), n - 1);
     const V v0 = mload(vp + (int64_t)k * SELL_C), v1 = mload(vp + (int64_t)(k + 1) * SELL_C);
-    zfma(acc0, v0, x[c0]);
-    zfma(acc1, v1, x[c1]);
+    const V v2 = mload(vp + (int64_t)(k + 2) * SELL_C), v3 = mload(vp + (int64_t)(k + 3) * SELL_C);
+    const V x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+    zfma(acc0, v0, x0);
+    zfma(acc1, v1, x1);
+    zfma(acc2, v2, x2);
+    zfma(acc3, v3, x3);
   }
-  if (k < width) zfma(acc0, mload(vp + (int64_t)k * SELL_C), x[min(max(row + U[k], 0), n - 1)]);
-  return zadd(acc0, acc1);
+  for (; k < width; ++k) zfma(acc0, mload(vp + (int64_t)k * SELL_C), x[min(max(row + U[k], 0), n - 1)]);
+  return zadd(zadd(acc0, acc1), zadd(acc2, acc3));
 }
 
 // MODE 0: y = alpha*A*x + beta*yin (yin may be y itself).   MODE 1: xout = xin + omega*dinv.*(b - A*xin) + mom*(xin - xprev)  (smoother step)

@@ -152,6 +152,19 @@ __global__ void k_csr_norm_inf(int32_t n, const int32_t* __restrict__ rp, const 
   if ((threadIdx.x & (HX_WAVE - 1)) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
 }
 
+// ||K||_inf of a device CSR (SYNC; d_scratch: 8 bytes of device memory)
+int hx_csr_norm_inf(int32_t n, const int32_t* rowptr, const hx_c128* val, void* d_scratch, double* h_out, hx_stream s) {
+  unsigned long long* d = (unsigned long long*)d_scratch;
+  HX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), hx_s(s)));
+  k_csr_norm_inf<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, rowptr, (const zc*)val, d);
+  HX_LAUNCH_CHECK("k_csr_norm_inf");
+  unsigned long long bits = 0;
+  HX_HIP(hipMemcpyAsync(&bits, d, sizeof(bits), hipMemcpyDeviceToHost, hx_s(s)));
+  HX_HIP(hipStreamSynchronize(hx_s(s)));
+  memcpy(h_out, &bits, sizeof(double));
+  return HX_OK;
+}
+
 extern "C" size_t hx_cocg_ws(int64_t n) {
   return 5 * (size_t)n + hx_panel_dot_ws(CG_MAXK + 1) + CG_SCALARS + 8;
 }
@@ -272,15 +285,8 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   const double BE_FLOOR = 10 * 2.220446049250313e-16;
   auto backward_error = [&](double rel) -> int {
     if (M->normK_val != (const void*)val) {
-      unsigned long long* d = (unsigned long long*)(sc + CG_TMP);
-      HX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), hx_s(s)));
-      k_csr_norm_inf<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, rowptr, (const zc*)val, d);
-      HX_LAUNCH_CHECK("k_csr_norm_inf");
-      unsigned long long bits = 0;
-      HX_HIP(hipMemcpyAsync(&bits, d, sizeof(bits), hipMemcpyDeviceToHost, hx_s(s)));
-      HX_HIP(hipStreamSynchronize(hx_s(s)));
-      double local;
-      memcpy(&local, &bits, sizeof(double));
+      double local = 0.0;
+      if ((rc = hx_csr_norm_inf(n, rowptr, val, sc + CG_TMP, &local, s))) return rc;
       if (sharded) {                                            // sum of the ranks' maxima: same number on every rank
         cd v(local, 0.0);
         HX_HIP(hipMemcpyAsync(sc + CG_TMP, &v, sizeof(cd), hipMemcpyHostToDevice, hx_s(s)));

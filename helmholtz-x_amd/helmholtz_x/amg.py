@@ -550,14 +550,20 @@ class AMGSolver:
         if self.use_cocg and (self.recycle_k == 0 or self.recycled):
             done = self._solve_cocg(b, x, rtol, it, rr)
         if not done:
-            self.backward_stable = False
             self._solve_gmres(b, x, rtol, it, rr)
+            be = C.c_double(-1.0)
+            if rr.value > 10 * rtol:
+                _hx.check(_hx.lib.hx_cocg_backward_error(self.handle, C.byref(be)))
+            self.backward_stable = 0.0 <= be.value <= 10 * 2.220446049250313e-16
+            self.attainable_stops += int(self.backward_stable)
         if self.recycle_k > 0 and not self.recycled:
             self._harvest()
         self.solve_s += time.perf_counter() - t0        # hx_gmres synchronises internally
         self.total_iters += it.value
         self.n_solves += 1
         self.last = (it.value, rr.value)
+        if os.environ.get("HX_AMG_LOG_ITS"):
+            print("[amg] solve %d: %d its, relres %.2e" % (self.n_solves, it.value, rr.value), file=__import__("sys").stderr)
         if rr.value > 100 * rtol and not getattr(self, "backward_stable", False):
             raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
                                   % (rr.value, it.value))

@@ -317,7 +317,8 @@ size_t hx_cocg_ws(int64_t n);
 /* When the recurrence stops improving above the tolerance, hx_cocg measures the normwise backward error
  * |b - K x| / (|K|_inf |x| + |b|) and accepts the iterate below 10 eps: what a backward-stable direct solve (the
  * reference's PCLU) delivers when the shift sits next to an eigenvalue and |x| >> |b|.  The value of the last such solve
- * (-1: the tolerance was met, nothing measured): */
+ * (-1: the tolerance was met, nothing measured).  hx_gmres applies the same test when its Arnoldi estimate meets the
+ * tolerance but the true residual does not, and reports through the same getter: */
 int hx_cocg_backward_error(const hx_amg* M, double* out);
 int hx_cocg(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
             const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it, hx_c128* ws, int* h_iters,

@@ -459,6 +459,42 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
     assert solver.stats()["vcycle_graph"] == ("graph_max_rows" in overrides)      # hipGraph replay of the V-cycle
 
 
+@pytest.mark.parametrize("krylov", ["fgmres", "cocg"])
+def test_inner_solve_stops_at_attainable_accuracy(krylov):
+    """Shift next to an eigenvalue: the solution is ~1e7 times larger than the right-hand side, eps |K| |x| exceeds
+    rtol |b| and no solver can reach the relative-residual tolerance.  Both Krylov methods must recognise the floor by the
+    normwise backward error (what the reference's backward-stable LU delivers) instead of cycling to max_it."""
+    import scipy.sparse.linalg as spla
+    import torch
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.amg import AMGSolver
+    from helmholtz_x.eigensolvers import pep_solver
+    from helmholtz_x.petsc import combine_csr, to_device
+    case = _annulus_case((8, 96, 10))
+    P, mesh = case["P"], case["mesh"]
+    M = AcousticMatrices(mesh, case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    lam = pep_solver(M.A, M.B, M.C, P.target, nev=1, st_type="lu").getEigenvalue(0)
+    s = lam * (1.0 + 2e-9)                                           # shift 2e-9 (relative) away from the eigenvalue
+    K = combine_csr(M.A.shape, M.A.csr_terms + [(s * c, m) for c, m in M.B.csr_terms]
+                    + [(s ** 2 * c, m) for c, m in M.C.csr_terms])
+    solver = AMGSolver(K, krylov=krylov, cocg_min_rows=0, recycle_min_rows=0)
+    Ks = K.to_scipy().tocsr()
+    normK = abs(Ks).sum(axis=1).max()
+    rng = np.random.default_rng(4)
+    for k in range(3):
+        b = rng.standard_normal(K.shape[0]) + 1j * rng.standard_normal(K.shape[0])
+        bd = to_device(b)
+        x = torch.empty_like(bd)
+        solver.solve(bd, x)
+        xh = x.cpu().numpy()
+        assert np.linalg.norm(xh) > 1e5 * np.linalg.norm(b) / normK * 1e0 and solver.last[0] < 150
+        be = np.linalg.norm(b - Ks @ xh) / (normK * np.linalg.norm(xh) + np.linalg.norm(b))
+        assert be < 1e-14, (k, be, solver.last)
+    # (at this distance from the eigenvalue the deflated recurrence of hx_cocg may give up: the solve is then repeated by
+    # hx_gmres, which must stop at the floor as well)
+    assert solver.stats()["attainable_stops"] >= 1
+
+
 def test_cocg_symmetry_probe_and_fallback():
     """hx_cocg is only chosen for complex symmetric operators (the probe rejects a Bloch-reduced / perturbed K), and a
     solve forced through it on an unsymmetric operator falls back to GMRES instead of returning a wrong answer."""

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Minimal driver for counter collection on the SELL-64 kernels: operator product (complex128), V-cycle residual and smoother
+step (complex64 arithmetic on complex-half values) on the annulus operator.  Usage: sell_kernels_only.py annulus-5M 10"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "helmholtz-x_amd"), os.path.join(ROOT, "tests")]
+os.environ.setdefault("HX_QUIET", "1")
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from helmholtz_x import _hx  # noqa: E402
+from helmholtz_x.acoustic_matrices import AcousticMatrices  # noqa: E402
+from helmholtz_x.petsc import combine_csr  # noqa: E402
+
+name, reps = sys.argv[1], int(sys.argv[2])
+case = bench.build_case(bench.WORKLOADS[name])
+P = case["P"]
+M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+K = combine_csr(M.A.shape, M.A.csr_terms + [(P.target * c, m) for c, m in M.B.csr_terms]
+                + [(P.target ** 2 * c, m) for c, m in M.C.csr_terms])
+n = K.shape[0]
+h = C.c_void_p()
+_hx.check(_hx.lib.hx_sell_create(C.byref(h), n, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val), 1, 2, _hx.stream()))
+x = torch.randn(n, dtype=torch.complex128, device=K.val.device)
+y = torch.empty_like(x)
+x32, y32, b32, d32, p32 = (torch.randn(n, dtype=torch.complex64, device=K.val.device) for _ in range(5))
+one, zero = _hx.z2(1.0), _hx.z2(0.0)
+for _ in range(reps):
+    _hx.lib.hx_sell_spmv_z(h, _hx.ptr(x), _hx.ptr(y), one, zero, _hx.stream())
+    _hx.lib.hx_sell_spmv_c64(h, _hx.ptr(x32), _hx.ptr(y32), -1.0, 1.0, _hx.stream())
+    _hx.lib.hx_sell_smooth_c64(h, _hx.ptr(d32), _hx.ptr(b32), _hx.ptr(x32), _hx.ptr(y32), 0.6, _hx.ptr(p32), 0.2, _hx.stream())
+torch.cuda.synchronize()
+print("n=%d nnz=%d stencil slices %d" % (n, K.nnz, _hx.lib.hx_sell_stencil_slices(h)))

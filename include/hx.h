@@ -353,7 +353,8 @@ int hx_cocg_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr
                     const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
                     hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s);
 /* ---- DEVICE set-up passes of the smoothed-aggregation hierarchy (once per K; all arrays are device pointers, K never
- * leaves HBM).  Same mathematics as the hx_host_* passes below, which remain for the row-sharded mode.
+ * leaves HBM).  replaces: PCSetUp behind ST sinvert -- the analysis + numeric factorisation MUMPS / SuperLU_DIST run for the
+ * reference at every E.solve() (eigensolvers.py:49-50, 62, 102-103, 113); here once per fixed-point call.  Same mathematics as the hx_host_* passes below, which remain for the row-sharded mode.
  *   hx_csr_diagonal_z       diagonal of a complex CSR (0 where none is stored)
  *   hx_sa_filter_*          Lf = strength-filtered L = sign*Re(K): |l_ij| >= theta sqrt(|l_ii l_jj|) kept, weak couplings
  *                           lumped on the diagonal; count pass (SYNC) fills out_rp (n+1) and *h_nnz, sd = n doubles kept

@@ -226,6 +226,7 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     }
     if (e0 != hipSuccess) { delete h; return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e0)); }
     h->n_cols = cmax + 1 > n ? cmax + 1 : n;
+    if (h->n_cols > (1 << 27)) { delete h; return hx_fail(HX_ERR_ARG, __func__, "more than 2^27 columns (32-bit byte offsets into x)"); }
   }
   if (hipMalloc((void**)&h->slice_ptr, sizeof(int64_t) * np) != hipSuccess) { delete h; return hx_fail(HX_ERR_ALLOC, __func__, "slice_ptr"); }
   (void)hipMemsetAsync(h->slice_ptr, 0, sizeof(int64_t) * np, s);
@@ -367,101 +368,168 @@ template <typename IT> __device__ __forceinline__ int32_t cidx(IT c, int32_t row
 template <> __device__ __forceinline__ int32_t cidx<int32_t>(int32_t c, int32_t) { return c; }
 template <> __device__ __forceinline__ int32_t cidx<int16_t>(int16_t c, int32_t row) { return row + (int32_t)c; }
 
-// one lane = one row of the slice: sum_k val[k] * x[col[k]], two independent chains (4 loads in flight per lane per step)
-template <typename V, typename MV, typename IT>
-__device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cp, const MV* __restrict__ vp, const V* __restrict__ x,
+// acc += v * x with v in its storage type (complex-half: the conversions ride inside mixed-precision multiply-adds)
+__device__ __forceinline__ void mfma_acc(zc& acc, zc v, zc x) { zfma(acc, v, x); }
+__device__ __forceinline__ void mfma_acc(cc& acc, cc v, cc x) { zfma(acc, v, x); }
+__device__ __forceinline__ void mfma_acc(cc& acc, ch v, cc x) {
+  const float vr = __low2float(v), vi = __high2float(v);
+  acc.x = fmaf(vr, x.x, acc.x);
+  acc.y = fmaf(vr, x.y, acc.y);
+  acc.x = fmaf(-vi, x.y, acc.x);
+  acc.y = fmaf(vi, x.x, acc.y);
+}
+// Addressing: every array of a slice is reached as (wave-uniform base) + (32-bit byte offset), the form the hardware adds for
+// free (scalar base + vector offset + immediate); columns are below 2^27 (checked by hx_sell_create), so offsets into x fit.
+template <typename T>
+__device__ __forceinline__ T ld32(const void* base, uint32_t byte_off) { return *(const T*)((const char*)base + byte_off); }
+__device__ __forceinline__ int32_t clampi(int32_t v, int32_t hi) { return min(max(v, 0), hi); }
+
+// One lane = one row of the slice: sum_k val[k] * x[col[k]].  The entries are taken G at a time: all G index loads, then all
+// G value loads and G gathers of x are in flight before the first multiply-add, so a slice of the usual 15 entries costs
+// two memory round trips (G = 8) instead of one per pair.  The last, partial group is padded by REPEATING the last entry
+// with weight zero (a multiplication, so that the compiler keeps the loads unconditional and together): no scalar tail.
+// Four accumulator chains.  cb / vb: the slice's index / value arrays (wave-uniform), lane: this row's position in them.
+template <typename V, typename MV, typename IT, int G>
+__device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cb, const MV* __restrict__ vb, int lane, const V* __restrict__ x,
                                           int width, int32_t row) {
-  V acc0 = czero<V>(), acc1 = czero<V>();
-  int k = 0;
-  for (; k + 1 < width; k += 2) {
-    const int32_t c0 = cidx<IT>(cp[(int64_t)k * SELL_C], row), c1 = cidx<IT>(cp[(int64_t)(k + 1) * SELL_C], row);
-    const V v0 = mload(vp + (int64_t)k * SELL_C), v1 = mload(vp + (int64_t)(k + 1) * SELL_C);
-    zfma(acc0, v0, x[c0]);
-    zfma(acc1, v1, x[c1]);
+  typedef typename real_of<V>::type R;
+  V acc[4] = {czero<V>(), czero<V>(), czero<V>(), czero<V>()};
+  const uint32_t lc = (uint32_t)lane * (uint32_t)sizeof(IT), lv = (uint32_t)lane * (uint32_t)sizeof(MV);
+  int k0 = 0;
+  for (; k0 + G <= width; k0 += G) {
+    IT ci[G];
+    MV v[G];
+    V xv[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      ci[j] = ld32<IT>(cb, (uint32_t)(k0 + j) * (uint32_t)(SELL_C * sizeof(IT)) + lc);
+      v[j] = ld32<MV>(vb, (uint32_t)(k0 + j) * (uint32_t)(SELL_C * sizeof(MV)) + lv);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) xv[j] = ld32<V>(x, (uint32_t)cidx<IT>(ci[j], row) * (uint32_t)sizeof(V));
+#pragma unroll
+    for (int j = 0; j < G; ++j) mfma_acc(acc[j & 3], v[j], xv[j]);
   }
-  if (k < width) zfma(acc0, mload(vp + (int64_t)k * SELL_C), x[cidx<IT>(cp[(int64_t)k * SELL_C], row)]);
-  return zadd(acc0, acc1);
+  if (k0 < width) {
+    IT ci[G];
+    MV v[G];
+    V xv[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int k = min(k0 + j, width - 1);
+      ci[j] = ld32<IT>(cb, (uint32_t)k * (uint32_t)(SELL_C * sizeof(IT)) + lc);
+      v[j] = ld32<MV>(vb, (uint32_t)k * (uint32_t)(SELL_C * sizeof(MV)) + lv);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) xv[j] = ld32<V>(x, (uint32_t)cidx<IT>(ci[j], row) * (uint32_t)sizeof(V));
+#pragma unroll
+    for (int j = 0; j < G; ++j) mfma_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv[j]));
+  }
+  return zadd(zadd(acc[0], acc[1]), zadd(acc[2], acc[3]));
 }
 
-// stencil slice: column of entry k = row + U[k] (U wave-uniform: scalar loads), clamped for the zero entries of rows that
-// lack that neighbour
-template <typename V, typename MV>
-__device__ __forceinline__ V sell_row_dot_stencil(const int32_t* __restrict__ U, const MV* __restrict__ vp,
-                                                  const V* __restrict__ x, int width, int32_t row, int32_t n /* columns */) {
-  // four independent chains: 8 loads in flight per lane and trip (values + gathered x; the deltas are scalar loads)
-  V acc0 = czero<V>(), acc1 = czero<V>(), acc2 = czero<V>(), acc3 = czero<V>();
-  int k = 0;
-  for (; k + 3 < width; k += 4) {
-    const int32_t c0 = min(max(row + U[k], 0), n - 1), c1 = min(max(row + U[k + 1], 0), n - 1);
-    const int32_t c2 = min(max(row + U[k + 2], 0), n - 1), c3 = min(max(row + U[k + 3], 0), n - 1);
-    const V v0 = mload(vp + (int64_t)k * SELL_C), v1 = mload(vp + (int64_t)(k + 1) * SELL_C);
-    const V v2 = mload(vp + (int64_t)(k + 2) * SELL_C), v3 = mload(vp + (int64_t)(k + 3) * SELL_C);
-    const V x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-    zfma(acc0, v0, x0);
-    zfma(acc1, v1, x1);
-    zfma(acc2, v2, x2);
-    zfma(acc3, v3, x3);
+// Stencil slice: column of entry k = row + U[k], clamped for the zero entries of rows that lack that neighbour.  The
+// slice's delta list (at most 64 long) sits in one register across the wave (lane k holds U[k]) and is broadcast with
+// v_readlane: no memory access on the way to the address of x.
+template <typename V, typename MV, int G>
+__device__ __forceinline__ V sell_row_dot_stencil(int32_t u, const MV* __restrict__ vb, int lane, const V* __restrict__ x, int width,
+                                                  int32_t row, int32_t n /* columns */) {
+  typedef typename real_of<V>::type R;
+  V acc[4] = {czero<V>(), czero<V>(), czero<V>(), czero<V>()};
+  const uint32_t lv = (uint32_t)lane * (uint32_t)sizeof(MV);
+  int k0 = 0;
+  for (; k0 + G <= width; k0 += G) {
+    MV v[G];
+    V xv[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      v[j] = ld32<MV>(vb, (uint32_t)(k0 + j) * (uint32_t)(SELL_C * sizeof(MV)) + lv);
+      xv[j] = ld32<V>(x, (uint32_t)clampi(row + __builtin_amdgcn_readlane(u, k0 + j), n - 1) * (uint32_t)sizeof(V));
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) mfma_acc(acc[j & 3], v[j], xv[j]);
   }
-  for (; k < width; ++k) zfma(acc0, mload(vp + (int64_t)k * SELL_C), x[min(max(row + U[k], 0), n - 1)]);
-  return zadd(zadd(acc0, acc1), zadd(acc2, acc3));
+  if (k0 < width) {
+    MV v[G];
+    V xv[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int k = min(k0 + j, width - 1);
+      v[j] = ld32<MV>(vb, (uint32_t)k * (uint32_t)(SELL_C * sizeof(MV)) + lv);
+      xv[j] = ld32<V>(x, (uint32_t)clampi(row + __builtin_amdgcn_readlane(u, k), n - 1) * (uint32_t)sizeof(V));
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) mfma_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv[j]));
+  }
+  return zadd(zadd(acc[0], acc[1]), zadd(acc[2], acc[3]));
 }
 
 // MODE 0: y = alpha*A*x + beta*yin (yin may be y itself).   MODE 1: xout = xin + omega*dinv.*(b - A*xin) + mom*(xin - xprev)  (smoother step)
 // MV = storage type of the matrix values (V itself, or complex-half for V = complex64: entries are then vscale * half2).
 // dcol / wide: 16-bit column deltas for the slices flagged narrow (wave-uniform branch); both null -> 32-bit everywhere.
-template <typename V, int MODE, typename MV = V>
+// One wave = one slice.  The slice offsets are wave-uniform (scalar loads); the row-wise operands of the update (b, x, dinv,
+// xprev / yin) are requested BEFORE the row sum so that they travel with its first group of loads.
+template <typename V>
+struct SellOp {            // the scalars of the update
+  V alpha, beta;
+  int beta_is_zero;
+  typename real_of<V>::type omega, mom, vscale;
+};
+
+template <typename V, int MODE, typename MV, int G>
 __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
-       const int32_t* __restrict__ st_delta, int32_t n_cols,
-       const MV* __restrict__ val, const V* __restrict__ x, V* y, const V* yin, V alpha, V beta, int beta_is_zero,
-       const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev,
-       typename real_of<V>::type omega, typename real_of<V>::type mom, typename real_of<V>::type vscale) {
+       const int32_t* __restrict__ st_delta, int32_t n_cols, const MV* __restrict__ val, const V* __restrict__ x, V* y,
+       const V* yin, const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev, const SellOp<V> a) {
   const int lane = threadIdx.x & 63;
-  const int32_t wave = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
-  const int32_t n_waves = (int32_t)(((int64_t)gridDim.x * blockDim.x) >> 6);
-  for (int32_t slice = wave; slice < n_slices; slice += n_waves) {
-    const int64_t base = slice_ptr[slice];
-    const int width = (int)((slice_ptr[slice + 1] - base) >> 6);
-    const int32_t row = slice * SELL_C + lane;
-    const MV* vp = val + base + lane;
-    int32_t st0 = 0, st1 = 0;
-    if (st_ptr) { st0 = __builtin_amdgcn_readfirstlane(st_ptr[slice]); st1 = __builtin_amdgcn_readfirstlane(st_ptr[slice + 1]); }
-    V acc = st1 > st0 ? sell_row_dot_stencil<V, MV>(st_delta + st0, vp, x, width, row, n_cols)
-            : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t>(dcol + base + lane, vp, x, width, row)
-                                     : sell_row_dot<V, MV, int32_t>(col + base + lane, vp, x, width, row);
-    if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(vscale, acc);
-    if (row < n) {
-      if (MODE == 0) {
-        V r = zmul(alpha, acc);
-        if (!beta_is_zero) zfma(r, beta, yin[row]);
-        y[row] = r;
-      } else {
-        const V res = zsub(b[row], acc);
-        const V x0 = x[row];
-        V xn = x0;
-        zfma(xn, zscale(omega, dinv[row]), res);
-        if (mom != 0) xn = zadd(xn, zscale(mom, xprev ? zsub(x0, xprev[row]) : x0));
-        y[row] = xn;
-      }
+  const int32_t slice = __builtin_amdgcn_readfirstlane((int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6));
+  if (slice >= n_slices) return;
+  const int64_t base = slice_ptr[slice];
+  const int32_t width = (int32_t)((slice_ptr[slice + 1] - base) >> 6);
+  int32_t st0 = 0, stw = 0;
+  if (st_ptr) { st0 = st_ptr[slice]; stw = st_ptr[slice + 1] - st0; }
+  const int32_t u = lane < stw ? st_delta[st0 + lane] : 0;       // the slice's delta list, one entry per lane
+  const int32_t row = slice * SELL_C + lane;
+  const bool live = row < n;
+  V rb = czero<V>(), rx = czero<V>(), rd = czero<V>(), rp = czero<V>();
+  if (live) {
+    if (MODE == 0) {
+      if (!a.beta_is_zero) rb = yin[row];
+    } else {
+      rb = b[row];
+      rx = x[row];
+      rd = dinv[row];
+      if (a.mom != 0 && xprev) rp = xprev[row];
     }
+  }
+  const MV* vb = val + base;
+  V acc = stw > 0 ? sell_row_dot_stencil<V, MV, G>(u, vb, lane, x, width, row, n_cols)
+          : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t, G>(dcol + base, vb, lane, x, width, row)
+                                   : sell_row_dot<V, MV, int32_t, G>(col + base, vb, lane, x, width, row);
+  if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(a.vscale, acc);
+  if (!live) return;
+  if (MODE == 0) {
+    V r = zmul(a.alpha, acc);
+    if (!a.beta_is_zero) zfma(r, a.beta, rb);
+    y[row] = r;
+  } else {
+    V xn = rx;
+    zfma(xn, zscale(a.omega, rd), zsub(rb, acc));
+    if (a.mom != 0) xn = zadd(xn, zscale(a.mom, xprev ? zsub(rx, rp) : rx));
+    y[row] = xn;
   }
 }
 
-static int sell_grid(int32_t n_slices) {
-  int64_t blocks = ((int64_t)n_slices + 3) / 4;           // 4 waves (slices) per 256-thread block
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  return (int)(blocks < 1 ? 1 : blocks);
-}
-// one launch site
+static int sell_grid(int32_t n_slices) { return (n_slices + 3) / 4; }   // 4 waves (slices) per 256-thread block
+// one launch site.  G = 8 entries per group of the row sums (4 ties, measured)
 template <typename V, int MODE, typename MV>
 static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alpha, V beta, int beta_is_zero, const V* dinv,
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
                         typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr) {
-  k_sell<V, MODE, MV><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide,
-                                                                   h->st_ptr, h->st_delta, h->n_cols, val, x,
-                                                                   y, yin ? yin : y, alpha, beta, beta_is_zero, dinv, b, xprev,
-                                                                   omega, mom, vscale);
+  const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale};
+  k_sell<V, MODE, MV, 8><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
+                                                                      h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op);
 }
 
 // In-situ timing of the operator product (the roofline kernel of bench.py): when enabled, every k_sell<c128,0> launch is

@@ -28,9 +28,21 @@ x = torch.randn(n, dtype=torch.complex128, device=K.val.device)
 y = torch.empty_like(x)
 x32, y32, b32, d32, p32 = (torch.randn(n, dtype=torch.complex64, device=K.val.device) for _ in range(5))
 one, zero = _hx.z2(1.0), _hx.z2(0.0)
-for _ in range(reps):
-    _hx.lib.hx_sell_spmv_z(h, _hx.ptr(x), _hx.ptr(y), one, zero, _hx.stream())
-    _hx.lib.hx_sell_spmv_c64(h, _hx.ptr(x32), _hx.ptr(y32), -1.0, 1.0, _hx.stream())
-    _hx.lib.hx_sell_smooth_c64(h, _hx.ptr(d32), _hx.ptr(b32), _hx.ptr(x32), _hx.ptr(y32), 0.6, _hx.ptr(p32), 0.2, _hx.stream())
-torch.cuda.synchronize()
+calls = {
+    "k_sell<c128,0>   operator product": lambda: _hx.lib.hx_sell_spmv_z(h, _hx.ptr(x), _hx.ptr(y), one, zero, _hx.stream()),
+    "k_sell<c64,0,h2> residual        ": lambda: _hx.lib.hx_sell_spmv_c64(h, _hx.ptr(x32), _hx.ptr(y32), -1.0, 1.0, _hx.stream()),
+    "k_sell<c64,1,h2> smoother step   ": lambda: _hx.lib.hx_sell_smooth_c64(h, _hx.ptr(d32), _hx.ptr(b32), _hx.ptr(x32), _hx.ptr(y32), 0.6,
+                                                                            _hx.ptr(p32), 0.2, _hx.stream()),
+}
+
 print("n=%d nnz=%d stencil slices %d" % (n, K.nnz, _hx.lib.hx_sell_stencil_slices(h)))
+for label, fn in calls.items():          # back-to-back launches between two events: average time per launch
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print("%s  %.1f us per launch" % (label, 1e3 * e0.elapsed_time(e1) / reps))

@@ -89,6 +89,34 @@ extern "C" int hx_zscatter_axpy(int64_t m, const double alpha[2], const hx_c128*
   return HX_OK;
 }
 
+// slot[e] = position of entry e of the pattern (rp, ci) inside the pattern (brp, bci) (columns sorted within rows: binary
+// search inside the base row); *missing = 1 if some entry is absent.  One thread per row of the smaller pattern.
+__global__ void k_locate_slots(int32_t n, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                               const int32_t* __restrict__ brp, const int32_t* __restrict__ bci, int32_t* __restrict__ slot,
+                               int32_t* __restrict__ missing) {
+  for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const int32_t e0 = rp[r], e1 = rp[r + 1];
+    if (e1 == e0) continue;
+    const int32_t b0 = brp[r], b1 = brp[r + 1];
+    for (int32_t e = e0; e < e1; ++e) {
+      const int32_t c = ci[e];
+      int32_t lo = b0, hi = b1;
+      while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (bci[mid] < c) lo = mid + 1; else hi = mid; }
+      if (lo < b1 && bci[lo] == c) slot[e] = lo;
+      else { slot[e] = 0; atomicOr(missing, 1); }
+    }
+  }
+}
+extern "C" int hx_csr_locate_slots(int32_t n, const int32_t* rp, const int32_t* ci, const int32_t* brp, const int32_t* bci,
+                                   int32_t* slot, int32_t* missing, hx_stream s) {
+  HX_REQUIRE(n >= 0 && rp && brp && slot && missing, "bad argument");
+  HX_HIP(hipMemsetAsync(missing, 0, sizeof(int32_t), hx_s(s)));
+  if (n == 0) return HX_OK;
+  k_locate_slots<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, rp, ci, brp, bci, slot, missing);
+  HX_LAUNCH_CHECK("k_locate_slots");
+  return HX_OK;
+}
+
 __global__ void k_zgather(int64_t m, const zc* __restrict__ x, const int32_t* __restrict__ idx, zc* __restrict__ y) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = x[idx[i]];

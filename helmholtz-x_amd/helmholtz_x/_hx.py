@@ -31,6 +31,7 @@ SIGNATURES = {
     "hx_zscal": (C.c_int, [_i64, _dp, _vp, _vp]),
     "hx_zlincomb": (C.c_int, [_i64, _int, _dp, C.POINTER(_vp), _vp, _vp]),
     "hx_zscatter_axpy": (C.c_int, [_i64, _dp, _vp, _vp, _vp, _vp]),
+    "hx_csr_locate_slots": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hx_zgather": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "hx_panel_dot_ws": (C.c_size_t, [_int]),
     "hx_zpanel_dot": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp, _vp]),

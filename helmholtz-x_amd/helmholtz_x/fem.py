@@ -265,6 +265,12 @@ class Function:
         pts = self.function_space.tabulate_dof_coordinates()
         self.x.array[:] = fn(pts.T)
 
+    def resident(self):
+        """Keep a copy of the values in HBM for the assembly kernels (an input field that stays the same over several
+        assemblies is then uploaded once).  Call it again after changing ``x.array``.  Returns self."""
+        self._dev = to_device(self.x.array.astype(np.complex128))
+        return self
+
 
 # ----------------------------------------------------------------------------- device assembly
 class P1Assembler:
@@ -313,7 +319,10 @@ class P1Assembler:
         if isinstance(f, tuple) and len(f) == 2 and isinstance(f[0], torch.Tensor):
             return f
         if isinstance(f, Function):
-            return to_device(f.x.array.astype(np.complex128)), f.function_space.kind == "DG0"
+            dev = getattr(f, "_dev", None)                      # Function.resident(): already in HBM
+            if dev is None or dev.numel() != f.x.array.size:
+                dev = to_device(f.x.array.astype(np.complex128))
+            return dev, f.function_space.kind == "DG0"
         raise TypeError("coefficient must be a Function")
 
     # ---- operators

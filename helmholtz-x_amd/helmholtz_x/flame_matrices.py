@@ -166,7 +166,9 @@ class PointwiseFlameMatrix(FlameMatrix):
         from .petsc import to_device
         asm = self.mesh.assembler()
         if getattr(self, "_h_dev", None) is None:
-            self._h_dev = to_device(self.h.x.array.astype(np.complex128))
+            dev_h = getattr(self.h, "_dev", None)                    # Function.resident(): already in HBM
+            self._h_dev = dev_h if dev_h is not None and dev_h.numel() == self.h.x.array.size \
+                else to_device(self.h.x.array.astype(np.complex128))
         nf, n = len(self.x_r), self.mesh.num_vertices
         cap = min(cap, n)
         dev = self._h_dev.device

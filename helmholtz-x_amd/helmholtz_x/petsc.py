@@ -414,6 +414,18 @@ def locate_slots(ncols, brp, bci, rp, ci):
     return idx[pos_c].astype(np.int32)
 
 
+def locate_slots_device(base, m):
+    """Device form of locate_slots: slots (int32 device tensor) of the entries of CSR ``m`` inside CSR ``base``, or None if
+    some entry of ``m`` is missing from ``base`` (hx_csr_locate_slots: one binary search per entry, nothing leaves HBM)."""
+    slots = torch.empty(max(m.nnz, 1), dtype=torch.int32, device=_dev())[:m.nnz]
+    if m.nnz == 0:
+        return slots
+    missing = torch.zeros(1, dtype=torch.int32, device=_dev())
+    _hx.check(_hx.lib.hx_csr_locate_slots(m.shape[0], _hx.ptr(m.rowptr), _hx.ptr(m.col), _hx.ptr(base.rowptr),
+                                          _hx.ptr(base.col), _hx.ptr(slots), _hx.ptr(missing), _hx.stream()))
+    return None if int(missing.item()) else slots
+
+
 def combine_csr(shape, terms):
     """sum_i coef_i CSR_i on the device.  Same-pattern terms are one fused lincomb kernel; terms on a different
     pattern are scatter-added through a host-computed slot map (integer work only)."""
@@ -431,10 +443,10 @@ def combine_csr(shape, terms):
         others = []
     if others:
         n = shape[0]
-
-        brp, bci = base.host_pattern()
-        found = {m.pattern_id: locate_slots(shape[1], brp, bci, *m.host_pattern()) for m in others}
+        found = {m.pattern_id: locate_slots_device(base, m) for m in others}       # patterns stay in HBM
         need_union = any(v is None for v in found.values())
+        if need_union:
+            brp, bci = base.host_pattern()
         if need_union:
             U = sp.csr_matrix((np.ones(len(bci), np.int8), bci, brp), shape=shape)
             for m in others:
@@ -450,7 +462,8 @@ def combine_csr(shape, terms):
         for m in others:
             if m.pattern_id in slot_maps:
                 continue
-            slot_maps[m.pattern_id] = to_device(found[m.pattern_id])
+            f = found[m.pattern_id]
+            slot_maps[m.pattern_id] = f if isinstance(f, torch.Tensor) else to_device(f)
             if not need_union:
                 _SLOT_CACHE[(base.pattern_id, m.pattern_id)] = (slot_maps[m.pattern_id], base, m)   # keep ids alive
                 while len(_SLOT_CACHE) > 8:

@@ -58,6 +58,11 @@ int hx_zlincomb(int64_t n, int nterms, const double* h_coefs, const hx_c128* con
 /* dst[slot[i]] += alpha * src[i]; slots must be unique. */
 int hx_zscatter_axpy(int64_t m, const double alpha[2], const hx_c128* src, const int32_t* slot,
                      hx_c128* dst, hx_stream s);
+/* slot[e] = position of entry e of the CSR pattern (rp, ci) inside the pattern (brp, bci) of the same n rows, columns sorted
+ * within rows; *missing (device) = 1 if some entry is absent.  Replaces MatAXPY's DIFFERENT_NONZERO_PATTERN merge behind
+ * `A + omega*B` (eigensolvers.py:174-176,240) by a slot map computed once per pattern pair. */
+int hx_csr_locate_slots(int32_t n, const int32_t* rp, const int32_t* ci, const int32_t* brp, const int32_t* bci,
+                        int32_t* slot, int32_t* missing, hx_stream s);
 /* y[i] = x[idx[i]] (gather) */
 int hx_zgather(int64_t m, const hx_c128* x, const int32_t* idx, hx_c128* y, hx_stream s);
 /* Classical Gram-Schmidt panel: out[j] = V_j^H w (j < k), out[k] = w^H w.  V is column-major with

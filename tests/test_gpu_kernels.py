@@ -67,6 +67,42 @@ def test_spmv_empty_rows_and_ragged(hx):
         assert np.allclose(y.cpu().numpy(), M @ x, rtol=1e-12, atol=1e-12)
 
 
+def test_locate_slots_on_the_device_matches_the_host_map(hx):
+    """hx_csr_locate_slots (behind combine_csr: B's boundary pattern inside the volume pattern, `A + omega*B`,
+    eigensolvers.py:174-176) against the host integer map; a missing entry and an empty pattern."""
+    from helmholtz_x.petsc import CSR, combine_csr, locate_slots, locate_slots_device
+    rng = np.random.default_rng(5)
+    n = 3000
+    base = sp.random(n, n, density=0.004, random_state=3, format="csr") + sp.eye(n, format="csr")
+    base.sort_indices()
+    keep = rng.random(base.nnz) < 0.2
+    keep[base.indptr[500]:base.indptr[2200]] = False
+    rows = np.repeat(np.arange(n), np.diff(base.indptr))
+    sub = sp.csr_matrix((_rand_c(rng, int(keep.sum())), (rows[keep], base.indices[keep])), shape=(n, n))
+    sub.sort_indices()
+    cb = CSR.from_scipy(sp.csr_matrix(base, dtype=np.complex128))
+    cs = CSR.from_scipy(sub)
+    ref = locate_slots(n, base.indptr.astype(np.int32), base.indices.astype(np.int32),
+                       sub.indptr.astype(np.int32), sub.indices.astype(np.int32))
+    got = locate_slots_device(cb, cs)
+    assert got.dtype == __import__("torch").int32 and np.array_equal(got.cpu().numpy(), ref)
+    K = combine_csr((n, n), [(1.0, cb), (0.5 - 2j, cs)])
+    want = sp.csr_matrix(base, dtype=np.complex128) + (0.5 - 2j) * sub
+    assert abs(K.to_scipy() - want).max() < 1e-13
+    extra = sub.tolil()
+    r = 10
+    absent = np.setdiff1d(np.arange(n), base.indices[base.indptr[r]:base.indptr[r + 1]])[0]
+    extra[r, absent] = 1.0
+    extra = extra.tocsr()
+    extra.sort_indices()
+    ce = CSR.from_scipy(sp.csr_matrix(extra, dtype=np.complex128))
+    assert locate_slots_device(cb, ce) is None
+    K2 = combine_csr((n, n), [(1.0, cb), (1.0, ce)])                   # union pattern on the host path
+    assert abs(K2.to_scipy() - (sp.csr_matrix(base, dtype=np.complex128) + extra)).max() < 1e-13
+    empty = CSR.from_scipy(sp.csr_matrix((n, n), dtype=np.complex128))
+    assert locate_slots_device(cb, empty).numel() == 0
+
+
 def test_vector_and_panel_kernels(hx):
     import torch
     from helmholtz_x.petsc import panel_dot

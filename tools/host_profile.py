@@ -25,3 +25,5 @@ with contextlib.redirect_stdout(sys.stderr):
     pr.disable()
 st = pstats.Stats(pr, stream=sys.stdout)
 st.sort_stats("cumulative").print_stats(int(sys.argv[2]) if len(sys.argv) > 2 else 60)
+for pat in sys.argv[3:]:                   # who calls these (regular expressions on the function name)
+    st.print_callers(pat)

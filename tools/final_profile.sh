@@ -12,4 +12,5 @@ rm -rf /tmp/prof_final
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --warmup 1 --steps 1 \
     > "$OLDPWD/gpurun_out/bench_final_5M_under_rocprof.json" 2> "$OLDPWD/gpurun_out/bench_final_prof.err") || exit 1
 find /tmp/prof_final -name "*kernel_stats.csv" -exec cp {} gpurun_out/final_kernel_stats.csv \;
-ls -la gpurun_out/final_kernel_stats.csv
+find /tmp/prof_final -name "*kernel_trace.csv" -exec python3 tools/trace_by_grid.py {} 45 \; > gpurun_out/final_kernel_time_by_level.txt
+ls -la gpurun_out/final_kernel_stats.csv gpurun_out/final_kernel_time_by_level.txt

@@ -30,6 +30,23 @@ for f in ("_dev_filter", "_dev_aggregate", "_dev_transpose", "_dev_spgemm", "bui
           "_filter", "_aggregate", "_prolongator", "_galerkin", "_spectral_radius_dinv", "build_hierarchy"):
     setattr(amg, f, timed(f, getattr(amg, f)))
 from helmholtz_x.petsc import CSR  # noqa: E402
+from helmholtz_x import _hx  # noqa: E402
+
+
+class _TimedLib:
+    """libhx entry points of the set-up, timed (synchronised) by name"""
+
+    def __init__(self, lib, names):
+        self._lib, self._names = lib, set(names)
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        return timed("lib." + name, fn) if name in self._names else fn
+
+
+_hx.lib = _TimedLib(_hx.lib, ["hx_sell_create", "hx_amg_enable_recycling", "hx_amg_set_level_c", "hx_amg_set_coarse_c",
+                              "hx_amg_create", "hx_amg_destroy", "hx_sell_destroy", "hx_amg_set_level_sell"])
+amg._hx = _hx
 CSR.to_scipy = timed("K.to_scipy (D2H + scipy)", CSR.to_scipy)
 
 case = bench.build_case(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "annulus-5M"])

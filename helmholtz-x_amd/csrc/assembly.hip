@@ -77,27 +77,78 @@ extern "C" int hx_build_v2e(int32_t n_vert, int32_t n_ent, int k, const int32_t*
 }
 
 // ------------------------------------------------------------------------------------------------ pattern
-// Row v = sorted unique union of the vertices of the entities incident to v, built by
-// insert-if-absent into the row's scratch region [k*ptr[v], k*ptr[v+1]).
-__global__ void k_pattern_rows(int32_t n, int k, const int32_t* __restrict__ ents, const int32_t* __restrict__ ptr,
-                               const int32_t* __restrict__ idx, int32_t* __restrict__ scratch,
-                               int32_t* __restrict__ rowlen) {
-  for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
-    int32_t* list = scratch + (int64_t)k * ptr[v];
-    int32_t len = 0;
-    for (int32_t p = ptr[v]; p < ptr[v + 1]; ++p) {
-      const int32_t* ev = ents + (int64_t)idx[p] * k;
-      for (int j = 0; j < k; ++j) {
-        int32_t c = ev[j];
-        int32_t lo = 0, hi = len;                   // lower bound
-        while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (list[mid] < c) lo = mid + 1; else hi = mid; }
-        if (lo < len && list[lo] == c) continue;
-        for (int32_t t = len; t > lo; --t) list[t] = list[t - 1];
-        list[lo] = c;
-        ++len;
-      }
+// Row v = sorted unique union of the vertices of the entities incident to v, written to the row's scratch region
+// [k*ptr[v], k*ptr[v+1]).  A group of 16 lanes owns a row: the candidates (k per incident entity) go to the group's LDS
+// region; a candidate is KEPT if no earlier candidate has the same value, and a kept candidate's position in the sorted
+// list is the number of kept candidates below it -- two all-pairs passes over LDS (<= 128^2 / 16 comparisons per lane),
+// no data-dependent shifting in memory.  Rows with more than PR_MAX candidates take the serial insertion walk.
+#define PR_GL 16
+#define PR_MAX 128
+__device__ __forceinline__ void pattern_row_serial(int32_t v, int k, const int32_t* __restrict__ ents, const int32_t* __restrict__ ptr,
+                                                   const int32_t* __restrict__ idx, int32_t* __restrict__ scratch,
+                                                   int32_t* __restrict__ rowlen) {
+  int32_t* list = scratch + (int64_t)k * ptr[v];
+  int32_t len = 0;
+  for (int32_t p = ptr[v]; p < ptr[v + 1]; ++p) {
+    const int32_t* ev = ents + (int64_t)idx[p] * k;
+    for (int j = 0; j < k; ++j) {
+      int32_t c = ev[j];
+      int32_t lo = 0, hi = len;                   // lower bound
+      while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (list[mid] < c) lo = mid + 1; else hi = mid; }
+      if (lo < len && list[lo] == c) continue;
+      for (int32_t t = len; t > lo; --t) list[t] = list[t - 1];
+      list[lo] = c;
+      ++len;
     }
-    rowlen[v] = len;
+  }
+  rowlen[v] = len;
+}
+__global__ void __launch_bounds__(256)
+k_pattern_rows(int32_t n, int k, const int32_t* __restrict__ ents, const int32_t* __restrict__ ptr,
+               const int32_t* __restrict__ idx, int32_t* __restrict__ scratch, int32_t* __restrict__ rowlen) {
+  constexpr int GPB = 256 / PR_GL;
+  __shared__ int32_t s_cand[GPB][PR_MAX];
+  __shared__ uint8_t s_keep[GPB][PR_MAX];
+  const int g = threadIdx.x / PR_GL, t = threadIdx.x % PR_GL;
+  const int64_t n_groups = (int64_t)gridDim.x * GPB;
+  for (int64_t v64 = (int64_t)blockIdx.x * GPB + g; v64 < n; v64 += n_groups) {
+    const int32_t v = (int32_t)v64;
+    const int32_t p0 = ptr[v], p1 = ptr[v + 1];
+    const int N = (p1 - p0) * k;
+    if (N > PR_MAX) {
+      if (t == 0) pattern_row_serial(v, k, ents, ptr, idx, scratch, rowlen);
+      continue;
+    }
+    for (int e = t; e < N; e += PR_GL) s_cand[g][e] = ents[(int64_t)idx[p0 + e / k] * k + e % k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = t; e < N; e += PR_GL) {
+      const int32_t val = s_cand[g][e];
+      bool keep = true;
+      for (int f = 0; f < e; ++f) keep = keep && (s_cand[g][f] != val);
+      s_keep[g][e] = keep ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int32_t* list = scratch + (int64_t)k * p0;
+    int kept = 0;
+    for (int e = t; e < N; e += PR_GL) {
+      if (!s_keep[g][e]) continue;
+      const int32_t val = s_cand[g][e];
+      int pos = 0;
+      for (int f = 0; f < N; ++f) pos += (s_keep[g][f] && s_cand[g][f] < val) ? 1 : 0;
+      list[pos] = val;
+      ++kept;
+    }
+    // row length = number of kept candidates (sum over the group's lanes)
+#pragma unroll
+    for (int o = PR_GL / 2; o > 0; o >>= 1) kept += __shfl_xor(kept, o, PR_GL);
+    if (t == 0) rowlen[v] = kept;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 __global__ void k_pattern_fill(int32_t n, int k, const int32_t* __restrict__ ptr, const int32_t* __restrict__ rowptr,
@@ -116,7 +167,7 @@ extern "C" int hx_p1_pattern_count(int32_t n_vert, int32_t n_ent, int k, const i
   HX_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * ((size_t)n_vert + 1), s));
   if (n_ent > 0) {
     HX_REQUIRE(ents && v2e_idx && scratch, "null argument");
-    k_pattern_rows<<<hx_grid(n_vert, 128), 128, 0, s>>>(n_vert, k, ents, v2e_ptr, v2e_idx, scratch, rowptr);
+    k_pattern_rows<<<hx_grid(n_vert, 256 / PR_GL, 256 * 64), 256, 0, s>>>(n_vert, k, ents, v2e_ptr, v2e_idx, scratch, rowptr);
     HX_LAUNCH_CHECK("k_pattern_rows");
   }
   int rc = exclusive_scan_i32(rowptr, (int64_t)n_vert + 1, s);
@@ -191,48 +242,138 @@ __device__ __forceinline__ int32_t find_slot(const int32_t* __restrict__ col, in
 }
 
 // ------------------------------------------------------------------------------------------------ A and C
+// A group of SM_GL = 16 lanes owns one CSR row.  Round by round, each lane takes one incident cell, computes its geometry
+// and leaves the cell's K contributions to this row (column, grad.grad product, mass entry; the cell's weight int c^2)
+// in the group's LDS region; then every lane scans the round's contributions IN ORDER (cell ascending, local vertex
+// ascending: the order a single thread walking the row would use, so the sums are bitwise those of a serial walk) and
+// adds the ones that fall on the column slots it owns (slots t, t + 16, ... of the row, held in registers).  Nothing
+// is accumulated in global memory; rows longer than SM_GL * SM_Q entries take the single-thread walk below.
+#define SM_GL 16
+#define SM_Q 4
 template <int D>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(256)
 k_stiff_mass(int32_t n, const double* __restrict__ x, const int32_t* __restrict__ cells,
              const int32_t* __restrict__ v2c_ptr, const int32_t* __restrict__ v2c_idx,
              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ cf,
              int cellwise, zc* __restrict__ A, zc* __restrict__ C) {
   constexpr int K = D + 1;
   constexpr double MT = 1.0 / ((D + 1) * (D + 2));
-  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  constexpr int GPB = 256 / SM_GL;                       // row groups per block
+  __shared__ int32_t s_col[GPB][SM_GL * K];
+  __shared__ double s_gg[GPB][SM_GL * K];
+  __shared__ double s_cm[GPB][SM_GL * K];
+  __shared__ zc s_w[GPB][SM_GL];
+  const int g = threadIdx.x / SM_GL, t = threadIdx.x % SM_GL;
+  const int64_t n_groups = (int64_t)gridDim.x * GPB;
+  for (int64_t i64 = (int64_t)blockIdx.x * GPB + g; i64 < n; i64 += n_groups) {
+    const int32_t i = (int32_t)i64;
     const int32_t rs = rowptr[i], re = rowptr[i + 1];
-    for (int32_t t = rs; t < re; ++t) {
-      if (A) A[t] = make_double2(0.0, 0.0);
-      if (C) C[t] = make_double2(0.0, 0.0);
-    }
-    for (int32_t p = v2c_ptr[i]; p < v2c_ptr[i + 1]; ++p) {
-      const int32_t c = v2c_idx[p];
-      int32_t v[K];
-      int j = 0;
+    if (re - rs > SM_GL * SM_Q) {
+      // long row (never on a simplicial mesh of bounded vertex degree): lane 0 walks it, accumulating in place
+      if (t == 0) {
+        for (int32_t u = rs; u < re; ++u) {
+          if (A) A[u] = make_double2(0.0, 0.0);
+          if (C) C[u] = make_double2(0.0, 0.0);
+        }
+        for (int32_t p = v2c_ptr[i]; p < v2c_ptr[i + 1]; ++p) {
+          const int32_t c = v2c_idx[p];
+          int32_t v[K];
+          int j = 0;
 #pragma unroll
-      for (int a = 0; a < K; ++a) { v[a] = cells[(int64_t)c * K + a]; if (v[a] == i) j = a; }
-      double G[K][D], vol;
-      p1_geometry<D>(x, v, G, vol);
-      zc w = make_double2(0.0, 0.0);  // int_K c^2 dx  (complex square, acoustic_matrices.py:101)
-      if (!A) {
-        // mass matrix only: the sound-speed field may be absent
-      } else if (cellwise) {
-        zc cc = cf[c];
-        w = zscale(vol, zmul(cc, cc));
-      } else {
-        zc sum = make_double2(0.0, 0.0), sq = make_double2(0.0, 0.0);
+          for (int a = 0; a < K; ++a) { v[a] = cells[(int64_t)c * K + a]; if (v[a] == i) j = a; }
+          double G[K][D], vol;
+          p1_geometry<D>(x, v, G, vol);
+          zc w = make_double2(0.0, 0.0);
+          if (A) {
+            if (cellwise) { const zc cc = cf[c]; w = zscale(vol, zmul(cc, cc)); }
+            else {
+              zc sum = make_double2(0.0, 0.0), sq = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int a = 0; a < K; ++a) { zc ca = cf[v[a]]; sum = zadd(sum, ca); sq = zadd(sq, zmul(ca, ca)); }
-        w = zscale(vol * MT, zadd(zmul(sum, sum), sq));
+              for (int a = 0; a < K; ++a) { zc ca = cf[v[a]]; sum = zadd(sum, ca); sq = zadd(sq, zmul(ca, ca)); }
+              w = zscale(vol * MT, zadd(zmul(sum, sum), sq));
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < K; ++m) {
+            double gg = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) gg += G[j][d] * G[m][d];
+            const int32_t slot = find_slot(col, rs, re, v[m]);
+            if (A) { zc a = A[slot]; a.x -= w.x * gg; a.y -= w.y * gg; A[slot] = a; }
+            if (C) { zc cm = C[slot]; cm.x += vol * MT * (m == j ? 2.0 : 1.0); C[slot] = cm; }
+          }
+        }
       }
+      continue;
+    }
+    int32_t mycol[SM_Q];
+    zc accA[SM_Q];
+    double accC[SM_Q];
 #pragma unroll
-      for (int m = 0; m < K; ++m) {
-        double gg = 0.0;
+    for (int q = 0; q < SM_Q; ++q) {
+      const int32_t u = rs + t + q * SM_GL;
+      mycol[q] = u < re ? col[u] : -1;
+      accA[q] = make_double2(0.0, 0.0);
+      accC[q] = 0.0;
+    }
+    const int32_t p0 = v2c_ptr[i], p1 = v2c_ptr[i + 1];
+    for (int32_t pb = p0; pb < p1; pb += SM_GL) {
+      const int nround = min(p1 - pb, SM_GL);
+      if (t < nround) {
+        const int32_t c = v2c_idx[pb + t];
+        int32_t v[K];
+        int j = 0;
 #pragma unroll
-        for (int d = 0; d < D; ++d) gg += G[j][d] * G[m][d];
-        const int32_t slot = find_slot(col, rs, re, v[m]);
-        if (A) { zc a = A[slot]; a.x -= w.x * gg; a.y -= w.y * gg; A[slot] = a; }
-        if (C) { zc cm = C[slot]; cm.x += vol * MT * (m == j ? 2.0 : 1.0); C[slot] = cm; }
+        for (int a = 0; a < K; ++a) { v[a] = cells[(int64_t)c * K + a]; if (v[a] == i) j = a; }
+        double G[K][D], vol;
+        p1_geometry<D>(x, v, G, vol);
+        zc w = make_double2(0.0, 0.0);  // int_K c^2 dx  (complex square, acoustic_matrices.py:101)
+        if (A) {
+          if (cellwise) { const zc cc = cf[c]; w = zscale(vol, zmul(cc, cc)); }
+          else {
+            zc sum = make_double2(0.0, 0.0), sq = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int a = 0; a < K; ++a) { zc ca = cf[v[a]]; sum = zadd(sum, ca); sq = zadd(sq, zmul(ca, ca)); }
+            w = zscale(vol * MT, zadd(zmul(sum, sum), sq));
+          }
+        }
+        s_w[g][t] = w;
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+          double gg = 0.0;
+#pragma unroll
+          for (int d = 0; d < D; ++d) gg += G[j][d] * G[m][d];
+          s_col[g][t * K + m] = v[m];
+          s_gg[g][t * K + m] = gg;
+          s_cm[g][t * K + m] = vol * MT * (m == j ? 2.0 : 1.0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int e = 0; e < nround * K; ++e) {
+        const int32_t cc = s_col[g][e];
+#pragma unroll
+        for (int q = 0; q < SM_Q; ++q) {
+          if (cc == mycol[q]) {
+            const double gg = s_gg[g][e];
+            const zc w = s_w[g][e / K];
+            accA[q].x -= w.x * gg;
+            accA[q].y -= w.y * gg;
+            accC[q] += s_cm[g][e];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int q = 0; q < SM_Q; ++q) {
+      const int32_t u = rs + t + q * SM_GL;
+      if (u < re) {
+        if (A) A[u] = accA[q];
+        if (C) C[u] = make_double2(accC[q], 0.0);
       }
     }
   }
@@ -245,8 +386,8 @@ extern "C" int hx_assemble_p1_stiff_mass(int dim, int32_t n_vert, const double* 
   HX_REQUIRE(dim >= 1 && dim <= 3 && n_vert > 0 && x && cells && v2c_ptr && v2c_idx && rowptr && col, "bad argument");
   HX_REQUIRE(A_val || C_val, "nothing to assemble");
   HX_REQUIRE(!A_val || c, "A needs the sound-speed field");
-  const int grid = hx_grid(n_vert, 128, 256 * 16);
-#define HX_GO(D) k_stiff_mass<D><<<grid, 128, 0, hx_s(s)>>>(n_vert, x, cells, v2c_ptr, v2c_idx, rowptr, col, \
+  const int grid = hx_grid(n_vert, 256 / SM_GL, 256 * 64);
+#define HX_GO(D) k_stiff_mass<D><<<grid, 256, 0, hx_s(s)>>>(n_vert, x, cells, v2c_ptr, v2c_idx, rowptr, col, \
                                                               (const zc*)c, c_is_cellwise, (zc*)A_val, (zc*)C_val)
   if (dim == 1) HX_GO(1); else if (dim == 2) HX_GO(2); else HX_GO(3);
 #undef HX_GO
@@ -362,53 +503,71 @@ __device__ __forceinline__ double quad2_bary(int q, int a) {
   return (q == a) ? 0.5854101966249685 : 0.1381966011250105;
 }
 
+// load-vector entry of vertex i: sum over its incident cells (ascending), optionally only those tagged `tag`
+template <int D, int KIND>
+__device__ __forceinline__ zc load_row(int32_t i, const double* __restrict__ x, const int32_t* __restrict__ cells,
+                                       const int32_t* __restrict__ v2c_ptr, const int32_t* __restrict__ v2c_idx,
+                                       const zc* __restrict__ fa, const zc* __restrict__ fb,
+                                       const int32_t* __restrict__ cell_tag, int32_t tag) {
+  constexpr int K = D + 1;
+  zc acc = make_double2(0.0, 0.0);
+  for (int32_t p = v2c_ptr[i]; p < v2c_ptr[i + 1]; ++p) {
+    const int32_t c = v2c_idx[p];
+    if (cell_tag && cell_tag[c] != tag) continue;
+    int32_t v[K];
+    int j = 0;
+#pragma unroll
+    for (int a = 0; a < K; ++a) { v[a] = cells[(int64_t)c * K + a]; if (v[a] == i) j = a; }
+    double G[K][D], vol;
+    p1_geometry<D>(x, v, G, vol);
+    if (KIND == 0) {
+      acc = zadd(acc, zscale(vol / K, fa[c]));
+    } else if (KIND == 1) {
+      zc e = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int m = 0; m < K; ++m) {
+        zc am = fa[v[m]];
+#pragma unroll
+        for (int l = 0; l < K; ++l) zfma(e, zscale(triple_T(D, j, m, l), am), fb[v[l]]);
+      }
+      acc = zadd(acc, zscale(vol, e));
+    } else {
+      zc sq = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int q = 0; q < Quad2<D>::NQ; ++q) {
+        zc rq = make_double2(0.0, 0.0), wq = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+          const double l = quad2_bary<D>(q, a);
+          rq = zadd(rq, zscale(l, fa[v[a]]));
+          wq = zadd(wq, zscale(l, fb[v[a]]));
+        }
+        sq = zadd(sq, zscale(1.0 / Quad2<D>::NQ, zdiv(wq, rq)));
+      }
+      const double gn = G[j][D == 3 ? 2 : 0];   // n_r = e_x (1D/2D), e_z (3D): flame_matrices.py:35-40
+      acc = zadd(acc, zscale(vol * gn, sq));
+    }
+  }
+  return acc;
+}
+
 template <int D, int KIND>
 __global__ void __launch_bounds__(128)
 k_load(int32_t n, const double* __restrict__ x, const int32_t* __restrict__ cells, const int32_t* __restrict__ v2c_ptr,
        const int32_t* __restrict__ v2c_idx, const zc* __restrict__ fa, const zc* __restrict__ fb, zc scale,
        const int32_t* __restrict__ cell_tag, int32_t tag, zc* __restrict__ out) {
-  constexpr int K = D + 1;
-  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    zc acc = make_double2(0.0, 0.0);
-    for (int32_t p = v2c_ptr[i]; p < v2c_ptr[i + 1]; ++p) {
-      const int32_t c = v2c_idx[p];
-      if (cell_tag && cell_tag[c] != tag) continue;
-      int32_t v[K];
-      int j = 0;
-#pragma unroll
-      for (int a = 0; a < K; ++a) { v[a] = cells[(int64_t)c * K + a]; if (v[a] == i) j = a; }
-      double G[K][D], vol;
-      p1_geometry<D>(x, v, G, vol);
-      if (KIND == 0) {
-        acc = zadd(acc, zscale(vol / K, fa[c]));
-      } else if (KIND == 1) {
-        zc e = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int m = 0; m < K; ++m) {
-          zc am = fa[v[m]];
-#pragma unroll
-          for (int l = 0; l < K; ++l) zfma(e, zscale(triple_T(D, j, m, l), am), fb[v[l]]);
-        }
-        acc = zadd(acc, zscale(vol, e));
-      } else {
-        zc sq = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int q = 0; q < Quad2<D>::NQ; ++q) {
-          zc rq = make_double2(0.0, 0.0), wq = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int a = 0; a < K; ++a) {
-            const double l = quad2_bary<D>(q, a);
-            rq = zadd(rq, zscale(l, fa[v[a]]));
-            wq = zadd(wq, zscale(l, fb[v[a]]));
-          }
-          sq = zadd(sq, zscale(1.0 / Quad2<D>::NQ, zdiv(wq, rq)));
-        }
-        const double gn = G[j][D == 3 ? 2 : 0];   // n_r = e_x (1D/2D), e_z (3D): flame_matrices.py:35-40
-        acc = zadd(acc, zscale(vol * gn, sq));
-      }
-    }
-    out[i] = zmul(scale, acc);
-  }
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = zmul(scale, load_row<D, KIND>(i, x, cells, v2c_ptr, v2c_idx, fa, fb, cell_tag, tag));
+}
+// the same for a LIST of vertices, each with its own tag (the supports of the flames: a few hundred vertices each)
+template <int D, int KIND>
+__global__ void __launch_bounds__(128)
+k_load_rows(int32_t n_rows, const int32_t* __restrict__ rows, const int32_t* __restrict__ row_tag, const double* __restrict__ x,
+            const int32_t* __restrict__ cells, const int32_t* __restrict__ v2c_ptr, const int32_t* __restrict__ v2c_idx,
+            const zc* __restrict__ fa, const zc* __restrict__ fb, zc scale, const int32_t* __restrict__ cell_tag,
+            zc* __restrict__ out) {
+  for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_rows; t += gridDim.x * blockDim.x)
+    out[t] = zmul(scale, load_row<D, KIND>(rows[t], x, cells, v2c_ptr, v2c_idx, fa, fb, cell_tag, row_tag ? row_tag[t] : 0));
 }
 
 extern "C" int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const double* x, const int32_t* cells,
@@ -427,6 +586,31 @@ extern "C" int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const doub
 #undef HX_DIM
 #undef HX_GO
   HX_LAUNCH_CHECK("k_load");
+  return HX_OK;
+}
+
+
+// out[t] = entry rows[t] of the load vector of hx_assemble_p1_load, restricted (when cell_tag is given) to the cells tagged
+// row_tag[t]: the flames' load vectors (flame_matrices.py:139-141) live on a few hundred vertices each.
+extern "C" int hx_assemble_p1_load_rows(int kind, int dim, int32_t n_rows, const int32_t* rows, const int32_t* row_tag,
+                                        const double* x, const int32_t* cells, const int32_t* v2c_ptr, const int32_t* v2c_idx,
+                                        const hx_c128* fa, const hx_c128* fb, const double scale[2], const int32_t* cell_tag,
+                                        hx_c128* out, hx_stream s) {
+  HX_REQUIRE(kind >= 0 && kind <= 2 && dim >= 1 && dim <= 3 && n_rows >= 0 && x && cells && v2c_ptr && v2c_idx && fa && scale,
+             "bad argument");
+  HX_REQUIRE(kind == 0 || fb, "kind 1/2 need both fields");
+  HX_REQUIRE(!cell_tag || row_tag, "tagged cells need a tag per row");
+  if (n_rows == 0) return HX_OK;
+  HX_REQUIRE(rows && out, "null argument");
+  const int grid = hx_grid(n_rows, 128, 256 * 16);
+  const zc sc = hx_z(scale);
+#define HX_GO(D, KD) k_load_rows<D, KD><<<grid, 128, 0, hx_s(s)>>>(n_rows, rows, row_tag, x, cells, v2c_ptr, v2c_idx, \
+                                                                    (const zc*)fa, (const zc*)fb, sc, cell_tag, (zc*)out)
+#define HX_DIM(KD) do { if (dim == 1) HX_GO(1, KD); else if (dim == 2) HX_GO(2, KD); else HX_GO(3, KD); } while (0)
+  if (kind == 0) HX_DIM(0); else if (kind == 1) HX_DIM(1); else HX_DIM(2);
+#undef HX_DIM
+#undef HX_GO
+  HX_LAUNCH_CHECK("k_load_rows");
   return HX_OK;
 }
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "hx_assemble_p1_robin": (C.c_int, [_int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "hx_csr_apply_dirichlet": (C.c_int, [_i32, _vp, _vp, _vp, _vp, C.c_double, _vp]),
     "hx_assemble_p1_load": (C.c_int, [_int, _int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _dp, _vp, _i32, _vp, _vp]),
+    "hx_assemble_p1_load_rows": (C.c_int, [_int, _int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dp, _vp, _vp, _vp]),
     "hx_assemble_p2_stiff_mass": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "hx_assemble_p2_robin": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "hx_assemble_p2_load": (C.c_int, [_int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dp, _int, _vp, _vp, _vp]),

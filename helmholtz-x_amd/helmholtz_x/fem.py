@@ -378,6 +378,20 @@ class P1Assembler:
                                               _hx.stream()))
         return out
 
+    def load_rows(self, kind, rows, fa, fb=None, scale=1.0, cell_tag=None, row_tag=None):
+        """Entries ``rows`` (int32 array) of the load vector of ``load``; with ``cell_tag`` only the cells tagged row_tag[t]
+        contribute to entry t.  Returns a device tensor of len(rows) values."""
+        rows_t = to_device(np.ascontiguousarray(rows, dtype=np.int32))
+        tag_t = None if row_tag is None else to_device(np.ascontiguousarray(row_tag, dtype=np.int32))
+        fa_t = fa if isinstance(fa, torch.Tensor) else to_device(np.asarray(fa, dtype=np.complex128))
+        fb_t = None if fb is None else (fb if isinstance(fb, torch.Tensor) else to_device(np.asarray(fb, np.complex128)))
+        out = torch.empty(max(rows_t.numel(), 1), dtype=torch.complex128, device=self.x.device)[:rows_t.numel()]
+        _hx.check(_hx.lib.hx_assemble_p1_load_rows(kind, self.dim, rows_t.numel(), _hx.ptr(rows_t), _hx.ptr(tag_t),
+                                                   _hx.ptr(self.x), _hx.ptr(self.cells), _hx.ptr(self.v2c_ptr),
+                                                   _hx.ptr(self.v2c_idx), _hx.ptr(fa_t), _hx.ptr(fb_t), _hx.z2(scale),
+                                                   _hx.ptr(cell_tag), _hx.ptr(out), _hx.stream()))
+        return out
+
     def cell_tag_array(self, tags):
         """Dense int32 device array of cell tags (-1 = untagged) from a MeshTags, cached per MeshTags object."""
         cache = self.__dict__.setdefault("_tag_cache", {})

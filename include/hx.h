@@ -191,6 +191,14 @@ int hx_assemble_p1_load(int kind, int dim, int32_t n_vert, const double* x, cons
                         const int32_t* v2c_ptr, const int32_t* v2c_idx, const hx_c128* fa,
                         const hx_c128* fb, const double scale[2], const int32_t* cell_tag, int32_t tag,
                         hx_c128* out, hx_stream s);
+/* The same entries for a LIST of vertices: out[t] = entry rows[t], restricted (cell_tag given) to the cells tagged
+ * row_tag[t].  The load vector of a flame (dx(flame), flame_matrices.py:139-141) lives on the few hundred vertices of its
+ * subdomain, so all flames are assembled by one launch over the union of their supports instead of one sweep of the mesh
+ * per flame. */
+int hx_assemble_p1_load_rows(int kind, int dim, int32_t n_rows, const int32_t* rows, const int32_t* row_tag,
+                             const double* x, const int32_t* cells, const int32_t* v2c_ptr, const int32_t* v2c_idx,
+                             const hx_c128* fa, const hx_c128* fb, const double scale[2], const int32_t* cell_tag,
+                             hx_c128* out, hx_stream s);
 
 /* |K_c| of every cell (assemble_scalar(Constant(1)*dx(tag)) in parameters_utils.py:215-216,235-236). */
 int hx_p1_cell_volumes(int dim, int32_t n_cells, const double* x, const int32_t* cells, double* vol,

@@ -24,6 +24,8 @@
 
 struct hx_sell;
 extern "C" int hx_sell_spmv_z(const hx_sell*, const hx_c128*, hx_c128*, const double*, const double*, hx_stream);
+int hx_sell_residual_z(const hx_sell*, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
+int hx_csr_residual_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
 int hx_zpanel_bdot(int64_t, int, const hx_c128*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
 int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 int hx_zpanel_bdot_c64(int64_t, int, const hx_c64*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
@@ -34,7 +36,7 @@ int hx_amg_vcycle_c64(hx_amg*, hx_stream);
 int hx_panel_dot_blocks(int64_t n, int64_t* rows_per_block);
 int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* out, hx_stream s);
 
-static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 0.0};
+static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0};
 
 // Scalar block on the device (complex128 entries): OUT = raw reduction results (always at the FRONT: in row-sharded mode
 // the all-reduce callback sums the first `count` entries of the registered buffer), ST = state, T = deflation coefficients.
@@ -223,6 +225,15 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     if (Ksell) return hx_sell_spmv_z(Ksell, in, out, a, bt, s);
     return hx_csr_spmv_z(n, nnz, rowptr, col, val, in, out, a, bt, 0, s);
   };
+  auto Kres = [&](const hx_c128* in, hx_c128* out) -> int {          // out = b - K in
+    if (sharded) {
+      HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+      if (M->halo(M->ctx, HX_BUF_GMRES_XE) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
+      in = xe;
+    }
+    if (Ksell) return hx_sell_residual_z(Ksell, in, b, out, s);
+    return hx_csr_residual_z(n, nnz, rowptr, col, val, in, b, out, s);
+  };
   auto reduce = [&](int count) -> int {       // sum the first `count` scalars over the ranks
     if (sharded && M->allreduce(M->ctx, sc_buf, count) != 0)
       return hx_fail(HX_ERR_COMM, "hx_cocg", "all-reduce callback failed");
@@ -273,8 +284,8 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   bool converged = false, x_zero = true;
   M->last_backward = -1.0;
   auto true_residual = [&]() -> int {        // r = b - K x, relres = |r| / |b|  (SYNC)
-    HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
-    if (!x_zero) { if ((rc = Kx(x, r, MONE, ONE))) return rc; }
+    if (x_zero) HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+    else if ((rc = Kres(x, r))) return rc;   // one pass, no copy of b first
     if ((rc = hx_zpanel_dot(n, 0, nullptr, n, r, sc, part, s))) return rc;
     if ((rc = reduce(1))) return rc;
     if ((rc = fetch(1))) return rc;

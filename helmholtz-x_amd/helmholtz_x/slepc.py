@@ -619,7 +619,10 @@ class PEP(_EigenSolverBase):
         if ops is None:
             K = combine_csr(A.shape, A.csr_terms + [(sigma * c, m) for c, m in b_terms]
                             + [(sigma ** 2 * c, m) for c, m in Cm.csr_terms])
-            BsC = combine_csr(A.shape, list(b_terms) + [(sigma * c, m) for c, m in Cm.csr_terms])
+            # B + sigma C as one operator only where the row-sharded run localises it; the single-GPU operator below
+            # applies C once to sigma x1 + x2 and B on its own (boundary-only) pattern
+            BsC = combine_csr(A.shape, list(b_terms) + [(sigma * c, m) for c, m in Cm.csr_terms]) \
+                if self.shard is not None else None
             if self.inner_cache is not None:
                 self.inner_cache[("ops",) + key] = (K, BsC)
         else:
@@ -654,12 +657,18 @@ class PEP(_EigenSolverBase):
             self._n = m
             return
         tmp = torch.empty(n, dtype=torch.complex128, device=Ccsr.val.device)
+        t2 = torch.empty_like(tmp)
 
         def op(z, y):
             x1, x2 = z[:n], z[n:]
             y1, y2 = y[:n], y[n:]
-            BsC.spmv(x1, tmp, alpha=-1.0)
-            Ccsr.spmv(x2, tmp, alpha=-1.0, beta=1.0)
+            # (B + sigma C) x1 + C x2 = C (sigma x1 + x2) + B x1: ONE product on the volume pattern per application
+            arr = (C.c_void_p * 2)(x1.data_ptr(), x2.data_ptr())
+            cf = (C.c_double * 4)(sigma.real, sigma.imag, 1.0, 0.0)
+            _hx.check(_hx.lib.hx_zlincomb(n, 2, cf, arr, _hx.ptr(t2), _hx.stream()))
+            Ccsr.spmv(t2, tmp, alpha=-1.0)
+            for coef, m in b_terms:
+                m.spmv(x1, tmp, alpha=-coef, beta=1.0)
             solver.solve(tmp, y1, relax=basis.relax)             # y1 = -K^-1[(B + sigma C) x1 + C x2]
             arr = (C.c_void_p * 2)(x1.data_ptr(), y1.data_ptr())
             cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)

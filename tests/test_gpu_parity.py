@@ -75,6 +75,36 @@ def test_pattern_and_passive_matrices(golden_dir):
         _csr_equal(M.A, fem.assemble_A(x, cells, cf.x.array, c_is_cellwise=True))
 
 
+def test_assembly_of_a_high_degree_vertex():
+    """A double fan: one vertex shared by 160 tetrahedra (row of 83 entries, 640 pattern candidates) and two apexes
+    shared by 80 each -- the rows that leave the 16-lane fast paths of the pattern and stiffness kernels (more than 128
+    candidates / more than 64 entries) and take their serial walks.  Pattern bit-exact, values against the oracle."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.fem import Function, FunctionSpace, Mesh, MeshTags
+    from oracle import fem
+    m = 80
+    th = 2 * np.pi * np.arange(m) / m
+    rng = np.random.default_rng(3)
+    ring = np.stack([(1 + 0.1 * rng.random(m)) * np.cos(th), (1 + 0.1 * rng.random(m)) * np.sin(th), 0.05 * rng.random(m)], axis=1)
+    x = np.concatenate([[[0.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, -1.0]], ring], axis=0)
+    nxt = 3 + (np.arange(m) + 1) % m
+    cur = 3 + np.arange(m)
+    cells = np.concatenate([np.stack([np.zeros(m, int), np.full(m, 1), cur, nxt], axis=1),
+                            np.stack([np.zeros(m, int), np.full(m, 2), nxt, cur], axis=1)], axis=0).astype(np.int32)
+    mesh = Mesh(x, cells)
+    facet_tags = MeshTags(mesh, 2, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    cf = Function(FunctionSpace(mesh, "DG", 0), "soundspeed")
+    cf.x.array[:] = 300 + 100 * rng.random(mesh.num_cells) + 5j * rng.random(mesh.num_cells)
+    M = AcousticMatrices(mesh, facet_tags, {}, cf)
+    A_ref = fem.assemble_A(x, cells, cf.x.array, c_is_cellwise=True)
+    assert np.diff(A_ref.tocsr().indptr).max() == m + 3
+    _csr_equal(M.A, A_ref)
+    _csr_equal(M.C, fem.assemble_C(x, cells))
+    cn = Function(FunctionSpace(mesh, "Lagrange", 1), "c")
+    cn.x.array[:] = 340 + 20 * rng.random(mesh.num_vertices)
+    _csr_equal(AcousticMatrices(mesh, facet_tags, {}, cn).A, fem.assemble_A(x, cells, cn.x.array))
+
+
 def test_robin_choked_and_dirichlet(golden_dir):
     from helmholtz_x.acoustic_matrices import AcousticMatrices
     from helmholtz_x.fem import Function, FunctionSpace

@@ -98,9 +98,9 @@ k_cocg_small(int k, const zc* __restrict__ Einv, zc* __restrict__ sc, int first,
   }
 }
 
-// p = z - sum_j t_j U_j + beta p   (U complex64; z complex128 or the V-cycle's complex64 output; t, beta from the scalar block)
 __device__ __forceinline__ zc widen(zc v) { return v; }
 __device__ __forceinline__ zc widen(cc v) { return make_double2((double)v.x, (double)v.y); }
+// p = z - sum_j t_j U_j + beta p   (U complex64; z complex128 or the V-cycle's complex64 output; t, beta from the scalar block)
 template <typename ZT>
 __global__ void __launch_bounds__(256)
 k_cocg_direction(int64_t n, int k, const cc* __restrict__ Uf, int64_t ldu, const ZT* __restrict__ z, zc* __restrict__ p,
@@ -122,19 +122,20 @@ k_cocg_direction(int64_t n, int k, const cc* __restrict__ Uf, int64_t ldu, const
   }
 }
 
-// x -= sum_j t_j U_j
+// x -= sum_j t_j U_j (SIGN = -1, U complex64)  /  r += sum_j t_j C_j (SIGN = +1, C = K U complex128: the residual that goes
+// with the start correction of x, without an operator product)
+template <typename PT, int SIGN>
 __global__ void __launch_bounds__(256)
-k_cocg_start(int64_t n, int k, const cc* __restrict__ U, int64_t ldu, zc* __restrict__ x, const zc* __restrict__ sc) {
+k_cocg_start(int64_t n, int k, const PT* __restrict__ U, int64_t ldu, zc* __restrict__ x, const zc* __restrict__ sc) {
   __shared__ zc ts[CG_MAXK];
   if ((int)threadIdx.x < k) ts[threadIdx.x] = sc[CG_T + threadIdx.x];
   __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     zc acc = x[i];
     for (int j = 0; j < k; ++j) {
-      const cc u = U[(int64_t)j * ldu + i];
-      const zc v = make_double2((double)u.x, (double)u.y), tj = ts[j];
-      acc.x = fma(-v.x, tj.x, acc.x); acc.x = fma(v.y, tj.y, acc.x);
-      acc.y = fma(-v.x, tj.y, acc.y); acc.y = fma(-v.y, tj.x, acc.y);
+      const zc v = widen(U[(int64_t)j * ldu + i]), tj = ts[j];
+      acc.x = fma((double)SIGN * v.x, tj.x, acc.x); acc.x = fma(-(double)SIGN * v.y, tj.y, acc.x);
+      acc.y = fma((double)SIGN * v.x, tj.y, acc.y); acc.y = fma((double)SIGN * v.y, tj.x, acc.y);
     }
     x[i] = acc;
   }
@@ -351,10 +352,22 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       if ((rc = reduce(k))) return rc;
       k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, (const zc*)rec->Einv, (zc*)sc, 1, 1);
       HX_LAUNCH_CHECK("k_cocg_small");
-      k_cocg_start<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const cc*)rec->Uf, n, (zc*)x, (const zc*)sc);
+      k_cocg_start<cc, -1><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const cc*)rec->Uf, n, (zc*)x, (const zc*)sc);
       HX_LAUNCH_CHECK("k_cocg_start");
-      x_zero = false;
-      if ((rc = true_residual())) return rc;
+      if (cycle == 0 && x_zero) {
+        // x was zero, so x = U t' and r = b - K U t' = b - C t' exactly (C = K U in complex128): update r from the panel
+        // C (k columns) instead of an operator product
+        k_cocg_start<zc, +1><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const zc*)rec->Cd, n, (zc*)r, (const zc*)sc);
+        HX_LAUNCH_CHECK("k_cocg_start<r>");
+        x_zero = false;
+        if ((rc = hx_zpanel_dot(n, 0, nullptr, n, r, sc, part, s))) return rc;
+        if ((rc = reduce(1))) return rc;
+        if ((rc = fetch(1))) return rc;
+        relres = std::sqrt(host[0].real()) / bnorm;
+      } else {
+        x_zero = false;
+        if ((rc = true_residual())) return rc;
+      }
       if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "non-finite residual");
     }
     if (r32) { if ((rc = hx_cast_z2c(n, r, (float*)r32, s))) return rc; }     // later residuals: written by k_cocg_update

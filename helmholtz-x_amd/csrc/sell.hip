@@ -464,6 +464,97 @@ __device__ __forceinline__ V sell_row_dot_stencil(int32_t u, const MV* __restric
   return zadd(zadd(acc[0], acc[1]), zadd(acc[2], acc[3]));
 }
 
+// Stencil slice with the neighbourhood of x STAGED IN LDS.  The deltas of a slice fall into a few BANDS (runs of deltas less
+// than SX_GAP apart: on an extruded mesh the plane below, the own plane, the plane above); since the 64 rows of a slice are
+// consecutive, entry k of all rows reads the contiguous window x[row0 + U[k] .. + 63], and a whole band reads one window
+// x[row0 + first .. row0 + last + 63].  The wave loads each band's window ONCE (coalesced, clamped like the gathers), keeps
+// it in its LDS region and takes the 15 operands of every row from there: 3 windows of 114 + 164 + 114 entries instead of 15
+// gathers of 64 through the CU's vector-memory path.  Same operands in the same order as the gather form: identical sums.
+// Returns false (wave-uniform) when the slice does not fit (more than SX_NB bands, a band wider than SX_Q * 64, more than
+// SX_CAP entries in all): the caller then takes the gather form.
+#define SX_NB 4
+#define SX_Q 3
+#define SX_CAP 512
+#define SX_GAP 128
+template <typename V, typename MV, int G>
+__device__ __forceinline__ bool sell_row_dot_stencil_lds(int32_t u, int32_t stw, const MV* __restrict__ vb, int lane,
+                                                         const V* __restrict__ x, int width, int32_t row0, int32_t n, V* lds,
+                                                         V& result) {
+  typedef typename real_of<V>::type R;
+  const int32_t prev = __shfl_up(u, 1);
+  // a band = a run of ASCENDING deltas less than SX_GAP apart (the list of a row-sharded local operator is not sorted:
+  // its ghost columns sit behind the owned ones whatever their global position, so a decrease also starts a band)
+  const bool start = lane < stw && (lane == 0 || u - prev >= SX_GAP || u < prev);
+  unsigned long long m = __ballot(start);
+  const int nb = __popcll(m);
+  if (nb > SX_NB || nb == 0) return false;
+  int32_t bf[SX_NB], bl[SX_NB], bo[SX_NB];
+  int32_t lofs = 0, total = 0;
+  bool fits = true;
+#pragma unroll
+  for (int b = 0; b < SX_NB; ++b) {
+    bf[b] = 0;
+    bl[b] = 0;
+    bo[b] = total;
+    if (b < nb) {
+      const int sl = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int el = (m ? __ffsll((long long)m) - 1 : stw) - 1;
+      const int32_t f = __builtin_amdgcn_readlane(u, sl), l = __builtin_amdgcn_readlane(u, el);
+      bf[b] = f;
+      bl[b] = l - f + SELL_C;
+      if (lane >= sl && lane <= el) lofs = total + (u - f);
+      total += bl[b];
+      fits = fits && bl[b] <= SX_Q * 64;
+    }
+  }
+  if (!fits || total > SX_CAP) return false;
+  // the windows: requested together, then written to LDS
+  V tmp[SX_NB][SX_Q];
+#pragma unroll
+  for (int b = 0; b < SX_NB; ++b)
+#pragma unroll
+    for (int q = 0; q < SX_Q; ++q) {
+      const int32_t e = lane + 64 * q;
+      if (e < bl[b]) tmp[b][q] = ld32<V>(x, (uint32_t)clampi(row0 + bf[b] + e, n - 1) * (uint32_t)sizeof(V));
+    }
+  V acc[4] = {czero<V>(), czero<V>(), czero<V>(), czero<V>()};
+  const uint32_t lv = (uint32_t)lane * (uint32_t)sizeof(MV);
+  // first group of matrix values: in flight together with the windows
+  MV v0[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) v0[j] = ld32<MV>(vb, (uint32_t)min(j, width - 1) * (uint32_t)(SELL_C * sizeof(MV)) + lv);
+#pragma unroll
+  for (int b = 0; b < SX_NB; ++b)
+#pragma unroll
+    for (int q = 0; q < SX_Q; ++q) {
+      const int32_t e = lane + 64 * q;
+      if (e < bl[b]) lds[bo[b] + e] = tmp[b][q];
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const int k = min(j, width - 1);
+    const V xv = lds[__builtin_amdgcn_readlane(lofs, k) + lane];
+    mfma_acc(acc[j & 3], v0[j], zscale((R)(j < width ? 1 : 0), xv));
+  }
+  for (int k0 = G; k0 < width; k0 += G) {
+    MV v[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) v[j] = ld32<MV>(vb, (uint32_t)min(k0 + j, width - 1) * (uint32_t)(SELL_C * sizeof(MV)) + lv);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int k = min(k0 + j, width - 1);
+      const V xv = lds[__builtin_amdgcn_readlane(lofs, k) + lane];
+      mfma_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv));
+    }
+  }
+  result = zadd(zadd(acc[0], acc[1]), zadd(acc[2], acc[3]));
+  return true;
+}
+
 // MODE 0: y = alpha*A*x + beta*yin (yin may be y itself).   MODE 1: xout = xin + omega*dinv.*(b - A*xin) + mom*(xin - xprev)  (smoother step)
 // MV = storage type of the matrix values (V itself, or complex-half for V = complex64: entries are then vscale * half2).
 // dcol / wide: 16-bit column deltas for the slices flagged narrow (wave-uniform branch); both null -> 32-bit everywhere.
@@ -476,7 +567,7 @@ struct SellOp {            // the scalars of the update
   typename real_of<V>::type omega, mom, vscale;
 };
 
-template <typename V, int MODE, typename MV, int G>
+template <typename V, int MODE, typename MV, int G, bool LDSX>
 __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
@@ -504,7 +595,15 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     }
   }
   const MV* vb = val + base;
-  V acc = stw > 0 ? sell_row_dot_stencil<V, MV, G>(u, vb, lane, x, width, row, n_cols)
+  V acc;
+  bool staged = false;
+  if constexpr (LDSX) {
+    __shared__ V s_x[4][SX_CAP];
+    if (stw > 0) staged = sell_row_dot_stencil_lds<V, MV, (sizeof(MV) == 4 ? 16 : G)>(u, stw, vb, lane, x, width, slice * SELL_C, n_cols,
+                                                                                    s_x[threadIdx.x >> 6], acc);
+  }
+  if (!staged)
+    acc = stw > 0 ? sell_row_dot_stencil<V, MV, G>(u, vb, lane, x, width, row, n_cols)
           : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t, G>(dcol + base, vb, lane, x, width, row)
                                    : sell_row_dot<V, MV, int32_t, G>(col + base, vb, lane, x, width, row);
   if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(a.vscale, acc);
@@ -528,7 +627,11 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
                         typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr) {
   const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale};
-  k_sell<V, MODE, MV, 8><<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
+  // x windows of the stencil slices through LDS (HX_SELL_LDS=0: gathers everywhere; =2: also for complex128 values)
+  static const int lds_mode = getenv("HX_SELL_LDS") ? atoi(getenv("HX_SELL_LDS")) : 1;
+  const bool use_lds = h->st_ptr && (lds_mode == 2 || (lds_mode == 1 && sizeof(MV) == 4));
+  auto kern = use_lds ? k_sell<V, MODE, MV, 8, true> : k_sell<V, MODE, MV, 8, false>;
+  kern<<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
                                                                       h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op);
 }
 

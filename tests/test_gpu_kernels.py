@@ -370,6 +370,56 @@ def test_sell64_stencil_slices(hx, want):
     hx.check(hx.lib.hx_sell_destroy(h))
 
 
+def test_sell64_stencil_slices_of_a_row_sharded_local_operator(hx):
+    """Rows [r0, r1) of a 3-D 7-point operator over [owned | ghost] columns, as ShardContext.localize builds them: the
+    ghost columns come numbered behind the owned ones whatever their global position, so a row's column list -- and with
+    it the slice's delta list -- is NOT ascending (lower-plane ghosts first).  Stencil slices must still be found, and the
+    products (gather form for complex128, LDS-staged windows for the complex-half copy) must equal the CSR ones."""
+    import torch
+    nx, ny, nz = 16, 16, 24
+    n = nx * ny * nz
+    rng = np.random.default_rng(11)
+    idx = np.arange(n).reshape(nz, ny, nx)
+    rows, cols = [np.arange(n)], [np.arange(n)]
+    for axis, off in ((2, 1), (1, nx), (0, nx * ny)):
+        a = np.take(idx, np.arange(idx.shape[axis] - 1), axis=axis).ravel()
+        rows += [a, a + off]
+        cols += [a + off, a]
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    vals = _rand_c(rng, rows.size) + 6.0 * (rows == cols)
+    M = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    M.sort_indices()
+    r0, r1 = 8 * nx * ny, 16 * nx * ny
+    L = M[r0:r1].tocsr()
+    L.sort_indices()
+    gcol = L.indices
+    own = (gcol >= r0) & (gcol < r1)
+    ghost = np.unique(gcol[~own])
+    lcol = np.where(own, gcol - r0, (r1 - r0) + np.searchsorted(ghost, gcol)).astype(np.int32)   # global order kept: unsorted rows
+    n_own, n_ext = r1 - r0, r1 - r0 + ghost.size
+    Lloc = sp.csr_matrix((L.data, lcol, L.indptr), shape=(n_own, n_ext))
+    rp, ci, va = _dev(L.indptr.astype(np.int32)), _dev(lcol), _dev(L.data.astype(np.complex128))
+    h = C.c_void_p()
+    hx.check(hx.lib.hx_sell_create(C.byref(h), n_own, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), 1, 2, hx.stream()))
+    assert hx.lib.hx_sell_stencil_slices(h) >= (n_own // 64) // 2
+    x, y0 = _rand_c(rng, n_ext), _rand_c(rng, n_own)
+    xd, yd = _dev(x), _dev(y0.copy())
+    hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(xd), hx.ptr(yd), hx.z2(1.0), hx.z2(0.0), hx.stream()))
+    ref = Lloc @ x
+    assert np.max(np.abs(yd.cpu().numpy() - ref)) <= 1e-13 * np.max(np.abs(ref))
+    x32, y32 = _dev(x.astype(np.complex64)), _dev(y0.astype(np.complex64))
+    hx.check(hx.lib.hx_sell_spmv_c64(h, hx.ptr(x32), hx.ptr(y32), -1.0, 1.0, hx.stream()))
+    ref32 = y0 - ref
+    assert np.max(np.abs(y32.cpu().numpy() - ref32)) <= 2e-3 * np.max(np.abs(ref32))
+    d = M.diagonal()[r0:r1]
+    xin = _dev(x.astype(np.complex64))
+    d32, o32 = _dev((1.0 / d).astype(np.complex64)), torch.zeros(n_ext, dtype=torch.complex64, device=xin.device)
+    hx.check(hx.lib.hx_sell_smooth_c64(h, hx.ptr(d32), hx.ptr(y32), hx.ptr(xin), hx.ptr(o32), 0.6, None, 0.0, hx.stream()))
+    refs = x[:n_own] + 0.6 * (1.0 / d) * (y32.cpu().numpy() - ref)
+    assert np.max(np.abs(o32.cpu().numpy()[:n_own] - refs)) <= 2e-3 * np.max(np.abs(refs))
+    hx.check(hx.lib.hx_sell_destroy(h))
+
+
 @pytest.mark.parametrize("n,scale", [(64, 1.0), (5000, 3.0e6), (5000, 2.0e-7)])
 def test_sell64_complex_half_storage(hx, n, scale):
     """want_c64 = 2: values stored as scaled complex-half, arithmetic in complex64.  The products must equal those of the

@@ -473,8 +473,8 @@ __device__ __forceinline__ V sell_row_dot_stencil(int32_t u, const MV* __restric
 // Returns false (wave-uniform) when the slice does not fit (more than SX_NB bands, a band wider than SX_Q * 64, more than
 // SX_CAP entries in all): the caller then takes the gather form.
 #define SX_NB 4
-#define SX_Q 3
-#define SX_CAP 512
+#define SX_Q 4
+#define SX_CAP 640
 #define SX_GAP 128
 template <typename V, typename MV, int G>
 __device__ __forceinline__ bool sell_row_dot_stencil_lds(int32_t u, int32_t stw, const MV* __restrict__ vb, int lane,

@@ -212,6 +212,19 @@ def cpu_baseline(sample="annulus-16k"):
                 omega=[hist[-1].real, hist[-1].imag])
 
 
+_RESULT_FD = None
+
+
+def emit(out):
+    """The result line, on the process's ORIGINAL stdout (see main)."""
+    line = (json.dumps(out) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +235,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="annulus-16k")
     args = ap.parse_args()
+
+    # Exactly ONE line on stdout: the process's file descriptor 1 is pointed at stderr for the whole run (communication
+    # libraries print banners and warnings to stdout from C++: gloo's "[Gloo] Rank 0 is connected ...", RCCL's WARN lines),
+    # and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    global _RESULT_FD
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -326,7 +347,7 @@ def main():
         if rank == 0:
             out["sharded_solve"] = sharded
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -343,7 +364,7 @@ def sharded_solve_extra(case, ref_omegas, barrier, rank, out):
     def fire():
         if rank == 0:
             out["sharded_solve"] = {"error": "timed out after %.0f s" % budget}
-            print(json.dumps(out), flush=True)
+            emit(out)
         os._exit(0)
 
     dog = threading.Timer(budget, fire)
@@ -371,7 +392,7 @@ def sharded_solve_extra(case, ref_omegas, barrier, rank, out):
         # the other ranks may be waiting in a collective this rank left: finish here instead of joining a last barrier
         if rank == 0:
             out["sharded_solve"] = {"error": repr(e)[:500]}
-            print(json.dumps(out), flush=True)
+            emit(out)
         sys.stderr.flush()
         os._exit(0)
     dog.cancel()

@@ -679,7 +679,11 @@ extern "C" int hx_profile_sell_read(int kind, int64_t* launches, double* total_m
 extern "C" int hx_profile_sell_spmv_read(int64_t* launches, double* total_ms) { return hx_profile_sell_read(0, launches, total_ms); }
 static bool prof_begin(int kind, int32_t n, hx_stream s) {
   SpmvProfile& P = g_prof[kind];
-  const bool rec = P.on && n >= P.min_rows && P.used + 2 <= P.ev.size();
+  bool rec = P.on && n >= P.min_rows && P.used + 2 <= P.ev.size();
+  if (rec) {      // launches that are being captured into a hipGraph (V-cycle replay) cannot be bracketed by events
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(hx_s(s), &st) != hipSuccess || st != hipStreamCaptureStatusNone) rec = false;
+  }
   if (P.on && !rec && n >= P.min_rows) ++P.skipped;
   if (rec && hipEventRecord(P.ev[P.used], hx_s(s)) != hipSuccess) return false;
   return rec;

@@ -474,7 +474,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
   };
   int rc, it = 0, m_last = 0;
   static const bool trace = getenv("HX_GMRES_TRACE") != nullptr;     // convergence history on stderr (diagnostics)
-  if (M) M->last_backward = -1.0;
+  if (M) { M->last_backward = -1.0; M->x0_next = false; }     // (initial guesses are a feature of hx_cocg only)
   HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
   if ((rc = dots(Pn, 0, b))) return rc;
   const double bnorm = std::sqrt(hh[0].real());

@@ -59,6 +59,7 @@ struct hx_amg {
   double normK = 0.0;
   const void* normK_val = nullptr;
   double last_backward = -1.0;
+  bool x0_next = false;        // the next hx_cocg call takes the contents of x as its initial guess (hx_amg_next_solve_uses_x)
   // hipGraph of the complex64 V-cycle (all buffers of the cycle are owned by the handle, so the ~45 launches of one cycle
   // are captured once and replayed): for small and mid-size problems, where the cycle is launch-bound
   int graph_state = -1;        // -1 off, 0 requested (capture at the next cycle), 1 ready

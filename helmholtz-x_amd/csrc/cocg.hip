@@ -326,7 +326,17 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     if (trace) fprintf(stderr, "[hx_cocg] backward error %.3e  (|K| %.3e |x| %.3e |b| %.3e)\n", M->last_backward, M->normK, xnorm, bnorm);
     return HX_OK;
   };
-  HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
+  // initial guess: zero, or -- requested for this one solve by hx_amg_next_solve_uses_x -- what the caller left in x (a
+  // related solution); a guess that does not even bring the residual below a tenth of |b| is dropped
+  const bool given_x0 = M->x0_next;
+  M->x0_next = false;
+  if (given_x0) {
+    x_zero = false;
+    if ((rc = true_residual())) return rc;
+    if (trace) fprintf(stderr, "[hx_cocg] initial guess: true relres %.3e\n", relres);
+    if (!std::isfinite(relres) || relres > 0.1) x_zero = true;
+  }
+  if (x_zero) HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
   // A cycle = one run of the recurrences.  It ends when the recurrence residual meets the tolerance, when it reaches
   // the attainable accuracy (a right-hand side close to the eigenvector next to the shift has a solution 1e4..1e5
   // times larger than b, so eps * cond bounds the residual near 1e-11 |b|: progress stops there and the deflated
@@ -437,6 +447,14 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
 extern "C" int hx_cocg_backward_error(const hx_amg* M, double* out) {
   HX_REQUIRE(M && out, "bad argument");
   *out = M->last_backward;
+  return HX_OK;
+}
+
+// The next hx_cocg / hx_cocg_sharded call on this handle starts from the contents of its x argument instead of zero
+// (one solve only; ignored by hx_gmres).
+extern "C" int hx_amg_next_solve_uses_x(hx_amg* M) {
+  HX_REQUIRE(M, "null handle");
+  M->x0_next = true;
   return HX_OK;
 }
 

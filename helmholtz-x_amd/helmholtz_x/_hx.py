@@ -95,6 +95,7 @@ SIGNATURES = {
                            C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_cocg_ws": (C.c_size_t, [_i64]),
     "hx_cocg_backward_error": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "hx_amg_next_solve_uses_x": (C.c_int, [_vp]),
     "hx_cocg": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _vp,
                           C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_cocg_sharded": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _vp, _vp, _vp,

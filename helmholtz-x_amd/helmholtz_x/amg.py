@@ -538,8 +538,12 @@ class AMGSolver:
         info("- AMG hierarchy: " + " -> ".join("%d" % lv["n"] for lv in levels)
              + "  (operator complexity %.2f)" % (sum(lv["K"].nnz for lv in levels) / levels[0]["K"].nnz))
 
-    def solve(self, b, x, relax=1.0):
-        """``relax`` >= 1 multiplies the relative tolerance (inexact-Krylov relaxation decided by the eigen-solver)."""
+    supports_x0 = True
+
+    def solve(self, b, x, relax=1.0, x0=False):
+        """``relax`` >= 1 multiplies the relative tolerance (inexact-Krylov relaxation decided by the eigen-solver).
+        ``x0``: x holds an initial guess (a related solution); used by the COCG route only, and dropped by the solver when
+        it does not bring the residual below a tenth of |b| (hx_amg_next_solve_uses_x)."""
         import time
         t0 = time.perf_counter()
         it, rr = C.c_int(0), C.c_double(0.0)
@@ -548,6 +552,9 @@ class AMGSolver:
         # GMRES, whose Hessenberg matrix yields the harmonic Ritz vectors both methods recycle
         done = False
         if self.use_cocg and (self.recycle_k == 0 or self.recycled):
+            if x0:
+                _hx.check(_hx.lib.hx_amg_next_solve_uses_x(self.handle))
+                self.warm_starts = getattr(self, "warm_starts", 0) + 1
             done = self._solve_cocg(b, x, rtol, it, rr)
         if not done:
             self._solve_gmres(b, x, rtol, it, rr)
@@ -659,7 +666,8 @@ class AMGSolver:
                     attainable_stops=self.attainable_stops,
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1),
-                    harmonic_ritz=[round(float(t), 3) for t in getattr(self, "harmonic_ritz", [])])
+                    harmonic_ritz=[round(float(t), 3) for t in getattr(self, "harmonic_ritz", [])],
+                    warm_starts=getattr(self, "warm_starts", 0))
 
     def destroy(self):
         if getattr(self, "handle", None):

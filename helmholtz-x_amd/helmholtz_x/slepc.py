@@ -33,6 +33,7 @@ DEFAULTS = {"st_type": "auto", "lu_max_dofs": 20_000}
 # iterations, but on the Bloch sector (config 5) a factor of 300 moves the adjoint eigenvalue away from the conjugate of
 # the direct one from 2e-9 to 1.3e-8 relative -- past the parity bar -- so 30 stays.
 W_RELAX = float(__import__("os").environ.get("HX_WOODBURY_RELAX", "30"))
+W_WARM = __import__("os").environ.get("HX_WOODBURY_WARM", "1") != "0"      # translated initial guesses for identical flames (0: off)
 # Columns beyond twice SLEPc's default Krylov dimension: the 4-pair solve that ends a fixed-point call converges right at
 # the 38th column; a restart there (when the last pair misses the tolerance by a hair) costs five more shift-invert
 # applications of ~45 ms each at 5 M DOF, eight spare columns cost 1.3 GB of HBM.
@@ -134,6 +135,32 @@ def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=
     raise ValueError("unknown st_type %r" % st)
 
 
+def translation_shifts(lefts, n, rtol=1e-9):
+    """[s_0 = 0, s_1, ...] such that sparse vector f equals vector 0 translated by s_f rows (cyclically, modulo n), values equal
+    to rtol of the largest entry; None unless EVERY vector is such a translate.  ``lefts``: (int32 idx ascending, values)."""
+    i0, v0 = lefts[0]
+    if len(i0) == 0:
+        return None
+    scale = float(np.max(np.abs(v0)))
+    base = i0.astype(np.int64)
+    shifts = [0]
+    for idx, val in lefts[1:]:
+        if len(idx) != len(i0):
+            return None
+        found = None
+        for j in range(len(idx)):            # the image of the first entry of vector 0 is one of this vector's entries
+            s = (int(idx[j]) - int(base[0])) % n
+            t = (base + s) % n
+            order = np.argsort(t, kind="stable")
+            if np.array_equal(t[order], idx) and np.max(np.abs(v0[order] - val)) <= rtol * scale:
+                found = s
+                break
+        if found is None:
+            return None
+        shifts.append(found)
+    return shifts
+
+
 class WoodburySolver:
     """(K - sum_j c_j U_j V_j^T)^-1 through the inner solver of K.
 
@@ -177,10 +204,23 @@ class WoodburySolver:
             self.W, self.VtW = W_cache[key]
         else:
             self.W = torch.empty_like(U)                         # rows: K^-1 u_f
+            # identical flames on a periodically numbered mesh: u_f is u_0 translated by s_f rows.  The translated solution
+            # of flame 0 is then the initial guess for flame f -- exact when K has the same periodicity (an annular
+            # combustor with identical burners), in which case the solve ends at its first residual check; a guess
+            # that is no good is dropped by the solver.  Single GPU, COCG route only.
+            shifts = None
+            if shard is None and getattr(inner, "supports_x0", False) and self.r > 1 and W_WARM:
+                shifts = translation_shifts([u for _, lr in terms for (u, _) in lr.pairs], self.n)
+            self.warm_started = 0
             for f in range(self.r):
                 # W only enters through the rank-r correction, whose weight in the eigenvalue is the flame's (a few
                 # per cent): a looser tolerance (W_RELAX) leaves the eigenvalues unchanged far below the parity bar
-                inner.solve(U[f], self.W[f], relax=W_RELAX)
+                if shifts is not None and f > 0:
+                    self.W[f].copy_(torch.roll(self.W[0], shifts[f]))
+                    inner.solve(U[f], self.W[f], relax=W_RELAX, x0=True)
+                    self.warm_started += 1
+                else:
+                    inner.solve(U[f], self.W[f], relax=W_RELAX)
             self.VtW = np.empty((self.r, self.r), dtype=np.complex128)
             for f in range(self.r):
                 self.VtW[:, f] = self._vt(self.W[f])

@@ -327,6 +327,11 @@ int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const hx_c128* Cc
  * residual.  Returns HX_ERR_BREAKDOWN on a breakdown of the bilinear form or a stall: repeat the solve with hx_gmres.
  * ws: hx_cocg_ws(n) complex numbers (the hx_gmres workspace is large enough).  SYNC. */
 size_t hx_cocg_ws(int64_t n);
+/* Warm start: the NEXT hx_cocg / hx_cocg_sharded call on this handle takes the contents of its x argument as the initial
+ * guess instead of zero (one solve; a guess whose residual exceeds |b| / 10 is dropped).  Used for sequences of related
+ * right-hand sides -- the Woodbury columns K^-1 u_f of identical flames (flame_matrices.py:170-177 loops over them). */
+int hx_amg_next_solve_uses_x(hx_amg* M);
+
 /* When the recurrence stops improving above the tolerance, hx_cocg measures the normwise backward error
  * |b - K x| / (|K|_inf |x| + |b|) and accepts the iterate below 10 eps: what a backward-stable direct solve (the
  * reference's PCLU) delivers when the shift sits next to an eigenvalue and |x| >> |b|.  The value of the last such solve

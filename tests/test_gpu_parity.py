@@ -493,6 +493,45 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
     assert solver.stats()["vcycle_graph"] == ("graph_max_rows" in overrides)      # hipGraph replay of the V-cycle
 
 
+def test_cocg_initial_guess_is_used_checked_and_dropped():
+    """hx_amg_next_solve_uses_x (the warm start of the Woodbury columns of identical flames): the exact solution as
+    initial guess ends the solve at its first residual check (0 iterations), a perturbed solution saves iterations, a
+    useless guess is dropped (same iterations and result as a solve from zero), and the switch lasts for one solve."""
+    import torch
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.amg import AMGSolver
+    from helmholtz_x.petsc import combine_csr, to_device
+    case = _annulus_case((8, 96, 10))
+    P, mesh = case["P"], case["mesh"]
+    M = AcousticMatrices(mesh, case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    s = P.target
+    K = combine_csr(M.A.shape, M.A.csr_terms + [(s * c, m) for c, m in M.B.csr_terms]
+                    + [(s ** 2 * c, m) for c, m in M.C.csr_terms])
+    solver = AMGSolver(K, cocg_min_rows=0, recycle_min_rows=0, sell_min_rows=0)
+    rng = np.random.default_rng(1)
+    n = K.shape[0]
+    bd = to_device(rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    x = torch.empty_like(bd)
+    solver.solve(bd, x)                                   # first solve: GMRES, harvested
+    solver.solve(bd, x)                                   # COCG from zero
+    its0, ref = solver.last[0], x.clone()
+    assert solver.stats()["krylov"] == "cocg" and its0 > 3
+    y = ref.clone()
+    solver.solve(bd, y, x0=True)
+    assert solver.last[0] == 0 and torch.equal(y, ref)
+    y = ref * (1 + 1e-6) + 1e-6 * torch.abs(ref).max() * to_device(rng.standard_normal(n) + 0j)
+    solver.solve(bd, y, x0=True)
+    assert 0 < solver.last[0] < its0
+    assert float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)) < 1e-9
+    y = 1e6 * to_device(rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    solver.solve(bd, y, x0=True)
+    assert solver.last[0] == its0 and float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)) < 1e-9
+    y = 1e6 * torch.ones_like(ref)
+    solver.solve(bd, y)                                   # no guess requested: y is output only
+    assert solver.last[0] == its0 and solver.stats()["warm_starts"] == 3
+    solver.destroy()
+
+
 @pytest.mark.parametrize("krylov", ["fgmres", "cocg"])
 def test_inner_solve_stops_at_attainable_accuracy(krylov):
     """Shift next to an eigenvalue: the solution is ~1e7 times larger than the right-hand side, eps |K| |x| exceeds

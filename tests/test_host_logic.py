@@ -403,3 +403,25 @@ def test_mesh_renumbering_and_locality_order():
         c = m.topology.cells.astype(np.int64)
         return int(np.abs(c[:, :, None] - c[:, None, :]).max(axis=(1, 2)).mean())
     assert bandwidth(m3) < 0.35 * bandwidth(m2)
+
+
+def test_translation_shifts_of_identical_flames():
+    """Host logic behind the warm-started Woodbury columns: sparse vectors that are cyclic translates of the first one (with
+    a support that wraps around the end of the numbering) are recognised with their shifts; one deviating value or a
+    support of another shape switches the detection off altogether."""
+    from helmholtz_x.slepc import translation_shifts
+    n = 1000
+    i0 = np.array([5, 6, 7, 990, 995], np.int32)
+    v0 = np.array([1, 2 + 1j, 3, 4, 5 - 2j], complex)
+
+    def tr(s):
+        t = (i0.astype(np.int64) + s) % n
+        o = np.argsort(t)
+        return t[o].astype(np.int32), v0[o]
+
+    assert translation_shifts([(i0, v0), tr(100), tr(20), tr(997)], n) == [0, 100, 20, 997]
+    off = tr(20)
+    assert translation_shifts([(i0, v0), tr(100), (off[0], off[1] * 1.001)], n) is None
+    assert translation_shifts([(i0, v0), (np.array([1, 2, 3, 4, 9], np.int32), v0)], n) is None
+    assert translation_shifts([(i0, v0), (i0[:4], v0[:4])], n) is None
+    assert translation_shifts([(np.zeros(0, np.int32), np.zeros(0, complex)), tr(3)], n) is None

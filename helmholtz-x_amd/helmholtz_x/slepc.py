@@ -137,27 +137,28 @@ def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=
 
 def translation_shifts(lefts, n, rtol=1e-9):
     """[s_0 = 0, s_1, ...] such that sparse vector f equals vector 0 translated by s_f rows (cyclically, modulo n), values equal
-    to rtol of the largest entry; None unless EVERY vector is such a translate.  ``lefts``: (int32 idx ascending, values)."""
+    to rtol of the largest entry; None unless EVERY vector is such a translate.  ``lefts``: (int32 idx ascending, values).
+    O(support): both supports are rotated to start behind their largest cyclic gap, which a translation preserves."""
+    def canonical(idx, val):
+        idx = idx.astype(np.int64)
+        gaps = np.diff(np.concatenate([idx, idx[:1] + n]))
+        k = (int(np.argmax(gaps)) + 1) % len(idx)
+        return np.roll(idx, -k), np.roll(val, -k)
+
     i0, v0 = lefts[0]
     if len(i0) == 0:
         return None
+    c0, w0 = canonical(i0, v0)
     scale = float(np.max(np.abs(v0)))
-    base = i0.astype(np.int64)
     shifts = [0]
     for idx, val in lefts[1:]:
         if len(idx) != len(i0):
             return None
-        found = None
-        for j in range(len(idx)):            # the image of the first entry of vector 0 is one of this vector's entries
-            s = (int(idx[j]) - int(base[0])) % n
-            t = (base + s) % n
-            order = np.argsort(t, kind="stable")
-            if np.array_equal(t[order], idx) and np.max(np.abs(v0[order] - val)) <= rtol * scale:
-                found = s
-                break
-        if found is None:
+        cf, wf = canonical(idx, val)
+        s = int((cf[0] - c0[0]) % n)
+        if not np.array_equal((c0 + s) % n, cf) or np.max(np.abs(w0 - wf)) > rtol * scale:
             return None
-        shifts.append(found)
+        shifts.append(s)
     return shifts
 
 

@@ -199,6 +199,8 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
                      hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s) {
   HX_REQUIRE(M && n > 0 && rowptr && col && val && b && x && ws && max_it >= 1, "bad argument");
   HX_REQUIRE(M->pre == M->post, "hx_cocg needs a symmetric V-cycle (pre == post smoothing steps)");
+  const bool given_x0 = M->x0_next;       // one-shot switch (hx_amg_next_solve_uses_x): consumed by this call whatever its outcome
+  M->x0_next = false;
   const bool sharded = xe != nullptr;
   HX_REQUIRE(!sharded || (M->sharded && hbuf), "row-sharded COCG needs a sharded preconditioner handle");
   HX_REQUIRE(sharded || !M->sharded, "use hx_cocg_sharded with a row-sharded preconditioner");
@@ -328,8 +330,6 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   };
   // initial guess: zero, or -- requested for this one solve by hx_amg_next_solve_uses_x -- what the caller left in x (a
   // related solution); a guess that does not even bring the residual below a tenth of |b| is dropped
-  const bool given_x0 = M->x0_next;
-  M->x0_next = false;
   if (given_x0) {
     x_zero = false;
     if ((rc = true_residual())) return rc;

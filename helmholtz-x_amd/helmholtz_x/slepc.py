@@ -33,6 +33,7 @@ DEFAULTS = {"st_type": "auto", "lu_max_dofs": 20_000}
 # iterations, but on the Bloch sector (config 5) a factor of 300 moves the adjoint eigenvalue away from the conjugate of
 # the direct one from 2e-9 to 1.3e-8 relative -- past the parity bar -- so 30 stays.
 W_RELAX = float(__import__("os").environ.get("HX_WOODBURY_RELAX", "30"))
+PEP_COMPACT = __import__("os").environ.get("HX_PEP_COMPACT", "0") != "0"     # compact (TOAR) basis for quadratic problems
 W_WARM = __import__("os").environ.get("HX_WOODBURY_WARM", "1") != "0"      # translated initial guesses for identical flames (0: off)
 # Columns beyond twice SLEPc's default Krylov dimension: the 4-pair solve that ends a fixed-point call converges right at
 # the 38th column; a restart there (when the last pair misses the tolerance by a hair) costs five more shift-invert
@@ -352,6 +353,183 @@ class DeviceBasis:
         if mact < self.m:
             self.V2[k].copy_(self.V[mact])
         self.V, self.V2 = self.V2, self.V
+
+
+class CompactBasis:
+    """Krylov basis of the first companion form in the compact (TOAR) representation: v_j = [U g1_j; U g2_j] with ONE set of
+    orthonormal n-vectors U (rows of a (r, n) device panel) and small coefficient columns g_j = [g1_j; g2_j] on the host.
+
+    The shift-invert operator of the quadratic problem maps z = [x1; x2] to [y1; x1 + sigma y1], so every application
+    adds at most ONE direction to span(U) (y1 orthogonalised against U); the second block never needs an n-vector
+    operation: its coefficients follow from those of x1 and y1.  Orthogonality of the 2n-vectors is orthogonality of the
+    coefficient columns (U is orthonormal), which is host arithmetic on vectors of length 2 r.  Per expansion the device
+    does CGS2 on n-vectors (4 passes over U) plus one pass to form [x1; x2], instead of CGS2 on 2n-vectors (SLEPc's TOAR,
+    the reference's PEP solver -- eigensolvers.py:96-113 -- works the same way).  Same interface as DeviceBasis."""
+
+    def __init__(self, n, m, apply_op, sigma, seed=0, start=None, pool=None):
+        dev = _hx.require_gpu()
+        self.n, self.m, self.R = n, m, m + 3
+        self.shard, self.blocks = None, 2
+        self.sigma = complex(sigma)
+        self.start = start
+        self.apply_op, self.seed = apply_op, seed
+        got = None if pool is None else pool.get("compact")          # panels shared by the solves of one fixed-point call
+        if got is not None and got[0].shape[1] == n and got[0].shape[0] >= self.R and got[0].device == dev:
+            self.U, self.U2 = got[0][:self.R], got[1][:self.R]
+        else:
+            rows = self.R
+            if pool is not None:
+                pool.pop("compact", None)
+                rows = max(rows, min(int(pool.get("rows_hint", 0)) + 3, n))
+            Ua = torch.empty((rows, n), dtype=torch.complex128, device=dev)
+            Ub = torch.empty((rows, n), dtype=torch.complex128, device=dev)
+            if pool is not None:
+                pool["compact"] = (Ua, Ub)
+            self.U, self.U2 = Ua[:self.R], Ub[:self.R]
+        self.G1 = np.zeros((self.R, m + 1), dtype=np.complex128)
+        self.G2 = np.zeros((self.R, m + 1), dtype=np.complex128)
+        self.r = 0
+        self.z = torch.empty(2 * n, dtype=torch.complex128, device=dev)
+        self.y = torch.empty(2 * n, dtype=torch.complex128, device=dev)
+        self.h_dev = torch.empty(self.R + 1, dtype=torch.complex128, device=dev)
+        self.ws = torch.empty(_hx.lib.hx_panel_dot_ws(self.R), dtype=torch.complex128, device=dev)
+        self.n_ops = 0
+        self.relax = 1.0
+        self._nvalid, self._V = 0, None
+
+    set_inner_accuracy = DeviceBasis.set_inner_accuracy
+
+    # ---- device helpers on the n-vectors
+    def _dots(self, k, w):
+        _hx.check(_hx.lib.hx_zpanel_dot(self.n, k, _hx.ptr(self.U), self.U.stride(0), _hx.ptr(w), _hx.ptr(self.h_dev),
+                                        _hx.ptr(self.ws), _hx.stream()))
+
+    def _sub(self, k, w):
+        _hx.check(_hx.lib.hx_zpanel_sub(self.n, k, _hx.ptr(self.U), self.U.stride(0), _hx.ptr(self.h_dev), _hx.ptr(w),
+                                        _hx.stream()))
+
+    def _orth(self, w):
+        """CGS2 of the n-vector w against U[:r]: returns (coefficients s, norm of the remainder); w is overwritten."""
+        r = self.r
+        self._dots(r, w)
+        self._sub(r, w)
+        s1 = self.h_dev[:r].cpu().numpy().copy()
+        self._dots(r, w)
+        self._sub(r, w)
+        out = self.h_dev[:r + 1].cpu().numpy()
+        s2, ww = out[:r], out[r].real
+        a2 = ww - float(np.sum(np.abs(s2) ** 2))
+        if a2 <= 1e-8 * ww:                          # cancellation: measure the norm directly
+            self._dots(0, w)
+            a2 = self.h_dev[:1].cpu().numpy()[0].real
+        return s1 + s2, float(np.sqrt(max(a2, 0.0)))
+
+    def _combine(self, coef, out_rows):
+        """out_rows[c] = sum_m coef[m, c] U[m]  (coef: (r, k) host array)"""
+        r, k = coef.shape
+        Qd = to_device(np.ascontiguousarray(np.asarray(coef, dtype=np.complex128).T))
+        _hx.check(_hx.lib.hx_zpanel_mul(self.n, r, k, _hx.ptr(self.U), self.U.stride(0), _hx.ptr(Qd), _hx.ptr(out_rows),
+                                        out_rows.stride(0), _hx.stream()))
+
+    # ---- the DeviceBasis interface
+    def set_start(self, j):
+        assert j == 0
+        self.relax = 1.0
+        n = self.n
+        if self.start is not None and self.start.numel() == 2 * n:
+            v = self.start
+        else:
+            gen = torch.Generator(device=self.U.device)
+            gen.manual_seed(1234567 + self.seed)
+            v = torch.view_as_complex(torch.randn((2 * n, 2), generator=gen, device=self.U.device, dtype=torch.float64))
+        z1, z2 = v[:n], v[n:]
+        self.G1[:], self.G2[:] = 0.0, 0.0
+        a = float(torch.linalg.vector_norm(z1))
+        tot = float(torch.linalg.vector_norm(v))
+        r = 0
+        if a > 1e-14 * tot:
+            self.U[0].copy_(z1)
+            self.U[0].mul_(1.0 / a)
+            self.G1[0, 0] = a
+            r = 1
+        self.r = r
+        w = self.y[:n]
+        w.copy_(z2)
+        s, b = (np.zeros(0, complex), float(torch.linalg.vector_norm(w))) if r == 0 else self._orth(w)
+        self.G2[:r, 0] = s
+        if b > 1e-14 * tot:
+            self.U[r].copy_(w)
+            self.U[r].mul_(1.0 / b)
+            self.G2[r, 0] = b
+            r += 1
+        self.r = r
+        nrm = np.sqrt(np.sum(np.abs(self.G1[:, 0]) ** 2) + np.sum(np.abs(self.G2[:, 0]) ** 2))
+        self.G1[:, 0] /= nrm
+        self.G2[:, 0] /= nrm
+        self._nvalid, self._V = 1, None
+
+    def expand(self, j):
+        n, r = self.n, self.r
+        self._V = None
+        self._combine(np.stack([self.G1[:r, j], self.G2[:r, j]], axis=1), self.z.view(2, n))
+        self.apply_op(self.z, self.y)
+        self.n_ops += 1
+        w = self.y[:n]
+        s, alpha = self._orth(w)
+        g1 = np.zeros(self.R, dtype=np.complex128)
+        g1[:r] = s
+        scale = np.sqrt(float(np.sum(np.abs(s) ** 2)) + alpha * alpha)
+        if alpha > 1e-14 * max(scale, 1e-300) and r < self.R:
+            self.U[r].copy_(w)
+            self.U[r].mul_(1.0 / alpha)
+            g1[r] = alpha
+            self.r = r + 1
+        g2 = self.G1[:, j] + self.sigma * g1            # second block of OP v_j: x1 + sigma y1
+        G = np.vstack([self.G1[:, :j + 1], self.G2[:, :j + 1]])
+        g = np.concatenate([g1, g2])
+        h = G.conj().T @ g
+        g = g - G @ h
+        h2 = G.conj().T @ g
+        g = g - G @ h2
+        beta = float(np.linalg.norm(g))
+        if beta == 0.0:
+            raise ArithmeticError("Arnoldi breakdown (invariant subspace found)")
+        self.G1[:, j + 1] = g[:self.R] / beta
+        self.G2[:, j + 1] = g[self.R:] / beta
+        return h + h2, beta
+
+    def rotate(self, Q, k):
+        Q = np.asarray(Q, dtype=np.complex128)
+        mact = Q.shape[0]
+        cols = k + (1 if mact < self.m else 0)
+        N1, N2 = np.zeros_like(self.G1), np.zeros_like(self.G2)
+        N1[:, :k], N2[:, :k] = self.G1[:, :mact] @ Q, self.G2[:, :mact] @ Q
+        if mact < self.m:                              # the continuation vector moves behind the kept ones
+            N1[:, k], N2[:, k] = self.G1[:, mact], self.G2[:, mact]
+        # compress U to the span the kept vectors need: [N1 N2] = Qu (Qu^H [N1 N2]), rank <= cols + 1 in exact arithmetic
+        r = self.r
+        Mx = np.hstack([N1[:r, :cols], N2[:r, :cols]])
+        Uq, sv, _ = np.linalg.svd(Mx, full_matrices=False)
+        rr = max(int(np.sum(sv > 1e-13 * sv[0])), 1)
+        Qu = Uq[:, :rr]
+        self._combine(Qu, self.U2)
+        self.U, self.U2 = self.U2, self.U
+        self.G1[:], self.G2[:] = 0.0, 0.0
+        self.G1[:rr, :cols] = Qu.conj().T @ N1[:r, :cols]
+        self.G2[:rr, :cols] = Qu.conj().T @ N2[:r, :cols]
+        self.r = rr
+        self._nvalid, self._V = cols, None
+
+    @property
+    def V(self):
+        """The first columns as explicit 2n-vectors (rows of a device tensor): the Ritz vectors after the final rotation."""
+        if self._V is None:
+            k, n, r = self._nvalid, self.n, self.r
+            V = torch.empty((k, 2 * n), dtype=torch.complex128, device=self.U.device)
+            self._combine(self.G1[:r, :k], V[:, :n])
+            self._combine(self.G2[:r, :k], V[:, n:])
+            self._V = V
+        return self._V
 
 
 # ----------------------------------------------------------------------------- EPS / PEP
@@ -719,7 +897,10 @@ class PEP(_EigenSolverBase):
             cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
             _hx.check(_hx.lib.hx_zlincomb(n, 2, cf, arr, _hx.ptr(y2), _hx.stream()))   # y2 = x1 + sigma y1
 
-        basis = DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op, start=self._start(), pool=self._pool())
+        if PEP_COMPACT:
+            basis = CompactBasis(n, self._ncv_for(2 * n) + 1, op, sigma, start=self._start(), pool=self._pool())
+        else:
+            basis = DeviceBasis(2 * n, self._ncv_for(2 * n) + 1, op, start=self._start(), pool=self._pool())
         self._finish(basis, sigma)
         self._n = n
 

@@ -409,6 +409,38 @@ def test_prf_gmsh_pep_fixed_point_direct_and_adjoint(ref_logs, golden_dir, dim):
     assert _eigvec_error(golden_dir, "prf%dd_adj" % dim, mesh, p_adjoint) < 1e-7   # Results/Active/p_adj.h5
 
 
+def test_compact_toar_basis_gives_the_same_quadratic_eigenpairs(monkeypatch):
+    """The optional compact basis of the companion form (slepc.CompactBasis: one orthonormal set of n-vectors + small
+    coefficient columns, as SLEPc's TOAR keeps it) against the explicit 2n-vector basis on the PRF Rijke tube (Robin ends:
+    a quadratic problem): same eigenvalues, same eigenvectors, same number of operator applications."""
+    from helmholtz_x import slepc
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.dolfinx_utils import OneDimensionalSetup
+    from helmholtz_x.eigensolvers import pep_solver
+    from helmholtz_x.parameters_utils import c_step
+    mesh, subdomains, facet_tags = OneDimensionalSetup(400)
+    c = c_step(mesh, PRF.x_f, PRF.c_u, PRF.c_d)
+    M = AcousticMatrices(mesh, facet_tags, {1: {'Robin': PRF.R_in}, 2: {'Robin': PRF.R_out}}, c)
+    out = {}
+    for compact in (False, True):
+        monkeypatch.setattr(slepc, "PEP_COMPACT", compact)
+        E = pep_solver(M.A, M.B, M.C, np.pi, nev=3)
+        vr, _ = M.A.createVecs()
+        eigs, vecs = [], []
+        for i in range(3):
+            eigs.append(E.getEigenvalue(i))
+            E.getEigenvector(i, vr)
+            v = vr.array.copy()
+            vecs.append(v / v[np.argmax(np.abs(v))])
+        out[compact] = (np.array(eigs), vecs, E._basis.n_ops, type(E._basis).__name__)
+        E.destroy()
+    assert out[True][3] == "CompactBasis" and out[False][3] == "DeviceBasis"
+    assert np.max(np.abs(out[True][0] - out[False][0])) < 1e-10 * np.max(np.abs(out[False][0]))     # (one eigenvalue is 0)
+    assert out[True][2] == out[False][2]
+    for a, b in zip(out[True][1], out[False][1]):
+        assert np.max(np.abs(a - b)) < 1e-7
+
+
 def test_manufactured_2d_pep_against_dispersion_relation(ref_logs):
     from helmholtz_x.acoustic_matrices import AcousticMatrices
     from helmholtz_x.dolfinx_utils import RectangleSetup

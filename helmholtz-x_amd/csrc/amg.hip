@@ -186,6 +186,7 @@ extern "C" int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const
                                 const int32_t* rpP, const int32_t* ciP, const hx_c128* vaP, int64_t nnzR,
                                 const int32_t* rpR, const int32_t* ciR, const hx_c128* vaR) {
   HX_REQUIRE(h, "null handle");
+  h->normK_val = nullptr;      // new operator values: the cached |K|_inf of the backward-error test is stale
   return set_level<double>(h->real_transfers, h->D, l, n, nnzK, rpK, ciK, (const double*)vaK, (const double*)dinv, n_coarse, nnzP, rpP, ciP,
                            (const double*)vaP, nnzR, rpR, ciR, (const double*)vaR);
 }
@@ -195,6 +196,7 @@ extern "C" int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, con
                                   const int32_t* rpR, const int32_t* ciR, const hx_c64* vaR) {
   HX_REQUIRE(h, "null handle");
   h->single = true;
+  h->normK_val = nullptr;
   drop_graph(h);
   return set_level<float>(h->real_transfers, h->S, l, n, nnzK, rpK, ciK, (const float*)vaK, (const float*)dinv, n_coarse, nnzP, rpP, ciP,
                           (const float*)vaP, nnzR, rpR, ciR, (const float*)vaR);
@@ -652,6 +654,7 @@ extern "C" int hx_gmres_hessenberg(const hx_amg* h, int* m, hx_c128* H) {
 // last hx_gmres call left in `ws` / the handle.  Must directly follow that call (same ws).
 extern "C" int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const hx_c128* Ccoef, hx_c128* ws, hx_stream s) {
   HX_REQUIRE(h && Ucoef && Ccoef && ws, "bad argument");
+  h->normK_val = nullptr;      // (pairs are harvested once per operator: re-measure |K|_inf with them)
   Recycle& R = h->rec;
   const int m = R.m_last;
   HX_REQUIRE(R.kmax > 0 && k >= 1 && k <= R.kmax && m >= k, "nothing to harvest from");

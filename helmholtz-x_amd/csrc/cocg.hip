@@ -197,10 +197,12 @@ static bool invert_small(std::vector<cd>& A, int k) {
 static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
                      const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it, hx_c128* ws,
                      hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s) {
+  // one-shot switch (hx_amg_next_solve_uses_x): consumed by this call whatever its outcome -- read and cleared BEFORE any
+  // argument check can return, so that a rejected call never leaves it armed for an unrelated later solve
+  const bool given_x0 = M && M->x0_next;
+  if (M) M->x0_next = false;
   HX_REQUIRE(M && n > 0 && rowptr && col && val && b && x && ws && max_it >= 1, "bad argument");
   HX_REQUIRE(M->pre == M->post, "hx_cocg needs a symmetric V-cycle (pre == post smoothing steps)");
-  const bool given_x0 = M->x0_next;       // one-shot switch (hx_amg_next_solve_uses_x): consumed by this call whatever its outcome
-  M->x0_next = false;
   const bool sharded = xe != nullptr;
   HX_REQUIRE(!sharded || (M->sharded && hbuf), "row-sharded COCG needs a sharded preconditioner handle");
   HX_REQUIRE(sharded || !M->sharded, "use hx_cocg_sharded with a row-sharded preconditioner");
@@ -330,11 +332,13 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   };
   // initial guess: zero, or -- requested for this one solve by hx_amg_next_solve_uses_x -- what the caller left in x (a
   // related solution); a guess that does not even bring the residual below a tenth of |b| is dropped
+  bool have_r = false;                       // r already holds b - K x of the accepted guess: cycle 0 does not measure it again
   if (given_x0) {
     x_zero = false;
     if ((rc = true_residual())) return rc;
     if (trace) fprintf(stderr, "[hx_cocg] initial guess: true relres %.3e\n", relres);
     if (!std::isfinite(relres) || relres > 0.1) x_zero = true;
+    else have_r = true;
   }
   if (x_zero) HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
   // A cycle = one run of the recurrences.  It ends when the recurrence residual meets the tolerance, when it reaches
@@ -345,7 +349,7 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   // attainable accuracy: what a backward-stable direct solve would deliver); otherwise it re-projects on span(U) and
   // restarts from x.
   for (int cycle = 0; cycle < 4 && it < max_it; ++cycle) {
-    if ((rc = true_residual())) return rc;
+    if (!(cycle == 0 && have_r) && (rc = true_residual())) return rc;
     if (trace) fprintf(stderr, "[hx_cocg] cycle %d start  true relres %.3e\n", cycle, relres);
     if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "non-finite residual");
     if (relres <= (cycle == 0 ? rtol : 10 * rtol)) { converged = true; break; }

@@ -263,12 +263,26 @@ class Function:
 
     def interpolate(self, fn):
         pts = self.function_space.tabulate_dof_coordinates()
+        was_resident = getattr(self, "_dev", None) is not None
+        self.release()
         self.x.array[:] = fn(pts.T)
+        if was_resident:
+            self.resident()
 
     def resident(self):
         """Keep a copy of the values in HBM for the assembly kernels (an input field that stays the same over several
-        assemblies is then uploaded once).  Call it again after changing ``x.array``.  Returns self."""
+        assemblies is then uploaded once).  The host array is FROZEN while the device copy exists (numpy raises on
+        ``f.x.array[:] = ...``), so the copy can never go stale silently: call ``release()`` before changing the values
+        (``interpolate`` does both by itself).  Returns self."""
+        self.x.array.flags.writeable = True
         self._dev = to_device(self.x.array.astype(np.complex128))
+        self.x.array.flags.writeable = False
+        return self
+
+    def release(self):
+        """Drop the device copy made by ``resident()`` and make the host array writable again.  Returns self."""
+        self._dev = None
+        self.x.array.flags.writeable = True
         return self
 
 

@@ -144,10 +144,8 @@ class PointwiseFlameMatrix(FlameMatrix):
     def _assemble_vectors(self, flame, point):
         asm = self.mesh.assembler()
         # left: (gamma-1) q0/u_b int_{Omega_flame} h phi_j dx with h DG0  -> kind 0 load with a masked cell weight
-        if getattr(self, "_h_dev", None) is None:
-            from .petsc import to_device
-            self._h_dev = to_device(self.h.x.array.astype(np.complex128))
-        left = self.indices_and_values(asm.load(0, self._h_dev, scale=(self.gamma - 1) * self.q_0 / self.u_b,
+        h_dev = asm._field(self.h)[0]         # the resident copy (frozen with the host array) or a fresh upload
+        left = self.indices_and_values(asm.load(0, h_dev, scale=(self.gamma - 1) * self.q_0 / self.u_b,
                                                 cell_tag=asm.cell_tag_array(self.subdomains), tag=flame))
         # right: grad(phi_k).n_r / rho_u at x_r: 4 (d+1) numbers on the cell that holds the point
         if getattr(self, "_x_r_cells", None) is None:                 # all reference points in ONE device pass
@@ -162,19 +160,15 @@ class PointwiseFlameMatrix(FlameMatrix):
         so the entries are computed for exactly those vertices (hx_assemble_p1_load_rows, each with its flame's tag)
         instead of one sweep over the whole mesh per flame (the reference's loop, flame_matrices.py:170-177; 16 sweeps
         of 1.8 ms at 5 M DOF).  Same arithmetic per entry as the sweep: identical values."""
-        from .petsc import to_device
         asm = self.mesh.assembler()
-        if getattr(self, "_h_dev", None) is None:
-            dev_h = getattr(self.h, "_dev", None)                    # Function.resident(): already in HBM
-            self._h_dev = dev_h if dev_h is not None and dev_h.numel() == self.h.x.array.size \
-                else to_device(self.h.x.array.astype(np.complex128))
+        h_dev = asm._field(self.h)[0]         # Function.resident(): already in HBM (and frozen); else uploaded now
         nf = len(self.x_r)
         t_idx, t_val = np.asarray(self.subdomains.indices), np.asarray(self.subdomains.values)
         cells = self.mesh.topology.cells
         supports = [np.unique(cells[t_idx[t_val == f]]).astype(np.int32) for f in range(nf)]
         rows = np.concatenate(supports) if nf else np.zeros(0, np.int32)
         row_tag = np.repeat(np.arange(nf, dtype=np.int32), [len(sp_) for sp_ in supports])
-        vals = asm.load_rows(0, rows, self._h_dev, scale=(self.gamma - 1) * self.q_0 / self.u_b,
+        vals = asm.load_rows(0, rows, h_dev, scale=(self.gamma - 1) * self.q_0 / self.u_b,
                              cell_tag=asm.cell_tag_array(self.subdomains), row_tag=row_tag).cpu().numpy()
         out, o = [], 0
         for f in range(nf):

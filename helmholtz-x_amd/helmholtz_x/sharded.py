@@ -63,6 +63,15 @@ class ShardContext:
     def halo(self, x_ext):
         self.plan.exchange(x_ext, self.n_own)
 
+    def reset_counters(self):
+        self.n_allreduce = 0
+        if self.plan is not None:
+            self.plan.n_exchanges = 0
+
+    def counters(self):
+        return {"halo_exchanges": getattr(self.plan, "n_exchanges", 0) if self.plan is not None else 0,
+                "all_reduces": self.n_allreduce}
+
     # ---- operators
     def set_pattern(self, K):
         """Fix the ghost set from the widest fine pattern (K = A + sigma B + sigma^2 C contains all the others)."""
@@ -124,3 +133,35 @@ class ShardedCallbacks:
 
         self.halo = _hx.HALO_FN(halo)
         self.allreduce = _hx.ALLREDUCE_FN(allreduce)
+
+
+def bench_hot_path(case, st_type=None, nev=4, tol=1e-3, history=None):
+    """bench.hot_path(..., sharded=True): one pass of the hot path on the ONE problem partitioned over the ranks of the
+    default process group.  Leaves the ShardContext in case["shard"], this rank's rows of the shifted operator in
+    case["K_local"] and the set-up mode in case["setup_mode"]."""
+    import numpy as np
+    from .acoustic_matrices import AcousticMatrices
+    from .eigensolvers import fixed_point_iteration
+    from .flame_matrices import PointwiseFlameMatrix
+    from .parameters_utils import Q_multiple
+    from .petsc import combine_csr
+    P, mesh = case["P"], case["mesh"]
+    mesh.assembler().rebuild_maps()
+    matrices = AcousticMatrices(mesh, case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    h = case.get("h")
+    if h is None:
+        h = case["h"] = Q_multiple(mesh, case["subdomains"], P.N_sector).resident()
+    D = PointwiseFlameMatrix(mesh, case["subdomains"], P.x_r(), h, P.rho_amb, P.q_0, P.u_b, case["ftf"])
+    D.assemble_submatrices('direct')
+    x = mesh.geometry.x
+    th = np.arctan2(x[:, 1], x[:, 0])
+    plane = int(np.argmax(np.abs(th - th[0]) > 1e-12)) if case.get("numbering", "native") == "native" else 1
+    shard = case["shard"] = ShardContext(matrices.A.shape[0], align=max(plane, 1))
+    E = fixed_point_iteration(matrices, D, P.target, i=0, nev=nev, tol=tol, st_type=st_type or "amg", history=history,
+                              shard=shard)
+    A, B, Cm = matrices.A, matrices.B, matrices.C
+    K = combine_csr(A.shape, A.csr_terms + [(P.target * c, m) for c, m in B.csr_terms]
+                    + [(P.target ** 2 * c, m) for c, m in Cm.csr_terms])
+    case["K_local"] = shard.localize(K)
+    case["setup_mode"] = "replicated (every rank assembles the global operators and builds the whole hierarchy)"
+    return E, matrices

@@ -479,7 +479,10 @@ class CompactBasis:
         g1 = np.zeros(self.R, dtype=np.complex128)
         g1[:r] = s
         scale = np.sqrt(float(np.sum(np.abs(s) ** 2)) + alpha * alpha)
-        if alpha > 1e-14 * max(scale, 1e-300) and r < self.R:
+        if alpha > 1e-14 * max(scale, 1e-300):
+            if r >= self.R:           # (rank bound r <= columns + 1 broken by rounding noise in rotate(): never drop a direction)
+                raise ArithmeticError("compact basis: the U panel is full (%d rows) but the new direction is not "
+                                      "negligible (%.2e of %.2e)" % (self.R, alpha, scale))
             self.U[r].copy_(w)
             self.U[r].mul_(1.0 / alpha)
             g1[r] = alpha
@@ -510,7 +513,7 @@ class CompactBasis:
         r = self.r
         Mx = np.hstack([N1[:r, :cols], N2[:r, :cols]])
         Uq, sv, _ = np.linalg.svd(Mx, full_matrices=False)
-        rr = max(int(np.sum(sv > 1e-13 * sv[0])), 1)
+        rr = min(max(int(np.sum(sv > 1e-13 * sv[0])), 1), cols + 1)      # exact-arithmetic rank bound of the kept span
         Qu = Uq[:, :rr]
         self._combine(Qu, self.U2)
         self.U, self.U2 = self.U2, self.U

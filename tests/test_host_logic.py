@@ -425,3 +425,66 @@ def test_translation_shifts_of_identical_flames():
     assert translation_shifts([(i0, v0), (np.array([1, 2, 3, 4, 9], np.int32), v0)], n) is None
     assert translation_shifts([(i0, v0), (i0[:4], v0[:4])], n) is None
     assert translation_shifts([(np.zeros(0, np.int32), np.zeros(0, complex)), tr(3)], n) is None
+
+
+def _run_bench(args, env_extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=600)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver runs N = 1) must start the two ranks
+    itself, forward rank 0's one JSON line and exit 0 (reference: fullAnnulus/runAll.sh:9-10 runs
+    `mpirun -np 8`).  The launch-check hook replaces the GPU work by one gloo all-reduce that counts the ranks."""
+    import json
+    p = _run_bench(["--gpus", "2", "--steps", "1"], {"HX_BENCH_LAUNCH_CHECK": "1"})
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1                               # exactly one line on stdout
+    rec = json.loads(lines[0])
+    assert rec["launch_check"] is True and rec["n_gpus"] == 2 and rec["gpus_arg"] == 2
+
+
+def test_bench_failed_rank_gives_nonzero_exit_status():
+    """A rank that fails (here: the last one returns 7 after the all-reduce; and, without the hook, every rank failing for
+    want of a GPU) must surface in the exit status of `python bench.py --gpus N`."""
+    p = _run_bench(["--gpus", "2"], {"HX_BENCH_LAUNCH_CHECK": "fail"})
+    assert p.returncode != 0
+    import torch
+    if not torch.cuda.is_available():
+        q = _run_bench(["--gpus", "2"], {})
+        assert q.returncode != 0 and not q.stdout.decode().strip()
+        assert "needs an MI355X" in q.stderr.decode()
+
+
+def test_resident_field_is_frozen_until_released():
+    """Function.resident() keeps a device copy for the assembly kernels; the host array is read-only while that copy
+    exists, so a later `f.x.array[:] = ...` cannot leave it stale silently."""
+    import torch
+    from helmholtz_x.fem import Function, FunctionSpace
+    from oracle import meshes
+    from helmholtz_x.fem import Mesh
+    m = meshes.rectangle(3, 2, 1.0, 1.0)
+    f = Function(FunctionSpace(Mesh(m.x, m.cells), "DG", 0))
+    f.x.array[:] = 2.0
+    if not torch.cuda.is_available():
+        f.x.array.flags.writeable = False           # what resident() does after its upload
+        with pytest.raises(ValueError):
+            f.x.array[:] = 3.0
+        f.release()
+        f.x.array[:] = 3.0
+        assert f.x.array[0] == 3.0
+        return
+    f.resident()
+    with pytest.raises(ValueError):
+        f.x.array[:] = 3.0
+    f.interpolate(lambda x: 0 * x[0] + 5.0)          # releases, writes, uploads again
+    assert f.x.array[0] == 5.0 and complex(f._dev[0].item()) == 5.0
+    with pytest.raises(ValueError):
+        f.x.array[:] = 1.0

@@ -58,19 +58,10 @@ static void drop_graph(hx_amg* h) {
   if (h->vexec) { (void)hipGraphExecDestroy(h->vexec); h->vexec = nullptr; }
   if (h->graph_state == 1) h->graph_state = 0;          // re-capture with the new set-up
 }
-static int buf_id(const hx_amg* h, const void* p) {
-  const void* ids[3] = {h->single ? (const void*)h->S.L[0].x : (const void*)h->D.L[0].x,
-                        h->single ? (const void*)h->S.L[0].x2 : (const void*)h->D.L[0].x2,
-                        h->single ? (const void*)h->S.L[0].x3 : (const void*)h->D.L[0].x3};
-  for (int i = 0; i < 3; ++i) if (ids[i] == p) return HX_BUF_VCYCLE_X0 + i;
-  return -1;
-}
-// ghost block of a level-0 iterate must be current before K is applied to it
-static int halo_before_k(hx_amg* h, int l, const void* v) {
-  if (!h->sharded || l != 0) return HX_OK;
-  const int id = buf_id(h, v);
-  if (id < 0) return hx_fail(HX_ERR_ARG, __func__, "K applied to an unregistered buffer in sharded mode");
-  return h->halo(h->ctx, id) == 0 ? HX_OK : hx_fail(HX_ERR_COMM, __func__, "halo exchange callback failed");
+// ghost block of a sharded level's iterate must be current before K (or a transfer operator) is applied to it
+static int halo_level(hx_amg* h, int l, void* v, int elem_bytes, hx_stream s) {
+  if (!h->sharded || l >= h->n_sharded) return HX_OK;
+  return h->halo(h->ctx, l, v, elem_bytes, s) == 0 ? HX_OK : hx_fail(HX_ERR_COMM, __func__, "halo exchange callback failed");
 }
 
 // ---- per-precision kernel dispatch
@@ -140,9 +131,7 @@ extern "C" int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, doub
 extern "C" int hx_amg_destroy(hx_amg* h) {
   if (!h) return HX_OK;
   auto release = [](auto& l) {
-    if (!l.ext_x) { (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.x3); }
-    if (!l.ext_b) (void)hipFree(l.b);
-    (void)hipFree(l.r);
+    (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.x3); (void)hipFree(l.b); (void)hipFree(l.r);
   };
   for (auto& l : h->D.L) release(l);
   for (auto& l : h->S.L) release(l);
@@ -223,25 +212,32 @@ extern "C" int hx_amg_set_smoother(hx_amg* h, int l, double rho) {
   return HX_OK;
 }
 
+// work vectors of a sharded level carry a ghost block behind the owned entries
 template <typename T>
-static int adopt_buffers(HierT<T>& H, void* x, void* x2, void* x3, void* coarse_b) {
-  LevelT<T>& L0 = H.L[0];
-  LevelT<T>& L1 = H.L[1];
-  if (!L0.ext_x) { (void)hipFree(L0.x); (void)hipFree(L0.x2); (void)hipFree(L0.x3); }
-  if (!L1.ext_b) (void)hipFree(L1.b);
-  L0.x = (T*)x; L0.x2 = (T*)x2; L0.x3 = (T*)x3; L0.ext_x = true;
-  L1.b = (T*)coarse_b; L1.ext_b = true;
+static int resize_ext(HierT<T>& H, int n_sharded, const int32_t* n_ext) {
+  for (int l = 0; l < n_sharded; ++l) {
+    LevelT<T>& L = H.L[l];
+    HX_REQUIRE(L.n > 0 && n_ext[l] >= L.n, "n_ext must cover the owned rows of the level");
+    (void)hipFree(L.x); (void)hipFree(L.x2); (void)hipFree(L.x3); (void)hipFree(L.r);
+    L.x = L.x2 = L.x3 = L.r = nullptr;
+    const size_t bytes = 2 * sizeof(T) * (size_t)n_ext[l];
+    HX_HIP(hipMalloc((void**)&L.x, bytes));
+    HX_HIP(hipMalloc((void**)&L.x2, bytes));
+    HX_HIP(hipMalloc((void**)&L.x3, bytes));
+    HX_HIP(hipMalloc((void**)&L.r, bytes));
+    HX_HIP(hipMemset(L.x, 0, bytes)); HX_HIP(hipMemset(L.x2, 0, bytes)); HX_HIP(hipMemset(L.x3, 0, bytes)); HX_HIP(hipMemset(L.r, 0, bytes));
+    L.n_ext = n_ext[l];
+  }
   return HX_OK;
 }
-extern "C" int hx_amg_set_sharded(hx_amg* h, int32_t n_ext, void* x, void* x2, void* x3, void* coarse_b,
-                                  hx_halo_fn halo, hx_allreduce_fn allreduce, void* ctx) {
-  HX_REQUIRE(h && x && x2 && x3 && coarse_b && halo && allreduce, "bad argument");
+extern "C" int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext, hx_halo_fn halo,
+                                  hx_allreduce_fn allreduce, void* ctx) {
+  HX_REQUIRE(h && n_ext && halo && allreduce, "bad argument");
   const size_t nl = h->single ? h->S.L.size() : h->D.L.size();
-  HX_REQUIRE(nl >= 2, "row-sharded mode needs at least one replicated coarse level");
-  const int32_t n_own = h->single ? h->S.L[0].n : h->D.L[0].n;
-  HX_REQUIRE(n_own > 0 && n_ext >= n_own, "set level 0 (local rows) before hx_amg_set_sharded");
-  h->sharded = true; h->halo = halo; h->allreduce = allreduce; h->ctx = ctx; h->n_ext = n_ext;
-  return h->single ? adopt_buffers<float>(h->S, x, x2, x3, coarse_b) : adopt_buffers<double>(h->D, x, x2, x3, coarse_b);
+  HX_REQUIRE(n_sharded >= 1 && (size_t)n_sharded < nl, "row-sharded mode needs at least one replicated coarse level");
+  drop_graph(h);
+  h->sharded = true; h->halo = halo; h->allreduce = allreduce; h->ctx = ctx; h->n_sharded = n_sharded;
+  return h->single ? resize_ext<float>(h->S, n_sharded, n_ext) : resize_ext<double>(h->D, n_sharded, n_ext);
 }
 
 extern "C" int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
@@ -303,37 +299,50 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   T* cur = L.x;
   T* prev = nullptr;
   LevelT<T>& Lc = H.L[l + 1];
+  const int EB = (int)(2 * sizeof(T));                      // bytes per complex entry of this precision
+  const bool sh = h->sharded && l < h->n_sharded;           // this level is row-sharded ...
+  const bool shc = h->sharded && l + 1 < h->n_sharded;      // ... and so is the next one
+  // restriction of the residual in `res`: a sharded coarse level computes its OWNED entries from the exchanged fine
+  // residual (R: owned coarse rows over [owned | ghost] fine columns); the first replicated level sums the ranks'
+  // partial right-hand sides
+  auto restrict_from = [&](T* res) -> int {
+    if (shc && (rc = halo_level(h, l, res, EB, s))) return rc;
+    if ((rc = op_spmv(L.R, res, Lc.b, (T)1, (T)0, true, s))) return rc;
+    if (sh && !shc && h->allreduce(h->ctx, Lc.b, 2 * (int64_t)Lc.n, sizeof(T) == 8 ? 1 : 0, 0, s) != 0)
+      return hx_fail(HX_ERR_COMM, "vcycle", "all-reduce callback failed");
+    return HX_OK;
+  };
   if (n_pre == 0) {
     // no pre-smoothing: x = 0, so the residual IS b and no operator product is needed before the restriction
-    if ((rc = op_spmv(L.R, b, Lc.b, (T)1, (T)0, true, s))) return rc;
+    if (shc) {      // (b has no ghost block: stage it in the level's residual buffer)
+      HX_HIP(hipMemcpyAsync(L.r, b, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
+      if ((rc = restrict_from(L.r))) return rc;
+    } else if ((rc = restrict_from(const_cast<T*>(b)))) return rc;
   } else {
     // pre-smoothing from x = 0: the first step is a diagonal scaling
     if ((rc = op_diag(L, cheb ? C.a[0] : h->omega, b, cur, s))) return rc;
     for (int k = 1; k < n_pre; ++k) {
       T* nxt = other(cur, prev);
+      if ((rc = halo_level(h, l, cur, EB, s))) return rc;
       if (cheb) {   // for k = 1 the previous iterate is the zero start vector (prev == nullptr)
-        if ((rc = halo_before_k(h, l, cur))) return rc;
         if ((rc = op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], s))) return rc;
-      } else { if ((rc = halo_before_k(h, l, cur))) return rc;
-               if ((rc = op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s))) return rc; }
+      } else if ((rc = op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s))) return rc;
       prev = cur; cur = nxt;
     }
     // residual r = b - K x, restrict
-    if ((rc = halo_before_k(h, l, cur))) return rc;
+    if ((rc = halo_level(h, l, cur, EB, s))) return rc;
     if ((rc = op_residual(L, cur, b, L.r, s))) return rc;
-    if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
-  }
-  if (h->sharded && l == 0) {   // R holds this rank's columns only: the coarse right-hand side is the sum over ranks
-    if (h->allreduce(h->ctx, HX_BUF_COARSE_RHS, Lc.n) != 0) return hx_fail(HX_ERR_COMM, __func__, "all-reduce callback failed");
+    if ((rc = restrict_from(L.r))) return rc;
   }
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
   if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s))) return rc;
+  if (shc && (rc = halo_level(h, l + 1, ec, EB, s))) return rc;        // P: owned rows over [owned | ghost] coarse columns
   if ((rc = op_spmv(L.P, ec, cur, (T)1, n_pre == 0 ? (T)0 : (T)1, true, s))) return rc;    // x (+)= P e_c
   // post-smoothing: a fresh polynomial started from the corrected x; the last step writes xout
   prev = nullptr;
   for (int k = 0; k < n_post; ++k) {
     T* dst = (k == n_post - 1) ? xout : other(cur, prev);
-    if ((rc = halo_before_k(h, l, cur))) return rc;
+    if ((rc = halo_level(h, l, cur, EB, s))) return rc;
     if (cheb) { if ((rc = op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s))) return rc; }
     else if ((rc = op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s))) return rc;
     prev = cur; cur = dst;
@@ -420,8 +429,8 @@ extern "C" size_t hx_gmres_ws(int64_t n, int restart) {      // (room for up to 
 }
 
 
-// xe / hbuf: row-sharded mode only (registered buffers HX_BUF_GMRES_XE: owned + ghost staging vector for K products,
-// HX_BUF_GMRES_DOTS: inner products, all-reduced); n is then the OWNED row count.
+// xe / hbuf: row-sharded mode only (xe: owned + ghost staging vector for the K products, hbuf: inner products, all-reduced);
+// n is then the OWNED row count.
 //
 // Subspace recycling (GCRO, fixed operator): when M carries k recycled pairs (U, C) with K U = C, C^H C = I, every
 // cycle starts from the Galerkin guess x += U C^H r, the Arnoldi vectors are kept orthogonal to C as well (C simply
@@ -439,7 +448,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
   auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) -> int {
     if (sharded) {   // stage the owned block, let the host side fill the ghost block, multiply the local rows
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
-      if (M->halo(M->ctx, HX_BUF_GMRES_XE) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange callback failed");
+      if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange callback failed");
       in = xe;
     }
     if (Ksell) return hx_sell_spmv_z(Ksell, in, out, a, bt, s);       // same operator, SELL-64 layout
@@ -468,7 +477,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
     int rc = (Pf && k > 0) ? hx_zpanel_dot_c64(n, k, (const hx_c64*)Pf, n, w, hdev, part, s)
                            : hx_zpanel_dot(n, k, panel, n, w, hdev, part, s);
     if (rc) return rc;
-    if (sharded && M->allreduce(M->ctx, HX_BUF_GMRES_DOTS, k + 1) != 0)
+    if (sharded && M->allreduce(M->ctx, hdev, 2 * (int64_t)(k + 1), 1, 0, s) != 0)
       return hx_fail(HX_ERR_COMM, "hx_gmres", "all-reduce callback failed");
     HX_HIP(hipMemcpyAsync(hh.data(), hdev, sizeof(cd) * (size_t)(k + 1), hipMemcpyDeviceToHost, hx_s(s)));
     HX_HIP(hipStreamSynchronize(hx_s(s)));
@@ -593,11 +602,11 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
         if (M->normK_val != (const void*)val) {
           double local = 0.0;
           if ((rc = hx_csr_norm_inf(n, rowptr, val, hdev, &local, s))) return rc;
-          if (sharded) {                       // sum of the ranks' maxima: the same number on every rank
+          if (sharded) {                       // maximum over the ranks' row blocks = |K|_inf of the whole operator
             const cd v(local, 0.0);
             HX_HIP(hipMemcpyAsync(hdev, &v, sizeof(cd), hipMemcpyHostToDevice, hx_s(s)));
             HX_HIP(hipStreamSynchronize(hx_s(s)));
-            if (M->allreduce(M->ctx, HX_BUF_GMRES_DOTS, 1) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "all-reduce callback failed");
+            if (M->allreduce(M->ctx, hdev, 2, 1, 1, s) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "all-reduce callback failed");
             HX_HIP(hipMemcpyAsync(hh.data(), hdev, sizeof(cd), hipMemcpyDeviceToHost, hx_s(s)));
             HX_HIP(hipStreamSynchronize(hx_s(s)));
             local = hh[0].real();
@@ -704,6 +713,8 @@ extern "C" int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int
 template <typename W>
 static int host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci, const W* w, int32_t* agg, int32_t* n_agg) {
   if (!(n > 0 && rp && agg && n_agg)) return hx_fail(HX_ERR_ARG, "hx_host_aggregate", "bad argument");
+  // columns >= n are ghost columns of a row-sharded graph (owned rows over [owned | ghost]): they are no neighbours here, so
+  // aggregates never cross a rank boundary (uncoupled aggregation) and every rank aggregates its rows on its own
   for (int32_t i = 0; i < n; ++i) agg[i] = -1;
   int32_t na = 0;
   // pass 1: roots whose whole strong neighbourhood is free (a stored diagonal entry is not a neighbour)
@@ -711,13 +722,13 @@ static int host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci, const
     if (agg[i] != -1) continue;
     bool free_nb = true, has_nb = false;
     for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
-      if (ci[p] == i) continue;
+      if (ci[p] == i || ci[p] >= n) continue;
       has_nb = true;
       if (agg[ci[p]] != -1) { free_nb = false; break; }
     }
     if (!free_nb || !has_nb) continue;
     agg[i] = na;
-    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) agg[ci[p]] = na;
+    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] < n) agg[ci[p]] = na;
     ++na;
   }
   // pass 2: attach leftovers to the most strongly connected pass-1 aggregate
@@ -726,7 +737,7 @@ static int host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci, const
     if (agg[i] != -1) continue;
     double best = -1.0; int32_t tgt = -1;
     for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
-      if (ci[p] == i) continue;
+      if (ci[p] == i || ci[p] >= n) continue;
       const int32_t a = pass1[ci[p]];
       const double wp = std::fabs((double)w[p]);
       if (a >= 0 && wp > best) { best = wp; tgt = a; }
@@ -737,7 +748,7 @@ static int host_aggregate(int32_t n, const int32_t* rp, const int32_t* ci, const
   for (int32_t i = 0; i < n; ++i) {
     if (agg[i] != -1) continue;
     agg[i] = na;
-    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (agg[ci[p]] == -1) agg[ci[p]] = na;
+    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) if (ci[p] < n && agg[ci[p]] == -1) agg[ci[p]] = na;
     ++na;
   }
   *n_agg = na;

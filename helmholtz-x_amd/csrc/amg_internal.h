@@ -17,7 +17,7 @@ template <typename T> struct LevelT {
   double rho = 0.0;            // estimate of rho(D^-1 K) for the Chebyshev smoother (0: damped Jacobi with h->omega)
   const hx_sell* sell = nullptr;   // optional SELL-64 companion of K (fine level): used for the K products
   T *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
-  bool ext_x = false, ext_b = false;   // x/x2/x3 (resp. b) are caller-owned (row-sharded mode)
+  int32_t n_ext = 0;           // row-sharded level: owned + ghost length of x, x2, x3, r (0: not sharded)
 };
 template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
 
@@ -37,10 +37,9 @@ struct Recycle {
   bool have_E = false;
   std::vector<cd> Hraw;        // raw Hessenberg of the last first cycle, column-major, ld = restart + 1
 };
-// Row-sharded mode (one process per GPU): level 0 holds this rank's rows over [owned | ghost] columns, every coarser
-// level is replicated.  The two exchange steps of the path are delegated to the host side (torch.distributed over
-// RCCL): `halo(ctx, id)` fills the ghost block of registered buffer `id`, `allreduce(ctx, id, count)` sums a registered
-// buffer over the ranks.  Both are enqueued on / ordered against the stream the kernels run on.
+// Row-sharded mode (one process per GPU): the first `n_sharded` levels hold this rank's rows over [owned | ghost] columns,
+// every coarser level is replicated.  The two exchange steps go through callbacks (hx_comm_halo / hx_comm_allreduce:
+// RCCL issued by the library on the kernels' stream; or the caller's own), see include/hx.h.
 struct hx_amg {
   HierT<double> D;
   HierT<float> S;
@@ -52,7 +51,7 @@ struct hx_amg {
   hx_halo_fn halo = nullptr;
   hx_allreduce_fn allreduce = nullptr;
   void* ctx = nullptr;
-  int32_t n_ext = 0;           // owned + ghost length of the level-0 iterates
+  int n_sharded = 0;           // number of leading row-sharded levels
   Recycle rec;
   // hx_cocg: ||K||_inf of the operator last seen (by value pointer) and the backward error of the last solve that ended
   // above its tolerance (-1: not measured)

@@ -74,18 +74,30 @@ __global__ void k_sa_filter(int32_t n, const int32_t* __restrict__ rp, const int
     }
     double diag = 0.0, lump = 0.0;
     int32_t q = out_rp[i], qd = -1;
-    bool placed = false;
+    bool placed = false, stored = false;
+    // (rows of a row-sharded operator list their ghost columns -- local index >= n -- in any position: only a row WITHOUT a
+    // stored diagonal gets the slot inserted in front of its first larger column)
+    for (int32_t p = rp[i]; p < rp[i + 1]; ++p) stored |= ci[p] == i;
     for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
       const int32_t j = ci[p];
       const double l = sign * val[p].x;
       if (j == i) { diag = l; qd = q; out_ci[q] = i; ++q; placed = true; continue; }
-      if (!placed && j > i) { qd = q; out_ci[q] = i; ++q; placed = true; }     // keep columns sorted if no diagonal stored
+      if (!stored && !placed && j > i) { qd = q; out_ci[q] = i; ++q; placed = true; }     // keep columns sorted if no diagonal stored
       if (fabs(l) >= ti * sd[j]) { out_ci[q] = j; out_v[q] = l; ++q; }
       else lump += l;
     }
     if (!placed) { qd = q; out_ci[q] = i; ++q; }
     out_v[qd] = diag + lump;
   }
+}
+// sd_i = sqrt|l_ii| of the rows alone (row-sharded set-up: the ghost entries of sd are exchanged before the filter passes,
+// which recompute the owned entries and read the ghost ones)
+extern "C" int hx_sa_strength_diag(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, double sign,
+                                   double* sd, hx_stream s) {
+  HX_REQUIRE(n > 0 && rp && ci && val && sd, "bad argument");
+  k_sa_sd<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, rp, ci, (const zc*)val, sign, sd);
+  HX_LAUNCH_CHECK("k_sa_sd");
+  return HX_OK;
 }
 // count pass: out_rp (n + 1 entries) = row pointer of Lf, *h_nnz = its nnz; sd (n doubles) is kept for the fill pass.  SYNC.
 extern "C" int hx_sa_filter_count(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, double sign,
@@ -156,6 +168,26 @@ extern "C" int hx_sa_power_rho(int32_t n, const int32_t* rp, const int32_t* ci, 
   for (int q = 0; q < nb; ++q) { n_last += h[(size_t)((iters - 1) & 1) * nb + q]; n_prev += h[(size_t)((iters - 2) & 1) * nb + q]; }
   HX_REQUIRE(n_prev > 0.0 && n_last > 0.0, "power iteration collapsed (zero vector)");
   *h_rho = std::sqrt(n_last / n_prev);
+  return HX_OK;
+}
+
+// One step w = Df^-1 Lf v of that iteration with the squared norm of w written to *d_norm2 (device): the row-sharded set-up
+// exchanges the ghost entries of v between steps and sums the norms over the ranks (Lf: owned rows over [owned | ghost]).
+__global__ void k_sum_partials(int nb, const double* __restrict__ part, double* __restrict__ out) {
+  double t = 0.0;
+  for (int q = threadIdx.x; q < nb; q += HX_WAVE) t += part[q];
+#pragma unroll
+  for (int o = HX_WAVE / 2; o > 0; o >>= 1) t += __shfl_down(t, o, HX_WAVE);
+  if (threadIdx.x == 0) *out = t;
+}
+extern "C" int hx_sa_power_step(int32_t n, const int32_t* rp, const int32_t* ci, const double* lf, const double* v,
+                                double* w, double* d_norm2, double* d_scratch, hx_stream s) {
+  HX_REQUIRE(n > 0 && rp && ci && lf && v && w && d_norm2 && d_scratch, "bad argument");
+  const int nb = hx_grid(n, 256, 1024);           // d_scratch: 1024 doubles
+  k_dinv_spmv_norm<<<nb, 256, 0, hx_s(s)>>>(n, rp, ci, lf, v, w, d_scratch);
+  HX_LAUNCH_CHECK("k_dinv_spmv_norm");
+  k_sum_partials<<<1, HX_WAVE, 0, hx_s(s)>>>(nb, d_scratch, d_norm2);
+  HX_LAUNCH_CHECK("k_sum_partials");
   return HX_OK;
 }
 

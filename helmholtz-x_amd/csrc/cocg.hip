@@ -38,8 +38,8 @@ int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* ou
 
 static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0};
 
-// Scalar block on the device (complex128 entries): OUT = raw reduction results (always at the FRONT: in row-sharded mode
-// the all-reduce callback sums the first `count` entries of the registered buffer), ST = state, T = deflation coefficients.
+// Scalar block on the device (complex128 entries): OUT = raw reduction results (at the FRONT: in row-sharded mode the
+// all-reduce callback sums the first `count` entries), ST = state, T = deflation coefficients.
 #define CG_OUT 0      // [0, 33): dot results
 #define CG_RHO 34     // r^T z of the current iterate
 #define CG_BETA 35
@@ -218,13 +218,12 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   if ((rc0 = hx_amg_vcycle_buffers(M, &r32, &z32))) return rc0;
   hx_c128* part = tmp + n;
   hx_c128* sc = sharded ? hbuf : part + hx_panel_dot_ws(CG_MAXK + 1);
-  const int sc_buf = HX_BUF_GMRES_DOTS;
   int64_t rpb;
   const int nblocks = hx_panel_dot_blocks(n, &rpb);
   auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) -> int {
     if (sharded) {
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
-      if (M->halo(M->ctx, HX_BUF_GMRES_XE) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
+      if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
       in = xe;
     }
     if (Ksell) return hx_sell_spmv_z(Ksell, in, out, a, bt, s);
@@ -233,14 +232,14 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   auto Kres = [&](const hx_c128* in, hx_c128* out) -> int {          // out = b - K in
     if (sharded) {
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
-      if (M->halo(M->ctx, HX_BUF_GMRES_XE) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
+      if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
       in = xe;
     }
     if (Ksell) return hx_sell_residual_z(Ksell, in, b, out, s);
     return hx_csr_residual_z(n, nnz, rowptr, col, val, in, b, out, s);
   };
-  auto reduce = [&](int count) -> int {       // sum the first `count` scalars over the ranks
-    if (sharded && M->allreduce(M->ctx, sc_buf, count) != 0)
+  auto reduce = [&](int count, int op = 0) -> int {       // sum (op 1: max) of the first `count` scalars over the ranks
+    if (sharded && M->allreduce(M->ctx, sc, 2 * (int64_t)count, 1, op, s) != 0)
       return hx_fail(HX_ERR_COMM, "hx_cocg", "all-reduce callback failed");
     return HX_OK;
   };
@@ -303,12 +302,12 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     if (M->normK_val != (const void*)val) {
       double local = 0.0;
       if ((rc = hx_csr_norm_inf(n, rowptr, val, sc + CG_TMP, &local, s))) return rc;
-      if (sharded) {                                            // sum of the ranks' maxima: same number on every rank
+      if (sharded) {                                            // maximum over the ranks' row blocks = |K|_inf of the whole operator
         cd v(local, 0.0);
         HX_HIP(hipMemcpyAsync(sc + CG_TMP, &v, sizeof(cd), hipMemcpyHostToDevice, hx_s(s)));
         HX_HIP(hipMemcpyAsync(sc, sc + CG_TMP, sizeof(cd), hipMemcpyDeviceToDevice, hx_s(s)));
         HX_HIP(hipStreamSynchronize(hx_s(s)));
-        if ((rc = reduce(1))) return rc;
+        if ((rc = reduce(1, 1))) return rc;
         if ((rc = fetch(1))) return rc;
         local = host[0].real();
       }

@@ -18,9 +18,9 @@ lib = C.CDLL(LIB_PATH)
 _vp, _i32, _i64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_int
 _dp = C.POINTER(C.c_double)
 
-HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)                # hx_halo_fn
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)   # hx_allreduce_fn
-BUF_VCYCLE_X0, BUF_COARSE_RHS, BUF_GMRES_XE, BUF_GMRES_DOTS = 0, 3, 4, 5
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p)                    # hx_halo_fn
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p)      # hx_allreduce_fn
+COMM_ID_BYTES = 128
 ERR_BREAKDOWN = -5
 
 SIGNATURES = {
@@ -104,7 +104,18 @@ SIGNATURES = {
     "hx_amg_enable_recycling": (C.c_int, [_vp, _i64, _int, _int]),
     "hx_gmres_hessenberg": (C.c_int, [_vp, C.POINTER(_int), _vp]),
     "hx_amg_set_recycle": (C.c_int, [_vp, _int, _vp, _vp, _vp, _vp]),
-    "hx_amg_set_sharded": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
+    "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
+    "hx_comm_unique_id": (C.c_int, [_vp, _int]),
+    "hx_comm_create": (C.c_int, [C.POINTER(_vp), _int, _int, C.c_char_p, _int]),
+    "hx_comm_destroy": (C.c_int, [_vp]),
+    "hx_comm_library": (C.c_char_p, []),
+    "hx_comm_set_plan": (C.c_int, [_vp, _int, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
+    "hx_comm_exchange": (C.c_int, [_vp, _int, _vp, _vp, _int, _vp]),
+    "hx_comm_halo": (C.c_int, [_vp, _int, _vp, _int, _vp]),
+    "hx_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _int, _int, _vp]),
+    "hx_comm_counters": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _int]),
+    "hx_sa_strength_diag": (C.c_int, [_i32, _vp, _vp, _vp, C.c_double, _vp, _vp]),
+    "hx_sa_power_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hx_gmres_sharded": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp, _vp, _vp,
                                    C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_csr_diagonal_z": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),

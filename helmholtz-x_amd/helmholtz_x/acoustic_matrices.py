@@ -73,6 +73,8 @@ class AcousticMatrices:
 
         info("- Passive matrices are assembling..")
         bc_dofs = np.unique(np.concatenate(self.bcs_Dirichlet)) if self.bcs_Dirichlet else None
+        if bc_dofs is not None and getattr(mesh, "part", None) is not None:
+            raise NotImplementedError("Dirichlet rows on a distributed mesh (no reference example uses them)")
 
         c_dev = asm._field(self.c) if hasattr(asm, "_field") and degree == 1 else self.c    # one upload for A, C and B
         self._A, self._C = asm.stiffness_mass(c_dev)
@@ -106,6 +108,11 @@ class AcousticMatrices:
             vals = f.x.array[self.mesh.facet_cells[facets]]
         else:
             vals = f.x.array[fv].mean(axis=1)
+        part = getattr(self.mesh, "part", None)
+        if part is not None:            # distributed mesh: every facet counts on the rank that owns it (acoustic_matrices.py:76-90)
+            own = part["facet_owned"][facets]
+            num, den = self.mesh.comm.allreduce(np.array([(vals * meas)[own].sum(), meas[own].sum() + 0j]))
+            return num / den.real
         return (vals * meas).sum() / meas.sum()
 
     @property

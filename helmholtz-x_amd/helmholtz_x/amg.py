@@ -25,7 +25,8 @@ from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
               max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=int(os.environ.get("HX_SELL_MIN_ROWS", "50000")), sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
-              recycle_min_rows=100_000, recycle_theta=0.45, krylov="auto", cocg_min_rows=100_000, setup="device")
+              recycle_min_rows=100_000, recycle_theta=0.45, krylov="auto", cocg_min_rows=100_000, setup="device",
+              replicate_max_rows=int(os.environ.get("HX_AMG_REPLICATE_MAX_ROWS", "200000")))
 
 
 MAX_DENSE_COARSE = 6000          # the coarsest operator is inverted densely on the host
@@ -272,7 +273,8 @@ def _dev_spgemm(A, B):
     return DevCSR((A.shape[0], B.shape[1]), rp, ci, v)
 
 
-def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], coarse_size=PARAMS["coarse_size"]):
+def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], coarse_size=PARAMS["coarse_size"],
+                           level_offset=0):
     """Same smoothed-aggregation hierarchy as ``build_hierarchy``, built in HBM: K (petsc.CSR / DevCSR on the device) is
     never copied to the host.  Device passes (amg_setup.hip): diagonal, strength filter, power iteration, smoothed
     prolongator, transpose, Galerkin product as R (K P).  Host: the greedy aggregation of the filtered graph and the
@@ -280,9 +282,11 @@ def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_leve
     levels = []
     Kl = DevCSR(K.shape, K.rowptr, K.col, K.val)
     dev = K.val.device
-    th = float(os.environ.get("HX_AMG_THETA", theta))                    # experiment hooks (tools/sweep_r2.sh)
+    # (level_offset > 0: continuation of a row-sharded set-up below its last sharded level -- theta was halved per level)
+    th = float(os.environ.get("HX_AMG_THETA", theta)) if level_offset == 0 else float(theta)
     p_damp = float(os.environ.get("HX_AMG_PDAMP", 4.0 / 3.0))
     rho_iters = int(os.environ.get("HX_AMG_RHO_ITERS", "10"))
+    max_levels = max_levels - level_offset
     while True:
         n = Kl.shape[0]
         diag = torch.empty(n, dtype=torch.complex128, device=dev)
@@ -311,7 +315,7 @@ def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_leve
             levels.append(level)
             break
         gen = torch.Generator(device=dev)
-        gen.manual_seed(len(levels))
+        gen.manual_seed(len(levels) + level_offset)
         v = torch.randn(n, generator=gen, device=dev, dtype=torch.float64)
         w = torch.empty_like(v)
         rho = C.c_double(0.0)
@@ -339,6 +343,244 @@ def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_leve
     return levels
 
 
+
+# ----------------------------------------------------------------------------- row-sharded set-up
+def _host_sum(shard, *vals):
+    """Sum of host integers over the ranks (set-up decisions must be identical everywhere)."""
+    t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=_hx.require_gpu())
+    shard.all_reduce_(t)
+    return [int(round(x)) for x in t.cpu().tolist()]
+
+
+def _all_gather_var(shard, t):
+    """Concatenation over the ranks (rank order) of 1-D device tensors of different lengths: set-up only."""
+    import torch.distributed as dist
+    sizes = [None] * shard.world
+    dist.all_gather_object(sizes, int(t.numel()), group=shard.group)
+    cap = max(max(sizes), 1)
+    v = torch.view_as_real(t) if t.is_complex() else t
+    pad = torch.zeros((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+    pad[:t.numel()] = v
+    stage = shard.backend == "gloo" and pad.is_cuda
+    src = pad.cpu() if stage else pad
+    outs = [torch.empty_like(src) for _ in range(shard.world)]
+    dist.all_gather(outs, src, group=shard.group)
+    cat = torch.cat([o[:m] for o, m in zip(outs, sizes)]).to(t.device)
+    return torch.view_as_complex(cat.contiguous()) if t.is_complex() else cat
+
+
+def _is_complex_symmetric_sharded(K, shard, tol=1e-11):
+    """x^T K y == y^T K x on the row-sharded operator (K: owned rows over [owned | ghost]); collective."""
+    n_own = K.shape[0]
+    gen = torch.Generator(device=K.val.device)
+    gen.manual_seed(20260101)
+    xg, yg = (torch.view_as_complex(torch.randn((shard.n_global, 2), generator=gen, device=K.val.device, dtype=torch.float64))
+              for _ in range(2))
+    xe, ye = shard.ext_vector(), shard.ext_vector()
+    xe[:n_own], ye[:n_own] = xg[shard.r0:shard.r1], yg[shard.r0:shard.r1]
+    shard.halo(xe)
+    shard.halo(ye)
+    kx, ky = torch.empty(n_own, dtype=torch.complex128, device=K.val.device), torch.empty(n_own, dtype=torch.complex128, device=K.val.device)
+    K.spmv(xe, kx)
+    K.spmv(ye, ky)
+    t = torch.stack([torch.dot(ye[:n_own], kx), torch.dot(xe[:n_own], ky),
+                     (torch.linalg.vector_norm(kx) ** 2).to(torch.complex128),
+                     (torch.linalg.vector_norm(ye[:n_own]) ** 2).to(torch.complex128)])
+    shard.all_reduce_(t)
+    a, b, nk, ny = (complex(z) for z in t.cpu().tolist())
+    return abs(a - b) <= tol * max(float(np.sqrt(nk.real * ny.real)), 1e-300)
+
+
+def _rows_concat(a, b):
+    """CSR rows of ``a`` followed by the rows of ``b`` (same column space)."""
+    rp = torch.cat([a.rowptr, (b.rowptr[1:].to(torch.int64) + a.nnz).to(torch.int32)])
+    return DevCSR((a.shape[0] + b.shape[0], a.shape[1]), rp, torch.cat([a.col, b.col]), torch.cat([a.val, b.val]))
+
+
+def _select_columns(A, c0, c1):
+    """Entries of A with column in [c0, c1), columns shifted to start at 0 (device integer work)."""
+    keep = (A.col >= c0) & (A.col < c1)
+    n = A.shape[0]
+    lens = A.rowptr[1:] - A.rowptr[:-1]
+    row_of = torch.repeat_interleave(torch.arange(n, device=A.col.device, dtype=torch.int64), lens.to(torch.int64))
+    cnt = torch.zeros(n, dtype=torch.int64, device=A.col.device)
+    cnt.index_add_(0, row_of[keep], torch.ones(int(keep.sum()), dtype=torch.int64, device=A.col.device))
+    rp = torch.zeros(n + 1, dtype=torch.int32, device=A.col.device)
+    rp[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+    return DevCSR((n, c1 - c0), rp, (A.col[keep] - c0).contiguous(), A.val[keep].contiguous())
+
+
+def _localize_columns(A, c0, c1, ghost_sorted, n_own):
+    """Global column ids -> [owned | ghost] numbering: owned [c0, c1) -> col - c0, others -> n_own + position in the
+    ascending ghost list (device int64 tensor)."""
+    col = A.col.long()
+    own = (col >= c0) & (col < c1)
+    if ghost_sorted.numel():
+        pos = torch.searchsorted(ghost_sorted, col).clamp(max=int(ghost_sorted.numel()) - 1)
+        if not bool(torch.all(own | (ghost_sorted[pos] == col))):
+            raise ValueError("column outside the ghost set of the level")
+    else:
+        pos = torch.zeros_like(col)
+        if not bool(torch.all(own)):
+            raise ValueError("off-rank column but the ghost set is empty")
+    lcol = torch.where(own, col - c0, n_own + pos).to(torch.int32).contiguous()
+    return DevCSR((A.shape[0], n_own + int(ghost_sorted.numel())), A.rowptr, lcol, A.val)
+
+
+def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"],
+                            coarse_size=PARAMS["coarse_size"], replicate_max_rows=PARAMS["replicate_max_rows"]):
+    """Smoothed-aggregation hierarchy of the ROW-SHARDED operator: K holds this rank's rows over [owned | ghost] columns
+    (level-0 plan of ``shard``).  What PCSetUp does for the reference's distributed matrix (MUMPS / SuperLU_DIST analysis +
+    factorisation on N ranks, eigensolvers.py:49-50,102-103) -- here every rank builds its SLAB of every large level:
+
+      * strength filter row-local (the ghost entries of sqrt|l_jj| exchanged once);
+      * UNCOUPLED aggregation: the greedy pass runs on the owned sub-graph, aggregates never cross a rank boundary; coarse
+        ids are numbered rank after rank, so every level is again a contiguous row partition;
+      * rho(Df^-1 Lf) by a distributed power iteration (halo of the iterate per step, norms summed once);
+      * smoothed prolongator rows P[own, :] (aggregate ids and sizes of ghost vertices exchanged);
+      * Galerkin operator: K P from owned rows after a sparse-row halo of P, then R (K P) with R = the transpose of the
+        [owned | ghost] rows of P restricted to MY aggregates, after a sparse-row halo of K P: my rows of the coarse operator,
+        no reduction of partial sums and bitwise independent of timing;
+      * levels with more than ``replicate_max_rows`` global rows stay sharded (their own exchange plan); the first level
+        below that is all-gathered (rank blocks concatenate) and the remaining levels are built replicated from it by
+        ``build_hierarchy_device``.
+
+    Returns the level dicts: sharded ones carry K / P / R / dinv in local numbering plus ``sharded=True, n (owned rows),
+    n_ext, n_global``; then the replicated tail as ``build_hierarchy_device`` returns it."""
+    dev = K.val.device
+    levels = []
+    th = float(os.environ.get("HX_AMG_THETA", theta))
+    p_damp = float(os.environ.get("HX_AMG_PDAMP", 4.0 / 3.0))
+    rho_iters = int(os.environ.get("HX_AMG_RHO_ITERS", "10"))
+    Kl = DevCSR(K.shape, K.rowptr, K.col, K.val)
+    l = 0
+    ranges = list(shard.level_ranges[0])
+    n_glob = ranges[-1][1]
+    while True:
+        n_own, n_ext = Kl.shape
+        assert (n_own, n_ext) == shard.level_n[l], "operator does not match the level's exchange plan"
+        diag = torch.empty(n_own, dtype=torch.complex128, device=dev)
+        _hx.check(_hx.lib.hx_csr_diagonal_z(n_own, _hx.ptr(Kl.rowptr), _hx.ptr(Kl.col), _hx.ptr(Kl.val), _hx.ptr(diag),
+                                            _hx.stream()))
+        level = dict(K=Kl, n=n_own, n_ext=n_ext, n_global=n_glob, sharded=True)
+        (n_neg,) = _host_sum(shard, int((diag.real < 0).sum()))
+        sgn = -1.0 if 2 * n_neg > n_glob else 1.0
+        # strength filter with exchanged sqrt|l_jj| of the ghost columns
+        sd = torch.zeros(n_ext, dtype=torch.float64, device=dev)
+
+        def filtered(theta_l):
+            _hx.check(_hx.lib.hx_sa_strength_diag(n_own, _hx.ptr(Kl.rowptr), _hx.ptr(Kl.col), _hx.ptr(Kl.val), sgn,
+                                                  _hx.ptr(sd), _hx.stream()))
+            shard.halo(sd, l)
+            return _dev_filter(Kl, sgn, theta_l, sd)
+
+        Lf = filtered(th)
+        agg, na = _dev_aggregate(Lf)
+        for _ in range(3):
+            (na_glob,) = _host_sum(shard, na)
+            if na_glob < 0.8 * n_glob:
+                break
+            th *= 0.25
+            Lf = filtered(th)
+            agg, na = _dev_aggregate(Lf)
+        (na_glob,) = _host_sum(shard, na)
+        if na_glob >= 0.8 * n_glob or na == 0:
+            raise ArithmeticError("row-sharded AMG: coarsening stalled at %d unknowns (strength threshold %.3g)" % (n_glob, th))
+        # coarse numbering: rank after rank
+        counts = [None] * shard.world
+        import torch.distributed as dist
+        dist.all_gather_object(counts, int(na), group=shard.group)
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        c_ranges = [(int(offs[p]), int(offs[p + 1])) for p in range(shard.world)]
+        c0, c1 = c_ranges[shard.rank]
+        # aggregate id (global) and 1/sqrt(size) per vertex, ghosts by halo
+        agg_ext = torch.zeros(n_ext, dtype=torch.int32, device=dev)
+        agg_ext[:n_own] = to_device(agg) + int(c0)
+        shard.halo(agg_ext, l)
+        isc_own = 1.0 / np.sqrt(np.bincount(agg, minlength=na).astype(np.float64))
+        iscv = torch.zeros(n_ext, dtype=torch.float64, device=dev)
+        iscv[:n_own] = to_device(isc_own[agg])
+        shard.halo(iscv, l)
+        g_agg = agg_ext[n_own:].long()
+        ghost_aggs = torch.unique(g_agg)                                  # ascending global ids, all off-rank
+        na_ext = na + int(ghost_aggs.numel())
+        agg_loc = torch.empty(n_ext, dtype=torch.int32, device=dev)
+        agg_loc[:n_own] = agg_ext[:n_own] - int(c0)
+        isc = torch.zeros(na_ext, dtype=torch.float64, device=dev)
+        isc[:na] = to_device(isc_own)
+        if ghost_aggs.numel():
+            gpos = torch.searchsorted(ghost_aggs, g_agg)
+            agg_loc[n_own:] = (na + gpos).to(torch.int32)
+            isc[na + gpos] = iscv[n_own:]
+        # rho(Df^-1 Lf): distributed power iteration
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(l)
+        vg = torch.randn(n_glob, generator=gen, device=dev, dtype=torch.float64)     # same global start vector on every rank
+        r0_l = ranges[shard.rank][0]
+        v = torch.zeros(n_ext, dtype=torch.float64, device=dev)
+        v[:n_own] = vg[r0_l:r0_l + n_own]
+        del vg
+        w = torch.zeros(n_ext, dtype=torch.float64, device=dev)
+        norms = torch.zeros(rho_iters, dtype=torch.float64, device=dev)
+        scratch = torch.empty(1024, dtype=torch.float64, device=dev)
+        for it in range(rho_iters):
+            shard.halo(v, l)
+            _hx.check(_hx.lib.hx_sa_power_step(n_own, _hx.ptr(Lf.rowptr), _hx.ptr(Lf.col), _hx.ptr(Lf.val), _hx.ptr(v),
+                                               _hx.ptr(w), C.c_void_p(norms.data_ptr() + 8 * it), _hx.ptr(scratch),
+                                               _hx.stream()))
+            v, w = w, v
+        shard.all_reduce_(norms)
+        nh = norms.cpu().numpy()
+        rho = float(np.sqrt(nh[-1] / nh[-2]))
+        # smoothed prolongator rows of the owned vertices over [own | ghost] aggregates
+        prp = torch.empty(n_own + 1, dtype=torch.int32, device=dev)
+        pnnz = C.c_int64(0)
+        _hx.check(_hx.lib.hx_sa_prolongator_count(n_own, _hx.ptr(Lf.rowptr), _hx.ptr(Lf.col), _hx.ptr(agg_loc), _hx.ptr(prp),
+                                                  C.byref(pnnz), _hx.stream()))
+        pci = torch.empty(pnnz.value, dtype=torch.int32, device=dev)
+        pv = torch.empty(pnnz.value, dtype=torch.float64, device=dev)
+        _hx.check(_hx.lib.hx_sa_prolongator_fill(n_own, _hx.ptr(Lf.rowptr), _hx.ptr(Lf.col), _hx.ptr(Lf.val), _hx.ptr(agg_loc),
+                                                 _hx.ptr(isc), p_damp / rho, _hx.ptr(prp), _hx.ptr(pci), _hx.ptr(pv),
+                                                 _hx.stream()))
+        # columns -> GLOBAL coarse ids for the products (ascending local ids = own aggregates, then ghosts ascending)
+        loc2glob = torch.cat([torch.arange(c0, c1, device=dev, dtype=torch.int64), ghost_aggs])
+        P_glob = DevCSR((n_own, na_glob), prp, loc2glob[pci.long()].to(torch.int32).contiguous(), pv)
+        plan = shard.plans[l]
+        P_ext = _rows_concat(P_glob, DevCSR((n_ext - n_own, na_glob), *plan.exchange_rows(prp, P_glob.col, pv)))
+        KP = _dev_spgemm(Kl, P_ext)                                        # owned rows, global coarse columns
+        KP_ext = _rows_concat(KP, DevCSR((n_ext - n_own, na_glob), *plan.exchange_rows(KP.rowptr, KP.col, KP.val)))
+        R_loc = _dev_transpose(_select_columns(P_ext, c0, c1), na)         # my aggregates x [own | ghost] fine vertices
+        Kc = _dev_spgemm(R_loc, KP_ext)                                    # my coarse rows, global coarse columns
+        del KP, KP_ext, P_ext, Lf, sd, v, w
+        level.update(dinv=1.0 / diag, omega=4.0 / (3.0 * 1.05 * rho), rho=1.05 * rho, n_coarse=na, n_coarse_global=na_glob,
+                     R=R_loc)
+        levels.append(level)
+        th *= 0.5
+        next_sharded = na_glob > replicate_max_rows and len(levels) < max_levels - 2 and min(counts) > 0
+        if next_sharded:
+            # level l + 1 stays sharded: its ghost set = the off-rank columns of my coarse rows and of my prolongator rows
+            cols = torch.cat([Kc.col.long(), P_glob.col.long()])
+            ghost_c = torch.unique(cols[(cols < c0) | (cols >= c1)])
+            shard.set_level_plan(l + 1, c_ranges, ghost_c.cpu().numpy())
+            level["P"] = _localize_columns(P_glob, c0, c1, ghost_c, na)
+            level["coarse_sharded"] = True
+            Kl = _localize_columns(Kc, c0, c1, ghost_c, na)
+            ranges, n_glob, l = c_ranges, na_glob, l + 1
+            continue
+        # level l + 1 is replicated: P keeps global columns, the restriction is the transpose of MY prolongator rows (the
+        # ranks' partial right-hand sides are summed by one all-reduce), the coarse operator is all-gathered
+        level["P"] = P_glob
+        level["R"] = _dev_transpose(P_glob, na_glob)
+        level["coarse_sharded"] = False
+        lens = _all_gather_var(shard, (Kc.rowptr[1:] - Kc.rowptr[:-1]).contiguous())
+        rp_rep = torch.zeros(na_glob + 1, dtype=torch.int32, device=dev)
+        rp_rep[1:] = torch.cumsum(lens.to(torch.int64), 0).to(torch.int32)
+        K_rep = DevCSR((na_glob, na_glob), rp_rep, _all_gather_var(shard, Kc.col), _all_gather_var(shard, Kc.val))
+        level["n_coarse"] = na_glob
+        tail = build_hierarchy_device(K_rep, th, max_levels, coarse_size, level_offset=len(levels))
+        return levels + tail
+
+
 def harmonic_ritz_recycle(Hb, k):
     """Coefficients of the GCRO recycle pair from one (flexible) GMRES cycle  K Z_m = V_{m+1} Hbar_m  (Hb: (m+1) x m raw
     Hessenberg): the k harmonic Ritz vectors g of smallest |theta|,
@@ -364,8 +606,9 @@ class AMGSolver:
     name = "amg"
 
     def __init__(self, K_csr, hierarchy=None, shard=None, **overrides):
-        """``shard`` (sharded.ShardContext): K_csr is still the GLOBAL operator (replicated set-up); level 0 of the
-        device hierarchy then holds only this rank's rows and the solve is collective (hx_gmres_sharded)."""
+        """``shard`` (sharded.ShardContext): K_csr holds this rank's rows over [owned | ghost] columns (distributed assembly;
+        a global operator is cut to them first), the hierarchy is built and kept row-sharded on its large levels and the
+        solve is collective (hx_cocg_sharded / hx_gmres_sharded)."""
         import time
         t_setup = time.perf_counter()
         self.params = dict(PARAMS, **overrides)
@@ -374,9 +617,16 @@ class AMGSolver:
             if os.environ.get("HX_AMG_" + key.upper()):
                 self.params[key] = int(os.environ["HX_AMG_" + key.upper()])
         self.shard = shard
-        K_global = K_csr
         dev = K_csr.val.device
-        if hierarchy is not None:
+        if shard is not None:
+            # row-sharded: K_csr is this rank's rows (distributed assembly) or the global operator (cut to the rank's rows
+            # here); either way the hierarchy is BUILT sharded -- every rank its slab of every large level
+            K_csr = shard.localize(K_csr)
+            levels = hierarchy if hierarchy is not None else build_hierarchy_sharded(
+                K_csr, shard, self.params["theta"], self.params["max_levels"], self.params["coarse_size"],
+                self.params["replicate_max_rows"])
+            n_rows = shard.n_global
+        elif hierarchy is not None:
             levels = hierarchy
         elif os.environ.get("HX_AMG_SETUP", self.params["setup"]) == "host":      # round-1 host passes (comparison / tests)
             levels = build_hierarchy(K_csr.to_scipy(), self.params["theta"], self.params["max_levels"],
@@ -385,23 +635,23 @@ class AMGSolver:
             levels = build_hierarchy_device(K_csr, self.params["theta"], self.params["max_levels"],
                                             self.params["coarse_size"])
         self.levels = levels
+        self.n_sharded = sum(1 for lv in levels if lv.get("sharded"))
         # Krylov method of the inner solve: complex symmetric K (every shifted operator of the path except the
         # Bloch-reduced ones) + symmetric V-cycle (pre == post) -> deflated COCG (short recurrences, hx_cocg);
         # otherwise flexible GMRES.  "auto" probes the symmetry of the bilinear form with two random vectors.
         # Below ~1e5 rows the solve is launch-latency bound and the iteration COUNT decides: undeflated COCG needs
         # 14-18 iterations where GMRES needs 12-14 (measured at 34 k / 66 k rows), so "auto" keeps GMRES there.
         kry = os.environ.get("HX_AMG_KRYLOV", self.params["krylov"])
-        n_rows = K_global.shape[0]
+        if shard is None:
+            n_rows = K_csr.shape[0]
         self.use_cocg = len(levels) > 1 and self.params["pre"] == self.params["post"] and (
             kry == "cocg" or (kry == "auto" and n_rows >= self.params["cocg_min_rows"]
-                              and _is_complex_symmetric(K_global)))
+                              and (_is_complex_symmetric(K_csr) if shard is None
+                                   else _is_complex_symmetric_sharded(K_csr, shard))))
         self.cocg_solves = self.cocg_fallbacks = self.cocg_iters = self.attainable_stops = 0
         self.backward_stable = False
-        if shard is not None:
-            if len(levels) < 2:
-                raise ValueError("row-sharded AMG needs at least one coarse level (problem too small to shard)")
-            K_csr = shard.localize(K_global)          # this rank's rows over [owned | ghost] columns
-            del K_global
+        if shard is not None and len(levels) < 2:
+            raise ValueError("row-sharded AMG needs at least one coarse level (problem too small to shard)")
         self.n = K_csr.shape[0]
         self.K = K_csr
         omega = self.params["jacobi_omega"] or min(lv["omega"] for lv in levels if "omega" in lv) if len(levels) > 1 else 0.6
@@ -475,15 +725,7 @@ class AMGSolver:
                     self.coarse_sells.append(shl)
                     _hx.check(_hx.lib.hx_amg_set_level_sell(h, l, shl))
             if "P" in lv:
-                Pl, Rl, dl, nl = lv["P"], lv["R"], lv["dinv"], lv["n"]
-                if shard is not None and l == 0:      # owned rows of P; R = their transpose (partial sums per rank)
-                    if isinstance(Pl, DevCSR):
-                        Pl = Pl.rows(shard.r0, shard.r1)
-                        Rl = _dev_transpose(Pl, lv["n_coarse"])
-                    else:
-                        Pl = sp.csr_matrix(Pl)[shard.r0:shard.r1]
-                        Rl = Pl.T.tocsr()
-                    dl, nl = dl[shard.r0:shard.r1], shard.n_own
+                Pl, Rl, dl, nl = lv["P"], lv["R"], lv["dinv"], lv["n"]     # (sharded levels: already this rank's slabs)
                 (prp, pci, pva), pnnz = dev_csr(Pl)
                 (rrp, rci, rva), rnnz = dev_csr(Rl)
                 dinv = (dl if isinstance(dl, torch.Tensor) else to_device(np.asarray(dl, dtype=np.complex128))).to(cdt)
@@ -500,17 +742,11 @@ class AMGSolver:
                 (crp, cci, cva), cnnz = dev_csr(sp.csr_matrix(np.linalg.inv(Kc.toarray())))
                 _hx.check(set_coarse(h, lv["n"], cnnz, _hx.ptr(crp), _hx.ptr(cci), _hx.ptr(cva)))
         if shard is not None:
-            from .sharded import ShardedCallbacks
-            n1 = levels[1]["n"]
-            self._bufs = {0: shard.ext_vector(cdt), 1: shard.ext_vector(cdt), 2: shard.ext_vector(cdt),
-                          _hx.BUF_COARSE_RHS: torch.zeros(n1, dtype=cdt, device=dev),
-                          _hx.BUF_GMRES_XE: shard.ext_vector(torch.complex128),
-                          _hx.BUF_GMRES_DOTS: torch.zeros(max(self.params["restart"] + 2 + 32, 80), dtype=torch.complex128,
-                                                          device=dev)}
-            self._cb = ShardedCallbacks(shard, self._bufs)
-            _hx.check(_hx.lib.hx_amg_set_sharded(h, shard.n_ext, _hx.ptr(self._bufs[0]), _hx.ptr(self._bufs[1]),
-                                                 _hx.ptr(self._bufs[2]), _hx.ptr(self._bufs[_hx.BUF_COARSE_RHS]),
-                                                 self._cb.halo, self._cb.allreduce, None))
+            self._cb = shard.callbacks()             # (halo_fn, allreduce_fn, ctx): the library's own RCCL calls, or gloo trampolines
+            n_ext = np.ascontiguousarray([lv["n_ext"] for lv in levels[:self.n_sharded]], dtype=np.int32)
+            _hx.check(_hx.lib.hx_amg_set_sharded(h, self.n_sharded, _hx.nptr(n_ext), self._cb[0], self._cb[1], self._cb[2]))
+            self._xe = shard.ext_vector(torch.complex128)
+            self._hbuf = torch.zeros(max(self.params["restart"] + 2 + 32, 80), dtype=torch.complex128, device=dev)
         # hipGraph replay of the V-cycle where it is launch-bound (measured: see DESIGN.md section 5)
         gmax = int(os.environ.get("HX_AMG_GRAPH_MAX_ROWS", self.params["graph_max_rows"]))
         if mixed and shard is None and len(levels) > 1 and self.n <= gmax:
@@ -580,10 +816,10 @@ class AMGSolver:
         if self.shard is not None:
             rc = _hx.lib.hx_gmres_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                           self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
-                                          self.params["restart"], _hx.ptr(self.ws), _hx.ptr(self._bufs[_hx.BUF_GMRES_XE]),
-                                          _hx.ptr(self._bufs[_hx.BUF_GMRES_DOTS]), C.byref(it), C.byref(rr), _hx.stream())
-            if rc != 0 and self._cb.error:
-                raise RuntimeError("exchange callback failed inside hx_gmres_sharded:\n" + self._cb.error)
+                                          self.params["restart"], _hx.ptr(self.ws), _hx.ptr(self._xe),
+                                          _hx.ptr(self._hbuf), C.byref(it), C.byref(rr), _hx.stream())
+            if rc != 0 and self.shard.callback_error():
+                raise RuntimeError("exchange callback failed inside hx_gmres_sharded:\n" + self.shard.callback_error())
             _hx.check(rc)
         else:
             _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
@@ -597,10 +833,10 @@ class AMGSolver:
         if self.shard is not None:
             rc = _hx.lib.hx_cocg_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                          self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
-                                         _hx.ptr(self.ws), _hx.ptr(self._bufs[_hx.BUF_GMRES_XE]),
-                                         _hx.ptr(self._bufs[_hx.BUF_GMRES_DOTS]), C.byref(it), C.byref(rr), _hx.stream())
-            if rc != 0 and self._cb.error:
-                raise RuntimeError("exchange callback failed inside hx_cocg_sharded:\n" + self._cb.error)
+                                         _hx.ptr(self.ws), _hx.ptr(self._xe),
+                                         _hx.ptr(self._hbuf), C.byref(it), C.byref(rr), _hx.stream())
+            if rc != 0 and self.shard.callback_error():
+                raise RuntimeError("exchange callback failed inside hx_cocg_sharded:\n" + self.shard.callback_error())
         else:
             rc = _hx.lib.hx_cocg(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                  self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"], _hx.ptr(self.ws),
@@ -656,7 +892,9 @@ class AMGSolver:
         self.harmonic_ritz = theta
 
     def stats(self):
-        return dict(recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)), levels=[lv["n"] for lv in self.levels],
+        return dict(recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)),
+                    levels=[lv.get("n_global", lv["n"]) for lv in self.levels],
+                    sharded_levels=[[lv["n"], lv["n_ext"] - lv["n"]] for lv in self.levels if lv.get("sharded")],
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
                     if self.sell else "csr",
                     stencil_slices=_hx.lib.hx_sell_stencil_slices(self.sell) if self.sell else 0, vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",

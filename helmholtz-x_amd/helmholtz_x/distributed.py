@@ -50,6 +50,80 @@ def shard_mesh(x, cells, r0, r1):
                 local_to_global=l2g, cell_ids=keep)
 
 
+class DistComm:
+    """``mesh.comm`` of a distributed local mesh: the few host-side reductions the reference makes through
+    ``MPI.COMM_WORLD.allreduce`` (boundary areas, flame volumes, normalisation integrals: acoustic_matrices.py:76-90,
+    parameters_utils.py:216,236, dolfinx_utils.py:43,53) -- scalars or small arrays, summed (or max-ed) over the ranks."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.size = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def allreduce(self, v, op="sum"):
+        if self.size == 1:
+            return v
+        a = np.atleast_1d(np.asarray(v))
+        t = torch.from_numpy(np.ascontiguousarray(a.astype(np.complex128 if np.iscomplexobj(a) else np.float64)))
+        buf = torch.view_as_real(t) if t.is_complex() else t
+        if dist.get_backend(self.group) == "nccl":
+            dev = buf.cuda()
+            dist.all_reduce(dev, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(dev.cpu())
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
+        out = t.numpy()
+        return out[0].item() if np.ndim(v) == 0 else out.reshape(np.shape(v))
+
+
+def distribute_mesh(mesh, ranges, rank, cell_tags=None, facet_tags=None, fields=(), group=None):
+    """This rank's part of a mesh that every rank holds as host arrays (what ``XDMFFile.read_mesh`` hands each MPI rank of
+    the reference: its cells plus one ghost layer, io_utils.py:149-155): the cells touching a vertex of [r0, r1), vertices
+    renumbered [owned | ghost] (``shard_mesh``), the tagged facets with an owned vertex, tags and coefficient fields cut to
+    the local entities.  The assembly kernels run on it unchanged and produce this rank's matrix ROWS over
+    [owned | ghost] columns with no assembly communication (owner computes).
+
+    Returns (local_mesh, local_cell_tags, local_facet_tags, local_fields).  ``local_mesh.part`` carries the maps:
+    r0, r1, n_own, n_global, local_to_global, cell_ids, cell_owned (a cell belongs to the rank that owns its lowest
+    vertex: used for volume / area sums), facet_ids, ranges."""
+    from .fem import Function, FunctionSpace, Mesh, MeshTags
+    r0, r1 = ranges[rank]
+    x, cells = mesh.geometry.x, mesh.topology.cells
+    sh = shard_mesh(x, cells, r0, r1)
+    l2g, keep, n_own = sh["local_to_global"], sh["cell_ids"], sh["n_own"]
+    g2l = np.full(x.shape[0], -1, dtype=np.int64)
+    g2l[l2g] = np.arange(l2g.size)
+    fv = mesh.facets
+    fkeep = np.flatnonzero(((fv >= r0) & (fv < r1)).any(axis=1)) if fv.size else np.zeros(0, np.int64)
+    lf = np.sort(g2l[fv[fkeep]], axis=1) if fkeep.size else np.zeros((0, fv.shape[1] if fv.ndim == 2 else 1), np.int64)
+    fcell = np.searchsorted(keep, mesh.facet_cells[fkeep])
+    assert fkeep.size == 0 or (np.array_equal(keep[fcell], mesh.facet_cells[fkeep]) and lf.min() >= 0)
+    local = Mesh(sh["x"], sh["cells"], facets=lf.astype(np.int32), facet_cells=fcell.astype(np.int32))
+    low = cells[keep].min(axis=1)
+    local.part = dict(r0=r0, r1=r1, n_own=n_own, n_global=x.shape[0], local_to_global=l2g, cell_ids=keep,
+                      cell_owned=(low >= r0) & (low < r1), facet_ids=fkeep, ranges=list(ranges), rank=rank,
+                      n_cells_global=cells.shape[0])
+    flow = fv[fkeep].min(axis=1) if fkeep.size else np.zeros(0, np.int64)
+    local.part["facet_owned"] = (flow >= r0) & (flow < r1)
+    local.comm = DistComm(group)
+
+    def cut_tags(tags, ids):
+        if tags is None:
+            return None
+        pos = np.searchsorted(ids, tags.indices)
+        ok = (pos < ids.size)
+        ok[ok] = ids[pos[ok]] == tags.indices[ok]
+        return MeshTags(local, tags.dim, pos[ok], tags.values[ok])
+
+    out_fields = []
+    for f in fields:
+        kind = f.function_space.kind
+        g = Function(FunctionSpace(local, "DG", 0) if kind == "DG0" else FunctionSpace(local, "CG", 1), f.name)
+        g.x.array[:] = f.x.array[keep] if kind == "DG0" else f.x.array[l2g]
+        out_fields.append(g)
+    return local, cut_tags(cell_tags, keep), cut_tags(facet_tags, fkeep), out_fields
+
+
 class HaloPlan:
     """Ghost columns of a rank, grouped by owner, and the matching send lists (built with one all_gather of the
     ghost id lists -- integer set-up work)."""
@@ -75,12 +149,14 @@ class HaloPlan:
             if mine.size:
                 self.send_to[p] = (mine - self.r0).astype(np.int64)
         self.n_ghost = int(ghost_global.size)
+        self.n_exchanges = 0
         self._dev_idx = {}
         self._send_span = {}         # neighbour -> (a, b) if its send list is the contiguous owned range [a, b), else False
         self._send_buf = {}
 
     def exchange(self, x_ext, n_own):
-        """Fill x_ext[n_own:] (ghost block) with the owners' current values of x_ext[:n_own] (complex64 or complex128).
+        """Fill x_ext[n_own:] (ghost block) with the owners' current values of x_ext[:n_own] (complex64 / complex128 iterates;
+        int32 / float64 vectors of the hierarchy set-up).
         Ghost ids ascend and owners hold contiguous ranges, so each neighbour's entries form one contiguous slice of
         the ghost block: received in place, no scatter."""
         if self.world == 1 or (not self.send_to and not self.recv_from):
@@ -104,14 +180,15 @@ class HaloPlan:
                 if bkey not in self._send_buf:
                     self._send_buf[bkey] = torch.empty(len(idx), dtype=x_ext.dtype, device=x_ext.device)
                 src = torch.index_select(x_ext[:n_own], 0, self._dev_idx[key], out=self._send_buf[bkey])
-            buf = torch.view_as_real(src)
+            buf = torch.view_as_real(src) if src.is_complex() else src
             buf = buf.cpu() if stage else buf
             keep.append(buf)
             ops.append(dist.P2POp(dist.isend, buf, p, group=self.group))
         for p, pos in sorted(self.recv_from.items()):
             a, b = int(pos[0]), int(pos[-1]) + 1
             assert b - a == len(pos), "ghost entries of one owner must be contiguous"
-            dst = torch.view_as_real(x_ext[n_own + a:n_own + b])
+            dst = x_ext[n_own + a:n_own + b]
+            dst = torch.view_as_real(dst) if dst.is_complex() else dst
             if stage:
                 buf = torch.empty(dst.shape, dtype=dst.dtype, device="cpu")
                 staged.append((dst, buf))
@@ -122,7 +199,90 @@ class HaloPlan:
             req.wait()
         for dst, buf in staged:
             dst.copy_(buf)
-        self.n_exchanges = getattr(self, "n_exchanges", 0) + 1
+        self.n_exchanges += 1
+
+    def native_arrays(self):
+        """The plan as the HOST arrays hx_comm_set_plan takes: send lists (owned indices) per peer, receive ranges of the
+        extended vector per peer (ghost entries of one owner are contiguous: ghost ids ascend, owners hold ranges)."""
+        n_own = self.r1 - self.r0
+        sp = sorted(self.send_to)
+        send_peer = np.array(sp, dtype=np.int32)
+        send_ptr = np.zeros(len(sp) + 1, dtype=np.int64)
+        send_ptr[1:] = np.cumsum([len(self.send_to[p]) for p in sp])
+        send_idx = np.concatenate([self.send_to[p] for p in sp]).astype(np.int32) if sp else np.zeros(0, np.int32)
+        rp_ = sorted(self.recv_from)
+        recv_peer = np.array(rp_, dtype=np.int32)
+        recv_off = np.array([n_own + int(self.recv_from[p][0]) for p in rp_], dtype=np.int64)
+        recv_cnt = np.array([len(self.recv_from[p]) for p in rp_], dtype=np.int64)
+        for p in rp_:
+            pos = self.recv_from[p]
+            assert int(pos[-1]) - int(pos[0]) + 1 == len(pos), "ghost entries of one owner must be contiguous"
+        return send_peer, send_ptr, send_idx, recv_peer, recv_off, recv_cnt
+
+    def exchange_rows(self, rowptr, col, val):
+        """Sparse-row halo of the set-up: CSR rows (device: int32 rowptr over the OWNED rows, int32 col, val) of this rank's
+        owned entities listed in the send lists go to the ranks holding them as ghosts; returns the rows of MY ghost entities
+        in ghost order as (rowptr, col, val) device tensors.  Three messages per neighbour (row lengths, columns, values):
+        host-driven torch.distributed point-to-point -- set-up only, a handful of calls per hierarchy level."""
+        dev = col.device
+        backend = dist.get_backend(self.group) if dist.is_initialized() else "none"
+        stage = backend == "gloo"
+        lens_own = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        sends, keep = [], []
+        for p, idx in sorted(self.send_to.items()):
+            ii = torch.from_numpy(idx).to(dev)
+            ln = lens_own[ii]
+            start = rowptr[:-1].to(torch.int64)[ii]
+            tot = int(ln.sum().item())
+            # entry positions of the listed rows, row after row
+            off = torch.cumsum(ln, 0) - ln
+            pos = torch.repeat_interleave(start - off, ln) + torch.arange(tot, device=dev, dtype=torch.int64)
+            sends.append((p, ln.to(torch.int32).contiguous(), col[pos].contiguous(), val[pos].contiguous()))
+        # 1) row lengths
+        ops, recv_len = [], {}
+        for p, ln, _, _ in sends:
+            b = ln.cpu() if stage else ln
+            keep.append(b)
+            ops.append(dist.P2POp(dist.isend, b, p, group=self.group))
+        for p, pos in sorted(self.recv_from.items()):
+            b = torch.empty(len(pos), dtype=torch.int32, device="cpu" if stage else dev)
+            recv_len[p] = b
+            ops.append(dist.P2POp(dist.irecv, b, p, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        # 2) columns and values
+        ops, recv_col, recv_val = [], {}, {}
+        for p, _, c, v in sends:
+            vr = torch.view_as_real(v) if v.is_complex() else v
+            bc, bv = (c.cpu(), vr.cpu()) if stage else (c, vr)
+            keep += [bc, bv]
+            ops.append(dist.P2POp(dist.isend, bc, p, group=self.group))
+            ops.append(dist.P2POp(dist.isend, bv, p, group=self.group))
+        for p in sorted(self.recv_from):
+            tot = int(recv_len[p].sum().item())
+            bc = torch.empty(tot, dtype=torch.int32, device="cpu" if stage else dev)
+            shape = (tot, 2) if val.is_complex() else (tot,)
+            bv = torch.empty(shape, dtype=torch.float64 if val.dtype in (torch.complex128, torch.float64) else torch.float32,
+                             device="cpu" if stage else dev)
+            recv_col[p], recv_val[p] = bc, bv
+            ops.append(dist.P2POp(dist.irecv, bc, p, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, bv, p, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        order = sorted(self.recv_from, key=lambda p: int(self.recv_from[p][0]))      # ghost order = ascending position
+        lens = torch.cat([recv_len[p].to(dev) for p in order]) if order else torch.zeros(0, dtype=torch.int32, device=dev)
+        rp = torch.zeros(lens.numel() + 1, dtype=torch.int32, device=dev)
+        if lens.numel():
+            rp[1:] = torch.cumsum(lens.to(torch.int64), 0).to(torch.int32)
+        gc = torch.cat([recv_col[p].to(dev) for p in order]) if order else torch.zeros(0, dtype=torch.int32, device=dev)
+        if order:
+            gv = torch.cat([recv_val[p].to(dev) for p in order])
+            gv = torch.view_as_complex(gv.contiguous()) if val.is_complex() else gv
+        else:
+            gv = torch.zeros(0, dtype=val.dtype, device=dev)
+        return rp, gc, gv
 
 
 class ShardedOperator:

@@ -324,6 +324,27 @@ class P1Assembler:
     def _csr(self, val):
         out = CSR((self.n, self.n), self.rowptr, self.col, val, pattern_id=self.pattern_id)
         out.symmetric = True            # Galerkin P1 operators are (complex) symmetric: transpose() is the identity
+        return self._own_rows(out)
+
+    def _own_rows(self, csr):
+        """Distributed local mesh (``mesh.part``: vertices numbered [owned | ghost]): the assembled rows of the OWNED
+        vertices are complete (every cell touching them is local) -- keep those, over [owned | ghost] columns.  The ghost
+        rows (incomplete) are dropped: the owner computes them (acoustic_matrices.py:101-103 ships such rows instead)."""
+        part = getattr(self.mesh, "part", None)
+        if part is None:
+            return csr
+        n_own = part["n_own"]
+        key = ("own", csr.pattern_id)
+        cache = self.__dict__.setdefault("_own_cache", {})
+        if key not in cache:
+            nnz = int(csr.rowptr[n_own].item())
+            cache.clear()
+            cache[key] = (csr.rowptr[:n_own + 1].contiguous(), nnz)
+        rp, nnz = cache[key]
+        out = CSR((n_own, csr.shape[1]), rp, csr.col[:nnz], None if csr.val is None else csr.val[:nnz],
+                  pattern_id=("own", csr.pattern_id))
+        out.symmetric = getattr(csr, "symmetric", False)
+        out.local = True
         return out
 
     @staticmethod
@@ -378,6 +399,13 @@ class P1Assembler:
                                                _hx.stream()))
         out = CSR((self.n, self.n), rowptr, col, val)
         out.symmetric = True            # boundary mass matrix: B^T = B, so B_adj = B^H is the conjugate (no host transpose)
+        part = getattr(self.mesh, "part", None)
+        if part is not None:            # distributed local mesh: owned rows only
+            n_own = part["n_own"]
+            nnz = int(rowptr[n_own].item())
+            own = CSR((n_own, self.n), rowptr[:n_own + 1].contiguous(), col[:nnz], val[:nnz])
+            own.symmetric, own.local = True, True
+            return Mat.from_csr(own)
         return Mat.from_csr(out)
 
     # ---- load vectors (device tensors of length n)
@@ -443,8 +471,9 @@ class P1Assembler:
             self._vol = vol.cpu().numpy()
         return self._vol
 
-    def locate_points(self, points, tol=1e-10):
-        """Lowest-index cell containing each point (n_pts x 3) -> int32 host array (raises if a point is outside)."""
+    def locate_points(self, points, tol=1e-10, must_find=True):
+        """Lowest-index cell containing each point (n_pts x 3) -> int32 host array (raises if a point is outside; with
+        ``must_find=False`` -- distributed local meshes -- such points get -1 instead)."""
         pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
         d_pts = to_device(pts)
         out = torch.full((pts.shape[0],), 2 ** 31 - 1, dtype=torch.int32, device=self.x.device)
@@ -452,6 +481,8 @@ class P1Assembler:
                                               _hx.ptr(d_pts), float(tol), _hx.ptr(out), _hx.stream()))
         cells = out.cpu().numpy()
         if (cells == 2 ** 31 - 1).any():
+            if not must_find:
+                return np.where(cells == 2 ** 31 - 1, -1, cells)
             raise ValueError("reference point(s) %s outside the mesh" % (pts[cells == 2 ** 31 - 1],))
         return cells
 

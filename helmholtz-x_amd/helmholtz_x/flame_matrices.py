@@ -88,10 +88,14 @@ class FlameMatrix:
 
     def _store(self, pairs, problem_type):
         n = self.global_size
+        part = getattr(self.mesh, "part", None)
+        local = part is not None        # distributed local mesh: the factors hold this rank's OWNED entries (local indices)
+        if local:
+            n = part["n_own"]
         if problem_type == 'direct':
-            self._D_ij = Mat((n, n), lr_terms=[(1.0, LowRank(n, pairs))])
+            self._D_ij = Mat((n, n), lr_terms=[(1.0, LowRank(n, pairs, local))])
         elif problem_type == 'adjoint':            # plain transpose, no conjugate (flame_matrices.py:84-89)
-            self._D_ij_adj = Mat((n, n), lr_terms=[(1.0, LowRank(n, [(r, l) for l, r in pairs]))])
+            self._D_ij_adj = Mat((n, n), lr_terms=[(1.0, LowRank(n, [(r, l) for l, r in pairs], local))])
         else:
             raise ValueError("The problem type should be specified as 'direct' or 'adjoint'.")
         info("- Submatrix D is Assembled.")
@@ -166,10 +170,14 @@ class PointwiseFlameMatrix(FlameMatrix):
         t_idx, t_val = np.asarray(self.subdomains.indices), np.asarray(self.subdomains.values)
         cells = self.mesh.topology.cells
         supports = [np.unique(cells[t_idx[t_val == f]]).astype(np.int32) for f in range(nf)]
+        part = getattr(self.mesh, "part", None)
+        if part is not None:             # distributed local mesh: this rank's OWNED entries (every cell touching them is local)
+            supports = [sp_[sp_ < part["n_own"]] for sp_ in supports]
         rows = np.concatenate(supports) if nf else np.zeros(0, np.int32)
         row_tag = np.repeat(np.arange(nf, dtype=np.int32), [len(sp_) for sp_ in supports])
         vals = asm.load_rows(0, rows, h_dev, scale=(self.gamma - 1) * self.q_0 / self.u_b,
-                             cell_tag=asm.cell_tag_array(self.subdomains), row_tag=row_tag).cpu().numpy()
+                             cell_tag=asm.cell_tag_array(self.subdomains), row_tag=row_tag).cpu().numpy() \
+            if rows.size else np.zeros(0, np.complex128)
         out, o = [], 0
         for f in range(nf):
             v = vals[o:o + len(supports[f])].copy()
@@ -180,19 +188,45 @@ class PointwiseFlameMatrix(FlameMatrix):
             out.append((supports[f][nz], v[nz]))
         return out
 
+    def _locate_distributed(self):
+        """Reference points on a distributed mesh (flame_matrices.py:144-158: determine_point_ownership + broadcast): every
+        rank searches its local cells, the ranks agree on the LOWEST GLOBAL cell id that holds each point (the serial rule),
+        and a rank that holds that cell evaluates the gradient there.  Returns local cell indices, -1 where the cell is not
+        local (none of its vertices is owned here then)."""
+        part, asm = self.mesh.part, self.mesh.assembler()
+        loc = asm.locate_points(self.x_r, must_find=False).astype(np.int64)
+        big = np.iinfo(np.int64).max // 4
+        glob = np.where(loc >= 0, part["cell_ids"][np.maximum(loc, 0)], big).astype(np.float64)
+        chosen = -np.asarray(self.mesh.comm.allreduce(-glob, op="max"))            # min over ranks
+        if (chosen >= big).any():
+            raise ValueError("reference point(s) outside the mesh")
+        chosen = chosen.astype(np.int64)
+        pos = np.searchsorted(part["cell_ids"], chosen)
+        ok = (pos < part["cell_ids"].size)
+        ok[ok] = part["cell_ids"][pos[ok]] == chosen[ok]
+        return np.where(ok, pos, -1)
+
     def assemble_submatrices(self, problem_type='direct'):
         info("- Generating matrix D..")
         pairs = []
         lefts = self._left_vectors_batched()
+        part = getattr(self.mesh, "part", None)
         for flame, point in enumerate(self.x_r):
             if lefts is None:
                 pairs.append(self._assemble_vectors(flame, point))
             else:
                 if getattr(self, "_x_r_cells", None) is None:             # all reference points in ONE device pass
-                    self._x_r_cells = self.mesh.assembler().locate_points(self.x_r)
+                    self._x_r_cells = self._locate_distributed() if part is not None \
+                        else self.mesh.assembler().locate_points(self.x_r)
                 c = int(self._x_r_cells[flame])
-                right = (self.mesh.topology.cells[c].astype(np.int32),
-                         (_cell_gradients(self.mesh, c) @ self.n_r) / self.rho_u + 0j)
+                if c < 0:                 # the cell that holds the point lives on other ranks only
+                    right = (np.zeros(0, np.int32), np.zeros(0, np.complex128))
+                else:
+                    right = (self.mesh.topology.cells[c].astype(np.int32),
+                             (_cell_gradients(self.mesh, c) @ self.n_r) / self.rho_u + 0j)
+                    if part is not None:  # keep the entries of the vertices this rank owns
+                        mine = right[0] < part["n_own"]
+                        right = (right[0][mine], right[1][mine])
                 pairs.append((lefts[flame], right))
             info("- Matrix contribution of flame " + str(flame) + " is computed.")
         self._store(pairs, problem_type)

@@ -112,15 +112,26 @@ def Q_volumetric(mesh, subdomains, Q_total, flame_tag=0, degree=0):
     """DG0 heat-release density: Q_total / V_flame on the cells tagged ``flame_tag``."""
     q = Function(FunctionSpace(mesh, "DG", degree), "q")
     cells = subdomains.find(flame_tag)
-    q.x.array[cells] = Q_total / mesh.assembler().cell_volumes()[cells].sum()
+    q.x.array[cells] = Q_total / _volume(mesh, cells)
     return q
+
+
+def _volume(mesh, cells):
+    """Volume of a set of cells; on a distributed local mesh every cell counts on the one rank that owns it and the ranks'
+    sums are added (the reference: MPI allreduce, parameters_utils.py:216,236)."""
+    vol = mesh.assembler().cell_volumes()[cells]
+    part = getattr(mesh, "part", None)
+    if part is None:
+        return vol.sum()
+    return float(mesh.comm.allreduce(float(vol[part["cell_owned"][cells]].sum())))
 
 
 def Q_multiple(mesh, subdomains, N_sector, degree=0):
     """DG0 field equal to 1/V_f on the cells of flame f = 0..N_sector-1."""
     q = Function(FunctionSpace(mesh, "DG", degree), "q")
-    vol = mesh.assembler().cell_volumes()
     for flame in range(N_sector):
         cells = subdomains.find(flame)
-        q.x.array[cells] = 1.0 / vol[cells].sum()
+        v = _volume(mesh, cells)          # (collective on a distributed mesh: every rank takes part for every flame)
+        if cells.size:
+            q.x.array[cells] = 1.0 / v
     return q

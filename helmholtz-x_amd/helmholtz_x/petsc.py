@@ -150,6 +150,7 @@ class CSR:
     def with_values(self, val):
         out = CSR(self.shape, self.rowptr, self.col, val, self._h_rowptr, self._h_col, self.pattern_id)
         out.symmetric = getattr(self, "symmetric", False)
+        out.local = getattr(self, "local", False)      # this rank's rows over [owned | ghost] columns (row-sharded run)
         return out
 
     def spmv(self, x, y, alpha=1.0, beta=0.0, lanes=0):
@@ -161,7 +162,9 @@ class CSR:
 class LowRank:
     """sum_f u_f v_f^T with sparse u_f, v_f given as (int32 idx, complex128 val) host pairs."""
 
-    def __init__(self, n, pairs):
+    def __init__(self, n, pairs, local=False):
+        """``local``: indices are this rank's OWNED local rows (row-sharded run; n = owned rows)."""
+        self.local = bool(local)
         self.n = int(n)
         self.pairs = [((np.asarray(ui, np.int32), np.asarray(uv, np.complex128)),
                        (np.asarray(vi, np.int32), np.asarray(vv, np.complex128))) for (ui, uv), (vi, vv) in pairs]
@@ -171,10 +174,10 @@ class LowRank:
         return len(self.pairs)
 
     def transposed(self):
-        return LowRank(self.n, [(v, u) for u, v in self.pairs])
+        return LowRank(self.n, [(v, u) for u, v in self.pairs], self.local)
 
     def conjugated(self):
-        return LowRank(self.n, [((ui, uv.conj()), (vi, vv.conj())) for (ui, uv), (vi, vv) in self.pairs])
+        return LowRank(self.n, [((ui, uv.conj()), (vi, vv.conj())) for (ui, uv), (vi, vv) in self.pairs], self.local)
 
     def to_scipy(self):
         M = sp.csr_matrix((self.n, self.n), dtype=np.complex128)

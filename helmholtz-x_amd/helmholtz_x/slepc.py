@@ -181,13 +181,14 @@ class WoodburySolver:
         dev = inner.tmp.device if hasattr(inner, "tmp") else _hx.require_gpu()
         # stack all rank-1 pieces: U (r x n dense rows), V packed sparse, coefficient per piece
         self.coefs = np.concatenate([np.full(lr.rank, c, dtype=np.complex128) for c, lr in terms])
-        U = torch.cat([lr.left_dense() for _, lr in terms], dim=0)
-        if shard is not None:
-            U = shard.own_slice(U).contiguous()
+        # row-sharded: factors assembled on a distributed mesh hold this rank's owned entries already (lr.local); factors
+        # given on the global numbering are cut to the owned rows here
+        U = torch.cat([lr.left_dense() if (shard is None or lr.local) else shard.own_slice(lr.left_dense()).contiguous()
+                       for _, lr in terms], dim=0)
         ptrs, idxs, vals, off = [np.zeros(1, np.int32)], [], [], 0
         for _, lr in terms:
             for _, (vi, vv) in lr.pairs:
-                if shard is not None:
+                if shard is not None and not lr.local:
                     mine = (vi >= shard.r0) & (vi < shard.r1)
                     vi, vv = (vi[mine] - shard.r0).astype(np.int32), vv[mine]
                 idxs.append(vi)
@@ -795,7 +796,7 @@ class EPS(_EigenSolverBase):
                 Mloc.spmv(xe, tmp)
                 solver.solve(tmp, w, relax=basis.relax)
 
-            basis = DeviceBasis(n_loc, self._ncv_for(n) + 1, op, start=self._start(), shard=sh, pool=self._pool())
+            basis = DeviceBasis(n_loc, self._ncv_for(sh.n_global) + 1, op, start=self._start(), shard=sh, pool=self._pool())
             self._finish(basis, sigma)
             return
         tmp = torch.empty(n, dtype=torch.complex128, device=Mcsr.val.device)
@@ -877,7 +878,7 @@ class PEP(_EigenSolverBase):
                 cf = (C.c_double * 4)(1.0, 0.0, sigma.real, sigma.imag)
                 _hx.check(_hx.lib.hx_zlincomb(m, 2, cf, arr, _hx.ptr(y2), _hx.stream()))
 
-            basis = DeviceBasis(2 * m, self._ncv_for(2 * n) + 1, op, start=self._start(), shard=sh, blocks=2,
+            basis = DeviceBasis(2 * m, self._ncv_for(2 * sh.n_global) + 1, op, start=self._start(), shard=sh, blocks=2,
                                 pool=self._pool())
             self._finish(basis, sigma)
             self._n = m

@@ -342,27 +342,51 @@ int hx_cocg(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int3
             const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it, hx_c128* ws, int* h_iters,
             double* h_relres, hx_stream s);
 /* ---- Row-sharded mode (one process per GPU).  Replaces what the reference gets from PETSc's
- * parallel Mat/KSP under mpirun (eigensolvers.py:43-62 with a distributed A): level 0 of the hierarchy holds THIS rank's
- * rows of K over [owned | ghost] columns (hx_amg_set_level* with n = owned rows, R = (P rows owned)^T), every coarser
- * level is replicated.  The two exchange steps are delegated to the caller, which owns the communicator
- * (torch.distributed over RCCL on the host side):
- *   halo(ctx, buf)             fill the ghost block [n_own, n_ext) of registered buffer `buf` from the owning ranks
- *   allreduce(ctx, buf, count) sum the first `count` complex entries of registered buffer `buf` over all ranks
- * Both return 0 on success and must be ordered against the stream the library is launching on.  Registered buffers: */
-enum {
-  HX_BUF_VCYCLE_X0 = 0,   /* level-0 iterates x, x2, x3 (ids 0..2; working precision of the V-cycle; n_ext entries) */
-  HX_BUF_COARSE_RHS = 3,  /* level-1 right-hand side (working precision; n_1 entries; summed over ranks)        */
-  HX_BUF_GMRES_XE = 4,    /* complex128 staging vector for K products of hx_gmres_sharded (n_ext entries)        */
-  HX_BUF_GMRES_DOTS = 5   /* complex128 inner products of hx_gmres_sharded (restart + 2 + k_max entries)         */
-};
-typedef int (*hx_halo_fn)(void* ctx, int buf);
-typedef int (*hx_allreduce_fn)(void* ctx, int buf, int count);
-/* Call after level 0 and level 1 are set; x, x2, x3 (n_ext entries each) and coarse_b (n_1 entries) are caller-owned
- * device arrays in the V-cycle's working precision (complex64 once hx_amg_set_level_c was used, else complex128). */
-int hx_amg_set_sharded(hx_amg* h, int32_t n_ext, void* x, void* x2, void* x3, void* coarse_b, hx_halo_fn halo,
-                       hx_allreduce_fn allreduce, void* ctx);
+ * parallel Mat / KSP / PC under mpirun (eigensolvers.py:43-62 with a distributed A; run lines
+ * numerical_examples/AnnularCombustor/Micca/fullAnnulus/runAll.sh:9-10): the first `n_sharded` levels of the hierarchy
+ * hold THIS rank's rows of K_l over [owned | ghost] columns (hx_amg_set_level* with n = owned rows; P_l: owned rows over
+ * the [owned | ghost] columns of level l + 1; R_l: owned rows of level l + 1 over the [owned | ghost] columns of level l,
+ * i.e. the owner computes its coarse right-hand side from exchanged fine residuals), every coarser level is replicated
+ * (the restriction onto the first replicated level sums the ranks' partial right-hand sides with one all-reduce).
+ * The two exchange steps go through callbacks, both enqueued on / ordered against stream `s`:
+ *   halo(ctx, level, x_ext, elem_bytes, s)   fill the ghost block [n_own_l, n_ext_l) of the level-l vector x_ext (elements of
+ *                                            elem_bytes = 8: complex64, 16: complex128) from the owning ranks
+ *   allreduce(ctx, buf, count, dtype, op, s) reduce `count` REAL numbers in place over all ranks (dtype 0: float32,
+ *                                            1: float64; op 0: sum, 1: max); complex data = 2 reals per entry
+ * Production: hx_comm_halo / hx_comm_allreduce with an hx_comm as ctx (RCCL issued by the library, below).  The caller
+ * may supply its own (the gloo rehearsal path of the tests wraps torch.distributed).  Both return 0 on success. */
+typedef int (*hx_halo_fn)(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s);
+typedef int (*hx_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype, int op, hx_stream s);
+/* Call after every level is set.  n_ext[l] = owned + ghost length of level l < n_sharded (1 <= n_sharded < levels): the
+ * handle re-allocates its level-l work vectors with that length. */
+int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext, hx_halo_fn halo, hx_allreduce_fn allreduce,
+                       void* ctx);
+/* ---- RCCL communicator owned by the library (comm.hip).  librccl is bound at run time (the copy the process already
+ * loaded, else librccl.so.1; HX_RCCL_LIB overrides).  Rank 0 draws an id (hx_comm_unique_id) and ships its
+ * HX_COMM_ID_BYTES bytes to the other ranks by whatever channel the host side has (torch.distributed broadcast); every
+ * rank then calls hx_comm_create (collective, its GPU current).  Exchange plans are set once per hierarchy level from HOST
+ * arrays; hx_comm_exchange / hx_comm_halo / hx_comm_allreduce enqueue ncclSend/ncclRecv groups and ncclAllReduce on the
+ * caller's stream -- no host synchronisation.
+ * replaces: VecScatterBegin/End inside MatMult and MPI_Allreduce inside BVDot / VecNorm of the reference's PETSc / SLEPc
+ * objects (reached from eigensolvers.py:62, 113); dolfinx_utils.py:187-207 are its only hand-written collectives. */
+#define HX_COMM_ID_BYTES 128
+typedef struct hx_comm hx_comm;
+int hx_comm_unique_id(void* out, int nbytes);
+int hx_comm_create(hx_comm** out, int rank, int world, const void* id, int nbytes);
+int hx_comm_destroy(hx_comm* c);
+const char* hx_comm_library(void);        /* which librccl was bound ("" before the first use) */
+/* plan: send_peer[ns], send_ptr[ns + 1] into send_idx (indices into the source buffer, per peer) and recv_peer[nr],
+ * recv_off[nr], recv_cnt[nr] (element range of the destination buffer filled by that peer).  HOST arrays, copied. */
+int hx_comm_set_plan(hx_comm* c, int plan, int ns, const int32_t* send_peer, const int64_t* send_ptr,
+                     const int32_t* send_idx, int nr, const int32_t* recv_peer, const int64_t* recv_off,
+                     const int64_t* recv_cnt);
+int hx_comm_exchange(hx_comm* c, int plan, const void* src, void* dst, int elem_bytes, hx_stream s);
+int hx_comm_halo(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s);          /* an hx_halo_fn */
+int hx_comm_allreduce(void* ctx, void* buf, int64_t count, int dtype, int op, hx_stream s); /* an hx_allreduce_fn */
+int hx_comm_counters(const hx_comm* c, int64_t* n_exchange, int64_t* n_allreduce, int reset);
 /* hx_gmres on the row-sharded operator: K = local rows over [owned | ghost] columns, b / x / ws sized by n_own;
- * xe (n_ext) and hbuf (restart + 2 + k_max recycled pairs) are the registered buffers above.  Every rank must call it collectively. */
+ * xe (n_ext complex128: staging vector for the K products) and hbuf (restart + 2 + k_max complex128: inner products, all-reduced)
+ * are caller-owned device arrays.  Every rank must call it collectively. */
 int hx_gmres_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr, const int32_t* col,
                      const hx_c128* val, const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it,
                      int restart, hx_c128* ws, hx_c128* xe, hx_c128* hbuf, int* h_iters, double* h_relres, hx_stream s);
@@ -384,6 +408,13 @@ int hx_cocg_sharded(hx_amg* M, int32_t n_own, int64_t nnz, const int32_t* rowptr
  *                           numeric pass by binary search); values real (float64) or complex128 per operand, C complex128.
  *                           The Galerkin operator is R (K P): two products. */
 int hx_csr_diagonal_z(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, hx_c128* diag, hx_stream s);
+/* row-sharded set-up (owned rows over [owned | ghost] columns): hx_sa_strength_diag fills sd for the owned rows so that its
+ * ghost entries can be exchanged before the filter passes; hx_sa_power_step is ONE step w = Df^-1 Lf v of the power
+ * iteration with |w|^2 left on the device (d_scratch: 1024 doubles), the ghost entries of v being exchanged between steps */
+int hx_sa_strength_diag(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, double sign, double* sd,
+                        hx_stream s);
+int hx_sa_power_step(int32_t n, const int32_t* rp, const int32_t* ci, const double* lf, const double* v, double* w,
+                     double* d_norm2, double* d_scratch, hx_stream s);
 int hx_sa_filter_count(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, double sign, double theta,
                        double* sd, int32_t* out_rp, int64_t* h_nnz, hx_stream s);
 int hx_sa_filter_fill(int32_t n, const int32_t* rp, const int32_t* ci, const hx_c128* val, double sign, double theta,

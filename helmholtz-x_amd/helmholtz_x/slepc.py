@@ -210,16 +210,34 @@ class WoodburySolver:
             # identical flames on a periodically numbered mesh: u_f is u_0 translated by s_f rows.  The translated solution
             # of flame 0 is then the initial guess for flame f -- exact when K has the same periodicity (an annular
             # combustor with identical burners), in which case the solve ends at its first residual check; a guess
-            # that is no good is dropped by the solver.  Single GPU, COCG route only.
+            # that is no good is dropped by the solver.  COCG route.  Row-sharded: the supports are compared on the GLOBAL
+            # numbering (gathered: a few hundred entries per flame) and the translate is a global cyclic shift of the
+            # row-sharded vector (segments travel point-to-point between the ranks that own source and destination).
             shifts = None
-            if shard is None and getattr(inner, "supports_x0", False) and self.r > 1 and W_WARM:
-                shifts = translation_shifts([u for _, lr in terms for (u, _) in lr.pairs], self.n)
+            if getattr(inner, "supports_x0", False) and self.r > 1 and W_WARM:
+                lefts = [u for _, lr in terms for (u, _) in lr.pairs]
+                if shard is None:
+                    shifts = translation_shifts(lefts, self.n)
+                else:
+                    if any(lr.local for _, lr in terms):
+                        import torch.distributed as dist
+                        mine = [(ui.astype(np.int64) + shard.r0, uv) for (ui, uv) in lefts]
+                        parts = [None] * shard.world
+                        dist.all_gather_object(parts, mine, group=shard.group)
+                        lefts = []
+                        for f in range(len(mine)):
+                            idx = np.concatenate([parts[p][f][0] for p in range(shard.world)])
+                            val = np.concatenate([parts[p][f][1] for p in range(shard.world)])
+                            order = np.argsort(idx, kind="stable")
+                            lefts.append((idx[order], val[order]))
+                    shifts = translation_shifts(lefts, shard.n_global)
             self.warm_started = 0
             for f in range(self.r):
                 # W only enters through the rank-r correction, whose weight in the eigenvalue is the flame's (a few
                 # per cent): a looser tolerance (W_RELAX) leaves the eigenvalues unchanged far below the parity bar
                 if shifts is not None and f > 0:
-                    self.W[f].copy_(torch.roll(self.W[0], shifts[f]))
+                    self.W[f].copy_(torch.roll(self.W[0], shifts[f]) if shard is None
+                                    else shard.cyclic_shift(self.W[0], shifts[f]))
                     inner.solve(U[f], self.W[f], relax=W_RELAX, x0=True)
                     self.warm_started += 1
                 else:

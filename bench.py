@@ -62,9 +62,9 @@ METRIC = "converged eigenpairs/sec + SpMV GB/s (% HBM roofline), AnnularCombusto
 
 def build_case(shape, numbering="native", jitter=0.0, resident=True):
     """The synthetic annular combustor.  ``numbering``: "native" = theta-major grid numbering of the generator (periodic,
-    extruded: what a structured mesher writes); "morton" = vertices renumbered along a space-filling curve (what a
-    locality-reordering reader such as DOLFINx's produces on an unstructured mesh); "random" = a random permutation (worst
-    case).  ``jitter``: interior nodes displaced by +-jitter*h (numpy.random.default_rng(0)), so that no two element matrices
+    extruded: what a structured mesher writes); "rcm" = a random numbering passed through reverse Cuthill-McKee (what a
+    bandwidth-reducing reader such as DOLFINx's leaves of an unstructured mesh file); "morton" = vertices renumbered along
+    a space-filling curve; "random" = a random permutation (worst case).  ``jitter``: interior nodes displaced by +-jitter*h (numpy.random.default_rng(0)), so that no two element matrices
     are equal either."""
     import numpy as np
     from scipy.io import loadmat
@@ -85,11 +85,26 @@ def build_case(shape, numbering="native", jitter=0.0, resident=True):
         n = mesh.num_vertices
         if numbering == "morton":
             perm = locality_permutation(mesh.geometry.x)
-        elif numbering == "random":
+        elif numbering in ("random", "rcm"):
             perm = np.random.default_rng(1).permutation(n).astype(np.int64)
         else:
-            raise ValueError("numbering must be native, morton or random")
+            raise ValueError("numbering must be native, rcm, morton or random")
         mesh = mesh.renumbered(perm)
+        if numbering == "rcm":
+            # what a bandwidth-reducing dof reordering (DOLFINx applies one to every mesh it reads) leaves of an arbitrary
+            # file numbering: reverse Cuthill-McKee of the vertex graph, here taken from the P1 sparsity pattern the
+            # assembler builds on the device for the randomly numbered mesh (host graph pass, outside the timed region)
+            import scipy.sparse as sp
+            from scipy.sparse.csgraph import reverse_cuthill_mckee
+            asm = mesh.assembler()
+            rp, ci = asm.rowptr.cpu().numpy(), asm.col.cpu().numpy()
+            G = sp.csr_matrix((np.ones(ci.size, np.int8), ci, rp), shape=(n, n))
+            order = reverse_cuthill_mckee(G, symmetric_mode=True)          # order[new] = old
+            del G, rp, ci
+            p2 = np.empty(n, dtype=np.int64)
+            p2[order] = np.arange(n)
+            mesh._assembler = None
+            mesh = mesh.renumbered(p2)
     if jitter > 0.0 or numbering != "native":       # cells and tagged facets keep their order: tags carry over
         facet_tags = MeshTags(mesh, facet_tags.dim, facet_tags.indices, facet_tags.values)
         subdomains = MeshTags(mesh, subdomains.dim, subdomains.indices, subdomains.values)
@@ -320,7 +335,7 @@ def parse_args(argv=None):
     ap.add_argument("--st-type", default=None, help="inner solver for the shifted operator: lu | amg | auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="annulus-34k")
-    ap.add_argument("--numbering", default="native", choices=["native", "morton", "random"],
+    ap.add_argument("--numbering", default="native", choices=["native", "rcm", "morton", "random"],
                     help="vertex numbering of the synthetic mesh (native = the generator's periodic grid numbering)")
     ap.add_argument("--jitter", type=float, default=0.0, help="displace interior nodes by +-JITTER*h")
     return ap.parse_args(argv)

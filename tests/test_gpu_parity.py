@@ -1309,3 +1309,115 @@ def test_rijkeffd_degree2_fixed_point(ref_logs, golden_dir):
     assert abs(omega_dir - golden) / abs(golden) < 3e-5
     p1 = complex(*ref_logs["rijkeffd_degree1"]["direct"])
     assert abs(omega_dir - golden) < 0.4 * abs(p1 - golden)          # P2 here is 3x closer to the reference's P2 than P1 is
+
+
+# ----------------------------------------------------------------------------- BASELINE configs at their STATED sizes
+def test_full_size_eigenpair_residual_5M():
+    """BASELINE config 4 / the bench's headline workload (annulus-5M, 5,005,056 DOF, nev = 4): every eigenpair the fixed point
+    returns satisfies (A + w B + w^2 C - FTF(w_k) sum a_f b_f^T) p = 0 with a backward error below 1e-9 (residual formed
+    with the product's own operators: size-independent property), and the eigenvalue bench.py prints is the one three
+    rounds of runs agree on to ten digits."""
+    import bench
+    import torch
+    from helmholtz_x.petsc import Vec
+    case = bench.build_case(bench.WORKLOADS["annulus-5M"])
+    hist = []
+    E, M = bench.hot_path(case, None, nev=4, tol=1e-3, history=hist)
+    assert E.getConverged() >= 4 and len(hist) - 1 == 6
+    A_active = E.getOperators()[0]                     # A - D(w_k) as a lazy Mat (CSR + rank-16)
+    n = M.A.shape[0]
+    assert n == 5005056
+    scale_A = float(torch.abs(A_active.csr_part().val).max().item())
+    for i in range(4):
+        w = E.getEigenvalue(i)
+        p, _ = M.A.createVecs()
+        E.getEigenvector(i, p)
+        r, t = Vec.zeros(n), Vec.zeros(n)
+        A_active.mult(p, r)
+        M.B.mult(p, t)
+        r.axpy(w, t)
+        M.C.mult(p, t)
+        r.axpy(w * w, t)
+        assert r.norm() <= 1e-9 * scale_A * p.norm(), (i, r.norm(), scale_A * p.norm())
+    w0 = E.getEigenvalue(0)
+    assert abs(w0 - (3528.25173 + 358.922167j)) < 1e-8 * abs(w0) + 2e-6      # (printed to 1e-6 by bench.py since round 1)
+    assert abs(hist[-1] - w0) < 1e-3
+    E.destroy()
+
+
+def test_config2_manufactured_box_640x160_against_dispersion_relation():
+    """BASELINE config 2 at its stated size: rectangle (640, 160) -> 103,201 DOF / 204,800 triangles, Robin top wall, PEP
+    nev = 2, the shift of every solve chained to the previous eigenvalue (manufacturedHelmholtz.py:36-53).  The computed
+    frequency must satisfy the ANALYTIC dispersion relation (matlab_data/dispersion2d.m:1-3) to the discretisation error of
+    this mesh (1e-6: sixteen times smaller than on the (160, 40) mesh of the reference run) -- no oracle solve involved."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.dolfinx_utils import RectangleSetup
+    from helmholtz_x.eigensolvers import pep_solver
+    from helmholtz_x.parameters_utils import c_uniform
+    mesh, subdomains, facet_tags = RectangleSetup(640, 160, 0.4, 0.1)
+    assert mesh.num_vertices == 103201 and mesh.num_cells == 204800
+    c = c_uniform(mesh, 450.0)
+    omega = 600 * 2 * np.pi
+    errs = []
+    for Z in np.linspace(-10, 10, 10)[:5]:
+        M = AcousticMatrices(mesh, facet_tags, {4: {'Robin': (Z - 1) / (Z + 1)}}, c)
+        E = pep_solver(M.A, M.B, M.C, omega, nev=2)
+        assert E.getConverged() >= 2
+        omega = E.getEigenvalue(0)
+        k = dispersion_root(omega / 450.0, Z)
+        errs.append(abs(omega - 450.0 * k) / abs(omega))
+    assert max(errs) < 2e-6, errs
+    # (160, 40) mesh of the reference: the error is ~16x larger, i.e. second-order convergence towards the analytic root
+    mesh_c, _, ft_c = RectangleSetup(160, 40, 0.4, 0.1)
+    Z = np.linspace(-10, 10, 10)[0]
+    Mc = AcousticMatrices(mesh_c, ft_c, {4: {'Robin': (Z - 1) / (Z + 1)}}, c_uniform(mesh_c, 450.0))
+    wc = pep_solver(Mc.A, Mc.B, Mc.C, 600 * 2 * np.pi, nev=2).getEigenvalue(0)
+    ec = abs(wc - 450.0 * dispersion_root(wc / 450.0, Z)) / abs(wc)
+    assert 10.0 < ec / errs[0] < 24.0, (ec, errs[0])
+
+
+def test_config5_bloch_sector_1p9M_direct_and_adjoint():
+    """BASELINE config 5 at its stated size: 1/16 sector (76, 76, 316) -> 1,879,493 DOF, Bloch number b = 1 (complex phase
+    rows), one pointwise flame with the state-space FTF, direct AND adjoint fixed-point runs
+    (AnnularCombustor/Micca/bloch/active.py).  Size-independent properties: the eigenvector satisfies the Bloch relation
+    p(master) = f_b p(slave) to rounding, and the adjoint eigenvalue is the conjugate of the direct one to 1e-8 (two
+    different operators, D^T with conj(FTF(conj w)) and B^H, solved independently)."""
+    from scipy.io import loadmat
+    from cases import Micca
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.bloch_operator import Blochifier
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.eigenvectors import normalize_eigenvector
+    from helmholtz_x.flame_matrices import PointwiseFlameMatrix
+    from helmholtz_x.flame_transfer_function import stateSpace
+    from helmholtz_x.parameters_utils import Q_multiple
+    from helmholtz_x.synthetic import annulus, micca_sound_speed
+    half = np.pi / 16
+
+    class Geometry:
+        pass
+
+    geo = Geometry()
+    geo.mesh, subdomains, geo.facet_tags = annulus(76, 76, 316, n_flames=1, sector=(-half, half))
+    mesh = geo.mesh
+    assert mesh.num_vertices == 1879493
+    bcs = {11: 'Neumann', 12: 'Master', 13: 'Slave'}
+    M = AcousticMatrices(mesh, geo.facet_tags, bcs, micca_sound_speed(mesh))
+    bloch = Blochifier(geo, bcs, 16, M)
+    mat = loadmat(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "micca_ftf.mat"))
+    FTF = stateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+    h = Q_multiple(mesh, subdomains, 1)
+    x_r = np.array([[Micca.r_r, 0.0, Micca.z_r]])
+    D = PointwiseFlameMatrix(mesh, subdomains, x_r, h, Micca.rho_amb, Micca.q_0, Micca.u_b, FTF, bloch_object=bloch)
+    D.assemble_submatrices('direct')
+    D.blochify('direct')
+    E = fixed_point_iteration(bloch, D, Micca.target, i=0, nev=2, tol=1e-3)
+    omega_dir, p_dir = normalize_eigenvector(mesh, E, 0, BlochRemapper=bloch.remapper, print_eigs=False)
+    D.assemble_submatrices('adjoint')
+    D.blochify('adjoint')
+    E_adj = fixed_point_iteration(bloch, D, Micca.target.conjugate(), i=0, nev=2, tol=1e-3, problem_type='adjoint')
+    omega_adj, _ = normalize_eigenvector(mesh, E_adj, 0, BlochRemapper=bloch.remapper, print_eigs=False)
+    assert abs(omega_adj - omega_dir.conjugate()) < 1e-8 * abs(omega_dir), (omega_dir, omega_adj)
+    pm, ps = p_dir.x.array[bloch.dofs_master], p_dir.x.array[bloch.dofs_slave]
+    assert np.max(np.abs(pm - bloch.f_b * ps)) < 1e-12 * np.max(np.abs(ps))
+    assert 3000 < omega_dir.real < 4200 and omega_dir.imag > 0           # the unstable first azimuthal mode of the sector

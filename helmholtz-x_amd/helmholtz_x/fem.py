@@ -385,6 +385,16 @@ class P1Assembler:
         """B = sum_f coef_f int_F c phi_k phi_j ds over the listed facets (acoustic_matrices.py:71,108-110).
         Returns a Mat on B's own (boundary-only) pattern."""
         facet_ids = np.asarray(facet_ids, dtype=np.int64)
+        if facet_ids.size == 0:
+            # no such facet here (a rank of a distributed mesh whose part does not touch the boundary): an operator without
+            # entries -- the Mat still exists, so that `if not B` chooses the same branch on every rank
+            part = getattr(self.mesh, "part", None)
+            rows = part["n_own"] if part is not None else self.n
+            dev = self.x.device
+            out = CSR((rows, self.n), torch.zeros(rows + 1, dtype=torch.int32, device=dev),
+                      torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.complex128, device=dev))
+            out.symmetric, out.local = True, part is not None
+            return Mat.from_csr(out)
         facets = to_device(self.mesh.facets[facet_ids])
         nf, k = facets.shape
         fcell = to_device(self.mesh.facet_cells[facet_ids])

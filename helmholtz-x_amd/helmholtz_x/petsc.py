@@ -154,6 +154,12 @@ class CSR:
         return out
 
     def spmv(self, x, y, alpha=1.0, beta=0.0, lanes=0):
+        if self.nnz == 0:                        # an operator without entries: y = beta y
+            if beta == 0.0:
+                y.zero_()
+            elif beta != 1.0:
+                _hx.check(_hx.lib.hx_zscal(y.numel(), _hx.z2(beta), _hx.ptr(y), _hx.stream()))
+            return
         _hx.check(_hx.lib.hx_csr_spmv_z(self.shape[0], self.nnz, _hx.ptr(self.rowptr), _hx.ptr(self.col),
                                         _hx.ptr(self.val), _hx.ptr(x), _hx.ptr(y), _hx.z2(alpha), _hx.z2(beta),
                                         lanes, _hx.stream()))
@@ -435,6 +441,9 @@ def combine_csr(shape, terms):
     terms = [(c, m) for c, m in terms if m is not None]
     if not terms:
         return None
+    if len(terms) > 1:              # operators without entries (a rank's part of a boundary operator) contribute nothing
+        kept = [(c, m) for c, m in terms if m.nnz > 0]
+        terms = kept if kept else terms[:1]
     if len(terms) == 1 and terms[0][0] == 1.0:
         return terms[0][1]
     # base pattern = the one with most nonzeros; if some term's pattern is not contained in it, use the union

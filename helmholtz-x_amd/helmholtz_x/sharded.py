@@ -172,6 +172,16 @@ class ShardContext:
         self.set_level_plan(0, self.ranges, ghost_global)
         self.n_ext = self.n_own + int(ghost_global.size)
 
+    def distribute(self, mesh, cell_tags=None, facet_tags=None, fields=()):
+        """This rank's part of ``mesh`` (distributed.distribute_mesh) wired to this context: the level-0 exchange plan is
+        the ghost layer of the local mesh.  Returns (local_mesh, local_cell_tags, local_facet_tags, local_fields); operators
+        assembled on ``local_mesh`` are this rank's rows and go straight into ``fixed_point_iteration(..., shard=self)``."""
+        from .distributed import distribute_mesh
+        local, ct, ft, fl = distribute_mesh(mesh, self.ranges, self.rank, cell_tags, facet_tags, fields, group=self.group)
+        self.set_ghosts(local.part["local_to_global"][local.part["n_own"]:])
+        local.shard = self
+        return local, ct, ft, fl
+
     # ---- operators
     def localize(self, M):
         """Rows [r0, r1) of the global device CSR ``M`` over [owned | ghost] columns (integer work on the device); an
@@ -323,7 +333,6 @@ class ShardedCallbacks:
 def distributed_case(case, group=None):
     """Partition the synthetic annulus case over the ranks: ShardContext + this rank's local mesh, tags and input fields
     (built once per case, like the single-GPU mesh upload: inputs are resident before the timed region)."""
-    from .distributed import distribute_mesh
     from .parameters_utils import Q_multiple
     d = case.get("dist")
     if d is not None:
@@ -335,10 +344,7 @@ def distributed_case(case, group=None):
         th = np.arctan2(x[:, 1], x[:, 0])
         plane = max(int(np.argmax(np.abs(th - th[0]) > 1e-12)), 1)     # rows per theta-plane: cut the slabs between planes
     shard = ShardContext(mesh.num_vertices, group=group, align=plane)
-    local, sub_l, ft_l, (c_l,) = distribute_mesh(mesh, shard.ranges, shard.rank, case["subdomains"], case["facet_tags"],
-                                                  [case["c"]], group=group)
-    shard.set_ghosts(local.part["local_to_global"][local.part["n_own"]:])
-    local.shard = shard
+    local, sub_l, ft_l, (c_l,) = shard.distribute(mesh, case["subdomains"], case["facet_tags"], [case["c"]])
     local.assembler()                                  # local mesh arrays -> HBM
     c_l.resident()
     h_l = Q_multiple(local, sub_l, case["P"].N_sector).resident()

@@ -1,9 +1,10 @@
 """Bloch-periodic reduction of a 1/N sector (reference: helmholtz_x/bloch_operator.py:6-123).
 
 Same class / constructor / properties (``A, B, B_adj, C, D, remapper, blochify``).  The reduction
-``M_bloch = NB . M . BN`` is a one-shot sparse triple product; like the reference (scipy on the host,
-bloch_operator.py:106-110) it is structural work done once per matrix on the host, after which the reduced
-operator lives on the GPU as an ordinary CSR ``Mat`` and the eigen-iteration runs on the device.
+``M_bloch = NB . M . BN`` is a one-shot sparse triple product.  The reference forms it with scipy on the host
+(bloch_operator.py:104-111); here it is two device sparse products ``NB (M BN)`` by the hash-based SpGEMM of the
+hierarchy set-up (hx_spgemm_*, csrc/amg_setup.hip): M never leaves HBM (round 2 copied every operator to the host and
+back: 1.2 s of a 3.2 s sector run at 1.9 M DOF).  ``HX_BLOCH_HOST=1`` keeps the scipy product (tests compare the two).
 
 Differences, on purpose:
   * master/slave DOFs are paired GEOMETRICALLY (rotate the master face by 2 pi / N about the z axis) by default;
@@ -66,6 +67,7 @@ class Blochifier:
         vals = np.concatenate([np.ones(keep.size, dtype=np.complex128), np.full(dofs_master.size, 1 / self.f_b)])
         self.NB_csr = sp.csr_matrix((vals, (cols, rows)), shape=(keep.size, n))
         self._BN = Mat.from_csr(CSR.from_scipy(self.BN_csr))
+        self._NB_dev = self._BN_dev = None           # device copies of the two maps for the SpGEMM route (built on first use)
 
         self._A = self.blochify(passive_matrices.A)
         if passive_matrices.B:
@@ -115,14 +117,31 @@ class Blochifier:
     def remapper(self):
         return self._BN
 
+    def _triple_product_device(self, K):
+        """NB (K BN) on the device: two sparse products with sorted output rows (deterministic sums)."""
+        from .amg import DevCSR, _dev_spgemm
+        if self._NB_dev is None:
+            def dev(M):
+                M = sp.csr_matrix(M, dtype=np.complex128)
+                M.sort_indices()
+                c = CSR.from_scipy(M)
+                return DevCSR(M.shape, c.rowptr, c.col, c.val)
+            self._NB_dev, self._BN_dev = dev(self.NB_csr), dev(self.BN_csr)
+        red = _dev_spgemm(self._NB_dev, _dev_spgemm(DevCSR(K.shape, K.rowptr, K.col, K.val), self._BN_dev))
+        return CSR(red.shape, red.rowptr, red.col, red.val)
+
     def blochify(self, matrix):
         """NB . M . BN for a lazy Mat: CSR part by a host triple product, low-rank part factor-wise."""
         m = self.NB_csr.shape[0]
         csr_terms, lr_terms = [], []
         K = matrix.csr_part()
         if K is not None:
-            red = (self.NB_csr @ K.to_scipy() @ self.BN_csr).tocsr()
-            csr_terms.append((1.0, CSR.from_scipy(red)))
+            import os
+            if os.environ.get("HX_BLOCH_HOST", "0") != "0":
+                red = (self.NB_csr @ K.to_scipy() @ self.BN_csr).tocsr()
+                csr_terms.append((1.0, CSR.from_scipy(red)))
+            else:
+                csr_terms.append((1.0, self._triple_product_device(K)))
         for coef, lr in matrix.lr_terms:
             pairs = []
             for (ui, uv), (vi, vv) in lr.pairs:

@@ -436,6 +436,17 @@ int hx_spgemm_numeric(const hx_spgemm* plan, const int32_t* rpA, const int32_t* 
                       const int32_t* rpB, const int32_t* ciB, const void* vb, int b_complex, int32_t* out_ci,
                       hx_c128* out_v, hx_stream s);
 int hx_spgemm_destroy(hx_spgemm* plan);
+/* ---- Shape-derivative boundary functional.
+ * replaces: shape_derivatives.py:12-37 -- `assemble_scalar(form(inner(V_ffd, normal) * div(p_adj_conj * c**2 * grad(p_dir)) *
+ * ds(tag)))`, the UFL / FFCx boundary integral of the reference's shapeDerivativesFFD.  Per boundary facet (triangle of a
+ * tetrahedral mesh, listed with its adjacent cell) out[f] = int_f (V . n) [(c^2 grad q + 2 q c grad c) . grad p + q c^2 lap p] ds
+ * with q = conj(p_adj); p, q: P1 (degree 1: vertex values) or P2 (degree 2: dofs as in cell_dofs, 4 vertices + 6 edges) dof
+ * arrays, c: P1 nodal or cell-wise values, V: nodal displacement vectors (n x 3), quad: nq x 4 barycentric points + weights
+ * (sum 1) of a rule exact to degree 5.  The caller sums out[] (fixed order). */
+int hx_shape_derivative_facets(int degree, int32_t nf, const double* x, const int32_t* cells, const int32_t* cell_dofs,
+                               const int32_t* facets, const int32_t* facet_cell, const hx_c128* p, const hx_c128* q,
+                               const hx_c128* c, int c_is_cellwise, const double* V, int nq, const double* quad,
+                               hx_c128* out, hx_stream s);
 /* HOST set-up passes of the smoothed-aggregation hierarchy (graph / integer work, once per K):
  * hx_host_sa_filter: strength filter |l_ij| >= theta*sqrt(l_ii l_jj) with weak couplings lumped on the diagonal;
  *   L is the Laplacian-like real part (CSR), entry p = sign * h_lv[p * stride] (stride 2 = the real parts of an

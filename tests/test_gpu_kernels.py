@@ -601,3 +601,67 @@ def test_device_spgemm_and_transpose_random(hx, m, k, n, da, db):
             continue
         _same_csr(amg._dev_spgemm(_dcsr(X), _dcsr(Y)), ref, 1e-13)
     _same_csr(amg._dev_transpose(_dcsr(A), k), A.T.tocsr(), 0.0)
+
+
+def test_bloch_triple_product_on_the_device_equals_scipy(monkeypatch):
+    """Blochifier.blochify (reference: bloch_operator.py:104-111, scipy CSR x CSR x CSR on the host): the device route
+    NB (M BN) through hx_spgemm_* gives the same reduced operators -- pattern bit-exact, values to rounding -- for the real
+    symmetric volume operators and for the complex boundary operator of a Robin sector."""
+    import scipy.sparse as sp
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.bloch_operator import Blochifier
+    from helmholtz_x.synthetic import annulus, micca_sound_speed
+    half = np.pi / 16
+
+    class Geometry:
+        pass
+
+    geo = Geometry()
+    geo.mesh, _, geo.facet_tags = annulus(5, 4, 7, n_flames=1, sector=(-half, half))
+    bcs = {11: {'Robin': -0.875 - 0.2j}, 12: 'Master', 13: 'Slave'}
+    M = AcousticMatrices(geo.mesh, geo.facet_tags, bcs, micca_sound_speed(geo.mesh))
+    dev = Blochifier(geo, bcs, 16, M)
+    monkeypatch.setenv("HX_BLOCH_HOST", "1")
+    host = Blochifier(geo, bcs, 16, M)
+    for name in ("A", "B", "B_adj", "C"):
+        a, b = getattr(dev, name).to_scipy(), getattr(host, name).to_scipy()
+        a.sort_indices()
+        b.sort_indices()
+        b.eliminate_zeros()          # (scipy keeps the explicit zeros of cancelled sums; the device product stores the same slots)
+        a2 = sp.csr_matrix(a)
+        a2.eliminate_zeros()
+        assert a2.shape == b.shape and np.array_equal(a2.indptr, b.indptr) and np.array_equal(a2.indices, b.indices), name
+        assert np.max(np.abs(a2.data - b.data)) <= 1e-13 * np.max(np.abs(b.data)), name
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_shape_derivative_functional_kernel(degree):
+    """hx_shape_derivative_facets (shape_derivatives.py:12-37: the boundary integral of the Hadamard shape derivative) against
+    the analytic patch value and, with random complex fields on a distorted mesh, against oracle/shape.py."""
+    from helmholtz_x.fem import Function, FunctionSpace, MeshTags
+    from helmholtz_x.shape_derivatives import boundary_functional
+    from oracle import shape
+    from test_oracle_goldens import shape_patch_case
+    mesh, fids, V, p, q, c, exact, cell_dofs = shape_patch_case(degree, jitter=0.04)
+    tags = MeshTags(mesh, 2, fids, np.full(len(fids), 6))
+    cfun = Function(FunctionSpace(mesh, "CG", 1), "c")
+    cfun.x.array[:] = c
+    got = boundary_functional(mesh, tags, 6, V, p, q, cfun, degree=degree)
+    assert abs(got - exact) < 1e-11 * abs(exact), (got, exact)
+    rng = np.random.default_rng(11)
+    nd = p.size
+    p2, q2 = _rand_c(rng, nd), _rand_c(rng, nd)
+    c2 = 300.0 + 50 * rng.random(mesh.num_vertices) + 5j * rng.random(mesh.num_vertices)
+    V2 = rng.standard_normal((mesh.num_vertices, 3))
+    cfun.x.array[:] = c2
+    ref = shape.boundary_functional(mesh.geometry.x, mesh.topology.cells, mesh.facets[fids], mesh.facet_cells[fids], V2, p2, q2, c2,
+                                    degree=degree, cell_dofs=cell_dofs)
+    got = boundary_functional(mesh, tags, 6, V2, p2, q2, cfun, degree=degree)
+    assert abs(got - ref) < 1e-12 * abs(ref), (got, ref)
+    # DG0 sound speed (the MICCA parameter files give c per cell): grad c = 0 inside the cell
+    cd = Function(FunctionSpace(mesh, "DG", 0), "c")
+    cd.x.array[:] = 300.0 + 40 * rng.random(mesh.num_cells)
+    ref = shape.boundary_functional(mesh.geometry.x, mesh.topology.cells, mesh.facets[fids], mesh.facet_cells[fids], V2, p2, q2,
+                                    cd.x.array, degree=degree, cell_dofs=cell_dofs, c_is_cellwise=True)
+    got = boundary_functional(mesh, tags, 6, V2, p2, q2, cd, degree=degree)
+    assert abs(got - ref) < 1e-12 * abs(ref)

@@ -451,3 +451,80 @@ def test_p2_oracle_patch_tests_and_factored_flame(golden_dir):
     _, h1 = eigen.fixed_point_iteration(A1, Bsmall, C1, flame, Rijke.target, nev=2, i=0)
     _, h2 = eigen.fixed_point_iteration_factored(A1, Bsmall, C1, ff, Rijke.target, nev=2, i=0)
     assert len(h1) == len(h2) and np.max(np.abs(h1 - h2) / np.abs(h1)) < 1e-10
+
+
+# ----------------------------------------------------------------------------- shape-derivative functional: patch tests
+def _gauss_square(fn, n=8):
+    g, w = np.polynomial.legendre.leggauss(n)
+    g, w = 0.5 * (g + 1), 0.5 * w
+    return sum(wa * wb * fn(a, b) for a, wa in zip(g, w) for b, wb in zip(g, w))
+
+
+def shape_patch_case(degree, jitter=0.0):
+    """Unit cube split into tetrahedra, fields that lie IN the discrete spaces, and the analytic integrand on the face z = 1
+    (outward normal e_z).  Returns (mesh, facet ids of that face, V, p, q, c (P1 nodal), exact value, cell_dofs)."""
+    from helmholtz_x.fem import FunctionSpace
+    from helmholtz_x.synthetic import box
+    mesh, _, facet_tags = box(4, 3, 3)
+    x = mesh.geometry.x
+    if jitter:
+        rng = np.random.default_rng(2)
+        inner = np.all((x > 1e-9) & (x < 1 - 1e-9), axis=1)
+        x[inner] += rng.uniform(-jitter, jitter, size=(int(inner.sum()), 3))
+    a = np.array([0.7 - 0.2j, -1.1 + 0.4j, 0.5 + 0.9j])
+    b = np.array([0.3 + 0.6j, 0.8 - 0.1j, -0.4 + 0.2j])
+    g = np.array([30.0, -20.0, 45.0])
+    c0 = 340.0
+
+    def cf(X):
+        return c0 + X @ g
+
+    if degree == 1:
+        def pf(X): return X @ a + (0.2 - 0.3j)
+        def qf(X): return X @ b + (1.5 + 0.5j)
+        def gp(X): return np.broadcast_to(a, X.shape)
+        def gq(X): return np.broadcast_to(b, X.shape)
+        lap_p = 0.0
+        V_space = x
+        cell_dofs = None
+    else:
+        def pf(X): return (1 + 0.5j) * X[:, 0] ** 2 + 2 * X[:, 1] * X[:, 2] + (0.3 - 1j) * X[:, 2] + X[:, 0] * X[:, 1]
+        def qf(X): return X[:, 0] * X[:, 1] + (0.5 + 0.25j) * X[:, 2] ** 2 - 1j * X[:, 1] + 0.75
+        def gp(X): return np.stack([2 * (1 + 0.5j) * X[:, 0] + X[:, 1], 2 * X[:, 2] + X[:, 0], 2 * X[:, 1] + (0.3 - 1j)], axis=1)
+        def gq(X): return np.stack([X[:, 1], X[:, 0] - 1j, 2 * (0.5 + 0.25j) * X[:, 2]], axis=1)
+        lap_p = 2 * (1 + 0.5j)
+        Vs = FunctionSpace(mesh, "CG", 2)
+        V_space = Vs.tabulate_dof_coordinates()
+        cell_dofs = Vs.cell_dofs
+    V = np.zeros_like(x)
+    V[:, 2] = 0.5 + x[:, 0] - 0.25 * x[:, 1]                  # (V . n)(x, y) on the face z = 1, P1 in the face
+
+    def integrand(u, v):
+        X = np.array([[u, v, 1.0]])
+        c = cf(X)[0]
+        G = np.dot(c * c * gq(X)[0] + 2 * qf(X)[0] * c * g, gp(X)[0]) + qf(X)[0] * c * c * lap_p
+        return (0.5 + u - 0.25 * v) * G
+
+    exact = _gauss_square(integrand)
+    return mesh, facet_tags.find(6), V, pf(V_space), qf(V_space), cf(x).astype(complex), exact, cell_dofs
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_shape_derivative_functional_patch(degree):
+    """oracle/shape.py (restating shape_derivatives.py:12-37) integrates div(q c^2 grad p) (V . n) EXACTLY when p, q lie in
+    the P1 / P2 space, c and V . n are linear: compared with the analytic integrand (tensor Gauss rule on the face)."""
+    from oracle import shape
+    for jitter in (0.0, 0.04):
+        mesh, fids, V, p, q, c, exact, cell_dofs = shape_patch_case(degree, jitter)
+        got = shape.boundary_functional(mesh.geometry.x, mesh.topology.cells, mesh.facets[fids], mesh.facet_cells[fids], V, p, q, c,
+                                        degree=degree, cell_dofs=cell_dofs)
+        assert abs(got - exact) < 1e-11 * abs(exact), (degree, jitter, got, exact)
+    # constant-coefficient sanity value: p = a.x, q = b.x + q0, c = c0, V.n = 1  ->  c0^2 (a.b) area
+    if degree == 1:
+        x = mesh.geometry.x
+        a, b = np.array([1.0, 2.0, -1.0]), np.array([0.5, -1.0, 2.0 + 1j])
+        V1 = np.zeros_like(x)
+        V1[:, 2] = 1.0
+        got = shape.boundary_functional(x, mesh.topology.cells, mesh.facets[fids], mesh.facet_cells[fids], V1, x @ a + 0j, x @ b + 3.0,
+                                        np.full(x.shape[0], 340.0 + 0j))
+        assert abs(got - 340.0 ** 2 * np.dot(a, b)) < 1e-9 * abs(got)

@@ -56,8 +56,9 @@ def boundary_functional(mesh, facet_tags, tag, V, p_dir, p_adj_conj, c, degree=1
     Vd = to_device(np.ascontiguousarray(np.asarray(V, dtype=np.float64).reshape(mesh.num_vertices, 3)))
     quad = to_device(DUNAVANT6)
     out = torch.empty(ids.size, dtype=torch.complex128, device=asm.x.device)
+    pd, qd = dofs(p_dir), dofs(p_adj_conj)       # (named: the device copies must outlive the launch)
     _hx.check(_hx.lib.hx_shape_derivative_facets(int(degree), ids.size, _hx.ptr(asm.x), _hx.ptr(asm.cells), _hx.ptr(cell_dofs),
-                                                 _hx.ptr(facets), _hx.ptr(fcell), _hx.ptr(dofs(p_dir)), _hx.ptr(dofs(p_adj_conj)),
+                                                 _hx.ptr(facets), _hx.ptr(fcell), _hx.ptr(pd), _hx.ptr(qd),
                                                  _hx.ptr(cf), int(cellwise), _hx.ptr(Vd), DUNAVANT6.shape[0], _hx.ptr(quad),
                                                  _hx.ptr(out), _hx.stream()))
     vals = out.cpu().numpy()                     # O(n^(2/3)) numbers; summed in facet order

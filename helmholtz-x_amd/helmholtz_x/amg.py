@@ -23,7 +23,7 @@ from . import _hx
 from .petsc import to_device
 from .solver_utils import info
 
-PARAMS = dict(theta=0.04, max_levels=8, coarse_size=600, pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
+PARAMS = dict(theta=0.04, max_levels=8, coarse_size=int(os.environ.get("HX_AMG_COARSE_SIZE", "1000")), pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
               max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=int(os.environ.get("HX_SELL_MIN_ROWS", "50000")), sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
               recycle_min_rows=100_000, recycle_theta=0.45, krylov="auto", cocg_min_rows=100_000, setup="device",
               replicate_max_rows=int(os.environ.get("HX_AMG_REPLICATE_MAX_ROWS", "200000")))
@@ -738,8 +738,23 @@ class AMGSolver:
             else:
                 _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), None, 0, 0, None,
                                     None, None, 0, None, None, None))
-                Kc = lv["K"].to_scipy() if isinstance(lv["K"], DevCSR) else lv["K"]
-                (crp, cci, cva), cnnz = dev_csr(sp.csr_matrix(np.linalg.inv(Kc.toarray())))
+                if isinstance(lv["K"], DevCSR):
+                    # dense inverse of the coarsest operator in HBM (rocSOLVER through torch.linalg.inv: plain dense LAPACK
+                    # work, as the host's np.linalg.inv was), handed to the V-cycle as a dense CSR
+                    Kc, nc = lv["K"], lv["n"]
+                    dense = torch.zeros((nc, nc), dtype=torch.complex128, device=dev)
+                    lens = (Kc.rowptr[1:] - Kc.rowptr[:-1]).long()
+                    rows = torch.repeat_interleave(torch.arange(nc, device=dev), lens)
+                    dense[rows, Kc.col.long()] = Kc.val
+                    inv = torch.linalg.inv(dense)
+                    crp = torch.arange(0, nc * nc + 1, nc, dtype=torch.int32, device=dev)
+                    cci = torch.arange(nc, dtype=torch.int32, device=dev).repeat(nc)
+                    cva = inv.reshape(-1).to(cdt).contiguous()
+                    self._keep.append((crp, cci, cva))
+                    cnnz = nc * nc
+                else:
+                    Kh = lv["K"].to_scipy() if isinstance(lv["K"], DevCSR) else lv["K"]
+                    (crp, cci, cva), cnnz = dev_csr(sp.csr_matrix(np.linalg.inv(Kh.toarray())))
                 _hx.check(set_coarse(h, lv["n"], cnnz, _hx.ptr(crp), _hx.ptr(cci), _hx.ptr(cva)))
         if shard is not None:
             self._cb = shard.callbacks()             # (halo_fn, allreduce_fn, ctx): the library's own RCCL calls, or gloo trampolines

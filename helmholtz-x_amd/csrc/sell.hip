@@ -229,9 +229,16 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     if (h->n_cols > (1 << 27)) { delete h; return hx_fail(HX_ERR_ARG, __func__, "more than 2^27 columns (32-bit byte offsets into x)"); }
   }
   if (hipMalloc((void**)&h->slice_ptr, sizeof(int64_t) * np) != hipSuccess) { delete h; return hx_fail(HX_ERR_ALLOC, __func__, "slice_ptr"); }
-  (void)hipMemsetAsync(h->slice_ptr, 0, sizeof(int64_t) * np, s);
+  {
+    const hipError_t em = hipMemsetAsync(h->slice_ptr, 0, sizeof(int64_t) * np, s);
+    if (em != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, "hx_sell_create: hipMemsetAsync", hipGetErrorString(em)); }
+  }
   const int grid = (int)(((int64_t)h->n_slices * 64 + 255) / 256);
   k_sell_widths<<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, h->slice_ptr);
+  {
+    const hipError_t el = hipGetLastError();
+    if (el != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, "k_sell_widths", hipGetErrorString(el)); }
+  }
   // stencil slices (HX_SELL_STENCIL=0 switches the detection off)
   static const bool allow_stencil = !(getenv("HX_SELL_STENCIL") && atoi(getenv("HX_SELL_STENCIL")) == 0);
   int32_t* d_wu = nullptr;
@@ -239,17 +246,25 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   if (allow_stencil && h->n_slices > 0 &&
       hipMalloc((void**)&d_wu, sizeof(int32_t) * np) == hipSuccess &&
       hipMalloc((void**)&d_tmpU, sizeof(int32_t) * 64 * (size_t)h->n_slices) == hipSuccess) {
-    (void)hipMemsetAsync(d_wu, 0, sizeof(int32_t) * np, s);
-    k_sell_stencil_union<<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, h->slice_ptr, d_wu, d_tmpU);
-    k_sell_stencil_sizes<<<hx_grid(h->n_slices, 256), 256, 0, s>>>(h->n_slices, d_wu, h->slice_ptr);
+    // (an allocation failure above only skips the stencil detection -- the format is complete without it; an error of
+    // these launches is caught by the checked scan that follows on the same stream)
+    if (hipMemsetAsync(d_wu, 0, sizeof(int32_t) * np, s) == hipSuccess) {
+      k_sell_stencil_union<<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, h->slice_ptr, d_wu, d_tmpU);
+      k_sell_stencil_sizes<<<hx_grid(h->n_slices, 256), 256, 0, s>>>(h->n_slices, d_wu, h->slice_ptr);
+    }
   } else { (void)hipFree(d_wu); (void)hipFree(d_tmpU); d_wu = nullptr; d_tmpU = nullptr; (void)hipGetLastError(); }
   size_t bytes = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, h->slice_ptr, h->slice_ptr, (int)np, s);
+  hipError_t e = hipGetLastError();               // the width / stencil launches above
+  if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, h->slice_ptr, h->slice_ptr, (int)np, s);
   void* tmp = nullptr;
-  if (hipMalloc(&tmp, bytes ? bytes : 16) != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_ALLOC, __func__, "scan"); }
-  (void)hipcub::DeviceScan::ExclusiveSum(tmp, bytes, h->slice_ptr, h->slice_ptr, (int)np, s);
+  if (e != hipSuccess || hipMalloc(&tmp, bytes ? bytes : 16) != hipSuccess) {
+    (void)hipFree(d_wu); (void)hipFree(d_tmpU);
+    hx_sell_destroy(h);
+    return hx_fail(e != hipSuccess ? HX_ERR_HIP : HX_ERR_ALLOC, "hx_sell_create: slice scan", e != hipSuccess ? hipGetErrorString(e) : "workspace");
+  }
+  e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, h->slice_ptr, h->slice_ptr, (int)np, s);
   int64_t total = 0;
-  hipError_t e = hipMemcpyAsync(&total, h->slice_ptr + h->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, h->slice_ptr + h->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(tmp);
   if (e == hipSuccess && d_wu) {        // st_ptr = exclusive scan of the union lengths; keep it only if some slice qualified
@@ -349,10 +364,14 @@ extern "C" int hx_sell_stencil_slices(const hx_sell* h) {
   int32_t* d = nullptr;
   int32_t v = 0;
   if (hipMalloc((void**)&d, sizeof(int32_t)) != hipSuccess) return -1;
-  (void)hipMemset(d, 0, sizeof(int32_t));
-  k_count_stencil<<<hx_grid(h->n_slices, 256), 256>>>(h->n_slices, h->st_ptr, d);
-  (void)hipMemcpy(&v, d, sizeof(int32_t), hipMemcpyDeviceToHost);
+  hipError_t e = hipMemset(d, 0, sizeof(int32_t));
+  if (e == hipSuccess) {
+    k_count_stencil<<<hx_grid(h->n_slices, 256), 256>>>(h->n_slices, h->st_ptr, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&v, d, sizeof(int32_t), hipMemcpyDeviceToHost);
   (void)hipFree(d);
+  if (e != hipSuccess) { (void)hx_fail(HX_ERR_HIP, "hx_sell_stencil_slices", hipGetErrorString(e)); return -1; }
   return v;
 }
 

@@ -42,6 +42,15 @@ enum hx_status {
   HX_ERR_COMM = -6       /* an exchange callback of the row-sharded mode reported failure */
 };
 
+/* Environment switches of the library (experiment / diagnostics hooks; none is needed for normal use).  Each is read ONCE, at the
+ * first call that consults it, and cached for the life of the process: set them before the first libhx call -- changing one
+ * afterwards (e.g. from a test that monkey-patches os.environ mid-run) has no effect.
+ *   HX_SELL_STENCIL=0 / HX_SELL_INDEX=i32 / HX_SELL_LDS=0|2   SELL-64 format and kernel variants (hx_sell_create, k_sell)
+ *   HX_CHEB_LO, HX_CHEB_KIND, HX_AMG_COARSE_EXTRA             Chebyshev bounds / kind, extra coarse smoothing steps
+ *   HX_AMG_GRAPH_PRIVATE_STREAM                               hipGraph replay of the V-cycle on a private stream
+ *   HX_GMRES_TRACE=1                                          residual histories of hx_gmres / hx_cocg on stderr
+ *   HX_HOST_THREADS                                           threads of the hx_host_* set-up passes
+ *   HX_RCCL_LIB                                               librccl to bind in hx_comm_* (default: the loaded one / librccl.so.1) */
 int hx_version(void);
 const char* hx_last_error(void);
 /* SYNC. Device name, compute-unit count and HBM bytes of the current device. */

@@ -470,6 +470,11 @@ class P1Assembler:
         """int f dx for a nodal array (dolfinx_utils.py:42-43 ``normalize``)."""
         from .petsc import panel_dot
         f = to_device(np.asarray(f_array, np.complex128))
+        part = getattr(self.mesh, "part", None)
+        if part is not None:            # distributed mesh: the owned vertices' lumped weights are complete; ranks add up
+            n_own = part["n_own"]
+            local = panel_dot(self.lumped()[:n_own].reshape(1, -1), 1, f[:n_own].contiguous())[0]
+            return complex(self.mesh.comm.allreduce(complex(local)))
         return complex(panel_dot(self.lumped().reshape(1, -1), 1, f)[0])   # lumped weights are real: m^H f = m.f
 
     def cell_volumes(self):

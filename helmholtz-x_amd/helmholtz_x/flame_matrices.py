@@ -249,6 +249,11 @@ class DistributedFlameMatrix(FlameMatrix):
             gm1 = np.full(n_p1, self.gamma - 1.0, dtype=np.complex128)
         left = self.indices_and_values(asm.load(1, gm1, self.h.x.array, scale=self.q_0 / self.u_b))
         right = self.indices_and_values(asm.load(2, self.rho.x.array, self.w.x.array))
+        part = getattr(self.mesh, "part", None)
+        if part is not None:            # distributed mesh: the entries of the owned vertices are complete (every cell touching
+            n_own = part["n_own"]       # them is local); the ghost entries belong to their owners (flame_matrices.py:64-65
+            left = (left[0][left[0] < n_own], left[1][left[0] < n_own])        # does a ghost add + insert instead)
+            right = (right[0][right[0] < n_own], right[1][right[0] < n_own])
         return left, right
 
     def assemble_submatrices(self, problem_type='direct'):

@@ -509,3 +509,67 @@ def test_micca_real_mesh_distributed_over_three_ranks(ref_logs, golden_dir):
         assert len(r["peers"][0]) >= 1 and not all(r["contiguous_sends"])
     assert sum(out[r]["sizes"][0] for r in range(world)) == out[0]["sizes"][3]
     print("micca distributed:", out[0]["stats"], [out[r]["peers"] for r in range(world)], [out[r]["sizes"] for r in range(world)])
+
+
+def _rijke_distributed_worker(rank, world, port, out, golden_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
+    os.environ["HX_QUIET"] = "1"
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import contextlib
+        import io
+        from cases import Rijke as R
+        from helmholtz_x.acoustic_matrices import AcousticMatrices
+        from helmholtz_x.eigensolvers import fixed_point_iteration
+        from helmholtz_x.fem import MeshTags, locality_permutation
+        from helmholtz_x.flame_matrices import DistributedFlameMatrix
+        from helmholtz_x.flame_transfer_function import nTau
+        from helmholtz_x.io_utils import XDMFReader
+        from helmholtz_x.parameters_utils import c_step, gaussianFunction, rho_step, temperature_step
+        from helmholtz_x.sharded import ShardContext
+        res = {}
+        for dim in (2, 3):
+            mesh0, sub0, ft0 = XDMFReader(os.path.join(golden_dir, "meshes", "rijke%dd" % dim)).getAll()
+            mesh = mesh0.renumbered(locality_permutation(mesh0.geometry.x))
+            ft = MeshTags(mesh, ft0.dim, ft0.indices, ft0.values)
+            ctx = ShardContext(mesh.num_vertices)
+            local, _, ft_l, _ = ctx.distribute(mesh, None, ft, [])
+            with contextlib.redirect_stdout(io.StringIO()):
+                # every field is built ON the rank's part of the mesh, as the reference's script does under mpirun
+                T = temperature_step(local, R.x_f(dim), R.T_u, R.T_d)
+                param = T if dim == 2 else c_step(local, R.x_f(dim), R.c_u, R.c_d)        # (as the reference's two scripts)
+                M = AcousticMatrices(local, ft_l, {t: {'Neumann'} for t in (1, 2, 3, 4)}, param)
+                rho = rho_step(local, R.x_f(dim), R.a_f, R.rho_d, R.rho_u)
+                w = gaussianFunction(local, R.x_r(dim), R.a_r)            # normalised by a global integral (allreduce)
+                h = gaussianFunction(local, R.x_f(dim), R.a_f)
+                D = DistributedFlameMatrix(local, w, h, rho, T, R.q_0, R.u_b, nTau(R.n(dim), R.tau))
+                D.assemble_submatrices()
+                hist = []
+                fixed_point_iteration(M, D, R.target, nev=2, i=0, st_type="amg", history=hist, shard=ctx)
+            res[dim] = list(hist)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rijke_distributed_flame_eps_path_over_two_ranks(ref_logs, golden_dir):
+    """The linear (EPS) branch of the fixed-point iteration with a DistributedFlameMatrix (Gaussian heat-release and
+    measurement fields, flame_matrices.py:191-244) on distributed meshes: the reference's Rijke 2-D and 3-D cases
+    (NetworkCode/RijkeTube2D, RijkeTube3D: gmsh meshes, Neumann walls, n-tau flame) over two ranks.  Every coefficient field is
+    built on the rank's part of the mesh (the Gaussians are normalised by a global integral), the flame vectors keep the owned
+    entries, and the logged 5-step trajectories of the reference's runs are reproduced to 1e-8."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_rijke_distributed_worker, args=(world, port, out, golden_dir), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        for dim, key in ((2, "rijke2d"), (3, "rijke3d")):
+            hist, traj = out[rank][dim], ref_logs[key]["trajectory"]
+            assert len(hist) == len(traj)
+            for z, ref in zip(hist, traj):
+                ref = complex(*ref)
+                assert abs(z - ref) / abs(ref) < 1e-8, (dim, z, ref)

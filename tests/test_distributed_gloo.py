@@ -364,7 +364,7 @@ def _dist_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_distributed_mesh_rows_halo_and_shift(world):
     """The building blocks of the distributed set-up, on CPU under gloo: every rank's part of the mesh (cells + ghost layer,
     tags, fields, facet / cell ownership), owner-computes boundary rows, the exchange plan in the form the library's RCCL

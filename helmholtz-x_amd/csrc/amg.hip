@@ -46,6 +46,12 @@ extern "C" int hx_sell_smooth_c64(const hx_sell*, const hx_c64*, const hx_c64*, 
                                   const hx_c64*, float, hx_stream);
 int hx_sell_residual_c64(const hx_sell*, const hx_c64*, const hx_c64*, hx_c64*, hx_stream);
 int hx_sell_residual_z(const hx_sell*, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
+int hx_sell_has_parts(const hx_sell*);
+int hx_sell_spmv_z_part(const hx_sell*, int, const hx_c128*, hx_c128*, const double*, const double*, hx_stream);
+int hx_sell_residual_c64_part(const hx_sell*, int, const hx_c64*, const hx_c64*, hx_c64*, hx_stream);
+int hx_sell_residual_z_part(const hx_sell*, int, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
+int hx_sell_smooth_c64_part(const hx_sell*, int, const hx_c64*, const hx_c64*, const hx_c64*, hx_c64*, float, const hx_c64*, float, hx_stream);
+int hx_sell_smooth_z_part(const hx_sell*, int, const hx_c128*, const hx_c128*, const hx_c128*, hx_c128*, double, const hx_c128*, double, hx_stream);
 int hx_csr_residual_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*, float*, hx_stream);
 int hx_csr_residual_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
 int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
@@ -62,6 +68,23 @@ static void drop_graph(hx_amg* h) {
 static int halo_level(hx_amg* h, int l, void* v, int elem_bytes, hx_stream s) {
   if (!h->sharded || l >= h->n_sharded) return HX_OK;
   return h->halo(h->ctx, l, v, elem_bytes, s) == 0 ? HX_OK : hx_fail(HX_ERR_COMM, __func__, "halo exchange callback failed");
+}
+
+// A product with the level's operator whose operand needs its ghost block: exchange first, then the whole product -- or, when
+// the split callbacks are set and the level's SELL-64 operator carries slice lists, start the exchange, run the INTERIOR slices
+// (they read no ghost column) while it travels, wait, run the boundary slices.  apply(part): 0 all, 1 interior, 2 boundary.
+template <typename LT, typename F>
+static int with_halo(hx_amg* h, const LT& L, int l, void* v, int elem_bytes, hx_stream s, F&& apply) {
+  if (!h->sharded || l >= h->n_sharded) return apply(0);
+  int rc;
+  if (h->halo_begin && h->halo_end && L.sell && hx_sell_has_parts(L.sell)) {
+    if (h->halo_begin(h->ctx, l, v, elem_bytes, s) != 0) return hx_fail(HX_ERR_COMM, __func__, "halo exchange (begin) failed");
+    if ((rc = apply(1))) return rc;
+    if (h->halo_end(h->ctx, l, s) != 0) return hx_fail(HX_ERR_COMM, __func__, "halo exchange (end) failed");
+    return apply(2);
+  }
+  if ((rc = halo_level(h, l, v, elem_bytes, s))) return rc;
+  return apply(0);
 }
 
 // ---- per-precision kernel dispatch
@@ -89,26 +112,26 @@ static int op_kmult(const LevelT<float>& L, const float* x, float* y, float a, f
   return op_spmv(L.K, x, y, a, b, false, s);
 }
 // r = b - K x (one pass, no copy of b)
-static int op_residual(const LevelT<double>& L, const double* x, const double* b, double* r, hx_stream s) {
-  if (L.sell) return hx_sell_residual_z(L.sell, (const hx_c128*)x, (const hx_c128*)b, (hx_c128*)r, s);
+static int op_residual(const LevelT<double>& L, const double* x, const double* b, double* r, hx_stream s, int part = 0) {
+  if (L.sell) return hx_sell_residual_z_part(L.sell, part, (const hx_c128*)x, (const hx_c128*)b, (hx_c128*)r, s);
   return hx_csr_residual_z(L.K.rows, L.K.nnz, L.K.rp, L.K.ci, (const hx_c128*)L.K.va, (const hx_c128*)x, (const hx_c128*)b, (hx_c128*)r, s);
 }
-static int op_residual(const LevelT<float>& L, const float* x, const float* b, float* r, hx_stream s) {
-  if (L.sell) return hx_sell_residual_c64(L.sell, (const hx_c64*)x, (const hx_c64*)b, (hx_c64*)r, s);
+static int op_residual(const LevelT<float>& L, const float* x, const float* b, float* r, hx_stream s, int part = 0) {
+  if (L.sell) return hx_sell_residual_c64_part(L.sell, part, (const hx_c64*)x, (const hx_c64*)b, (hx_c64*)r, s);
   return hx_csr_residual_c(L.K.rows, L.K.nnz, L.K.rp, L.K.ci, L.K.va, x, b, r, s);
 }
 // xout = xin + w D^-1 (b - K xin) + mom (xin - xprev)     (xprev may be NULL)
 static int op_smooth(const LevelT<double>& L, const double* b, const double* xin, double* xout, double w,
-                     const double* xprev, double mom, hx_stream s) {
-  if (L.sell) return hx_sell_smooth_z(L.sell, (const hx_c128*)L.dinv, (const hx_c128*)b, (const hx_c128*)xin, (hx_c128*)xout,
-                                      w, (const hx_c128*)xprev, mom, s);
+                     const double* xprev, double mom, hx_stream s, int part = 0) {
+  if (L.sell) return hx_sell_smooth_z_part(L.sell, part, (const hx_c128*)L.dinv, (const hx_c128*)b, (const hx_c128*)xin, (hx_c128*)xout,
+                                           w, (const hx_c128*)xprev, mom, s);
   return hx_csr_smooth_z(L.n, L.K.nnz, L.K.rp, L.K.ci, (const hx_c128*)L.K.va, (const hx_c128*)L.dinv, (const hx_c128*)b,
                          (const hx_c128*)xin, (hx_c128*)xout, w, (const hx_c128*)xprev, mom, s);
 }
 static int op_smooth(const LevelT<float>& L, const float* b, const float* xin, float* xout, double w, const float* xprev,
-                     double mom, hx_stream s) {
-  if (L.sell) return hx_sell_smooth_c64(L.sell, (const hx_c64*)L.dinv, (const hx_c64*)b, (const hx_c64*)xin, (hx_c64*)xout,
-                                        (float)w, (const hx_c64*)xprev, (float)mom, s);
+                     double mom, hx_stream s, int part = 0) {
+  if (L.sell) return hx_sell_smooth_c64_part(L.sell, part, (const hx_c64*)L.dinv, (const hx_c64*)b, (const hx_c64*)xin, (hx_c64*)xout,
+                                             (float)w, (const hx_c64*)xprev, (float)mom, s);
   return hx_csr_smooth_c(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, xin, xout, (float)w, xprev, (float)mom, s);
 }
 static int op_diag(const LevelT<double>& L, double w, const double* b, double* x, hx_stream s) {
@@ -240,6 +263,12 @@ extern "C" int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext
   return h->single ? resize_ext<float>(h->S, n_sharded, n_ext) : resize_ext<double>(h->D, n_sharded, n_ext);
 }
 
+extern "C" int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_fn begin, hx_halo_end_fn end) {
+  HX_REQUIRE(h && ((begin && end) || (!begin && !end)), "both callbacks or none");
+  h->halo_begin = begin; h->halo_end = end;
+  return HX_OK;
+}
+
 extern "C" int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                                  const hx_c128* va) {
   HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->D.L.back().n == n_c, "bad argument");
@@ -323,15 +352,14 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
     if ((rc = op_diag(L, cheb ? C.a[0] : h->omega, b, cur, s))) return rc;
     for (int k = 1; k < n_pre; ++k) {
       T* nxt = other(cur, prev);
-      if ((rc = halo_level(h, l, cur, EB, s))) return rc;
-      if (cheb) {   // for k = 1 the previous iterate is the zero start vector (prev == nullptr)
-        if ((rc = op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], s))) return rc;
-      } else if ((rc = op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s))) return rc;
+      // (for k = 1 the previous iterate of the Chebyshev recurrence is the zero start vector: prev == nullptr)
+      if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part) {
+            return cheb ? op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], s, part)
+                        : op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s, part); }))) return rc;
       prev = cur; cur = nxt;
     }
     // residual r = b - K x, restrict
-    if ((rc = halo_level(h, l, cur, EB, s))) return rc;
-    if ((rc = op_residual(L, cur, b, L.r, s))) return rc;
+    if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part) { return op_residual(L, cur, b, L.r, s, part); }))) return rc;
     if ((rc = restrict_from(L.r))) return rc;
   }
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
@@ -342,9 +370,9 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   prev = nullptr;
   for (int k = 0; k < n_post; ++k) {
     T* dst = (k == n_post - 1) ? xout : other(cur, prev);
-    if ((rc = halo_level(h, l, cur, EB, s))) return rc;
-    if (cheb) { if ((rc = op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s))) return rc; }
-    else if ((rc = op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s))) return rc;
+    if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part) {
+          return cheb ? op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s, part)
+                      : op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s, part); }))) return rc;
     prev = cur; cur = dst;
   }
   if (n_post == 0)
@@ -446,8 +474,15 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
   HX_REQUIRE(!rec || (rec->n == n && rec->restart == restart), "recycling workspace was sized for another n / restart");
   const int kc = rec ? rec->k : 0;
   auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) -> int {
-    if (sharded) {   // stage the owned block, let the host side fill the ghost block, multiply the local rows
+    if (sharded) {   // stage the owned block, exchange the ghost block, multiply the local rows
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+      if (Ksell && M->halo_begin && M->halo_end && hx_sell_has_parts(Ksell)) {      // interior slices while the ghost entries travel
+        int rcx;
+        if (M->halo_begin(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange (begin) failed");
+        if ((rcx = hx_sell_spmv_z_part(Ksell, 1, xe, out, a, bt, s))) return rcx;
+        if (M->halo_end(M->ctx, 0, s) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange (end) failed");
+        return hx_sell_spmv_z_part(Ksell, 2, xe, out, a, bt, s);
+      }
       if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange callback failed");
       in = xe;
     }

@@ -25,6 +25,9 @@
 struct hx_sell;
 extern "C" int hx_sell_spmv_z(const hx_sell*, const hx_c128*, hx_c128*, const double*, const double*, hx_stream);
 int hx_sell_residual_z(const hx_sell*, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
+int hx_sell_has_parts(const hx_sell*);
+int hx_sell_spmv_z_part(const hx_sell*, int, const hx_c128*, hx_c128*, const double*, const double*, hx_stream);
+int hx_sell_residual_z_part(const hx_sell*, int, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
 int hx_csr_residual_z(int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
 int hx_zpanel_bdot(int64_t, int, const hx_c128*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
 int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
@@ -220,9 +223,19 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   hx_c128* sc = sharded ? hbuf : part + hx_panel_dot_ws(CG_MAXK + 1);
   int64_t rpb;
   const int nblocks = hx_panel_dot_blocks(n, &rpb);
+  // row-sharded products: the operand is staged in xe (owned block + ghost block); with the split callbacks the interior
+  // slices of the product run while the ghost entries travel
+  const bool split = sharded && Ksell && M->halo_begin && M->halo_end && hx_sell_has_parts(Ksell);
   auto Kx = [&](const hx_c128* in, hx_c128* out, const double* a, const double* bt) -> int {
     if (sharded) {
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+      if (split) {
+        int rcx;
+        if (M->halo_begin(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (begin) failed");
+        if ((rcx = hx_sell_spmv_z_part(Ksell, 1, xe, out, a, bt, s))) return rcx;
+        if (M->halo_end(M->ctx, 0, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (end) failed");
+        return hx_sell_spmv_z_part(Ksell, 2, xe, out, a, bt, s);
+      }
       if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
       in = xe;
     }
@@ -232,6 +245,13 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   auto Kres = [&](const hx_c128* in, hx_c128* out) -> int {          // out = b - K in
     if (sharded) {
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+      if (split) {
+        int rcx;
+        if (M->halo_begin(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (begin) failed");
+        if ((rcx = hx_sell_residual_z_part(Ksell, 1, xe, b, out, s))) return rcx;
+        if (M->halo_end(M->ctx, 0, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (end) failed");
+        return hx_sell_residual_z_part(Ksell, 2, xe, b, out, s);
+      }
       if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
       in = xe;
     }

@@ -101,7 +101,11 @@ struct hx_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   std::vector<Plan> plans;
-  int64_t n_exchange = 0, n_allreduce = 0;
+  int64_t n_exchange = 0, n_allreduce = 0, n_overlapped = 0;
+  // split halo (hx_comm_halo_begin / _end): the exchange runs on the communicator's own stream, ordered against the compute
+  // stream by two events, so that the interior slices of a product run while the ghost entries travel
+  hipStream_t cstream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
 };
 
 // ---- gather of listed entries (4-, 8- or 16-byte elements) into the contiguous send buffer
@@ -138,6 +142,9 @@ extern "C" int hx_comm_create(hx_comm** out, int rank, int world, const void* id
 extern "C" int hx_comm_destroy(hx_comm* c) {
   if (!c) return HX_OK;
   for (Plan& p : c->plans) { (void)hipFree(p.d_idx); (void)hipFree(p.stage); }
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->cstream) (void)hipStreamDestroy(c->cstream);
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   delete c;
   return HX_OK;
@@ -149,9 +156,11 @@ extern "C" int hx_comm_counters(const hx_comm* c, int64_t* n_exchange, int64_t* 
   HX_REQUIRE(c, "null communicator");
   if (n_exchange) *n_exchange = c->n_exchange;
   if (n_allreduce) *n_allreduce = c->n_allreduce;
-  if (reset) { const_cast<hx_comm*>(c)->n_exchange = 0; const_cast<hx_comm*>(c)->n_allreduce = 0; }
+  if (reset) { hx_comm* m = const_cast<hx_comm*>(c); m->n_exchange = 0; m->n_allreduce = 0; m->n_overlapped = 0; }
   return HX_OK;
 }
+// number of halo exchanges that ran split (hx_comm_halo_begin / _end: overlapped with the interior slices of their product)
+extern "C" int64_t hx_comm_overlapped(const hx_comm* c) { return c ? c->n_overlapped : 0; }
 
 // Exchange plan `plan` (>= 0; halo plans use the hierarchy level as their number).  HOST arrays:
 //   send_peer[ns], send_ptr[ns + 1] into send_idx (owned element indices, ascending per peer);
@@ -232,6 +241,34 @@ extern "C" int hx_comm_exchange(hx_comm* c, int plan, const void* src, void* dst
 // hx_halo_fn: ghost block of a level's extended vector (plan number = level)
 extern "C" int hx_comm_halo(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s) {
   return hx_comm_exchange((hx_comm*)ctx, level, x_ext, x_ext, elem_bytes, s);
+}
+
+// Split form of the halo (hx_halo_fn / hx_halo_end_fn for hx_amg_set_halo_overlap): _begin orders the exchange after everything
+// enqueued on `s` so far and runs it on the communicator's stream; _end makes `s` wait for it.  Between the two the caller may
+// launch, on `s`, kernels that read only the OWNED block of x_ext (the interior slices of a row-sharded product).  One exchange
+// may be pending at a time.
+extern "C" int hx_comm_halo_begin(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s) {
+  hx_comm* c = (hx_comm*)ctx;
+  HX_REQUIRE(c && x_ext, "bad argument");
+  if (!c->cstream) {
+    HX_HIP(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    HX_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    HX_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  }
+  HX_HIP(hipEventRecord(c->ev_ready, hx_s(s)));
+  HX_HIP(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+  const int rc = hx_comm_exchange(c, level, x_ext, x_ext, elem_bytes, (hx_stream)c->cstream);
+  if (rc) return rc;
+  HX_HIP(hipEventRecord(c->ev_done, c->cstream));
+  ++c->n_overlapped;
+  return HX_OK;
+}
+extern "C" int hx_comm_halo_end(void* ctx, int level, hx_stream s) {
+  hx_comm* c = (hx_comm*)ctx;
+  (void)level;
+  HX_REQUIRE(c && c->ev_done, "no exchange pending");
+  HX_HIP(hipStreamWaitEvent(hx_s(s), c->ev_done, 0));
+  return HX_OK;
 }
 
 // hx_allreduce_fn: in-place reduction of `count` reals (dtype 0: float32, 1: float64; op 0: sum, 1: max)

@@ -11,6 +11,8 @@
 #include <hip/hip_fp16.h>
 #include <hipcub/hipcub.hpp>
 
+#include <vector>
+
 #include "hx_common.h"
 
 #define SELL_C 64
@@ -43,6 +45,12 @@ struct hx_sell {
   int32_t* st_ptr = nullptr;         // n_slices + 1, or null when no slice qualified
   int32_t* st_delta = nullptr;
   int32_t n_stencil = 0;
+  // Row-sharded local operator (more columns than rows: [owned | ghost]): the slices that read NO ghost column ("interior")
+  // and the others ("boundary"), as two slice lists.  A product can then run its interior slices while the halo exchange
+  // of x is still in flight on another stream and its boundary slices after it (hx_sell_*_part).  Null for square operators.
+  int32_t* list_interior = nullptr;
+  int32_t* list_boundary = nullptr;
+  int32_t n_interior = 0, n_boundary = 0;
 };
 typedef __half2 ch;
 __device__ __forceinline__ zc mload(const zc* p) { return *p; }
@@ -189,10 +197,26 @@ __global__ void k_sell_narrow(int32_t n_slices, const int64_t* __restrict__ slic
     }
 }
 
+// flag[slice] = 1 when a stored entry of the slice (padding and the zero entries of stencil slices included: their clamped
+// columns are read too) addresses a column >= n_rows, i.e. the ghost block of a row-sharded operand
+__global__ void k_sell_ghost_flags(int32_t n_rows, int32_t n_slices, const int64_t* __restrict__ slice_ptr,
+                                   const int32_t* __restrict__ scol, uint8_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  if (slice >= n_slices) return;
+  const int64_t base = slice_ptr[slice];
+  const int width = (int)((slice_ptr[slice + 1] - base) / SELL_C);
+  bool g = false;
+  for (int k = 0; k < width; ++k) g = g || scol[base + (int64_t)k * SELL_C + lane] >= n_rows;
+  const bool any = __any(g);
+  if (lane == 0) flag[slice] = any ? 1 : 0;
+}
+
 extern "C" int hx_sell_destroy(hx_sell* h) {
   if (!h) return HX_OK;
   (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->dcol); (void)hipFree(h->wide); (void)hipFree(h->val_z); (void)hipFree(h->val_c);
   (void)hipFree(h->val_h); (void)hipFree(h->st_ptr); (void)hipFree(h->st_delta);
+  (void)hipFree(h->list_interior); (void)hipFree(h->list_boundary);
   delete h;
   return HX_OK;
 }
@@ -347,6 +371,29 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     }
     (void)hipGetLastError();
   } else h->n_wide = h->n_slices;
+  if (h->n_cols > n && total > 0) {          // rectangular: a row-sharded local operator -> interior / boundary slice lists
+    uint8_t* d_flag = nullptr;
+    std::vector<uint8_t> hf((size_t)h->n_slices);
+    hipError_t ef = hipMalloc((void**)&d_flag, (size_t)h->n_slices);
+    if (ef == hipSuccess) {
+      k_sell_ghost_flags<<<grid, 256, 0, s>>>(n, h->n_slices, h->slice_ptr, h->col, d_flag);
+      ef = hipMemcpyAsync(hf.data(), d_flag, (size_t)h->n_slices, hipMemcpyDeviceToHost, s);
+      if (ef == hipSuccess) ef = hipStreamSynchronize(s);
+    }
+    (void)hipFree(d_flag);
+    if (ef == hipSuccess) {
+      std::vector<int32_t> li, lb;
+      for (int32_t q = 0; q < h->n_slices; ++q) (hf[q] ? lb : li).push_back(q);
+      if (!li.empty() && !lb.empty() &&
+          hipMalloc((void**)&h->list_interior, sizeof(int32_t) * li.size()) == hipSuccess &&
+          hipMalloc((void**)&h->list_boundary, sizeof(int32_t) * lb.size()) == hipSuccess &&
+          hipMemcpy(h->list_interior, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice) == hipSuccess &&
+          hipMemcpy(h->list_boundary, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice) == hipSuccess) {
+        h->n_interior = (int32_t)li.size(); h->n_boundary = (int32_t)lb.size();
+      } else { (void)hipFree(h->list_interior); (void)hipFree(h->list_boundary); h->list_interior = h->list_boundary = nullptr; }
+    }
+    (void)hipGetLastError();
+  }
   *out = h;
   return HX_OK;
 }
@@ -591,10 +638,13 @@ __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
        const int32_t* __restrict__ st_delta, int32_t n_cols, const MV* __restrict__ val, const V* __restrict__ x, V* y,
-       const V* yin, const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev, const SellOp<V> a) {
+       const V* yin, const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev, const SellOp<V> a,
+       const int32_t* __restrict__ slice_list) {
   const int lane = threadIdx.x & 63;
-  const int32_t slice = __builtin_amdgcn_readfirstlane((int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6));
-  if (slice >= n_slices) return;
+  // n_slices counts the waves of this launch: all slices, or the entries of slice_list (interior / boundary part)
+  const int32_t wv = __builtin_amdgcn_readfirstlane((int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6));
+  if (wv >= n_slices) return;
+  const int32_t slice = slice_list ? __builtin_amdgcn_readfirstlane(slice_list[wv]) : wv;
   const int64_t base = slice_ptr[slice];
   const int32_t width = (int32_t)((slice_ptr[slice + 1] - base) >> 6);
   int32_t st0 = 0, stw = 0;
@@ -644,15 +694,20 @@ static int sell_grid(int32_t n_slices) { return (n_slices + 3) / 4; }   // 4 wav
 template <typename V, int MODE, typename MV>
 static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alpha, V beta, int beta_is_zero, const V* dinv,
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
-                        typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr) {
+                        typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr, int part = 0) {
   const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale};
   // x windows of the stencil slices through LDS (HX_SELL_LDS=0: gathers everywhere; =2: also for complex128 values)
   static const int lds_mode = getenv("HX_SELL_LDS") ? atoi(getenv("HX_SELL_LDS")) : 1;
   const bool use_lds = h->st_ptr && (lds_mode == 2 || (lds_mode == 1 && sizeof(MV) == 4));
   auto kern = use_lds ? k_sell<V, MODE, MV, 8, true> : k_sell<V, MODE, MV, 8, false>;
-  kern<<<sell_grid(h->n_slices), 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
-                                                                      h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op);
+  // part 0: every slice; 1 / 2: the interior / boundary slices of a row-sharded local operator (hx_sell::list_*)
+  const int32_t* list = part == 1 ? h->list_interior : part == 2 ? h->list_boundary : nullptr;
+  const int32_t nw = part == 1 ? h->n_interior : part == 2 ? h->n_boundary : h->n_slices;
+  if (nw == 0) return;
+  kern<<<sell_grid(nw), 256, 0, hx_s(s)>>>(h->n, nw, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
+                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list);
 }
+
 
 // In-situ timing of the operator product (the roofline kernel of bench.py): when enabled, every k_sell<c128,0> launch is
 // bracketed by a pair of HIP events on its launch stream (no synchronisation until the read-out).
@@ -712,14 +767,85 @@ static void prof_end(int kind, hx_stream s) {
   if (hipEventRecord(P.ev[P.used + 1], hx_s(s)) == hipSuccess) P.used += 2;
 }
 
+// ---- products by PART of a row-sharded local operator (internal; amg.hip / cocg.hip): part 0 = every slice, 1 = the slices that
+// read no ghost column (may run while the halo exchange of x is in flight), 2 = the others (after it).  An operator without
+// slice lists (square, or all slices of one kind) runs everything in part 1 and nothing in part 2.
+int hx_sell_has_parts(const hx_sell* h) { return h && h->list_interior && h->list_boundary ? 1 : 0; }
+static thread_local bool g_rec_pending[2] = {false, false};
+static inline int norm_part(const hx_sell* h, int part) { return hx_sell_has_parts(h) ? part : (part == 2 ? -1 : 0); }
+static inline void part_begin(int kind, const hx_sell* h, int part, hx_stream s) {
+  if (part == 0 || part == 1) g_rec_pending[kind] = prof_begin(kind, h->n, s);
+}
+static inline void part_end(int kind, int part, hx_stream s) {
+  if ((part == 0 || part == 2) && g_rec_pending[kind]) { prof_end(kind, s); g_rec_pending[kind] = false; }
+}
+
+int hx_sell_spmv_z_part(const hx_sell* h, int part, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
+                        hx_stream s) {
+  HX_REQUIRE(h && h->val_z && x && y && alpha && beta && part >= 0 && part <= 2, "bad argument");
+  const int req = part;
+  part = norm_part(h, part);
+  const zc a = hx_z(alpha), b = hx_z(beta);
+  part_begin(0, h, req, s);
+  if (part >= 0)
+    launch_sell<zc, 0, zc>(h, h->val_z, (const zc*)x, (zc*)y, a, b, (b.x == 0 && b.y == 0), nullptr, nullptr, nullptr, 0.0, 0.0, 1.0, s,
+                           nullptr, part);
+  part_end(0, req, s);
+  HX_LAUNCH_CHECK("k_sell<c128,spmv>");
+  return HX_OK;
+}
 extern "C" int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
                               hx_stream s) {
-  HX_REQUIRE(h && h->val_z && x && y && alpha && beta, "bad argument");
-  const zc a = hx_z(alpha), b = hx_z(beta);
-  const bool rec = prof_begin(0, h->n, s);
-  launch_sell<zc, 0, zc>(h, h->val_z, (const zc*)x, (zc*)y, a, b, (b.x == 0 && b.y == 0), nullptr, nullptr, nullptr, 0.0, 0.0, 1.0, s);
-  if (rec) prof_end(0, s);
-  HX_LAUNCH_CHECK("k_sell<c128,spmv>");
+  return hx_sell_spmv_z_part(h, 0, x, y, alpha, beta, s);
+}
+int hx_sell_residual_c64_part(const hx_sell* h, int part, const hx_c64* x, const hx_c64* b, hx_c64* r, hx_stream s) {
+  HX_REQUIRE(h && (h->val_c || h->val_h) && x && b && r && part >= 0 && part <= 2, "bad argument");
+  part = norm_part(h, part);
+  if (part < 0) return HX_OK;
+  if (h->val_h)
+    launch_sell<cc, 0, ch>(h, h->val_h, (const cc*)x, (cc*)r, make_float2(-1.f, 0.f), make_float2(1.f, 0.f), 0, nullptr, nullptr,
+                           nullptr, 0.f, 0.f, h->h_scale, s, (const cc*)b, part);
+  else
+    launch_sell<cc, 0, cc>(h, h->val_c, (const cc*)x, (cc*)r, make_float2(-1.f, 0.f), make_float2(1.f, 0.f), 0, nullptr, nullptr,
+                           nullptr, 0.f, 0.f, 1.f, s, (const cc*)b, part);
+  HX_LAUNCH_CHECK("k_sell<c64,residual>");
+  return HX_OK;
+}
+int hx_sell_residual_z_part(const hx_sell* h, int part, const hx_c128* x, const hx_c128* b, hx_c128* r, hx_stream s) {
+  HX_REQUIRE(h && h->val_z && x && b && r && part >= 0 && part <= 2, "bad argument");
+  part = norm_part(h, part);
+  if (part < 0) return HX_OK;
+  launch_sell<zc, 0, zc>(h, h->val_z, (const zc*)x, (zc*)r, make_double2(-1.0, 0.0), make_double2(1.0, 0.0), 0, nullptr, nullptr,
+                         nullptr, 0.0, 0.0, 1.0, s, (const zc*)b, part);
+  HX_LAUNCH_CHECK("k_sell<c128,residual>");
+  return HX_OK;
+}
+int hx_sell_smooth_c64_part(const hx_sell* h, int part, const hx_c64* dinv, const hx_c64* b, const hx_c64* xin, hx_c64* xout,
+                            float omega, const hx_c64* xprev, float mom, hx_stream s) {
+  HX_REQUIRE(h && (h->val_c || h->val_h) && dinv && b && xin && xout && xin != xout && part >= 0 && part <= 2, "bad argument");
+  const int req = part;
+  part = norm_part(h, part);
+  part_begin(1, h, req, s);
+  if (part >= 0) {
+    if (h->val_h)
+      launch_sell<cc, 1, ch>(h, h->val_h, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
+                             (const cc*)b, (const cc*)xprev, omega, mom, h->h_scale, s, nullptr, part);
+    else
+      launch_sell<cc, 1, cc>(h, h->val_c, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
+                             (const cc*)b, (const cc*)xprev, omega, mom, 1.f, s, nullptr, part);
+  }
+  part_end(1, req, s);
+  HX_LAUNCH_CHECK("k_sell<c64,smooth>");
+  return HX_OK;
+}
+int hx_sell_smooth_z_part(const hx_sell* h, int part, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin, hx_c128* xout,
+                          double omega, const hx_c128* xprev, double mom, hx_stream s) {
+  HX_REQUIRE(h && h->val_z && dinv && b && xin && xout && xin != xout && part >= 0 && part <= 2, "bad argument");
+  part = norm_part(h, part);
+  if (part < 0) return HX_OK;
+  launch_sell<zc, 1, zc>(h, h->val_z, (const zc*)xin, (zc*)xout, make_double2(0, 0), make_double2(0, 0), 1, (const zc*)dinv,
+                         (const zc*)b, (const zc*)xprev, omega, mom, 1.0, s, nullptr, part);
+  HX_LAUNCH_CHECK("k_sell<c128,smooth>");
   return HX_OK;
 }
 extern "C" int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, float alpha, float beta, hx_stream s) {
@@ -735,43 +861,17 @@ extern "C" int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, fl
 }
 // r = b - A x in one pass (internal; the V-cycle's residual: no copy of b into r first)
 int hx_sell_residual_c64(const hx_sell* h, const hx_c64* x, const hx_c64* b, hx_c64* r, hx_stream s) {
-  HX_REQUIRE(h && (h->val_c || h->val_h) && x && b && r, "bad argument");
-  if (h->val_h)
-    launch_sell<cc, 0, ch>(h, h->val_h, (const cc*)x, (cc*)r, make_float2(-1.f, 0.f), make_float2(1.f, 0.f), 0, nullptr, nullptr,
-                           nullptr, 0.f, 0.f, h->h_scale, s, (const cc*)b);
-  else
-    launch_sell<cc, 0, cc>(h, h->val_c, (const cc*)x, (cc*)r, make_float2(-1.f, 0.f), make_float2(1.f, 0.f), 0, nullptr, nullptr,
-                           nullptr, 0.f, 0.f, 1.f, s, (const cc*)b);
-  HX_LAUNCH_CHECK("k_sell<c64,residual>");
-  return HX_OK;
+  return hx_sell_residual_c64_part(h, 0, x, b, r, s);
 }
 int hx_sell_residual_z(const hx_sell* h, const hx_c128* x, const hx_c128* b, hx_c128* r, hx_stream s) {
-  HX_REQUIRE(h && h->val_z && x && b && r, "bad argument");
-  launch_sell<zc, 0, zc>(h, h->val_z, (const zc*)x, (zc*)r, make_double2(-1.0, 0.0), make_double2(1.0, 0.0), 0, nullptr, nullptr,
-                         nullptr, 0.0, 0.0, 1.0, s, (const zc*)b);
-  HX_LAUNCH_CHECK("k_sell<c128,residual>");
-  return HX_OK;
+  return hx_sell_residual_z_part(h, 0, x, b, r, s);
 }
 // smoother step (see hx_csr_jacobi_* / the Chebyshev recurrence in amg.hip); xprev may be NULL
 extern "C" int hx_sell_smooth_c64(const hx_sell* h, const hx_c64* dinv, const hx_c64* b, const hx_c64* xin, hx_c64* xout,
                                   float omega, const hx_c64* xprev, float mom, hx_stream s) {
-  HX_REQUIRE(h && (h->val_c || h->val_h) && dinv && b && xin && xout && xin != xout, "bad argument");
-  const bool rec = prof_begin(1, h->n, s);
-  if (h->val_h)
-    launch_sell<cc, 1, ch>(h, h->val_h, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
-                           (const cc*)b, (const cc*)xprev, omega, mom, h->h_scale, s);
-  else
-    launch_sell<cc, 1, cc>(h, h->val_c, (const cc*)xin, (cc*)xout, make_float2(0.f, 0.f), make_float2(0.f, 0.f), 1, (const cc*)dinv,
-                           (const cc*)b, (const cc*)xprev, omega, mom, 1.f, s);
-  if (rec) prof_end(1, s);
-  HX_LAUNCH_CHECK("k_sell<c64,smooth>");
-  return HX_OK;
+  return hx_sell_smooth_c64_part(h, 0, dinv, b, xin, xout, omega, xprev, mom, s);
 }
 extern "C" int hx_sell_smooth_z(const hx_sell* h, const hx_c128* dinv, const hx_c128* b, const hx_c128* xin, hx_c128* xout,
                                 double omega, const hx_c128* xprev, double mom, hx_stream s) {
-  HX_REQUIRE(h && h->val_z && dinv && b && xin && xout && xin != xout, "bad argument");
-  launch_sell<zc, 1, zc>(h, h->val_z, (const zc*)xin, (zc*)xout, make_double2(0, 0), make_double2(0, 0), 1, (const zc*)dinv,
-                         (const zc*)b, (const zc*)xprev, omega, mom, 1.0, s);
-  HX_LAUNCH_CHECK("k_sell<c128,smooth>");
-  return HX_OK;
+  return hx_sell_smooth_z_part(h, 0, dinv, b, xin, xout, omega, xprev, mom, s);
 }

@@ -20,6 +20,7 @@ _dp = C.POINTER(C.c_double)
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p)                    # hx_halo_fn
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p)      # hx_allreduce_fn
+HALO_END_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)                                        # hx_halo_end_fn
 COMM_ID_BYTES = 128
 ERR_BREAKDOWN = -5
 
@@ -105,6 +106,10 @@ SIGNATURES = {
     "hx_gmres_hessenberg": (C.c_int, [_vp, C.POINTER(_int), _vp]),
     "hx_amg_set_recycle": (C.c_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
+    "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_FN, HALO_END_FN]),
+    "hx_comm_halo_begin": (C.c_int, [_vp, _int, _vp, _int, _vp]),
+    "hx_comm_halo_end": (C.c_int, [_vp, _int, _vp]),
+    "hx_comm_overlapped": (_i64, [_vp]),
     "hx_comm_unique_id": (C.c_int, [_vp, _int]),
     "hx_comm_create": (C.c_int, [C.POINTER(_vp), _int, _int, C.c_char_p, _int]),
     "hx_comm_destroy": (C.c_int, [_vp]),

@@ -760,6 +760,11 @@ class AMGSolver:
             self._cb = shard.callbacks()             # (halo_fn, allreduce_fn, ctx): the library's own RCCL calls, or gloo trampolines
             n_ext = np.ascontiguousarray([lv["n_ext"] for lv in levels[:self.n_sharded]], dtype=np.int32)
             _hx.check(_hx.lib.hx_amg_set_sharded(h, self.n_sharded, _hx.nptr(n_ext), self._cb[0], self._cb[1], self._cb[2]))
+            if shard.comm is not None and os.environ.get("HX_HALO_OVERLAP", "1") != "0":
+                # library-issued exchanges: split every halo around the interior slices of its product (exchange on the
+                # communicator's stream, ordered by events)
+                self._ov = (C.cast(_hx.lib.hx_comm_halo_begin, _hx.HALO_FN), C.cast(_hx.lib.hx_comm_halo_end, _hx.HALO_END_FN))
+                _hx.check(_hx.lib.hx_amg_set_halo_overlap(h, self._ov[0], self._ov[1]))
             self._xe = shard.ext_vector(torch.complex128)
             self._hbuf = torch.zeros(max(self.params["restart"] + 2 + 32, 80), dtype=torch.complex128, device=dev)
         # hipGraph replay of the V-cycle where it is launch-bound (measured: see DESIGN.md section 5)

@@ -370,6 +370,14 @@ typedef int (*hx_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype, i
  * handle re-allocates its level-l work vectors with that length. */
 int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext, hx_halo_fn halo, hx_allreduce_fn allreduce,
                        void* ctx);
+/* Optional split form of the halo exchange: begin(ctx, level, x_ext, elem_bytes, s) starts the exchange ordered after the work
+ * enqueued on s and returns at once; end(ctx, level, s) makes s wait for it.  With both set, every product with a SELL-64
+ * operator of a sharded level (smoother steps, residuals, the operator product of hx_cocg_sharded / hx_gmres_sharded) runs its
+ * interior slices -- the ones that read no ghost column -- between the two and its boundary slices after: the exchange travels
+ * over xGMI while most of the product streams from HBM.  hx_comm_halo_begin / hx_comm_halo_end implement it on the communicator's
+ * own stream.  (PETSc overlaps the same way: VecScatterBegin, local part of MatMult, VecScatterEnd, off-diagonal part.) */
+typedef int (*hx_halo_end_fn)(void* ctx, int level, hx_stream s);
+int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_fn begin, hx_halo_end_fn end);
 /* ---- RCCL communicator owned by the library (comm.hip).  librccl is bound at run time (the copy the process already
  * loaded, else librccl.so.1; HX_RCCL_LIB overrides).  Rank 0 draws an id (hx_comm_unique_id) and ships its
  * HX_COMM_ID_BYTES bytes to the other ranks by whatever channel the host side has (torch.distributed broadcast); every
@@ -391,6 +399,9 @@ int hx_comm_set_plan(hx_comm* c, int plan, int ns, const int32_t* send_peer, con
                      const int64_t* recv_cnt);
 int hx_comm_exchange(hx_comm* c, int plan, const void* src, void* dst, int elem_bytes, hx_stream s);
 int hx_comm_halo(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s);          /* an hx_halo_fn */
+int hx_comm_halo_begin(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s);    /* split form: an hx_halo_fn ... */
+int hx_comm_halo_end(void* ctx, int level, hx_stream s);                                   /* ... and its hx_halo_end_fn */
+int64_t hx_comm_overlapped(const hx_comm* c);   /* exchanges that ran split since the last counter reset */
 int hx_comm_allreduce(void* ctx, void* buf, int64_t count, int dtype, int op, hx_stream s); /* an hx_allreduce_fn */
 int hx_comm_counters(const hx_comm* c, int64_t* n_exchange, int64_t* n_allreduce, int reset);
 /* hx_gmres on the row-sharded operator: K = local rows over [owned | ghost] columns, b / x / ws sized by n_own;

@@ -225,7 +225,7 @@ def spmv_roofline(K, reps=50, in_situ=None, pmc=None):
                             "frac": round(alg_bytes / (ms_csr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
 
 
-def smoother_roofline(inner, n, in_situ):
+def smoother_roofline(inner, n, in_situ, numbering="native"):
     """The kernel with the largest share of the run time: one Chebyshev smoother step of the V-cycle on the fine level
     (`k_sell<c64, 1, half>`: x' = x + a D^-1 (b - K x) + c (x - x_prev) in complex64 on complex-half values with 16-bit
     column deltas, or no index at all in stencil slices).  Bytes per launch = what the kernel must stream: stored entries * 4 +
@@ -244,7 +244,7 @@ def smoother_roofline(inner, n, in_situ):
     nbytes = padded.value * val_bytes + indexed * idx_bytes + n * 5 * 8
     ms = in_situ[1] / in_situ[0]
     gbs = nbytes / (ms * 1e-3) / 1e9
-    traffic = measured_traffic(n, None, kernel="k_sell<c64,1,half>")
+    traffic = measured_traffic(n, None, numbering, kernel="k_sell<c64,1,half>")
     return dict(kernel="k_sell<c64, 1, half> (hx_sell_smooth_c64, fine level)", launches=in_situ[0],
                 avg_launch_ms=round(ms, 5), bytes_per_launch=nbytes,
                 bytes_model="stored SELL-64 entries * 4 + indexed entries * index bytes + 5 complex64 vectors",
@@ -473,7 +473,7 @@ def main(argv=None):
     inner = next((v for v in (E.inner_cache or {}).values() if hasattr(v, "stats")), None)
     with contextlib.redirect_stdout(sys.stderr):
         roof = spmv_roofline(shifted_operator(matrices, case["P"].target), in_situ=in_situ, pmc=args.numbering)
-        roof["dominant_by_time"] = smoother_roofline(inner, n_dof, in_situ_smoother)
+        roof["dominant_by_time"] = smoother_roofline(inner, n_dof, in_situ_smoother, args.numbering)
     out = {
         "metric": METRIC,
         "value": round(pairs / dt, 5), "unit": "eigenpairs/s",

@@ -9,11 +9,11 @@ cd /tmp
 i=0
 GROUPS_DEFAULT=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum")
 GROUPS_SQ=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR")
-if [ "${PMC_SET:-mem}" = "sq" ]; then CSETS=("${GROUPS_SQ[@]}"); else CSETS=("${GROUPS_DEFAULT[@]}"); fi
+if [ "${PMC_SET:-mem}" = "sq" ]; then CSETS=("${GROUPS_SQ[@]}"); elif [ "${PMC_SET:-mem}" = "hbm" ]; then CSETS=("FETCH_SIZE" "WRITE_SIZE"); else CSETS=("${GROUPS_DEFAULT[@]}"); fi
 for c in "${CSETS[@]}"; do
   i=$((i + 1))
   rm -rf /tmp/pmcs_$i
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcs_$i -- python3 "$R/tools/sell_kernels_only.py" "$WL" 10 > "$R/gpurun_out/pmc_sell_$i.log" 2>&1 \
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcs_$i -- python3 "$R/tools/sell_kernels_only.py" "$WL" 10 ${NUMBERING:-native} ${JITTER:-0} > "$R/gpurun_out/pmc_sell_$i.log" 2>&1 \
     || echo "counter group '$c' failed (see gpurun_out/pmc_sell_$i.log)"
 done
 python3 - $(find /tmp/pmcs_* -name "*counter_collection.csv") > "$R/gpurun_out/pmc_sell_summary.txt" <<'PY'

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Minimal driver for counter collection on the SELL-64 kernels: operator product (complex128), V-cycle residual and smoother
-step (complex64 arithmetic on complex-half values) on the annulus operator.  Usage: sell_kernels_only.py annulus-5M 10"""
+step (complex64 arithmetic on complex-half values) on the annulus operator.
+Usage: sell_kernels_only.py annulus-5M 10 [numbering [jitter]]   (numbering: native | rcm | morton | random)"""
 import ctypes as C
 import os
 import sys
@@ -16,7 +17,9 @@ from helmholtz_x.acoustic_matrices import AcousticMatrices  # noqa: E402
 from helmholtz_x.petsc import combine_csr  # noqa: E402
 
 name, reps = sys.argv[1], int(sys.argv[2])
-case = bench.build_case(bench.WORKLOADS[name])
+numbering = sys.argv[3] if len(sys.argv) > 3 else "native"
+jitter = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+case = bench.build_case(bench.WORKLOADS[name], numbering, jitter)
 P = case["P"]
 M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
 K = combine_csr(M.A.shape, M.A.csr_terms + [(P.target * c, m) for c, m in M.B.csr_terms]

@@ -248,6 +248,11 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
     transport "fake_rccl": the exchanges are issued by the library itself (hx_comm: the production path under RCCL) through
     tests/fake_rccl, a host-staged stand-in for librccl (RCCL refuses two ranks on one GPU): zero Python frames per
     exchange, same plans and call sequence as on two GPUs."""
+    if transport == "fake_rccl":          # the stand-in is built by __graft_entry__.build(); build it here if it did not travel
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        if not os.path.exists(os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")):
+            subprocess.check_call(["make", "-C", os.path.join(root, "tests", "fake_rccl")])
     world, port = 2, _free_port()
     out = mp.Manager().dict()
     mp.spawn(_gpu_fpi_worker, args=(world, port, out, krylov, transport), nprocs=world, join=True)

@@ -29,6 +29,9 @@ def normalize_eigenvector(mesh, obj, i, absolute=False, degree=1, which='right',
     if BlochRemapper:
         vr = matrix_vector(BlochRemapper, vr)
     V = matrices.V if matrices else FunctionSpace(mesh, "CG", degree)
+    shard = getattr(obj, "shard", None)
+    if shard is not None:
+        return omega, _normalize_distributed(mesh, shard, V, vr, omega, absolute, print_eigs)
     FixSign(vr)
     C = V.assembler().stiffness_mass(None, want_A=False)[1].csr_part()
     Cp = torch.empty_like(vr.t)
@@ -43,6 +46,40 @@ def normalize_eigenvector(mesh, obj, i, absolute=False, degree=1, which='right',
     if print_eigs:
         print(f"Eigenvalue-> {omega:.6f} | Eigenfrequency-> {omega/(2*np.pi):.6f}\n ")
     return omega, p
+
+
+def _normalize_distributed(mesh, shard, V, vr, omega, absolute, print_eigs):
+    """The same conventions on a row-sharded eigenvector (vr: this rank's owned entries, room for the ghosts): the phase is
+    fixed on GLOBAL entry 0 (its owner contributes it to a one-number all-reduce, as the reference's FixSign does with a
+    broadcast, petsc4py_utils.py:100-111), the bilinear integral int p p dx is the sum of the ranks' p_own^T (C p)_own with the
+    owned rows of the mass matrix (one halo of p, one all-reduce; eigenvectors.py:47,54 are allreduces too).  Returns a
+    Function on the rank's local mesh (owned + ghost entries)."""
+    n_own = shard.n_own
+    first = torch.zeros(1, dtype=torch.complex128, device=vr.t.device)
+    if shard.r0 == 0:
+        first[0] = vr.t[0]
+    shard.all_reduce_(first)
+    x0 = complex(first[0].item())
+    vr.scale(1.0 / (x0 / abs(x0)))
+    shard.halo(vr.t)
+    C = V.assembler().stiffness_mass(None, want_A=False)[1].csr_part()          # owned rows over [owned | ghost]
+    Cp = torch.empty(n_own, dtype=torch.complex128, device=vr.t.device)
+    C.spmv(vr.t, Cp)
+    acc = torch.zeros(1, dtype=torch.complex128, device=vr.t.device)
+    acc[0] = torch.dot(vr.t[:n_own], Cp)                                        # bilinear: no conjugate
+    shard.all_reduce_(acc)
+    meas = np.sqrt(complex(acc[0].item()))
+    temp = vr.array / meas
+    if absolute:
+        temp = np.abs(temp)
+        mx = torch.tensor([float(temp[:n_own].max())], dtype=torch.float64, device=vr.t.device)
+        shard.all_reduce_(mx, op="max")
+        temp = temp / float(mx.item())
+    p = Function(V, "p")
+    p.x.array[:] = temp
+    if print_eigs and shard.rank == 0:
+        print(f"Eigenvalue-> {omega:.6f} | Eigenfrequency-> {omega/(2*np.pi):.6f}\n ")
+    return p
 
 
 def normalize_adjoint(omega_dir, p_dir, p_adj, matrices, D=None):

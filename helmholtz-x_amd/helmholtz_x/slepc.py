@@ -640,8 +640,10 @@ class _EigenSolverBase:
         return complex(self._eigs[i])
 
     def getEigenvector(self, i, vr, vi=None):
-        """Row-sharded mode: ``vr`` receives this rank's owned rows."""
-        vr.t.copy_(self._basis.V[i][:vr.t.numel()])
+        """Row-sharded mode: the first n_own entries of ``vr`` receive this rank's owned rows (a vector created by
+        ``createVecs`` of a local operator also has room for the ghost entries: fill them with ``shard.halo``)."""
+        n = vr.t.numel() if self.shard is None else self.shard.n_own
+        vr.t[:n].copy_(self._basis.V[i][:n])
 
     def _local_ops(self, key, *mats):
         """This rank's rows of the given global device CSRs (cached with the inner solver)."""
@@ -848,11 +850,15 @@ class PEP(_EigenSolverBase):
     def getEigenvector(self, i, vr, vi=None):
         """x from the Ritz vector z = [x; lambda x] of the companion form: taken from the block of larger norm
         (the relative accuracy of the small block is worse by the factor |lambda|), then normalised."""
-        n = vr.t.numel()
+        n = vr.t.numel() if self.shard is None else self.shard.n_own
         lam = self._eigs[i]
         z = self._basis.V[i]
-        vr.t.copy_(z[n:2 * n] if abs(lam) >= 1.0 else z[:n])
-        vr.scale(1.0 / vr.norm())
+        vr.t[:n].copy_(z[n:2 * n] if abs(lam) >= 1.0 else z[:n])
+        if self.shard is None:
+            vr.scale(1.0 / vr.norm())
+        else:                               # global 2-norm of the row-sharded vector
+            own = vr.t[:n]
+            vr.scale(1.0 / np.sqrt(self._bdot(own, own).real))
 
     def solve(self):
         A, B, Cm = self._ops

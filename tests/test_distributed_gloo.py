@@ -569,8 +569,14 @@ def _rijke_distributed_worker(rank, world, port, out, golden_dir):
                 D = DistributedFlameMatrix(local, w, h, rho, T, R.q_0, R.u_b, nTau(R.n(dim), R.tau))
                 D.assemble_submatrices()
                 hist = []
-                fixed_point_iteration(M, D, R.target, nev=2, i=0, st_type="amg", history=hist, shard=ctx)
-            res[dim] = list(hist)
+                E = fixed_point_iteration(M, D, R.target, nev=2, i=0, st_type="amg", history=hist, shard=ctx)
+                from helmholtz_x.eigenvectors import normalize_eigenvector
+                omega, p = normalize_eigenvector(local, E, 0, degree=1, which='right', print_eigs=False)
+            n_own = local.part["n_own"]
+            res[dim] = (list(hist), complex(omega), local.geometry.x[:n_own].copy(), p.x.array[:n_own].copy(),
+                        # ghost entries of the normalised mode equal their owners' values: checked below
+                        local.part["local_to_global"][n_own:].copy(), p.x.array[n_own:].copy(), ctx.r0)
+        out[rank] = res
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -582,15 +588,27 @@ def test_rijke_distributed_flame_eps_path_over_two_ranks(ref_logs, golden_dir):
     measurement fields, flame_matrices.py:191-244) on distributed meshes: the reference's Rijke 2-D and 3-D cases
     (NetworkCode/RijkeTube2D, RijkeTube3D: gmsh meshes, Neumann walls, n-tau flame) over two ranks.  Every coefficient field is
     built on the rank's part of the mesh (the Gaussians are normalised by a global integral), the flame vectors keep the owned
-    entries, and the logged 5-step trajectories of the reference's runs are reproduced to 1e-8."""
+    entries, the logged 5-step trajectories of the reference's runs are reproduced to 1e-8, and ``normalize_eigenvector`` on
+    the distributed mesh returns the committed eigenvector (Results/Active/p.h5) to 1e-7."""
     world, port = 2, _free_port()
     out = mp.Manager().dict()
     mp.spawn(_rijke_distributed_worker, args=(world, port, out, golden_dir), nprocs=world, join=True)
     assert len(out) == world
-    for rank in range(world):
-        for dim, key in ((2, "rijke2d"), (3, "rijke3d")):
-            hist, traj = out[rank][dim], ref_logs[key]["trajectory"]
+    from test_oracle_goldens import match_nodes, sign_free_error
+    vecs = np.load(os.path.join(golden_dir, "eigenvectors", "reference_eigenvectors.npz"))
+    for dim, key in ((2, "rijke2d"), (3, "rijke3d")):
+        for rank in range(world):
+            hist, traj = out[rank][dim][0], ref_logs[key]["trajectory"]
             assert len(hist) == len(traj)
             for z, ref in zip(hist, traj):
                 ref = complex(*ref)
                 assert abs(z - ref) / abs(ref) < 1e-8, (dim, z, ref)
+            assert abs(out[rank][dim][1] - hist[-1]) < 1e-6 * abs(hist[-1])
+        # normalize_eigenvector on the distributed mesh (phase on global entry 0, int p p dx = 1 by all-reduce): the ranks'
+        # owned parts together are the mode the reference committed (Results/Active/p.h5), matched by coordinates
+        x = np.concatenate([out[r][dim][2] for r in range(world)])[:, :dim]
+        p = np.concatenate([out[r][dim][3] for r in range(world)])
+        assert sign_free_error(p, vecs[key + "_dir_p"][match_nodes(x, vecs[key + "_dir_x"])]) < 1e-7
+        for r in range(world):          # ghost entries = the owners' values
+            ghosts, vals = out[r][dim][4], out[r][dim][5]
+            assert np.allclose(vals, p[ghosts], rtol=0, atol=1e-13 * np.abs(p).max())

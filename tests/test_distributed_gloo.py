@@ -495,7 +495,13 @@ def _micca_distributed_worker(rank, world, port, out, golden_dir):
             hist = []
             E = fixed_point_iteration(matrices, D, Micca.target, i=0, nev=4, tol=1e-3, st_type="amg", history=hist, shard=ctx)
         inner = [v for v in E.inner_cache.values() if hasattr(v, "stats")][0]
+        # the adjoint problem as active_fpi.py:64-69 runs it: transposed flame factors, B^H, conjugate target (default nev = 2)
+        with contextlib.redirect_stdout(io.StringIO()):
+            D.assemble_submatrices('adjoint')
+            E_adj = fixed_point_iteration(matrices, D, Micca.target.conjugate(), i=0, tol=1e-3, problem_type='adjoint',
+                                          st_type="amg", shard=ctx)
         out[rank] = dict(hist=list(hist), eigs=[E.getEigenvalue(i) for i in range(2)], stats=inner.stats(),
+                         eigs_adj=[E_adj.getEigenvalue(i) for i in range(2)],
                          peers=(sorted(ctx.plan.send_to), sorted(ctx.plan.recv_from)),
                          sizes=(local.part["n_own"], local.num_vertices, local.num_cells, mesh.num_vertices, mesh.num_cells),
                          contiguous_sends=[bool(np.all(np.diff(v) == 1)) for v in ctx.plan.send_to.values()])
@@ -510,7 +516,8 @@ def test_micca_real_mesh_distributed_over_three_ranks(ref_logs, golden_dir):
     holds a third of the mesh + ghost layer, assembles its rows, finds the cells of the reference points it holds (the ranks
     agree on the lowest global cell id), builds its slab of the hierarchy and takes part in the collective solve.  The
     logged trajectory (3 decimals) and the two stored 16-digit eigenvalues of the reference's own `mpirun` runs
-    (fullAnnulus/Results/Active/FPI/activeParallel.log, eigenvalues_dir.txt) must be reproduced to 1e-8.  The partition of
+    (fullAnnulus/Results/Active/FPI/activeParallel.log, eigenvalues_dir.txt) must be reproduced to 1e-8, and so must the two
+    adjoint eigenvalues (eigenvalues_adj.txt: transposed flame factors, B^H, conjugate target).  The partition of
     an unstructured mesh is no ring: ranks have several peers and send gathered (non-contiguous) lists."""
     world, port = 3, _free_port()
     out = mp.Manager().dict()
@@ -525,6 +532,9 @@ def test_micca_real_mesh_distributed_over_three_ranks(ref_logs, golden_dir):
         for i, ref in enumerate(g["direct"]):
             ref = complex(*ref)
             assert abs(r["eigs"][i] - ref) / abs(ref) < 1e-8, (i, r["eigs"][i], ref)
+        for i, ref in enumerate(g["adjoint"]):
+            ref = complex(*ref)
+            assert abs(r["eigs_adj"][i] - ref) / abs(ref) < 1e-8, (i, r["eigs_adj"][i], ref)
         n_own, nv_loc, nc_loc, nv, nc = r["sizes"]
         assert nv_loc < 0.55 * nv and nc_loc < 0.55 * nc
         assert len(r["peers"][0]) >= 1 and not all(r["contiguous_sends"])

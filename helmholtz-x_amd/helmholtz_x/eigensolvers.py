@@ -205,12 +205,13 @@ def fixed_point_iteration(operators, D, target, nev=2, i=0, tol=1e-8, maxiter=50
                   problem_type=problem_type, st_type=st_type, history=history, shard=shard)
 
 
-def newtonSolver(operators, D, init, nev=2, i=0, tol=1e-3, maxiter=100, print_results=False, st_type=None):
+def newtonSolver(operators, D, init, nev=2, i=0, tol=1e-3, maxiter=100, print_results=False, st_type=None, shard=None):
     """Two-sided Newton iteration on lambda(omega) of L(omega) p = lambda C p (reference: eigensolvers.py:278-348).
 
     Same update as the reference, including its geometrically decaying relaxation (relaxation *= 0.8 every
     iteration, :336-337) -- which is why the reference's own Newton logs stop short of the fixed-point eigenvalue;
-    ``maxiter`` is enforced.  Returns (omega, p) like the reference."""
+    ``maxiter`` is enforced.  Returns (omega, p) like the reference.  ``shard``: collective run on a distributed mesh (operators
+    and flame factors assembled on the rank's part; the brackets p_adj^H L' p are summed over the ranks)."""
     from .eigenvectors import normalize_eigenvector
     from .petsc4py_utils import vector_matrix_vector
     A, B, C = operators.A, operators.B, operators.C
@@ -231,7 +232,7 @@ def newtonSolver(operators, D, init, nev=2, i=0, tol=1e-3, maxiter=100, print_re
             L = A + omega[k] * B + omega[k] ** 2 * C - D.matrix
             dL_domega = B + (2 * omega[k] * C) - D.get_derivative(omega[k])
         # L(omega) p = lambda C p, eigenvalue nearest zero (shift-and-invert at 0), with left eigenvectors
-        E = eps_solver(L, -C, 0, nev, two_sided=True, print_results=print_results, st_type=st_type)
+        E = eps_solver(L, -C, 0, nev, two_sided=True, print_results=print_results, st_type=st_type, shard=shard)
         eig = E.getEigenvalue(i)
         omega_dir, p = normalize_eigenvector(operators.mesh, E, i, degree=1, which='right', print_eigs=False)
         omega_adj, p_adj = normalize_eigenvector(operators.mesh, E, i, degree=1, which='left', print_eigs=False)

@@ -238,8 +238,9 @@ def functionspace(mesh, element):
 class _X:
     """``Function.x``: the dof array (host numpy complex128, like a complex DOLFINx build)."""
 
-    def __init__(self, array):
+    def __init__(self, array, space=None):
         self.array = array
+        self._space = space
 
     def scatter_forward(self):
         pass
@@ -247,13 +248,16 @@ class _X:
     @property
     def petsc_vec(self):
         from .petsc import Vec
-        return Vec(self.array)
+        v = Vec(self.array)
+        # on a distributed local mesh the vector is row-sharded: dots are sums over the ranks' owned entries
+        v.shard = getattr(getattr(self._space, "mesh", None), "shard", None)
+        return v
 
 
 class Function:
     def __init__(self, V, name="f"):
         self.function_space = V
-        self.x = _X(np.zeros(V.size, dtype=np.complex128))
+        self.x = _X(np.zeros(V.size, dtype=np.complex128), V)
         self.name = name
 
     def copy(self):

@@ -33,6 +33,8 @@ def to_device(a, dtype=None):
 class Vec:
     """Device complex128 vector with the petsc4py Vec methods the reference calls."""
 
+    shard = None          # sharded.ShardContext when the vector lives on a distributed mesh ([owned | ghost] entries)
+
     def __init__(self, data):
         if isinstance(data, torch.Tensor):
             self.t = data
@@ -45,10 +47,14 @@ class Vec:
 
     # --- petsc4py surface
     def copy(self):
-        return Vec(self.t.clone())
+        v = Vec(self.t.clone())
+        v.shard = self.shard
+        return v
 
     def duplicate(self):
-        return Vec.zeros(self.t.numel())
+        v = Vec.zeros(self.t.numel())
+        v.shard = self.shard
+        return v
 
     def getSize(self):
         return self.t.numel()
@@ -62,11 +68,22 @@ class Vec:
     def axpy(self, alpha, x):
         _hx.check(_hx.lib.hx_zaxpy(self.t.numel(), _hx.z2(alpha), _hx.ptr(x.t), _hx.ptr(self.t), _hx.stream()))
 
+    def _reduced(self, value):
+        t = torch.tensor([complex(value)], dtype=torch.complex128, device=self.t.device)
+        self.shard.all_reduce_(t)
+        return complex(t[0].item())
+
     def dot(self, other):
-        """PETSc VecDot(x, y) = y^H x  (petsc4py_utils.py:57-61 relies on this)."""
+        """PETSc VecDot(x, y) = y^H x  (petsc4py_utils.py:57-61 relies on this).  Row-sharded vectors: owned entries, summed
+        over the ranks (what VecDot does on a distributed Vec)."""
+        if self.shard is not None:
+            n = self.shard.n_own
+            return self._reduced(panel_dot(other.t[:n].reshape(1, -1), 1, self.t[:n])[0])
         return panel_dot(other.t.reshape(1, -1), 1, self.t)[0]
 
     def norm(self):
+        if self.shard is not None:
+            return float(np.sqrt(self._reduced(panel_dot(None, 0, self.t[:self.shard.n_own])[-1].real).real))
         return float(np.sqrt(panel_dot(None, 0, self.t)[-1].real))
 
     def sum(self):
@@ -361,6 +378,9 @@ class Mat:
 
     def mult(self, x, y):
         K = self.csr_part()
+        shard = getattr(x, "shard", None)
+        if shard is not None:            # row-sharded operand: its ghost entries first (MatMult's scatter)
+            shard.halo(x.t)
         if K is None:
             y.t.zero_()
         else:
@@ -372,6 +392,8 @@ class Mat:
             t = torch.empty(lr.rank, dtype=torch.complex128, device=x.t.device)
             _hx.check(_hx.lib.hx_zsparse_dots(lr.rank, _hx.ptr(ptr), _hx.ptr(idx), _hx.ptr(val), _hx.ptr(x.t),
                                               _hx.ptr(t), _hx.stream()))
+            if shard is not None and lr.local:   # v_f^T x: the ranks hold their owned entries of v_f
+                shard.all_reduce_(t)
             h = (-coef) * t                      # y -= U (-(coef) t)
             U = lr.left_dense()
             _hx.check(_hx.lib.hx_zpanel_sub(lr.n, lr.rank, _hx.ptr(U), U.stride(0), _hx.ptr(h), _hx.ptr(y.t),

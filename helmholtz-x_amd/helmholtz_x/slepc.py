@@ -608,7 +608,8 @@ class _EigenSolverBase:
             raise RuntimeError("left eigenvectors need setTwoSided(True) before solve()")
         lam = self._eigs[i]
         j = int(np.argmin(np.abs(self._left._eigs - lam)))
-        vr.t.copy_(torch.conj_physical(self._left._basis.V[j][:vr.t.numel()]))
+        n = vr.t.numel() if self.shard is None else self.shard.n_own
+        vr.t[:n].copy_(torch.conj_physical(self._left._basis.V[j][:n]))
 
     def setDimensions(self, nev, ncv=None, mpd=None):
         self._nev = int(nev)
@@ -803,8 +804,6 @@ class EPS(_EigenSolverBase):
         solver = WoodburySolver(inner, A.lr_terms, self.W_cache, shard=sh)
         Mcsr = M.csr_part()
         if sh is not None:
-            if self._two_sided:
-                raise NotImplementedError("two-sided solves are single-GPU")
             (Mloc,) = self._local_ops(key, Mcsr)
             n_loc = sh.n_own
             tmp = torch.empty(n_loc, dtype=torch.complex128, device=Mloc.val.device)
@@ -818,6 +817,8 @@ class EPS(_EigenSolverBase):
 
             basis = DeviceBasis(n_loc, self._ncv_for(sh.n_global) + 1, op, start=self._start(), shard=sh, pool=self._pool())
             self._finish(basis, sigma)
+            if self._two_sided:
+                self._left = self._solve_transposed(A, M, sigma)
             return
         tmp = torch.empty(n, dtype=torch.complex128, device=Mcsr.val.device)
 
@@ -828,17 +829,22 @@ class EPS(_EigenSolverBase):
         basis = DeviceBasis(n, self._ncv_for(n) + 1, op, start=self._start(), pool=self._pool())
         self._finish(basis, sigma)
         if self._two_sided:
-            left = EPS()
-            At, Mt = A.copy(), M.copy()
-            At.transpose()
-            Mt.transpose()
-            left.setOperators(At, Mt)
-            left.setTarget(sigma)
-            left.setDimensions(self._nev, self._ncv)
-            left.setTolerances(self._tol, self._max_it)
-            left.st_type = self.st_type
-            left.solve()
-            self._left = left
+            self._left = self._solve_transposed(A, M, sigma)
+
+    def _solve_transposed(self, A, M, sigma):
+        """Right eigenvectors of the transposed pencil (their conjugates are the left eigenvectors, eigensolvers.py:56,319)."""
+        left = EPS()
+        At, Mt = A.copy(), M.copy()
+        At.transpose()
+        Mt.transpose()
+        left.setOperators(At, Mt)
+        left.setTarget(sigma)
+        left.setDimensions(self._nev, self._ncv)
+        left.setTolerances(self._tol, self._max_it)
+        left.st_type = self.st_type
+        left.shard = self.shard
+        left.solve()
+        return left
 
 
 class PEP(_EigenSolverBase):

@@ -455,7 +455,7 @@ def test_library_issued_rccl_calls_on_one_rank():
     assert out[0][0] == 4 and out[0][1] == 2
 
 
-def _micca_distributed_worker(rank, world, port, out, golden_dir):
+def _micca_distributed_worker(rank, world, port, out, golden_dir, mode="fpi"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
@@ -492,6 +492,18 @@ def _micca_distributed_worker(rank, world, port, out, golden_dir):
             h = Q_multiple(local, sub_l, Micca.N_sector)
             D = PointwiseFlameMatrix(local, sub_l, Micca.x_r(), h, Micca.rho_amb, Micca.q_0, Micca.u_b, FTF, degree=1)
             D.assemble_submatrices('direct')
+            if mode == "newton":
+                import re
+                from helmholtz_x.eigensolvers import newtonSolver
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    omega, p = newtonSolver(matrices, D, 3260 + 460j, i=0, nev=2, tol=1e-2, st_type="amg", shard=ctx)
+                lines = re.findall(r"iter =\s*(\d+),\s+omega = ([+-][\d.]+)\s+([+-][\d.]+)j,\s+\|domega\| = ([\d.e+-]+)",
+                                   buf.getvalue())
+                n_own = local.part["n_own"]
+                out[rank] = dict(omega=complex(omega), lines=[(float(a), float(b), float(c)) for _, a, b, c in lines],
+                                 p_own=p.x.array[:n_own].copy(), x_own=local.geometry.x[:n_own].copy())
+                return
             hist = []
             E = fixed_point_iteration(matrices, D, Micca.target, i=0, nev=4, tol=1e-3, st_type="amg", history=hist, shard=ctx)
         inner = [v for v in E.inner_cache.values() if hasattr(v, "stats")][0]
@@ -685,3 +697,26 @@ def test_flamedduct_distributed_over_two_ranks(ref_logs, golden_dir):
             assert abs(z - ref) / abs(ref) < 1e-8, (z, ref)
     # inlet and outlet sit at opposite ends of the duct: with two ranks each end belongs (mostly) to another rank
     assert sum(out[r][1][0] for r in range(world)) > 0 and sum(out[r][1][1] for r in range(world)) > 0
+
+
+@pytest.mark.gpu
+def test_micca_newton_solver_distributed_over_two_ranks(ref_logs, golden_dir):
+    """active_newton.py (eigensolvers.py:278-348) on the distributed real MICCA mesh: two-sided shift-invert solves (left
+    eigenvectors from the transposed pencil, collectively), eigenvectors normalised on the distributed mesh, the brackets
+    p_adj^H L'(omega) p and p_adj^H C p as sums over the ranks (row-sharded MatMult with the factored flame term + VecDot).  The
+    reference's logged run for mode 0 -- 19 iterations, omega to its 2 printed decimals, |domega| to its 3 digits -- and the stored
+    16-digit result to 1e-9, as on one GPU."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_micca_distributed_worker, args=(world, port, out, golden_dir, "newton"), nprocs=world, join=True)
+    assert len(out) == world
+    g = ref_logs["micca_full_newton"]
+    ref = g["iterations_omega_2dec_and_domega"][0]
+    final = complex(*g["final"][0])
+    for rank in range(world):
+        r = out[rank]
+        assert len(r["lines"]) == len(ref)
+        for (re_, im_, dom), (rr, ri, rd) in zip(r["lines"], ref):
+            assert abs(re_ - rr) < 0.011 and abs(im_ - ri) < 0.011
+            assert abs(dom - rd) <= 0.011 * rd
+        assert abs(r["omega"] - final) / abs(final) < 1e-9, (r["omega"], final)

@@ -33,6 +33,8 @@ int hx_zpanel_bdot(int64_t, int, const hx_c128*, int64_t, const hx_c128*, const 
 int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 int hx_zpanel_bdot_c64(int64_t, int, const hx_c64*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
 int hx_zpanel_bdot_w32(int64_t, int, const hx_c128*, int64_t, const hx_c64*, const hx_c128*, hx_c128*, hx_c128*, hx_stream);
+int hx_zpanel_bdot_partials(int64_t, int, const hx_c128*, int64_t, const hx_c128*, const hx_c128*, hx_c128*, hx_stream);
+int hx_zpanel_bdot_w32_partials(int64_t, int, const hx_c128*, int64_t, const hx_c64*, const hx_c128*, hx_c128*, hx_stream);
 int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
 int hx_amg_vcycle_buffers(hx_amg*, hx_c64**, hx_c64**);
 int hx_amg_vcycle_c64(hx_amg*, hx_stream);
@@ -55,9 +57,24 @@ static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0};
 __global__ void __launch_bounds__(256)
 k_cocg_update(int64_t n, const zc* __restrict__ p, const zc* __restrict__ q, zc* __restrict__ x, zc* __restrict__ r,
               cc* __restrict__ r32 /* may be NULL: complex64 copy of the new residual = the V-cycle's input */,
-              const zc* __restrict__ sc, zc* __restrict__ partials, int64_t rows_per_block) {
+              const zc* __restrict__ sc, zc* __restrict__ partials, int64_t rows_per_block,
+              const zc* __restrict__ pq_partials /* may be NULL */, int pq_blocks) {
   __shared__ double red[256 / HX_WAVE];
-  const zc alpha = zdiv(sc[CG_RHO], sc[CG_OUT]);
+  __shared__ zc s_pq;
+  // p^T q: reduced already (sc[CG_OUT]), or -- single-GPU path -- the stage-1 partials of its panel dot, summed here by every
+  // block in the fixed order of k_panel_dot_stage2 (lanes stride over the blocks, then the shuffle tree): same bits
+  zc pq;
+  if (pq_partials) {
+    if (threadIdx.x < HX_WAVE) {
+      zc v = make_double2(0.0, 0.0);
+      for (int bq = threadIdx.x; bq < pq_blocks; bq += HX_WAVE) v = zadd(v, pq_partials[bq]);
+      v = zreduce_sub<HX_WAVE>(v);
+      if (threadIdx.x == 0) s_pq = v;
+    }
+    __syncthreads();
+    pq = s_pq;
+  } else pq = sc[CG_OUT];
+  const zc alpha = zdiv(sc[CG_RHO], pq);
   const int64_t r0 = blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
@@ -86,16 +103,31 @@ k_cocg_update(int64_t n, const zc* __restrict__ p, const zc* __restrict__ q, zc*
 // After the reduction of [C^T z ; r^T z]: beta = rho_new / rho (0 on the first step), rho = rho_new, t = sign * E^-1 c.
 // mode 0: direction update (sign +, with beta); mode 1: Galerkin start (t = -E^-1 U^T b so that x = 0 - U t ... ), no rho.
 __global__ void __launch_bounds__(HX_WAVE)
-k_cocg_small(int k, const zc* __restrict__ Einv, zc* __restrict__ sc, int first, int mode) {
+k_cocg_small(int k, const zc* __restrict__ Einv, zc* __restrict__ sc, int first, int mode,
+             const zc* __restrict__ partials /* may be NULL */, int nblocks) {
   const int i = threadIdx.x;
+  __shared__ zc s_out[CG_MAXK + 1];
+  if (partials) {
+    // the k + 1 reductions arrive as per-block partials (stage 1 of the panel dot): summed here in the fixed order of
+    // k_panel_dot_stage2 -- same bits, one launch fewer
+    for (int j = 0; j <= k; ++j) {
+      zc v = make_double2(0.0, 0.0);
+      for (int b = i; b < nblocks; b += HX_WAVE) v = zadd(v, partials[(int64_t)b * (k + 1) + j]);
+      v = zreduce_sub<HX_WAVE>(v);
+      if (i == 0) { s_out[j] = v; sc[CG_OUT + j] = v; }
+    }
+  } else if (i <= k) s_out[i] = sc[CG_OUT + i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (i < k) {
     zc t = make_double2(0.0, 0.0);
-    for (int j = 0; j < k; ++j) zfma(t, Einv[i * k + j], sc[CG_OUT + j]);
+    for (int j = 0; j < k; ++j) zfma(t, Einv[i * k + j], s_out[j]);
     if (mode == 1) t = make_double2(-t.x, -t.y);
     sc[CG_T + i] = t;
   }
   if (i == 0 && mode == 0) {
-    const zc rho_new = sc[CG_OUT + k];
+    const zc rho_new = s_out[k];
     sc[CG_BETA] = first ? make_double2(0.0, 0.0) : zdiv(rho_new, sc[CG_RHO]);
     sc[CG_RHO] = rho_new;
   }
@@ -264,6 +296,9 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     return HX_OK;
   };
   cd host[CG_MAXK + 2];
+  const bool fuse = !sharded && getenv("HX_COCG_FUSE_REDUCTIONS") ? atoi(getenv("HX_COCG_FUSE_REDUCTIONS")) != 0 : !sharded;
+  const int PD_NB = 1024;                       // PD_MAXBLOCKS of vecops.hip: room of one column of partials
+  std::vector<cd> hpart(fuse ? (size_t)PD_NB : 0);
   auto fetch = [&](int count) -> int {        // first `count` scalars -> host (SYNC)
     HX_HIP(hipMemcpyAsync(host, sc, sizeof(cd) * (size_t)count, hipMemcpyDeviceToHost, hx_s(s)));
     HX_HIP(hipStreamSynchronize(hx_s(s)));
@@ -383,7 +418,7 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     if (k > 0) {     // Galerkin correction on span(U): x += U E^-1 U^T r, so that U^T r = 0 again
       if ((rc = hx_zpanel_bdot_c64(n, k, (const hx_c64*)rec->Uf, n, r, r, sc, part, s))) return rc;   // U^T r (entry k unused)
       if ((rc = reduce(k))) return rc;
-      k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, (const zc*)rec->Einv, (zc*)sc, 1, 1);
+      k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, (const zc*)rec->Einv, (zc*)sc, 1, 1, nullptr, 0);
       HX_LAUNCH_CHECK("k_cocg_small");
       k_cocg_start<cc, -1><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const cc*)rec->Uf, n, (zc*)x, (const zc*)sc);
       HX_LAUNCH_CHECK("k_cocg_start");
@@ -409,15 +444,21 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     int since_best = 0;
     while (it < max_it) {
       // z = M r ;  [c ; rho] = [C^T z ; r^T z] ;  t = E^-1 c, beta ;  p = z - U t + beta p
+      // single GPU: the consumers of the three reductions of an iteration sum the stage-1 partials themselves (k_cocg_small,
+      // k_cocg_update, the host for |r|^2) in the order of stage 2: three launches fewer, same bits.  Row-sharded: the reduced
+      // scalars have to exist on the device for the all-reduce, so the two-stage form stays.
       if (r32) {
         if ((rc = hx_amg_vcycle_c64(M, s))) return rc;
-        if ((rc = hx_zpanel_bdot_w32(n, k, k > 0 ? rec->Cd : nullptr, n, z32, r, sc, part, s))) return rc;
+        if ((rc = fuse ? hx_zpanel_bdot_w32_partials(n, k, k > 0 ? rec->Cd : nullptr, n, z32, r, part, s)
+                       : hx_zpanel_bdot_w32(n, k, k > 0 ? rec->Cd : nullptr, n, z32, r, sc, part, s))) return rc;
       } else {
         if ((rc = hx_amg_vcycle(M, r, z, s))) return rc;
-        if ((rc = hx_zpanel_bdot(n, k, k > 0 ? rec->Cd : nullptr, n, z, r, sc, part, s))) return rc;
+        if ((rc = fuse ? hx_zpanel_bdot_partials(n, k, k > 0 ? rec->Cd : nullptr, n, z, r, part, s)
+                       : hx_zpanel_bdot(n, k, k > 0 ? rec->Cd : nullptr, n, z, r, sc, part, s))) return rc;
       }
       if ((rc = reduce(k + 1))) return rc;
-      k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, rec ? (const zc*)rec->Einv : nullptr, (zc*)sc, first ? 1 : 0, 0);
+      k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, rec ? (const zc*)rec->Einv : nullptr, (zc*)sc, first ? 1 : 0, 0,
+                                               fuse ? (const zc*)part : nullptr, nblocks);
       HX_LAUNCH_CHECK("k_cocg_small");
       if (r32) k_cocg_direction<cc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, rec ? (const cc*)rec->Uf : nullptr, n,
                                                                           (const cc*)z32, (zc*)p, (const zc*)sc);
@@ -427,17 +468,31 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       first = false;
       // q = K p ;  alpha = rho / p^T q ;  x += alpha p, r -= alpha q, |r|^2
       if ((rc = Kx(p, q, ONE, ZERO))) return rc;
-      if ((rc = hx_zpanel_bdot(n, 0, nullptr, n, q, p, sc, part, s))) return rc;
+      if ((rc = fuse ? hx_zpanel_bdot_partials(n, 0, nullptr, n, q, p, part, s)
+                     : hx_zpanel_bdot(n, 0, nullptr, n, q, p, sc, part, s))) return rc;
       if ((rc = reduce(1))) return rc;
+      hx_c128* part_r = part + PD_NB;             // |r|^2 partials of the update: behind the p^T q partials it reads
       k_cocg_update<<<nblocks, 256, 0, hx_s(s)>>>(n, (const zc*)p, (const zc*)q, (zc*)x, (zc*)r, (cc*)r32, (const zc*)sc,
-                                                  (zc*)part, rpb);
+                                                  (zc*)part_r, rpb, fuse ? (const zc*)part : nullptr, nblocks);
       HX_LAUNCH_CHECK("k_cocg_update");
       x_zero = false;
-      if ((rc = hx_panel_dot_finish(nblocks, 0, part, sc, s))) return rc;
-      if ((rc = reduce(1))) return rc;
-      if ((rc = fetch(1))) return rc;
+      double r2;
+      if (fuse) {        // the host sums the update's per-block partials in the order of stage 2
+        HX_HIP(hipMemcpyAsync(hpart.data(), part_r, sizeof(cd) * (size_t)nblocks, hipMemcpyDeviceToHost, hx_s(s)));
+        HX_HIP(hipStreamSynchronize(hx_s(s)));
+        double lane[HX_WAVE];
+        for (int l = 0; l < HX_WAVE; ++l) lane[l] = 0.0;
+        for (int bq = 0; bq < nblocks; ++bq) lane[bq % HX_WAVE] += hpart[bq].real();
+        for (int o = HX_WAVE / 2; o > 0; o >>= 1) for (int l = 0; l < o; ++l) lane[l] += lane[l + o];
+        r2 = lane[0];
+      } else {
+        if ((rc = hx_panel_dot_finish(nblocks, 0, part_r, sc, s))) return rc;
+        if ((rc = reduce(1))) return rc;
+        if ((rc = fetch(1))) return rc;
+        r2 = host[0].real();
+      }
       ++it;
-      relres = std::sqrt(host[0].real()) / bnorm;
+      relres = std::sqrt(r2) / bnorm;
       if (trace) fprintf(stderr, "[hx_cocg] it %3d  relres %.3e\n", it, relres);
       if (h_iters) *h_iters = it;
       if (h_relres) *h_relres = relres;

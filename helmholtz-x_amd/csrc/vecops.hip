@@ -224,13 +224,14 @@ int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* ou
 }
 template <typename PT, int JT, bool BILIN, typename WT = zc>
 static int panel_dot_launch(int64_t n, int k, const PT* V, int64_t ldv, const void* w, const hx_c128* e, hx_c128* out,
-                            hx_c128* partials, hx_stream s) {
+                            hx_c128* partials, hx_stream s, bool finish = true) {
   HX_REQUIRE(n > 0 && k >= 0 && w && out && partials && (k == 0 || V) && ldv >= n && (!BILIN || e), "bad argument");
   int64_t rpb;
   const int nblocks = hx_panel_dot_blocks(n, &rpb);
   k_panel_dot_stage1<PT, JT, BILIN, WT><<<nblocks, PD_BLOCK, 0, hx_s(s)>>>(n, k, V, ldv, (const WT*)w, (const zc*)e,
                                                                           (zc*)partials, rpb);
   HX_LAUNCH_CHECK("k_panel_dot_stage1");
+  if (!finish) return HX_OK;          // the consumer kernel sums the per-block partials itself (hx_cocg: one launch fewer)
   return hx_panel_dot_finish(nblocks, k, partials, out, s);
 }
 extern "C" int hx_zpanel_dot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, hx_c128* out,
@@ -246,6 +247,15 @@ extern "C" int hx_zpanel_dot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv
 int hx_zpanel_bdot(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, const hx_c128* e, hx_c128* out,
                    hx_c128* partials, hx_stream s) {
   return panel_dot_launch<zc, PD_JT, true>(n, k, (const zc*)V, ldv, w, e, out, partials, s);
+}
+// stage 1 only: partials[b * (k + 1) + j], b < hx_panel_dot_blocks(n), summed by the consumer in the order of stage 2
+int hx_zpanel_bdot_partials(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c128* w, const hx_c128* e,
+                            hx_c128* partials, hx_stream s) {
+  return panel_dot_launch<zc, PD_JT, true>(n, k, (const zc*)V, ldv, w, e, partials, partials, s, false);
+}
+int hx_zpanel_bdot_w32_partials(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c64* w, const hx_c128* e,
+                                hx_c128* partials, hx_stream s) {
+  return panel_dot_launch<zc, PD_JT, true, cc>(n, k, (const zc*)V, ldv, w, e, partials, partials, s, false);
 }
 // the same with w given in complex64 (panel complex128)
 int hx_zpanel_bdot_w32(int64_t n, int k, const hx_c128* V, int64_t ldv, const hx_c64* w, const hx_c128* e, hx_c128* out,

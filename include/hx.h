@@ -46,6 +46,7 @@ enum hx_status {
  * first call that consults it, and cached for the life of the process: set them before the first libhx call -- changing one
  * afterwards (e.g. from a test that monkey-patches os.environ mid-run) has no effect.
  *   HX_SELL_STENCIL=0 / HX_SELL_INDEX=i32 / HX_SELL_LDS=0|2   SELL-64 format and kernel variants (hx_sell_create, k_sell)
+ *   HX_COCG_FUSE_REDUCTIONS=0                                  hx_cocg (read per solve): two-stage reductions on one GPU too
  *   HX_CHEB_LO, HX_CHEB_KIND, HX_AMG_COARSE_EXTRA             Chebyshev bounds / kind, extra coarse smoothing steps
  *   HX_AMG_GRAPH_PRIVATE_STREAM                               hipGraph replay of the V-cycle on a private stream
  *   HX_GMRES_TRACE=1                                          residual histories of hx_gmres / hx_cocg on stderr

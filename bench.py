@@ -454,6 +454,7 @@ def main(argv=None):
         t0 = time.perf_counter()
         pairs = 0
         hist = []
+        step_marks = [t0]
         E = matrices = None
         for _ in range(args.steps):
             hist = []
@@ -463,6 +464,7 @@ def main(argv=None):
             gc.collect()
             E, matrices = hot_path(case, args.st_type, history=hist)
             pairs += min(E.getConverged(), 4)
+            step_marks.append(time.perf_counter())      # (a call ends with its eigenvalues on the host: the queue is empty)
         barrier()
         dt = time.perf_counter() - t0
         in_situ, in_situ_smoother = read_in_situ()
@@ -479,6 +481,7 @@ def main(argv=None):
         "value": round(pairs / dt, 5), "unit": "eigenpairs/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / max(args.steps, 1), 2),
+        "ms_each_step": [round(1e3 * (b - a), 1) for a, b in zip(step_marks[:-1], step_marks[1:])],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "c128", "data": "synthetic",
         "config": {"workload": args.workload, "grid_nr_ntheta_nz": list(shape), "dofs": n_dof, "tets": n_cells,

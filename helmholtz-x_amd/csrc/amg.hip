@@ -164,6 +164,8 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
   if (h->ev_in) (void)hipEventDestroy(h->ev_in);
   if (h->ev_out) (void)hipEventDestroy(h->ev_out);
   if (h->gstream) (void)hipStreamDestroy(h->gstream);
+  if (h->cg_pin) (void)hipHostFree(h->cg_pin);
+  for (hipEvent_t e : h->cg_ev) if (e) (void)hipEventDestroy(e);
   delete h;
   return HX_OK;
 }

@@ -67,4 +67,8 @@ struct hx_amg {
   hipGraphExec_t vexec = nullptr;
   hipStream_t gstream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // hx_cocg (single GPU): two pinned landing areas for the per-block partials of |r|^2 and the events that mark their arrival,
+  // so that the host can read the norm of iteration j while iteration j + 1 is already queued
+  void* cg_pin = nullptr;
+  hipEvent_t cg_ev[2] = {nullptr, nullptr};
 };

@@ -298,7 +298,6 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   cd host[CG_MAXK + 2];
   const bool fuse = !sharded && getenv("HX_COCG_FUSE_REDUCTIONS") ? atoi(getenv("HX_COCG_FUSE_REDUCTIONS")) != 0 : !sharded;
   const int PD_NB = 1024;                       // PD_MAXBLOCKS of vecops.hip: room of one column of partials
-  std::vector<cd> hpart(fuse ? (size_t)PD_NB : 0);
   auto fetch = [&](int count) -> int {        // first `count` scalars -> host (SYNC)
     HX_HIP(hipMemcpyAsync(host, sc, sizeof(cd) * (size_t)count, hipMemcpyDeviceToHost, hx_s(s)));
     HX_HIP(hipStreamSynchronize(hx_s(s)));
@@ -442,7 +441,56 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     bool first = true;
     double best = relres, prev = relres;
     int since_best = 0;
-    while (it < max_it) {
+    // One residual norm judged (in iteration order): leave = true ends this run of the recurrences.
+    bool leave = false;
+    auto judge = [&](double r2) -> int {
+      ++it;
+      relres = std::sqrt(r2) / bnorm;
+      if (trace) fprintf(stderr, "[hx_cocg] it %3d  relres %.3e\n", it, relres);
+      if (h_iters) *h_iters = it;
+      if (h_relres) *h_relres = relres;
+      if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "breakdown (p^T K p = 0 or r^T z = 0)");
+      if (relres <= rtol) { leave = true; return HX_OK; }
+      if (relres <= 1e3 * rtol && relres > 0.5 * prev) {               // progress slows down near the goal: attainable accuracy?
+        if ((rc = backward_error(relres))) return rc;
+        if (M->last_backward <= BE_FLOOR) { leave = true; return HX_OK; }
+      }
+      prev = relres;
+      if (relres < best) { best = relres; since_best = 0; }
+      else {
+        ++since_best;
+        if (since_best >= 3 && best <= 1e3 * rtol) leave = true;       // drifting away from a nearly converged iterate
+        else if (since_best >= 6) leave = true;                         // stagnation: let the next cycle judge it (backward error)
+        else if (relres > 1e6 * best) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "diverging recurrence");
+      }
+      return HX_OK;
+    };
+    // Single GPU: the host does not wait for |r_j| while the residual is still far from every stopping rule.  The partials of
+    // the update land in one of two pinned areas; while the last JUDGED residual is above LAG_MARGIN * rtol (and the recurrence is
+    // not stalling) iteration j + 1 is queued first and |r_j| is read after it -- the queue never drains on the host round trip
+    // (42 us per inner iteration at 1 M DOF).  None of the rules can fire on |r_j| in that regime except "converged" after a
+    // single-step drop by more than LAG_MARGIN; the recurrence then simply ends one (converged) iteration later.  Closer to the
+    // tolerance every norm is awaited as before.  HX_COCG_LAG=0: always wait.
+    static const int lag_env = getenv("HX_COCG_LAG") ? atoi(getenv("HX_COCG_LAG")) : 1;
+    const double LAG_MARGIN = 1e4;
+    const bool may_lag = fuse && lag_env != 0 && !trace;
+    if (fuse && !M->cg_pin) {
+      HX_HIP(hipHostMalloc(&M->cg_pin, 2 * sizeof(cd) * (size_t)PD_NB, hipHostMallocDefault));
+      for (int e = 0; e < 2; ++e) HX_HIP(hipEventCreateWithFlags(&M->cg_ev[e], hipEventDisableTiming));
+    }
+    auto arrived = [&](int slot, double* r2) -> int {      // waits for the partials of one update, sums them in the order of stage 2
+      HX_HIP(hipEventSynchronize(M->cg_ev[slot]));
+      const cd* hp = (const cd*)M->cg_pin + (size_t)slot * PD_NB;
+      double lane[HX_WAVE];
+      for (int l = 0; l < HX_WAVE; ++l) lane[l] = 0.0;
+      for (int bq = 0; bq < nblocks; ++bq) lane[bq % HX_WAVE] += hp[bq].real();
+      for (int o = HX_WAVE / 2; o > 0; o >>= 1) for (int l = 0; l < o; ++l) lane[l] += lane[l + o];
+      *r2 = lane[0];
+      return HX_OK;
+    };
+    int queued = it;                 // iterations queued (it = iterations judged)
+    int pending = -1;                // landing area of a queued, not yet judged iteration
+    while (queued < max_it) {
       // z = M r ;  [c ; rho] = [C^T z ; r^T z] ;  t = E^-1 c, beta ;  p = z - U t + beta p
       // single GPU: the consumers of the three reductions of an iteration sum the stage-1 partials themselves (k_cocg_small,
       // k_cocg_update, the host for |r|^2) in the order of stage 2: three launches fewer, same bits.  Row-sharded: the reduced
@@ -477,39 +525,40 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       HX_LAUNCH_CHECK("k_cocg_update");
       x_zero = false;
       double r2;
-      if (fuse) {        // the host sums the update's per-block partials in the order of stage 2
-        HX_HIP(hipMemcpyAsync(hpart.data(), part_r, sizeof(cd) * (size_t)nblocks, hipMemcpyDeviceToHost, hx_s(s)));
-        HX_HIP(hipStreamSynchronize(hx_s(s)));
-        double lane[HX_WAVE];
-        for (int l = 0; l < HX_WAVE; ++l) lane[l] = 0.0;
-        for (int bq = 0; bq < nblocks; ++bq) lane[bq % HX_WAVE] += hpart[bq].real();
-        for (int o = HX_WAVE / 2; o > 0; o >>= 1) for (int l = 0; l < o; ++l) lane[l] += lane[l + o];
-        r2 = lane[0];
-      } else {
+      if (!fuse) {
         if ((rc = hx_panel_dot_finish(nblocks, 0, part_r, sc, s))) return rc;
         if ((rc = reduce(1))) return rc;
         if ((rc = fetch(1))) return rc;
-        r2 = host[0].real();
+        ++queued;
+        if ((rc = judge(host[0].real()))) return rc;
+        if (leave) break;
+        continue;
       }
-      ++it;
-      relres = std::sqrt(r2) / bnorm;
-      if (trace) fprintf(stderr, "[hx_cocg] it %3d  relres %.3e\n", it, relres);
-      if (h_iters) *h_iters = it;
-      if (h_relres) *h_relres = relres;
-      if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "breakdown (p^T K p = 0 or r^T z = 0)");
-      if (relres <= rtol) break;
-      if (relres <= 1e3 * rtol && relres > 0.5 * prev) {               // progress slows down near the goal: attainable accuracy?
-        if ((rc = backward_error(relres))) return rc;
-        if (M->last_backward <= BE_FLOOR) break;
+      const int slot = queued & 1;
+      HX_HIP(hipMemcpyAsync((cd*)M->cg_pin + (size_t)slot * PD_NB, part_r, sizeof(cd) * (size_t)nblocks, hipMemcpyDeviceToHost,
+                            hx_s(s)));
+      HX_HIP(hipEventRecord(M->cg_ev[slot], hx_s(s)));
+      ++queued;
+      if (pending >= 0) {            // the iteration before this one: its norm arrived long ago
+        if ((rc = arrived(pending, &r2))) return rc;
+        pending = -1;
+        if ((rc = judge(r2))) return rc;
+        if (leave) {                 // (a drop by more than LAG_MARGIN in one step) x is one iteration further: judge that one, stop
+          if ((rc = arrived(slot, &r2))) return rc;
+          if ((rc = judge(r2))) return rc;
+          leave = true;
+          break;
+        }
       }
-      prev = relres;
-      if (relres < best) { best = relres; since_best = 0; }
-      else {
-        ++since_best;
-        if (since_best >= 3 && best <= 1e3 * rtol) break;               // drifting away from a nearly converged iterate
-        if (since_best >= 6) break;                                     // stagnation: let the next cycle judge it (backward error)
-        if (relres > 1e6 * best) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "diverging recurrence");
-      }
+      if (may_lag && relres > LAG_MARGIN * rtol && since_best <= 3 && queued < max_it) { pending = slot; continue; }
+      if ((rc = arrived(slot, &r2))) return rc;
+      if ((rc = judge(r2))) return rc;
+      if (leave) break;
+    }
+    if (pending >= 0) {              // (iteration limit reached with one norm outstanding)
+      double r2;
+      if ((rc = arrived(pending, &r2))) return rc;
+      if ((rc = judge(r2))) return rc;
     }
   }
   if (!converged) {                           // iteration / cycle limit: report the true residual of what we have

@@ -639,10 +639,15 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
        const int32_t* __restrict__ st_delta, int32_t n_cols, const MV* __restrict__ val, const V* __restrict__ x, V* y,
        const V* yin, const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev, const SellOp<V> a,
-       const int32_t* __restrict__ slice_list) {
+       const int32_t* __restrict__ slice_list, int32_t xcd_chunk) {
   const int lane = threadIdx.x & 63;
   // n_slices counts the waves of this launch: all slices, or the entries of slice_list (interior / boundary part)
-  const int32_t wv = __builtin_amdgcn_readfirstlane((int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6));
+  // xcd_chunk > 0: workgroups are dealt round-robin to the eight XCDs, so workgroup g of XCD k = blockIdx.x % 8 takes the
+  // g-th group of four slices of the k-th EIGHTH of the operator: neighbouring slices (which share their x windows: the
+  // plane below, the own plane, the plane above) then meet in ONE L2 instead of being fetched through every XCD's
+  int64_t blk = blockIdx.x;
+  if (xcd_chunk > 0) blk = (int64_t)(blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3);
+  const int32_t wv = __builtin_amdgcn_readfirstlane((int32_t)((blk * (int64_t)blockDim.x + threadIdx.x) >> 6));
   if (wv >= n_slices) return;
   const int32_t slice = slice_list ? __builtin_amdgcn_readfirstlane(slice_list[wv]) : wv;
   const int64_t base = slice_ptr[slice];
@@ -704,8 +709,18 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
   const int32_t* list = part == 1 ? h->list_interior : part == 2 ? h->list_boundary : nullptr;
   const int32_t nw = part == 1 ? h->n_interior : part == 2 ? h->n_boundary : h->n_slices;
   if (nw == 0) return;
-  kern<<<sell_grid(nw), 256, 0, hx_s(s)>>>(h->n, nw, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
-                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list);
+  // XCD-contiguous schedule (see k_sell).  It pays while the pass is served from the 256 MB Infinity Cache (every launch of
+  // a solve re-reads the same operator): the x windows refetched through eight L2s are then a fifth of the fabric traffic
+  // (1.9 M rows: smoother step 35.4 -> 29.0 us, residual 33.5 -> 26.1; 1 M rows: operator product 45.4 -> 41.5 us).  Beyond
+  // that size the pass streams from HBM, the refetches come from the cache beside it and the interleaved schedule is as fast or
+  // faster (5 M rows: 95 vs 98 us).  HX_SELL_XCD = 0 / 3: never / always (bit 0 complex64 kernels, bit 1 complex128).
+  static const int xcd_mode = getenv("HX_SELL_XCD") ? atoi(getenv("HX_SELL_XCD")) : -1;
+  const double footprint = (double)h->padded * sizeof(MV) + (double)h->n * sizeof(V) * (MODE == 1 ? 5 : 3);
+  const bool xcd = sell_grid(nw) >= 64 &&
+                   (xcd_mode < 0 ? footprint <= 288e6 : (xcd_mode & (sizeof(V) == 8 ? 1 : 2)) != 0);
+  const int32_t chunk = xcd ? (sell_grid(nw) + 7) / 8 : 0;
+  kern<<<xcd ? 8 * chunk : sell_grid(nw), 256, 0, hx_s(s)>>>(h->n, nw, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
+                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list, chunk);
 }
 
 

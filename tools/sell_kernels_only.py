@@ -19,7 +19,8 @@ from helmholtz_x.petsc import combine_csr  # noqa: E402
 name, reps = sys.argv[1], int(sys.argv[2])
 numbering = sys.argv[3] if len(sys.argv) > 3 else "native"
 jitter = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
-case = bench.build_case(bench.WORKLOADS[name], numbering, jitter)
+shape = bench.WORKLOADS[name] if name in bench.WORKLOADS else tuple(int(v) for v in name.split("x"))   # or NRxNTxNZ
+case = bench.build_case(shape, numbering, jitter)
 P = case["P"]
 M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
 K = combine_csr(M.A.shape, M.A.csr_terms + [(P.target * c, m) for c, m in M.B.csr_terms]

@@ -631,6 +631,7 @@ struct SellOp {            // the scalars of the update
   V alpha, beta;
   int beta_is_zero;
   typename real_of<V>::type omega, mom, vscale;
+  int ablate;              // timing-only experiment hook (HX_SELL_ABLATE; results are WRONG): bit 0 no D^-1 stream, bit 1 one entry fewer per row
 };
 
 template <typename V, int MODE, typename MV, int G, bool LDSX>
@@ -651,7 +652,7 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
   if (wv >= n_slices) return;
   const int32_t slice = slice_list ? __builtin_amdgcn_readfirstlane(slice_list[wv]) : wv;
   const int64_t base = slice_ptr[slice];
-  const int32_t width = (int32_t)((slice_ptr[slice + 1] - base) >> 6);
+  const int32_t width = (int32_t)((slice_ptr[slice + 1] - base) >> 6) - ((a.ablate >> 1) & 1);
   int32_t st0 = 0, stw = 0;
   if (st_ptr) { st0 = st_ptr[slice]; stw = st_ptr[slice + 1] - st0; }
   const int32_t u = lane < stw ? st_delta[st0 + lane] : 0;       // the slice's delta list, one entry per lane
@@ -664,7 +665,7 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     } else {
       rb = b[row];
       rx = x[row];
-      rd = dinv[row];
+      if (a.ablate & 1) rd.x = 1; else rd = dinv[row];
       if (a.mom != 0 && xprev) rp = xprev[row];
     }
   }
@@ -700,7 +701,8 @@ template <typename V, int MODE, typename MV>
 static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alpha, V beta, int beta_is_zero, const V* dinv,
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
                         typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr, int part = 0) {
-  const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale};
+  static const int ablate = getenv("HX_SELL_ABLATE") ? atoi(getenv("HX_SELL_ABLATE")) : 0;
+  const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale, MODE == 1 || sizeof(V) == 8 ? ablate : 0};
   // x windows of the stencil slices through LDS (HX_SELL_LDS=0: gathers everywhere; =2: also for complex128 values)
   static const int lds_mode = getenv("HX_SELL_LDS") ? atoi(getenv("HX_SELL_LDS")) : 1;
   const bool use_lds = h->st_ptr && (lds_mode == 2 || (lds_mode == 1 && sizeof(MV) == 4));

@@ -46,6 +46,8 @@ enum hx_status {
  * first call that consults it, and cached for the life of the process: set them before the first libhx call -- changing one
  * afterwards (e.g. from a test that monkey-patches os.environ mid-run) has no effect.
  *   HX_SELL_STENCIL=0 / HX_SELL_INDEX=i32 / HX_SELL_LDS=0|2   SELL-64 format and kernel variants (hx_sell_create, k_sell)
+ *   HX_SELL_XCD=0|3, HX_SELL_ABLATE                            XCD-contiguous slice schedule never / always (default: by footprint); timing-only ablations
+ *   HX_COCG_LAG=0                                             hx_cocg: wait for every residual norm (default: read one iteration late while far from the tolerance)
  *   HX_COCG_FUSE_REDUCTIONS=0                                  hx_cocg (read per solve): two-stage reductions on one GPU too
  *   HX_CHEB_LO, HX_CHEB_KIND, HX_AMG_COARSE_EXTRA             Chebyshev bounds / kind, extra coarse smoothing steps
  *   HX_AMG_GRAPH_PRIVATE_STREAM                               hipGraph replay of the V-cycle on a private stream

@@ -525,6 +525,53 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
     assert solver.stats()["vcycle_graph"] == ("graph_max_rows" in overrides)      # hipGraph replay of the V-cycle
 
 
+_COCG_AB_SCRIPT = r"""
+import hashlib, json, os, sys
+sys.path[:0] = [os.environ["HX_TEST_ROOT"], os.path.join(os.environ["HX_TEST_ROOT"], "helmholtz-x_amd")]
+os.environ.setdefault("HX_QUIET", "1")
+import numpy as np, torch
+import bench
+from helmholtz_x.acoustic_matrices import AcousticMatrices
+from helmholtz_x.amg import AMGSolver
+from helmholtz_x.petsc import combine_csr, to_device
+case = bench.build_case((10, 128, 12))
+P = case["P"]
+M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+K = combine_csr(M.A.shape, M.A.csr_terms + [(P.target * c, m) for c, m in M.B.csr_terms]
+                + [(P.target ** 2 * c, m) for c, m in M.C.csr_terms])
+solver = AMGSolver(K, cocg_min_rows=0, recycle_min_rows=0, sell_min_rows=0)
+rng = np.random.default_rng(5)
+out = []
+for k in range(4):
+    b = to_device(rng.standard_normal(K.shape[0]) + 1j * rng.standard_normal(K.shape[0]))
+    x = torch.empty_like(b)
+    solver.solve(b, x, relax=1.0 if k < 3 else 1e3)
+    out.append([int(solver.last[0]), float(solver.last[1]), hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest()])
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_cocg_fused_reductions_and_lagged_norm_reads_leave_the_solve_bitwise_unchanged():
+    """The single-GPU short cuts of hx_cocg -- consumers summing the stage-1 partials of the three reductions, |r_j| read while
+    iteration j + 1 is queued -- change neither an iterate nor a stopping decision: same iteration counts, residuals and
+    solution BITS as the two-stage, wait-for-every-norm form (HX_COCG_FUSE_REDUCTIONS=0 HX_COCG_LAG=0), in separate processes
+    (the switches are read once per process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for env_extra in ({}, {"HX_COCG_LAG": "0"}, {"HX_COCG_LAG": "0", "HX_COCG_FUSE_REDUCTIONS": "0"}):
+        env = dict(os.environ, HX_TEST_ROOT=root, **env_extra)
+        p = subprocess.run([sys.executable, "-c", _COCG_AB_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        runs.append(json.loads(line[len("RESULT "):]))
+    assert runs[0] == runs[1] == runs[2]
+    assert all(its > 3 for its, _, _ in runs[0][1:])          # (solve 0 is the harvested GMRES run; the others are COCG)
+
+
 def test_cocg_initial_guess_is_used_checked_and_dropped():
     """hx_amg_next_solve_uses_x (the warm start of the Woodbury columns of identical flames): the exact solution as
     initial guess ends the solve at its first residual check (0 iterations), a perturbed solution saves iterations, a

@@ -465,22 +465,23 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       }
       return HX_OK;
     };
-    // Single GPU: the host does not wait for |r_j| while the residual is still far from every stopping rule.  The partials of
-    // the update land in one of two pinned areas; while the last JUDGED residual is above LAG_MARGIN * rtol (and the recurrence is
+    // The host does not wait for |r_j| while the residual is still far from every stopping rule.  The partials of the update
+    // (row-sharded: the all-reduced norm -- every rank judges the same number) land in one of two pinned areas; while the last JUDGED residual is above LAG_MARGIN * rtol (and the recurrence is
     // not stalling) iteration j + 1 is queued first and |r_j| is read after it -- the queue never drains on the host round trip
     // (42 us per inner iteration at 1 M DOF).  None of the rules can fire on |r_j| in that regime except "converged" after a
     // single-step drop by more than LAG_MARGIN; the recurrence then simply ends one (converged) iteration later.  Closer to the
     // tolerance every norm is awaited as before.  HX_COCG_LAG=0: always wait.
     static const int lag_env = getenv("HX_COCG_LAG") ? atoi(getenv("HX_COCG_LAG")) : 1;
     const double LAG_MARGIN = 1e4;
-    const bool may_lag = fuse && lag_env != 0 && !trace;
-    if (fuse && !M->cg_pin) {
+    const bool may_lag = lag_env != 0 && !trace;
+    if (!M->cg_pin) {
       HX_HIP(hipHostMalloc(&M->cg_pin, 2 * sizeof(cd) * (size_t)PD_NB, hipHostMallocDefault));
       for (int e = 0; e < 2; ++e) HX_HIP(hipEventCreateWithFlags(&M->cg_ev[e], hipEventDisableTiming));
     }
     auto arrived = [&](int slot, double* r2) -> int {      // waits for the partials of one update, sums them in the order of stage 2
       HX_HIP(hipEventSynchronize(M->cg_ev[slot]));
       const cd* hp = (const cd*)M->cg_pin + (size_t)slot * PD_NB;
+      if (!fuse) { *r2 = hp[0].real(); return HX_OK; }      // (two-stage form: the reduced -- row-sharded: all-reduced -- norm itself)
       double lane[HX_WAVE];
       for (int l = 0; l < HX_WAVE; ++l) lane[l] = 0.0;
       for (int bq = 0; bq < nblocks; ++bq) lane[bq % HX_WAVE] += hp[bq].real();
@@ -525,18 +526,13 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       HX_LAUNCH_CHECK("k_cocg_update");
       x_zero = false;
       double r2;
-      if (!fuse) {
+      const int slot = queued & 1;
+      if (!fuse) {                   // second stage on the device (and the sum over the ranks), one scalar travels
         if ((rc = hx_panel_dot_finish(nblocks, 0, part_r, sc, s))) return rc;
         if ((rc = reduce(1))) return rc;
-        if ((rc = fetch(1))) return rc;
-        ++queued;
-        if ((rc = judge(host[0].real()))) return rc;
-        if (leave) break;
-        continue;
       }
-      const int slot = queued & 1;
-      HX_HIP(hipMemcpyAsync((cd*)M->cg_pin + (size_t)slot * PD_NB, part_r, sizeof(cd) * (size_t)nblocks, hipMemcpyDeviceToHost,
-                            hx_s(s)));
+      HX_HIP(hipMemcpyAsync((cd*)M->cg_pin + (size_t)slot * PD_NB, fuse ? part_r : sc, sizeof(cd) * (size_t)(fuse ? nblocks : 1),
+                            hipMemcpyDeviceToHost, hx_s(s)));
       HX_HIP(hipEventRecord(M->cg_ev[slot], hx_s(s)));
       ++queued;
       if (pending >= 0) {            // the iteration before this one: its norm arrived long ago

@@ -96,17 +96,8 @@ def build_case(shape, numbering="native", jitter=0.0, resident=True):
             # what a bandwidth-reducing dof reordering (DOLFINx applies one to every mesh it reads) leaves of an arbitrary
             # file numbering: reverse Cuthill-McKee of the vertex graph, here taken from the P1 sparsity pattern the
             # assembler builds on the device for the randomly numbered mesh (host graph pass, outside the timed region)
-            import scipy.sparse as sp
-            from scipy.sparse.csgraph import reverse_cuthill_mckee
-            asm = mesh.assembler()
-            rp, ci = asm.rowptr.cpu().numpy(), asm.col.cpu().numpy()
-            G = sp.csr_matrix((np.ones(ci.size, np.int8), ci, rp), shape=(n, n))
-            order = reverse_cuthill_mckee(G, symmetric_mode=True)          # order[new] = old
-            del G, rp, ci
-            p2 = np.empty(n, dtype=np.int64)
-            p2[order] = np.arange(n)
-            mesh._assembler = None
-            mesh = mesh.renumbered(p2)
+            mesh.assembler()                               # (pattern on the device: the graph of the host pass)
+            mesh = mesh.locality_renumbered("rcm")         # fem.bandwidth_permutation: what XDMFReader applies at ingestion
     if jitter > 0.0 or numbering != "native":       # cells and tagged facets keep their order: tags carry over
         facet_tags = MeshTags(mesh, facet_tags.dim, facet_tags.indices, facet_tags.values)
         subdomains = MeshTags(mesh, subdomains.dim, subdomains.indices, subdomains.values)

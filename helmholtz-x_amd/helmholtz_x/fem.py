@@ -88,6 +88,26 @@ class Mesh:
         x[perm] = x_old
         return Mesh(x, perm[self.topology.cells], facets=np.sort(perm[self.facets], axis=1), facet_cells=self.facet_cells)
 
+    def locality_renumbered(self, kind="rcm"):
+        """The same mesh with its vertices renumbered for locality -- ``kind`` "rcm": reverse Cuthill-McKee of the vertex graph
+        (``bandwidth_permutation``; what DOLFINx applies to the dofs of every mesh the reference reads), "morton": along a
+        space-filling curve (``locality_permutation``).  ``input_vertex[new]`` of the result = the vertex id in the numbering
+        this mesh was first given in (DOLFINx: ``geometry.input_global_indices``), composed over repeated renumberings, so
+        nodal results can be reported in the numbering of the mesh file.  Cells and tagged facets keep their order (rebuild
+        MeshTags on the new mesh with the same indices / values)."""
+        if kind == "rcm":
+            perm = bandwidth_permutation(self)
+        elif kind == "morton":
+            perm = locality_permutation(self.geometry.x)
+        else:
+            raise ValueError("kind must be 'rcm' or 'morton'")
+        out = self.renumbered(perm)
+        old = getattr(self, "input_vertex", None)
+        new_to_old = np.empty(perm.size, dtype=np.int64)
+        new_to_old[perm] = np.arange(perm.size)
+        out.input_vertex = new_to_old if old is None else np.asarray(old)[new_to_old]
+        return out
+
     def assembler(self):
         if self._assembler is None:
             self._assembler = P1Assembler(self)
@@ -117,6 +137,40 @@ def locality_permutation(x, bits=21):
     order = np.argsort(code, kind="stable")            # order[new] = old
     perm = np.empty(x.shape[0], dtype=np.int64)
     perm[order] = np.arange(x.shape[0])
+    return perm
+
+
+def vertex_bandwidth(cells):
+    """max |i - j| over the vertex pairs sharing a cell: the half bandwidth of every P1 operator on the mesh."""
+    cells = np.asarray(cells, dtype=np.int64)
+    return int((cells.max(axis=1) - cells.min(axis=1)).max()) if cells.size else 0
+
+
+def bandwidth_permutation(mesh):
+    """perm[old] = new vertex id in the reverse Cuthill-McKee order of the vertex graph (vertices sharing a cell are adjacent).
+    A mesh file numbers vertices entity by entity (gmsh: points, curves, surfaces, volumes), which scatters the neighbours
+    of a row over the whole index range: a randomly numbered 5 M-DOF annulus runs the hot path five times slower than the
+    same mesh in this order, because the SpMV gathers lose their locality and the column
+    deltas of the SELL-64 format no longer fit 16 bits.  The graph is the P1 sparsity pattern: taken from the assembler
+    when it has been built on the device, else formed on the host from the cells.  One-off integer work at ingestion
+    (scipy.sparse.csgraph, O(nnz))."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    n = mesh.num_vertices
+    asm = getattr(mesh, "_assembler", None)
+    if asm is not None and getattr(asm, "rowptr", None) is not None:
+        rp, ci = asm.rowptr.cpu().numpy(), asm.col.cpu().numpy()
+        G = sp.csr_matrix((np.ones(ci.size, np.int8), ci, rp), shape=(n, n))
+    else:
+        cells = np.asarray(mesh.topology.cells, dtype=np.int32)
+        k = cells.shape[1]
+        rows = np.repeat(cells, k, axis=1).ravel()
+        cols = np.tile(cells, (1, k)).ravel()
+        G = sp.coo_matrix((np.ones(rows.size, np.int8), (rows, cols)), shape=(n, n)).tocsr()
+        del rows, cols
+    order = reverse_cuthill_mckee(G, symmetric_mode=True)          # order[new] = old
+    perm = np.empty(n, dtype=np.int64)
+    perm[order] = np.arange(n)
     return perm
 
 

@@ -212,6 +212,7 @@ class XDMFReader:
             self._mesh, self._cell_tags, self._facet_tags = read_xdmf(name)
         else:
             self._mesh, self._cell_tags, self._facet_tags = read_gmsh(name + ".msh", dim)
+        self._renumber_for_locality()
         info("\nXDMF Mesh - Cell data loaded.")
         info("XDMF Mesh - Facet data loaded.")
 
@@ -230,6 +231,29 @@ class XDMFReader:
     @property
     def dimension(self):
         return self._mesh.topology.dim
+
+    def _renumber_for_locality(self):
+        """Meshes of ``HX_RENUMBER_MIN`` vertices or more (default 200 000; 0: never) are renumbered by reverse Cuthill-McKee
+        as they are read -- what the reference gets from DOLFINx, which reorders the dofs of every mesh it reads: a file
+        numbers vertices entity by entity, and the device kernels pay a factor for a numbering without locality
+        (fem.bandwidth_permutation).  Cell and facet tags keep their entity order; ``mesh.input_vertex`` maps back to the
+        numbering of the file.  Smaller meshes (all fixtures of the reference) keep the file numbering, which its index-based
+        conventions (FixSign on entry 0, Bloch pairing by index) refer to."""
+        import os
+        from .fem import MeshTags, vertex_bandwidth
+        limit = int(os.environ.get("HX_RENUMBER_MIN", "200000"))
+        mesh = self._mesh
+        if limit <= 0 or mesh.num_vertices < limit:
+            return
+        before = vertex_bandwidth(mesh.topology.cells)
+        new = mesh.locality_renumbered("rcm")
+        after = vertex_bandwidth(new.topology.cells)
+        if after >= before:                       # already well ordered (a structured generator): keep the file numbering
+            return
+        self._mesh = new
+        self._cell_tags = MeshTags(new, self._cell_tags.dim, self._cell_tags.indices, self._cell_tags.values)
+        self._facet_tags = MeshTags(new, self._facet_tags.dim, self._facet_tags.indices, self._facet_tags.values)
+        info("- vertices renumbered for locality (reverse Cuthill-McKee): half bandwidth %d -> %d" % (before, after))
 
     def getAll(self):
         return self.mesh, self.subdomains, self.facet_tags

@@ -368,6 +368,36 @@ def test_rijke_gmsh_fixed_point(ref_logs, golden_dir, dim):
     assert _eigvec_error(golden_dir, "rijke%dd_dir" % dim, mesh, uh) < 1e-7        # Results/Active/p.h5 (EPS path)
 
 
+def test_rijke3d_read_with_ingestion_renumbering_gives_the_same_eigenpair(ref_logs, golden_dir, monkeypatch):
+    """The 3-D Rijke tube read through XDMFReader with the reverse Cuthill-McKee renumbering forced on (HX_RENUMBER_MIN=1: what
+    a mesh of 200 k vertices or more gets by default): logged passive eigenvalue and fixed-point trajectory as in file
+    numbering, and the eigenvector mapped back by ``mesh.input_vertex`` equals the reference's stored mode."""
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import eps_solver, fixed_point_iteration
+    from helmholtz_x.eigenvectors import normalize_eigenvector
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.parameters_utils import c_step
+    g = ref_logs["rijke3d"]
+    path = os.path.join(golden_dir, "meshes", "rijke3d")
+    mesh_file = XDMFReader(path).getAll()[0]
+    monkeypatch.setenv("HX_RENUMBER_MIN", "1")
+    mesh, subdomains, facet_tags = XDMFReader(path).getAll()
+    assert hasattr(mesh, "input_vertex") and not np.array_equal(mesh.input_vertex, np.arange(mesh.num_vertices))
+    bcs = {t: {'Neumann'} for t in (1, 2, 3, 4)}
+    M = AcousticMatrices(mesh, facet_tags, bcs, c_step(mesh, Rijke.x_f(3), Rijke.c_u, Rijke.c_u))
+    E = eps_solver(M.A, M.C, Rijke.target, nev=2)
+    assert abs(E.getEigenvalue(0) - g["passive_lambda0"]) / g["passive_lambda0"] < 1e-9
+    M = AcousticMatrices(mesh, facet_tags, bcs, c_step(mesh, Rijke.x_f(3), Rijke.c_u, Rijke.c_d))
+    D = _distributed_flame(mesh, 3)[0]
+    D.assemble_submatrices()
+    hist = []
+    E = fixed_point_iteration(M, D, Rijke.target, nev=2, i=0, history=hist)
+    _check_traj(hist, g["trajectory"])
+    omega, uh = normalize_eigenvector(mesh, E, 0, degree=1, which='right')
+    assert _eigvec_error(golden_dir, "rijke3d_dir", mesh, uh) < 1e-7              # (nodes matched by coordinates, sign free)
+    assert np.array_equal(mesh.geometry.x, mesh_file.geometry.x[mesh.input_vertex])   # and the way back to file numbering
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_prf_gmsh_pep_fixed_point_direct_and_adjoint(ref_logs, golden_dir, dim):
     """PRF/RijkeTube2D and RijkeTube3D (active.py:18-62, written the same way): Robin inlet and outlet, distributed n-tau

@@ -405,6 +405,45 @@ def test_mesh_renumbering_and_locality_order():
     assert bandwidth(m3) < 0.35 * bandwidth(m2)
 
 
+def test_rcm_renumbering_at_ingestion(golden_dir, monkeypatch):
+    """bandwidth_permutation (reverse Cuthill-McKee of the vertex graph) undoes a random numbering; locality_renumbered keeps
+    the map back to the input numbering, also over repeated renumberings; XDMFReader applies it to meshes of HX_RENUMBER_MIN
+    vertices or more (what DOLFINx does to every mesh the reference reads) with cell / facet tags carried over, and leaves
+    smaller meshes -- all reference fixtures at the default limit -- in file numbering."""
+    from helmholtz_x.fem import bandwidth_permutation, vertex_bandwidth
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.synthetic import annulus
+    mesh, _, _ = annulus(4, 24, 5)
+    n = mesh.num_vertices
+    shuffled = mesh.renumbered(np.random.default_rng(0).permutation(n))
+    perm = bandwidth_permutation(shuffled)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    m2 = shuffled.locality_renumbered("rcm")
+    assert vertex_bandwidth(m2.topology.cells) < 0.25 * vertex_bandwidth(shuffled.topology.cells)
+    assert np.array_equal(m2.geometry.x, shuffled.geometry.x[m2.input_vertex])
+    m3 = m2.locality_renumbered("morton")
+    assert np.array_equal(m3.geometry.x, shuffled.geometry.x[m3.input_vertex])
+    with pytest.raises(ValueError):
+        mesh.locality_renumbered("hilbert")
+    # the reader
+    path = os.path.join(golden_dir, "meshes", "rijke3d")
+    mesh0, sub0, ft0 = XDMFReader(path).getAll()
+    assert not hasattr(mesh0, "input_vertex")                                   # below the default limit: file numbering
+    monkeypatch.setenv("HX_RENUMBER_MIN", "1")
+    mesh1, sub1, ft1 = XDMFReader(path).getAll()
+    assert hasattr(mesh1, "input_vertex")
+    assert vertex_bandwidth(mesh1.topology.cells) < vertex_bandwidth(mesh0.topology.cells)
+    assert np.array_equal(mesh1.geometry.x, mesh0.geometry.x[mesh1.input_vertex])
+    inv = np.empty(mesh0.num_vertices, dtype=np.int64)
+    inv[mesh1.input_vertex] = np.arange(mesh0.num_vertices)
+    assert np.array_equal(mesh1.topology.cells, inv[mesh0.topology.cells])      # same cells, same order
+    assert np.array_equal(mesh1.facets, np.sort(inv[mesh0.facets], axis=1))
+    for a, b in ((sub0, sub1), (ft0, ft1)):
+        assert np.array_equal(a.indices, b.indices) and np.array_equal(a.values, b.values) and b.mesh is mesh1
+    monkeypatch.setenv("HX_RENUMBER_MIN", "0")
+    assert not hasattr(XDMFReader(path).getAll()[0], "input_vertex")
+
+
 def test_translation_shifts_of_identical_flames():
     """Host logic behind the warm-started Woodbury columns: sparse vectors that are cyclic translates of the first one (with
     a support that wraps around the end of the numbering) are recognised with their shifts; one deviating value or a

@@ -102,24 +102,24 @@ k_cocg_update(int64_t n, const zc* __restrict__ p, const zc* __restrict__ q, zc*
 
 // After the reduction of [C^T z ; r^T z]: beta = rho_new / rho (0 on the first step), rho = rho_new, t = sign * E^-1 c.
 // mode 0: direction update (sign +, with beta); mode 1: Galerkin start (t = -E^-1 U^T b so that x = 0 - U t ... ), no rho.
-__global__ void __launch_bounds__(HX_WAVE)
+// Launched with 64 threads (partials == NULL: the reduced scalars are in sc) or with one wave per column, at most 16 waves.
+__global__ void __launch_bounds__(1024)
 k_cocg_small(int k, const zc* __restrict__ Einv, zc* __restrict__ sc, int first, int mode,
              const zc* __restrict__ partials /* may be NULL */, int nblocks) {
   const int i = threadIdx.x;
   __shared__ zc s_out[CG_MAXK + 1];
   if (partials) {
-    // the k + 1 reductions arrive as per-block partials (stage 1 of the panel dot): summed here in the fixed order of
-    // k_panel_dot_stage2 -- same bits, one launch fewer
-    for (int j = 0; j <= k; ++j) {
+    // the k + 1 reductions arrive as per-block partials (stage 1 of the panel dot): summed here, one wave per column, in the
+    // fixed order of k_panel_dot_stage2 (lanes stride over the blocks, then the shuffle tree) -- same bits, one launch fewer
+    const int lane = i & (HX_WAVE - 1), nw = blockDim.x / HX_WAVE;
+    for (int j = i / HX_WAVE; j <= k; j += nw) {
       zc v = make_double2(0.0, 0.0);
-      for (int b = i; b < nblocks; b += HX_WAVE) v = zadd(v, partials[(int64_t)b * (k + 1) + j]);
+      for (int b = lane; b < nblocks; b += HX_WAVE) v = zadd(v, partials[(int64_t)b * (k + 1) + j]);
       v = zreduce_sub<HX_WAVE>(v);
-      if (i == 0) { s_out[j] = v; sc[CG_OUT + j] = v; }
+      if (lane == 0) { s_out[j] = v; sc[CG_OUT + j] = v; }
     }
   } else if (i <= k) s_out[i] = sc[CG_OUT + i];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __syncthreads();
   if (i < k) {
     zc t = make_double2(0.0, 0.0);
     for (int j = 0; j < k; ++j) zfma(t, Einv[i * k + j], s_out[j]);
@@ -506,8 +506,8 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
                        : hx_zpanel_bdot(n, k, k > 0 ? rec->Cd : nullptr, n, z, r, sc, part, s))) return rc;
       }
       if ((rc = reduce(k + 1))) return rc;
-      k_cocg_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, rec ? (const zc*)rec->Einv : nullptr, (zc*)sc, first ? 1 : 0, 0,
-                                               fuse ? (const zc*)part : nullptr, nblocks);
+      k_cocg_small<<<1, fuse ? HX_WAVE * std::min(k + 1, 16) : HX_WAVE, 0, hx_s(s)>>>(
+          k, rec ? (const zc*)rec->Einv : nullptr, (zc*)sc, first ? 1 : 0, 0, fuse ? (const zc*)part : nullptr, nblocks);
       HX_LAUNCH_CHECK("k_cocg_small");
       if (r32) k_cocg_direction<cc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, rec ? (const cc*)rec->Uf : nullptr, n,
                                                                           (const cc*)z32, (zc*)p, (const zc*)sc);

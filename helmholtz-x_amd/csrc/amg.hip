@@ -265,6 +265,21 @@ extern "C" int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext
   return h->single ? resize_ext<float>(h->S, n_sharded, n_ext) : resize_ext<double>(h->D, n_sharded, n_ext);
 }
 
+// The prolongators of the first `n_levels` row-sharded levels carry n_ext ROWS: behind this rank's rows the owners' rows of its
+// ghost vertices (same values, this rank's column numbering).  The prolongation then corrects the ghost block of the iterate as
+// well -- it held the pre-smoothed values since the exchange in front of the residual -- so the first post-smoothing step needs
+// no exchange: one halo fewer per sharded level and cycle.  Call after hx_amg_set_sharded.
+extern "C" int hx_amg_set_prolongator_ghost_rows(hx_amg* h, int n_levels) {
+  HX_REQUIRE(h && h->sharded && n_levels >= 0 && n_levels <= h->n_sharded, "bad argument");
+  drop_graph(h);
+  for (int l = 0; l < h->n_sharded; ++l) {
+    const bool on = l < n_levels;
+    if (h->single) { auto& L = h->S.L[l]; L.p_ghost_rows = on; L.P.rows = on ? L.n_ext : L.n; }
+    else { auto& L = h->D.L[l]; L.p_ghost_rows = on; L.P.rows = on ? L.n_ext : L.n; }
+  }
+  return HX_OK;
+}
+
 extern "C" int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_fn begin, hx_halo_end_fn end) {
   HX_REQUIRE(h && ((begin && end) || (!begin && !end)), "both callbacks or none");
   h->halo_begin = begin; h->halo_end = end;
@@ -370,11 +385,14 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   if ((rc = op_spmv(L.P, ec, cur, (T)1, n_pre == 0 ? (T)0 : (T)1, true, s))) return rc;    // x (+)= P e_c
   // post-smoothing: a fresh polynomial started from the corrected x; the last step writes xout
   prev = nullptr;
+  // (P with ghost rows: the prolongation has corrected the ghost block of cur too, the first step needs no exchange)
+  const bool ghosts_current = sh && L.p_ghost_rows && n_pre > 0;
   for (int k = 0; k < n_post; ++k) {
     T* dst = (k == n_post - 1) ? xout : other(cur, prev);
-    if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part) {
-          return cheb ? op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s, part)
-                      : op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s, part); }))) return rc;
+    auto step = [&](int part) {
+      return cheb ? op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s, part)
+                  : op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s, part); };
+    if ((rc = (k == 0 && ghosts_current) ? step(0) : with_halo(h, L, l, cur, EB, s, step))) return rc;
     prev = cur; cur = dst;
   }
   if (n_post == 0)

@@ -18,6 +18,7 @@ template <typename T> struct LevelT {
   const hx_sell* sell = nullptr;   // optional SELL-64 companion of K (fine level): used for the K products
   T *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
   int32_t n_ext = 0;           // row-sharded level: owned + ghost length of x, x2, x3, r (0: not sharded)
+  bool p_ghost_rows = false;   // row-sharded level: P carries n_ext rows (the owners' rows of the ghost vertices behind the owned ones)
 };
 template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
 

@@ -107,6 +107,7 @@ SIGNATURES = {
     "hx_amg_set_recycle": (C.c_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
     "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_FN, HALO_END_FN]),
+    "hx_amg_set_prolongator_ghost_rows": (C.c_int, [_vp, C.c_int]),
     "hx_comm_halo_begin": (C.c_int, [_vp, _int, _vp, _int, _vp]),
     "hx_comm_halo_end": (C.c_int, [_vp, _int, _vp]),
     "hx_comm_overlapped": (_i64, [_vp]),

@@ -427,6 +427,10 @@ def _localize_columns(A, c0, c1, ghost_sorted, n_own):
     return DevCSR((A.shape[0], n_own + int(ghost_sorted.numel())), A.rowptr, lcol, A.val)
 
 
+# row-sharded levels: prolongators with the ghost vertices' rows (one halo fewer per level and cycle); HX_AMG_GHOST_P=0: owned rows only
+PARAMS_GHOST_P = os.environ.get("HX_AMG_GHOST_P", "1") != "0"
+
+
 def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"],
                             coarse_size=PARAMS["coarse_size"], replicate_max_rows=PARAMS["replicate_max_rows"]):
     """Smoothed-aggregation hierarchy of the ROW-SHARDED operator: K holds this rank's rows over [owned | ghost] columns
@@ -551,6 +555,9 @@ def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["
         KP_ext = _rows_concat(KP, DevCSR((n_ext - n_own, na_glob), *plan.exchange_rows(KP.rowptr, KP.col, KP.val)))
         R_loc = _dev_transpose(_select_columns(P_ext, c0, c1), na)         # my aggregates x [own | ghost] fine vertices
         Kc = _dev_spgemm(R_loc, KP_ext)                                    # my coarse rows, global coarse columns
+        # The level's prolongator keeps the owners' rows of my ghost vertices behind my own (hx_amg_set_prolongator_ghost_rows):
+        # the prolongation then corrects the ghost block of the iterate too and the first post-smoothing step needs no exchange
+        P_lvl = P_ext if PARAMS_GHOST_P else P_glob
         del KP, KP_ext, P_ext, Lf, sd, v, w
         level.update(dinv=1.0 / diag, omega=4.0 / (3.0 * 1.05 * rho), rho=1.05 * rho, n_coarse=na, n_coarse_global=na_glob,
                      R=R_loc)
@@ -559,17 +566,19 @@ def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["
         next_sharded = na_glob > replicate_max_rows and len(levels) < max_levels - 2 and min(counts) > 0
         if next_sharded:
             # level l + 1 stays sharded: its ghost set = the off-rank columns of my coarse rows and of my prolongator rows
-            cols = torch.cat([Kc.col.long(), P_glob.col.long()])
+            cols = torch.cat([Kc.col.long(), P_lvl.col.long()])
             ghost_c = torch.unique(cols[(cols < c0) | (cols >= c1)])
             shard.set_level_plan(l + 1, c_ranges, ghost_c.cpu().numpy())
-            level["P"] = _localize_columns(P_glob, c0, c1, ghost_c, na)
+            level["P"] = _localize_columns(P_lvl, c0, c1, ghost_c, na)
+            level["p_ghost_rows"] = PARAMS_GHOST_P
             level["coarse_sharded"] = True
             Kl = _localize_columns(Kc, c0, c1, ghost_c, na)
             ranges, n_glob, l = c_ranges, na_glob, l + 1
             continue
         # level l + 1 is replicated: P keeps global columns, the restriction is the transpose of MY prolongator rows (the
         # ranks' partial right-hand sides are summed by one all-reduce), the coarse operator is all-gathered
-        level["P"] = P_glob
+        level["P"] = P_lvl
+        level["p_ghost_rows"] = PARAMS_GHOST_P
         level["R"] = _dev_transpose(P_glob, na_glob)
         level["coarse_sharded"] = False
         lens = _all_gather_var(shard, (Kc.rowptr[1:] - Kc.rowptr[:-1]).contiguous())
@@ -760,6 +769,11 @@ class AMGSolver:
             self._cb = shard.callbacks()             # (halo_fn, allreduce_fn, ctx): the library's own RCCL calls, or gloo trampolines
             n_ext = np.ascontiguousarray([lv["n_ext"] for lv in levels[:self.n_sharded]], dtype=np.int32)
             _hx.check(_hx.lib.hx_amg_set_sharded(h, self.n_sharded, _hx.nptr(n_ext), self._cb[0], self._cb[1], self._cb[2]))
+            n_pg = 0
+            while n_pg < self.n_sharded and levels[n_pg].get("p_ghost_rows"):
+                n_pg += 1
+            if n_pg:
+                _hx.check(_hx.lib.hx_amg_set_prolongator_ghost_rows(h, n_pg))
             if shard.comm is not None and os.environ.get("HX_HALO_OVERLAP", "1") != "0":
                 # library-issued exchanges: split every halo around the interior slices of its product (exchange on the
                 # communicator's stream, ordered by events)

@@ -381,6 +381,11 @@ int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext, hx_halo_f
  * own stream.  (PETSc overlaps the same way: VecScatterBegin, local part of MatMult, VecScatterEnd, off-diagonal part.) */
 typedef int (*hx_halo_end_fn)(void* ctx, int level, hx_stream s);
 int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_fn begin, hx_halo_end_fn end);
+/* The prolongators of the first n_levels row-sharded levels were given with n_ext ROWS (behind this rank's rows the owners' rows of
+ * its ghost vertices): the prolongation then also corrects the ghost block of the iterate, and the first post-smoothing step of a
+ * cycle runs without an exchange -- one halo fewer per sharded level and cycle.  After hx_amg_set_sharded.  (PETSc: the ghost
+ * update MatMult would do in front of that step, /root/reference/helmholtz_x/eigensolvers.py:62,113 via KSPSolve.) */
+int hx_amg_set_prolongator_ghost_rows(hx_amg* h, int n_levels);
 /* ---- RCCL communicator owned by the library (comm.hip).  librccl is bound at run time (the copy the process already
  * loaded, else librccl.so.1; HX_RCCL_LIB overrides).  Rank 0 draws an id (hx_comm_unique_id) and ships its
  * HX_COMM_ID_BYTES bytes to the other ranks by whatever channel the host side has (torch.distributed broadcast); every

@@ -57,6 +57,12 @@ WORKLOADS = {
     "annulus-66k": (12, 384, 12),      # 64,896 DOF
     "annulus-34k": (10, 256, 11),      # 33,792 DOF ~ the reference's real MICCA mesh (34,787 DOF)
     "annulus-16k": (8, 160, 10),       # 15,840 DOF
+    # the reference's REAL MICCA mesh (tests/golden/meshes/micca_full: 34,787 vertices, unstructured, the mesh of its logged
+    # run) as it is, and refined uniformly once / twice (synthetic.refine_tets): 0.25 M / 1.9 M DOF with the real geometry
+    # and none of the generator's regularity; vertices renumbered by reverse Cuthill-McKee as XDMFReader does for large meshes
+    "micca-real": ("real", 0),
+    "micca-real-r1": ("real", 1),
+    "micca-real-r2": ("real", 2),
 }
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 METRIC = "converged eigenpairs/sec + SpMV GB/s (% HBM roofline), AnnularCombustor 5M DOF"
@@ -74,6 +80,8 @@ def build_case(shape, numbering="native", jitter=0.0, resident=True):
     from helmholtz_x.fem import Mesh, MeshTags, locality_permutation
     from helmholtz_x.flame_transfer_function import stateSpace
     from helmholtz_x.synthetic import annulus, micca_sound_speed
+    if shape[0] == "real":
+        return build_case_real(shape[1], resident)
     mesh, subdomains, facet_tags = annulus(*shape)
     if jitter > 0.0:
         x = mesh.geometry.x.copy()
@@ -109,6 +117,39 @@ def build_case(shape, numbering="native", jitter=0.0, resident=True):
     ftf = stateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
     return dict(mesh=mesh, subdomains=subdomains, facet_tags=facet_tags, c=c, ftf=ftf, P=Micca, np=np,
                 numbering=numbering, jitter=jitter)
+
+
+def build_case_real(refinements, resident=True):
+    """The reference's own MICCA mesh (read by the package's XDMF / HDF5 reader), refined uniformly ``refinements`` times,
+    with the set-up of its active_fpi.py: DG0 sound speed by the cell-midpoint rule, 16 flames, Robin outlet."""
+    import numpy as np
+    from scipy.io import loadmat
+    from cases import Micca
+    from helmholtz_x.fem import Function, FunctionSpace, MeshTags
+    from helmholtz_x.flame_transfer_function import stateSpace
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.synthetic import refine_tets
+    mesh, subdomains, facet_tags = XDMFReader(os.path.join(ROOT, "tests", "golden", "meshes", "micca_full", "mesh")).getAll()
+    for _ in range(refinements):
+        mesh, subdomains, facet_tags = refine_tets(mesh, subdomains, facet_tags)
+    numbering = "file"
+    if refinements > 0:                                     # what the reader does to a mesh of this size (>= 200 k vertices)
+        import torch
+        if torch.cuda.is_available():
+            mesh.assembler()                                # (pattern on the device: the graph of the host pass)
+        mesh = mesh.locality_renumbered("rcm")
+        facet_tags = MeshTags(mesh, facet_tags.dim, facet_tags.indices, facet_tags.values)
+        subdomains = MeshTags(mesh, subdomains.dim, subdomains.indices, subdomains.values)
+        numbering = "rcm"
+    c = Function(FunctionSpace(mesh, "DG", 0), "soundspeed")
+    c.x.array[:] = Micca.c_of_z(c.function_space.tabulate_dof_coordinates()[:, 2])
+    import torch
+    if resident and torch.cuda.is_available():
+        c.resident()
+    mat = loadmat(os.path.join(ROOT, "tests", "golden", "micca_ftf.mat"))
+    ftf = stateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+    return dict(mesh=mesh, subdomains=subdomains, facet_tags=facet_tags, c=c, ftf=ftf, P=Micca, np=np,
+                numbering=numbering, jitter=0.0)
 
 
 def hot_path(case, st_type=None, nev=4, tol=1e-3, history=None, sharded=False):
@@ -422,6 +463,7 @@ def main(argv=None):
 
     shape = WORKLOADS[args.workload]
     case = build_case(shape, args.numbering, args.jitter, resident=(world == 1))   # N > 1: only the rank's part goes to HBM
+    args.numbering = case["numbering"]         # (the real-mesh workloads: "file" / "rcm")
     if world > 1:
         rc = run_sharded(args, case, shape, rank, world, backend, n_dev, barrier)
         sys.stdout.flush()

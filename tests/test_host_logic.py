@@ -444,6 +444,42 @@ def test_rcm_renumbering_at_ingestion(golden_dir, monkeypatch):
     assert not hasattr(XDMFReader(path).getAll()[0], "input_vertex")
 
 
+def test_uniform_refinement_of_the_real_micca_mesh(golden_dir):
+    """synthetic.refine_tets on the reference's own unstructured mesh: conforming (every face belongs to one or two cells,
+    boundary faces = 4 x the parent's), volume and tagged areas preserved to rounding, every child an eighth of its parent
+    with the parent's orientation, tags inherited, every child facet on a face of its adjacent child cell."""
+    from itertools import combinations
+    from helmholtz_x.io_utils import XDMFReader
+    from helmholtz_x.synthetic import refine_tets
+    mesh, sub, ft = XDMFReader(os.path.join(golden_dir, "meshes", "micca_full", "mesh")).getAll()
+    fine, sub1, ft1 = refine_tets(mesh, sub, ft)
+
+    def signed_volumes(m):
+        X = m.geometry.x[m.topology.cells]
+        return np.linalg.det(X[:, 1:] - X[:, :1]) / 6
+
+    def faces_by_count(m):
+        c = m.topology.cells.astype(np.int64)
+        f = np.sort(np.concatenate([c[:, list(k)] for k in combinations(range(4), 3)]), axis=1)
+        return np.bincount(np.unique(f, axis=0, return_counts=True)[1], minlength=3)
+
+    def area(m, idx):
+        X = m.geometry.x[m.facets[idx]]
+        return 0.5 * np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1).sum()
+
+    v0, v1 = signed_volumes(mesh), signed_volumes(fine)
+    assert fine.num_cells == 8 * mesh.num_cells and fine.num_vertices > 7 * mesh.num_vertices
+    assert np.allclose(v1.reshape(-1, 8), v0[:, None] / 8, rtol=1e-10, atol=0)
+    n0, n1 = faces_by_count(mesh), faces_by_count(fine)
+    assert n1[0] == 0 and len(n1) == 3 and n1[1] == 4 * n0[1]
+    for tag in np.unique(ft.values):
+        assert abs(area(fine, ft1.find(tag)) - area(mesh, ft.find(tag))) < 1e-12
+    for tag in np.unique(sub.values):
+        assert abs(np.abs(v1[sub1.find(tag)]).sum() - np.abs(v0[sub.find(tag)]).sum()) < 1e-15
+    adj = np.sort(fine.topology.cells[fine.facet_cells], axis=1)
+    assert np.all([(fine.facets[:, k, None] == adj).any(axis=1) for k in range(3)])
+
+
 def test_translation_shifts_of_identical_flames():
     """Host logic behind the warm-started Woodbury columns: sparse vectors that are cyclic translates of the first one (with
     a support that wraps around the end of the numbering) are recognised with their shifts; one deviating value or a

@@ -621,7 +621,9 @@ def run_sharded(args, case, shape, rank, world, backend, n_dev, barrier):
             out.update({"value": round(pairs / dt, 5), "ms_per_step": round(1e3 * dt / max(args.steps, 1), 2)})
             out["config"].update({
                 "dofs": sh.n_global, "nev": 4, "fpi_tol": 1e-3, "fpi_iterations": len(hist) - 1, "flames": 16,
-                "partition": "theta-slabs: %d rows + %d ghost rows on rank 0" % (sh.n_own, sh.n_ext - sh.n_own),
+                "partition": "%s: %d rows + %d ghost rows on rank 0" % (
+                    "contiguous row ranges of the RCM numbering" if shape[0] == "real" else "theta-slabs", sh.n_own,
+                    sh.n_ext - sh.n_own),
                 "setup": case.get("setup_mode"),
                 "inner_solver": getattr(inner, "name", None),
                 "inner_stats": inner.stats() if inner is not None else None,

@@ -25,7 +25,7 @@ from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=int(os.environ.get("HX_AMG_COARSE_SIZE", "1000")), pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
               max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=int(os.environ.get("HX_SELL_MIN_ROWS", "50000")), sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
-              recycle_min_rows=100_000, recycle_theta=0.45, krylov="auto", cocg_min_rows=100_000, setup="device",
+              recycle_min_rows=100_000, recycle_theta=0.45, krylov="auto", cocg_min_rows=0, setup="device",
               replicate_max_rows=int(os.environ.get("HX_AMG_REPLICATE_MAX_ROWS", "200000")))
 
 
@@ -648,8 +648,10 @@ class AMGSolver:
         # Krylov method of the inner solve: complex symmetric K (every shifted operator of the path except the
         # Bloch-reduced ones) + symmetric V-cycle (pre == post) -> deflated COCG (short recurrences, hx_cocg);
         # otherwise flexible GMRES.  "auto" probes the symmetry of the bilinear form with two random vectors.
-        # Below ~1e5 rows the solve is launch-latency bound and the iteration COUNT decides: undeflated COCG needs
-        # 14-18 iterations where GMRES needs 12-14 (measured at 34 k / 66 k rows), so "auto" keeps GMRES there.
+        # (Rounds 1-2 kept GMRES below 1e5 rows, where the solve is launch-latency bound; since the reductions of hx_cocg are
+        # summed by their consumers and its residual norm is read one iteration late, COCG wins at every size measured --
+        # 16 k rows: 0.21 -> 0.14 s per fixed-point call, 34 k: 0.26 -> 0.17, 66 k: 0.37 -> 0.27, the reference's 34,787-DOF
+        # MICCA mesh: 0.50 -> 0.40 s, tools/r3_small.sh -- and cocg_min_rows is 0.)
         kry = os.environ.get("HX_AMG_KRYLOV", self.params["krylov"])
         if shard is None:
             n_rows = K_csr.shape[0]

@@ -191,7 +191,9 @@ def _gpu_fpi_worker(rank, world, port, out, krylov, transport="gloo"):
     if transport == "fake_rccl":    # exchanges issued BY THE LIBRARY (hx_comm) through the host-staged librccl stand-in
         os.environ["HX_NATIVE_COMM"] = "1"
         os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
-    if krylov == "cocg":            # "auto" keeps GMRES below 1e5 rows: force the deflated COCG path (hx_cocg_sharded)
+    if krylov == "fgmres":          # the flexible GMRES path (hx_gmres_sharded): "auto" picks COCG for this symmetric operator
+        os.environ["HX_AMG_KRYLOV"] = "fgmres"
+    if krylov == "cocg":            # the deflated COCG path (hx_cocg_sharded) with recycling, SELL-64 and two sharded levels
         os.environ["HX_AMG_KRYLOV"] = "cocg"
         os.environ["HX_AMG_RECYCLE"] = "6"
         os.environ["HX_SELL_MIN_ROWS"] = "0"    # SELL-64 (stencil slices included) on the rectangular local operator
@@ -236,7 +238,7 @@ def _gpu_fpi_worker(rank, world, port, out, krylov, transport="gloo"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("krylov,transport", [("auto", "gloo"), ("cocg", "gloo"), ("cocg", "fake_rccl")])
+@pytest.mark.parametrize("krylov,transport", [("fgmres", "gloo"), ("cocg", "gloo"), ("cocg", "fake_rccl")])
 def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport):
     """The whole hot path partitioned over two ranks (sharing the one GPU; gloo stages the exchanges through the host): every
     rank assembles ITS rows on its part of the mesh (owner computes), builds its slab of the hierarchy (uncoupled aggregation,

@@ -498,13 +498,16 @@ def _annulus_case(shape):
     return bench.build_case(shape)
 
 
-@pytest.mark.parametrize("overrides", [dict(), dict(sell_min_rows=0), dict(precision="double", smoother="jacobi"),
-                                       dict(precision="double", sell_min_rows=0),
-                                       dict(recycle_min_rows=0, sell_min_rows=0),
-                                       dict(recycle_min_rows=0, sell_min_rows=0, vcycle_values="c64"),
-                                       dict(graph_max_rows=10 ** 9),
-                                       # deflated / plain COCG ("auto" only picks it from 1e5 rows on)
-                                       dict(cocg_min_rows=0), dict(cocg_min_rows=0, sell_min_rows=0),
+_GM = dict(krylov="fgmres")          # ("auto" picks COCG for a complex symmetric operator: flexible GMRES has to be asked for)
+
+
+@pytest.mark.parametrize("overrides", [dict(_GM), dict(_GM, sell_min_rows=0), dict(_GM, precision="double", smoother="jacobi"),
+                                       dict(_GM, precision="double", sell_min_rows=0),
+                                       dict(_GM, recycle_min_rows=0, sell_min_rows=0),
+                                       dict(_GM, recycle_min_rows=0, sell_min_rows=0, vcycle_values="c64"),
+                                       dict(_GM, graph_max_rows=10 ** 9),
+                                       # deflated / plain COCG (what "auto" picks for this operator)
+                                       dict(), dict(cocg_min_rows=0, sell_min_rows=0),
                                        dict(cocg_min_rows=0, precision="double", smoother="jacobi"),
                                        dict(cocg_min_rows=0, recycle_min_rows=0, sell_min_rows=0),
                                        dict(krylov="cocg", recycle_min_rows=0, recycle=6)])
@@ -537,7 +540,7 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
         tol = 1e-9 if k < 2 else 1e-7                     # third solve: relaxed tolerance requested by the caller
         assert np.linalg.norm(x.cpu().numpy() - ref) <= tol * np.linalg.norm(ref)
     st = solver.stats()
-    want = "cocg" if (overrides.get("krylov") == "cocg" or overrides.get("cocg_min_rows") == 0) else "fgmres"
+    want = "fgmres" if overrides.get("krylov") == "fgmres" else "cocg"
     assert st["krylov"] == want and st["cocg_fallbacks"] == 0
     if st["krylov"] == "cocg":      # the first solve of a recycling hierarchy is the harvested GMRES run
         assert st["cocg_solves"] == (2 if overrides.get("recycle_min_rows") == 0 else 3)
@@ -698,7 +701,7 @@ def test_cocg_symmetry_probe_and_fallback():
     Kd = CSR.from_scipy(Ku)
     assert not _is_complex_symmetric(Kd)
     assert AMGSolver(Kd, cocg_min_rows=0).stats()["krylov"] == "fgmres"
-    assert AMGSolver(K, cocg_min_rows=0).stats()["krylov"] == "cocg" and AMGSolver(K).stats()["krylov"] == "fgmres"
+    assert AMGSolver(K).stats()["krylov"] == "cocg" and AMGSolver(K, cocg_min_rows=10 ** 9).stats()["krylov"] == "fgmres"
     solver = AMGSolver(Kd, krylov="cocg")                                 # forced: must not return garbage
     lu = spla.splu(Ku.tocsc())
     rng = np.random.default_rng(1)

@@ -25,7 +25,7 @@ from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=int(os.environ.get("HX_AMG_COARSE_SIZE", "1000")), pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
               max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=int(os.environ.get("HX_SELL_MIN_ROWS", "50000")), sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
-              recycle_min_rows=100_000, recycle_theta=0.45, krylov="auto", cocg_min_rows=0, setup="device",
+              recycle_min_rows=0, recycle_theta=0.45, krylov="auto", cocg_min_rows=0, setup="device",
               replicate_max_rows=int(os.environ.get("HX_AMG_REPLICATE_MAX_ROWS", "200000")))
 
 
@@ -790,9 +790,11 @@ class AMGSolver:
         self.ws = torch.empty(max(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), _hx.lib.hx_cocg_ws(self.n)),
                               dtype=torch.complex128, device=dev)
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
-        # subspace recycling (all solves of a fixed-point call share K): worth its panel rows once the hierarchy is deep
-        # enough for the preconditioned operator to show a few near-null modes (measured: plateau of 5 its at 1 M DOF,
-        # 9 at 5 M; none below ~100 k)
+        # subspace recycling (all solves of a fixed-point call share K): the harvest keeps the modes the spectrum asks for (3 on
+        # the small synthetic annuli, 6 on the reference's MICCA mesh, 6-8 from 1 M DOF on).  Rounds 1-2 enabled it from 1e5 rows;
+        # with COCG a deflation vector costs bytes, not launches, and small problems are launch-bound: 34,787-DOF MICCA mesh
+        # 0.45 -> 0.35 s per call (25.1 -> 17.3 iterations per solve), 66 k DOF 0.27 -> 0.25, 16 k / 34 k unchanged
+        # (tools/r3_small.sh): recycle_min_rows is 0.
         n_glob = self.n if shard is None else shard.n_global
         self.recycle_k = int(os.environ.get("HX_AMG_RECYCLE", self.params["recycle"])) if len(levels) > 1 else 0
         if n_glob < self.params["recycle_min_rows"] and "HX_AMG_RECYCLE" not in os.environ:

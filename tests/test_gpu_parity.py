@@ -499,18 +499,20 @@ def _annulus_case(shape):
 
 
 _GM = dict(krylov="fgmres")          # ("auto" picks COCG for a complex symmetric operator: flexible GMRES has to be asked for)
+_NR = dict(recycle=0)                # (recycled deflation vectors are on by default at every size)
 
 
-@pytest.mark.parametrize("overrides", [dict(_GM), dict(_GM, sell_min_rows=0), dict(_GM, precision="double", smoother="jacobi"),
-                                       dict(_GM, precision="double", sell_min_rows=0),
-                                       dict(_GM, recycle_min_rows=0, sell_min_rows=0),
-                                       dict(_GM, recycle_min_rows=0, sell_min_rows=0, vcycle_values="c64"),
-                                       dict(_GM, graph_max_rows=10 ** 9),
-                                       # deflated / plain COCG (what "auto" picks for this operator)
-                                       dict(), dict(cocg_min_rows=0, sell_min_rows=0),
-                                       dict(cocg_min_rows=0, precision="double", smoother="jacobi"),
-                                       dict(cocg_min_rows=0, recycle_min_rows=0, sell_min_rows=0),
-                                       dict(krylov="cocg", recycle_min_rows=0, recycle=6)])
+@pytest.mark.parametrize("overrides", [dict(_GM, **_NR), dict(_GM, sell_min_rows=0, **_NR),
+                                       dict(_GM, precision="double", smoother="jacobi", **_NR),
+                                       dict(_GM, precision="double", sell_min_rows=0, **_NR),
+                                       dict(_GM, sell_min_rows=0),
+                                       dict(_GM, sell_min_rows=0, vcycle_values="c64"),
+                                       dict(_GM, graph_max_rows=10 ** 9, **_NR),
+                                       # plain / deflated COCG (what "auto" picks for this operator)
+                                       dict(_NR), dict(sell_min_rows=0, **_NR),
+                                       dict(precision="double", smoother="jacobi", **_NR),
+                                       dict(sell_min_rows=0),
+                                       dict(krylov="cocg", recycle=6)])
 def test_amg_gmres_inner_solver_matches_direct(overrides):
     """K^-1 b from the device AMG-GMRES equals the SuperLU solution on a 3-D annulus (complex shifted operator):
     default (CSR, complex64 Chebyshev V-cycle), SELL-64 fine level, and the all-double variants."""
@@ -543,8 +545,8 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
     want = "fgmres" if overrides.get("krylov") == "fgmres" else "cocg"
     assert st["krylov"] == want and st["cocg_fallbacks"] == 0
     if st["krylov"] == "cocg":      # the first solve of a recycling hierarchy is the harvested GMRES run
-        assert st["cocg_solves"] == (2 if overrides.get("recycle_min_rows") == 0 else 3)
-    if overrides.get("recycle_min_rows") == 0:
+        assert st["cocg_solves"] == (2 if overrides.get("recycle") != 0 else 3)
+    if overrides.get("recycle") != 0:
         # between 3 and `recycle` pairs: the harvest keeps the modes whose harmonic Ritz value is below the threshold
         st_r = solver.stats()
         assert 3 <= st_r["recycled_pairs"] <= overrides.get("recycle", 8) and its[1] <= its[0]
@@ -702,7 +704,8 @@ def test_cocg_symmetry_probe_and_fallback():
     assert not _is_complex_symmetric(Kd)
     assert AMGSolver(Kd, cocg_min_rows=0).stats()["krylov"] == "fgmres"
     assert AMGSolver(K).stats()["krylov"] == "cocg" and AMGSolver(K, cocg_min_rows=10 ** 9).stats()["krylov"] == "fgmres"
-    solver = AMGSolver(Kd, krylov="cocg")                                 # forced: must not return garbage
+    solver = AMGSolver(Kd, krylov="cocg", recycle=0)                      # forced: must not return garbage (recycle=0: with
+                                                                          # recycling the first solve is the harvested GMRES run)
     lu = spla.splu(Ku.tocsc())
     rng = np.random.default_rng(1)
     b = rng.standard_normal(K.shape[0]) + 1j * rng.standard_normal(K.shape[0])

@@ -57,6 +57,9 @@ WORKLOADS = {
     "annulus-66k": (12, 384, 12),      # 64,896 DOF
     "annulus-34k": (10, 256, 11),      # 33,792 DOF ~ the reference's real MICCA mesh (34,787 DOF)
     "annulus-16k": (8, 160, 10),       # 15,840 DOF
+    "annulus-8k": (6, 128, 8),         # 8,064 DOF   (the small sizes: crossover of the direct and the iterative inner solver)
+    "annulus-4k": (5, 96, 6),          # 4,032 DOF
+    "annulus-2k": (4, 64, 6),          # 2,240 DOF
     # the reference's REAL MICCA mesh (tests/golden/meshes/micca_full: 34,787 vertices, unstructured, the mesh of its logged
     # run) as it is, and refined uniformly once / twice (synthetic.refine_tets): 0.25 M / 1.9 M DOF with the real geometry
     # and none of the generator's regularity; vertices renumbered by reverse Cuthill-McKee as XDMFReader does for large meshes

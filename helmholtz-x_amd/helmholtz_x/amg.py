@@ -24,7 +24,7 @@ from .petsc import to_device
 from .solver_utils import info
 
 PARAMS = dict(theta=0.04, max_levels=8, coarse_size=int(os.environ.get("HX_AMG_COARSE_SIZE", "1000")), pre=2, post=2, jacobi_omega=None, rtol=1e-11, restart=50,
-              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=int(os.environ.get("HX_SELL_MIN_ROWS", "50000")), sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
+              max_it=200, precision="mixed", smoother="chebyshev", sell_min_rows=int(os.environ.get("HX_SELL_MIN_ROWS", "150000")), sell_max_row=int(os.environ.get("HX_SELL_MAX_ROW", "40")), vcycle_values="fp16", graph_max_rows=0, recycle=8,
               recycle_min_rows=0, recycle_theta=0.45, krylov="auto", cocg_min_rows=0, setup="device",
               replicate_max_rows=int(os.environ.get("HX_AMG_REPLICATE_MAX_ROWS", "200000")))
 
@@ -705,7 +705,11 @@ class AMGSolver:
         # SELL-64 companion of the fine operator (complex128 for K z in GMRES, working precision for the V-cycle)
         self.sell = None
         self.coarse_sells = []
-        if self.n >= self.params["sell_min_rows"] and len(levels) > 1:
+        # (threshold: CSR with several lanes per row wins below ~1e5 rows -- 66 k DOF 0.20 s per call against 0.24 s with SELL-64,
+        # 260 k DOF 0.39 against 0.35; row-sharded levels are judged by their GLOBAL size and keep SELL-64, whose slice lists the
+        # halo overlap needs)
+        sell_rows = lambda lv: (lv.get("n_global", lv["n"]) if lv.get("sharded") else lv["n"])
+        if sell_rows(levels[0]) >= self.params["sell_min_rows"] and len(levels) > 1:
             sh = C.c_void_p()
             # complex128 copy for K z in GMRES; V-cycle copy in the working precision -- stored as scaled complex-half
             # when the cycle runs in complex64 (8 instead of 12 bytes per entry; same GMRES iteration counts measured)
@@ -726,7 +730,7 @@ class AMGSolver:
                 (krp, kci, kva), knnz = dev_csr(lv["K"])
                 # (one lane per row only pays for short rows: measured 33 us per SELL smoothing step on 88 k rows of
                 # ~60 entries, a latency-bound walk, so long-row levels stay on the multi-lane CSR kernels)
-                if "P" in lv and lv["n"] >= self.params["sell_min_rows"] and knnz <= self.params["sell_max_row"] * lv["n"]:
+                if "P" in lv and sell_rows(lv) >= self.params["sell_min_rows"] and knnz <= self.params["sell_max_row"] * lv["n"]:
                     # coarse operators with enough rows also get a SELL-64 companion (values in the working precision)
                     tmp = values_c128(lv["K"])
                     shl = C.c_void_p()

@@ -27,7 +27,7 @@ from .krylov import default_ncv, krylov_schur
 from .petsc import combine_csr, to_device
 from .solver_utils import info
 
-DEFAULTS = {"st_type": "auto", "lu_max_dofs": 20_000}
+DEFAULTS = {"st_type": "auto", "lu_max_dofs": 1_000}
 # Tolerance factor of the Woodbury columns W = K^-1 U (inner tolerance 1e-11 -> 3e-10).  Larger factors were measured: at
 # 5 M DOF 300 and 1000 give the same four eigenvalues to the printed 1e-6 (3e-10 relative) with 2 % / 3 % fewer inner
 # iterations, but on the Bloch sector (config 5) a factor of 300 moves the adjoint eigenvalue away from the conjugate of
@@ -126,7 +126,9 @@ def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=
         return AMGSolver(K_csr, hierarchy=hierarchy, shard=shard)
     if st == "auto":
         # measured (MI355X, round 1): 2-D 103 k DOF PEP solve 3.8 s with LU (host SuperLU 2.5 s + latency-bound
-        # triangular solves) vs 0.29 s with AMG-GMRES; 3-D 34 k DOF fixed point 20.8 s vs < 3 s.
+        # triangular solves) vs 0.29 s with AMG-GMRES; 3-D 34 k DOF fixed point 20.8 s vs < 3 s.  Round 3, with COCG at every
+        # size (one fixed-point call of the 3-D annulus): 2.2 k DOF 0.35 s (LU) vs 0.15 s (AMG), 4 k 0.59 vs 0.16, 8 k 1.38 vs
+        # 0.16, 16 k 2.35 vs 0.14 -- the direct route only serves problems too small for a two-level hierarchy.
         st = "lu" if n <= DEFAULTS["lu_max_dofs"] else "amg"
     if st == "lu":
         return LUSolver(K_csr)

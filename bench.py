@@ -492,6 +492,7 @@ def main(argv=None):
         import ctypes as C
         # in-situ HIP-event timing of the roofline kernel (operator product on the fine operator) over the timed region
         _hx.check(_hx.lib.hx_profile_sell_spmv(1, n_dof if n_dof >= 50_000 else 2 ** 31 - 1))
+        _hx.check(_hx.lib.hx_pool_stats(None, None, None, None, None, 1))          # device-buffer pool: count the timed region
         barrier()
         t0 = time.perf_counter()
         pairs = 0
@@ -510,6 +511,12 @@ def main(argv=None):
         barrier()
         dt = time.perf_counter() - t0
         in_situ, in_situ_smoother = read_in_situ()
+        pr, ph, pd, pb = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        ps = C.c_double(0.0)
+        _hx.check(_hx.lib.hx_pool_stats(C.byref(pr), C.byref(ph), C.byref(pd), C.byref(ps), C.byref(pb), 0))
+        pool = {"requests_per_step": round(pr.value / max(args.steps, 1), 1), "served_from_cache_per_step": round(ph.value / max(args.steps, 1), 1),
+                "driver_calls_per_step": round(pd.value / max(args.steps, 1), 1), "driver_ms_per_step": round(1e3 * ps.value / max(args.steps, 1), 2),
+                "cached_gib": round(pb.value / 2 ** 30, 2)}
         free_b, total_b = torch.cuda.mem_get_info()            # device-wide: torch's pool + the library's own hipMallocs
         hbm_used_gb = round((total_b - free_b) / 2 ** 30, 1)
 
@@ -533,7 +540,7 @@ def main(argv=None):
                    "inner_stats": inner.stats() if inner is not None else None,
                    "krylov": {k: v for k, v in (E.state or {}).items() if not k.startswith(("start", "_"))},
                    "parallelism": "1 gpu",
-                   "hbm_in_use_after_step_gib": hbm_used_gb,
+                   "hbm_in_use_after_step_gib": hbm_used_gb, "device_buffer_pool": pool,
                    "omega": [[round(w.real, 6), round(w.imag, 6)] for w in omegas]},
         "roofline": roof,
     }

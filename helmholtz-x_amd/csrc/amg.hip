@@ -154,12 +154,12 @@ extern "C" int hx_amg_create(hx_amg** out, int n_levels, int pre, int post, doub
 extern "C" int hx_amg_destroy(hx_amg* h) {
   if (!h) return HX_OK;
   auto release = [](auto& l) {
-    (void)hipFree(l.x); (void)hipFree(l.x2); (void)hipFree(l.x3); (void)hipFree(l.b); (void)hipFree(l.r);
+    (void)hx_free(l.x); (void)hx_free(l.x2); (void)hx_free(l.x3); (void)hx_free(l.b); (void)hx_free(l.r);
   };
   for (auto& l : h->D.L) release(l);
   for (auto& l : h->S.L) release(l);
-  (void)hipFree(h->rec.U); (void)hipFree(h->rec.CV); (void)hipFree(h->rec.CVf);
-  (void)hipFree(h->rec.Uf); (void)hipFree(h->rec.Cd); (void)hipFree(h->rec.Einv);
+  (void)hx_free(h->rec.U); (void)hx_free(h->rec.CV); (void)hx_free(h->rec.CVf);
+  (void)hx_free(h->rec.Uf); (void)hx_free(h->rec.Cd); (void)hx_free(h->rec.Einv);
   if (h->vexec) (void)hipGraphExecDestroy(h->vexec);
   if (h->ev_in) (void)hipEventDestroy(h->ev_in);
   if (h->ev_out) (void)hipEventDestroy(h->ev_out);
@@ -186,11 +186,11 @@ static int set_level(bool real_transfers, HierT<T>& H, int l, int32_t n, int64_t
   }
   if (!L.x) {
     const size_t bytes = 2 * sizeof(T) * (size_t)n;
-    HX_HIP(hipMalloc((void**)&L.x, bytes));
-    HX_HIP(hipMalloc((void**)&L.x2, bytes));
-    HX_HIP(hipMalloc((void**)&L.x3, bytes));
-    HX_HIP(hipMalloc((void**)&L.b, bytes));
-    HX_HIP(hipMalloc((void**)&L.r, bytes));
+    HX_HIP(hx_malloc((void**)&L.x, bytes));
+    HX_HIP(hx_malloc((void**)&L.x2, bytes));
+    HX_HIP(hx_malloc((void**)&L.x3, bytes));
+    HX_HIP(hx_malloc((void**)&L.b, bytes));
+    HX_HIP(hx_malloc((void**)&L.r, bytes));
   }
   return HX_OK;
 }
@@ -243,13 +243,13 @@ static int resize_ext(HierT<T>& H, int n_sharded, const int32_t* n_ext) {
   for (int l = 0; l < n_sharded; ++l) {
     LevelT<T>& L = H.L[l];
     HX_REQUIRE(L.n > 0 && n_ext[l] >= L.n, "n_ext must cover the owned rows of the level");
-    (void)hipFree(L.x); (void)hipFree(L.x2); (void)hipFree(L.x3); (void)hipFree(L.r);
+    (void)hx_free(L.x); (void)hx_free(L.x2); (void)hx_free(L.x3); (void)hx_free(L.r);
     L.x = L.x2 = L.x3 = L.r = nullptr;
     const size_t bytes = 2 * sizeof(T) * (size_t)n_ext[l];
-    HX_HIP(hipMalloc((void**)&L.x, bytes));
-    HX_HIP(hipMalloc((void**)&L.x2, bytes));
-    HX_HIP(hipMalloc((void**)&L.x3, bytes));
-    HX_HIP(hipMalloc((void**)&L.r, bytes));
+    HX_HIP(hx_malloc((void**)&L.x, bytes));
+    HX_HIP(hx_malloc((void**)&L.x2, bytes));
+    HX_HIP(hx_malloc((void**)&L.x3, bytes));
+    HX_HIP(hx_malloc((void**)&L.r, bytes));
     HX_HIP(hipMemset(L.x, 0, bytes)); HX_HIP(hipMemset(L.x2, 0, bytes)); HX_HIP(hipMemset(L.x3, 0, bytes)); HX_HIP(hipMemset(L.r, 0, bytes));
     L.n_ext = n_ext[l];
   }
@@ -690,12 +690,12 @@ extern "C" int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int rest
   HX_REQUIRE(h && n > 0 && k_max >= 1 && k_max <= 32 && restart >= 2 && restart <= 120, "bad argument");
   Recycle& R = h->rec;
   HX_REQUIRE(R.kmax == 0, "recycling already enabled");
-  HX_HIP(hipMalloc((void**)&R.U, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
-  HX_HIP(hipMalloc((void**)&R.CV, sizeof(hx_c128) * (size_t)(k_max + restart + 1) * (size_t)n));
-  HX_HIP(hipMalloc((void**)&R.CVf, sizeof(hx_c64) * (size_t)(k_max + restart + 1) * (size_t)n));
-  HX_HIP(hipMalloc((void**)&R.Uf, sizeof(hx_c64) * (size_t)k_max * (size_t)n));
-  HX_HIP(hipMalloc((void**)&R.Cd, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
-  HX_HIP(hipMalloc((void**)&R.Einv, sizeof(hx_c128) * (size_t)k_max * (size_t)k_max));
+  HX_HIP(hx_malloc((void**)&R.U, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
+  HX_HIP(hx_malloc((void**)&R.CV, sizeof(hx_c128) * (size_t)(k_max + restart + 1) * (size_t)n));
+  HX_HIP(hx_malloc((void**)&R.CVf, sizeof(hx_c64) * (size_t)(k_max + restart + 1) * (size_t)n));
+  HX_HIP(hx_malloc((void**)&R.Uf, sizeof(hx_c64) * (size_t)k_max * (size_t)n));
+  HX_HIP(hx_malloc((void**)&R.Cd, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
+  HX_HIP(hx_malloc((void**)&R.Einv, sizeof(hx_c128) * (size_t)k_max * (size_t)k_max));
   R.kmax = k_max; R.k = 0; R.n = n; R.restart = restart; R.m_last = 0;
   R.Hraw.assign((size_t)(restart + 1) * restart, cd(0));
   return HX_OK;
@@ -725,7 +725,7 @@ extern "C" int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const 
   const int64_t n = R.n;
   hx_c128* Z = ws + (size_t)(R.restart + 1) * n;
   hx_c128* coef = nullptr;
-  HX_HIP(hipMalloc((void**)&coef, sizeof(hx_c128) * (size_t)(m + 1) * k));
+  HX_HIP(hx_malloc((void**)&coef, sizeof(hx_c128) * (size_t)(m + 1) * k));
   int rc;
   HX_HIP(hipMemcpyAsync(coef, Ucoef, sizeof(hx_c128) * (size_t)m * k, hipMemcpyHostToDevice, hx_s(s)));
   rc = hx_zpanel_mul(n, m, k, Z, n, coef, R.U, n, s);
@@ -739,7 +739,7 @@ extern "C" int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const 
     if (!rc) rc = hx_cast_z2c((int64_t)k * n, R.CV, R.CVf, s);
     HX_HIP(hipStreamSynchronize(hx_s(s)));
   }
-  (void)hipFree(coef);
+  (void)hx_free(coef);
   if (rc) return rc;
   R.k = k; R.m_last = 0; R.have_E = false;
   return HX_OK;

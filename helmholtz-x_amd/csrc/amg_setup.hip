@@ -20,10 +20,10 @@ static int exclusive_scan_inplace(T* d, int64_t count, hipStream_t s) {
   size_t bytes = 0;
   HX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d, d, (int)count, s));
   void* tmp = nullptr;
-  HX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  HX_HIP(hx_malloc(&tmp, bytes ? bytes : 16));
   hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, d, d, (int)count, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(tmp);
+  (void)hx_free(tmp);
   HX_HIP(e);
   return HX_OK;
 }
@@ -151,7 +151,7 @@ extern "C" int hx_sa_power_rho(int32_t n, const int32_t* rp, const int32_t* ci, 
   HX_REQUIRE(n > 0 && rp && ci && lf && v && w && h_rho && iters >= 2, "bad argument");
   const int nb = hx_grid(n, 256, 1024);
   double* part = nullptr;
-  HX_HIP(hipMalloc((void**)&part, sizeof(double) * 2 * (size_t)nb));
+  HX_HIP(hx_malloc((void**)&part, sizeof(double) * 2 * (size_t)nb));
   std::vector<double> h(2 * (size_t)nb);
   double *a = v, *b = w;
   for (int it = 0; it < iters; ++it) {
@@ -162,7 +162,7 @@ extern "C" int hx_sa_power_rho(int32_t n, const int32_t* rp, const int32_t* ci, 
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(h.data(), part, sizeof(double) * 2 * (size_t)nb, hipMemcpyDeviceToHost, hx_s(s));
   if (e == hipSuccess) e = hipStreamSynchronize(hx_s(s));
-  (void)hipFree(part);
+  (void)hx_free(part);
   HX_HIP(e);
   double n_last = 0.0, n_prev = 0.0;
   for (int q = 0; q < nb; ++q) { n_last += h[(size_t)((iters - 1) & 1) * nb + q]; n_prev += h[(size_t)((iters - 2) & 1) * nb + q]; }
@@ -274,14 +274,14 @@ extern "C" int hx_csr_transpose_d(int32_t n_rows, int32_t n_cols, int64_t nnz, c
   void* tmp = nullptr;
   size_t bytes = 0;
   int rc = HX_OK;
-  hipError_t e = hipMalloc((void**)&row_of, sizeof(int32_t) * (size_t)nnz);
-  if (e == hipSuccess) e = hipMalloc((void**)&idx, sizeof(int32_t) * (size_t)nnz);
-  if (e == hipSuccess) e = hipMalloc((void**)&keys_out, sizeof(int32_t) * (size_t)nnz);
-  if (e == hipSuccess) e = hipMalloc((void**)&perm, sizeof(int32_t) * (size_t)nnz);
+  hipError_t e = hx_malloc((void**)&row_of, sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess) e = hx_malloc((void**)&idx, sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess) e = hx_malloc((void**)&keys_out, sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess) e = hx_malloc((void**)&perm, sizeof(int32_t) * (size_t)nnz);
   int bits = 1;
   while ((1ll << bits) < (int64_t)n_cols) ++bits;
   if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ci, keys_out, idx, perm, (int)nnz, 0, bits, hx_s(s));
-  if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 16);
+  if (e == hipSuccess) e = hx_malloc(&tmp, bytes ? bytes : 16);
   if (e == hipSuccess) {
     k_expand_rows<<<hx_grid(n_rows, 256), 256, 0, hx_s(s)>>>(n_rows, rp, row_of);
     k_iota<<<hx_grid(nnz, 256), 256, 0, hx_s(s)>>>(nnz, idx);
@@ -295,7 +295,7 @@ extern "C" int hx_csr_transpose_d(int32_t n_rows, int32_t n_cols, int64_t nnz, c
     if (e == hipSuccess) rc = exclusive_scan_inplace(out_rp, (int64_t)n_cols + 1, hx_s(s));
     if (e == hipSuccess && rc == HX_OK) e = hipStreamSynchronize(hx_s(s));
   }
-  (void)hipFree(row_of); (void)hipFree(idx); (void)hipFree(keys_out); (void)hipFree(perm); (void)hipFree(tmp);
+  (void)hx_free(row_of); (void)hx_free(idx); (void)hx_free(keys_out); (void)hx_free(perm); (void)hx_free(tmp);
   HX_HIP(e);
   return rc;
 }
@@ -383,20 +383,20 @@ extern "C" int hx_spgemm_symbolic(hx_spgemm** out, int32_t nA, const int32_t* rp
   int rc = HX_OK;
   hipError_t e = hipSuccess;
   auto cleanup = [&]() {
-    (void)hipFree(ub); (void)hipFree(cap); (void)hipFree(tables); (void)hipFree(lists); (void)hipFree(cnt);
-    (void)hipFree(keys); (void)hipFree(keys2); (void)hipFree(tmp);
+    (void)hx_free(ub); (void)hx_free(cap); (void)hx_free(tables); (void)hx_free(lists); (void)hx_free(cnt);
+    (void)hx_free(keys); (void)hx_free(keys2); (void)hx_free(tmp);
   };
   auto fail = [&](int code, const char* what, const char* detail) {
     cleanup();
-    (void)hipFree(P->rpC); (void)hipFree(P->ciC);
+    (void)hx_free(P->rpC); (void)hx_free(P->ciC);
     delete P;
     return hx_fail(code, what, detail);
   };
 #define SP_HIP(call) do { e = (call); if (e != hipSuccess) return fail(HX_ERR_HIP, #call, hipGetErrorString(e)); } while (0)
-  SP_HIP(hipMalloc((void**)&ub, sizeof(int64_t) * ((size_t)nA + 1)));
-  SP_HIP(hipMalloc((void**)&cap, sizeof(int32_t) * (size_t)nA));
-  SP_HIP(hipMalloc((void**)&cnt, sizeof(int32_t) * ((size_t)nA + 1)));
-  SP_HIP(hipMalloc((void**)&P->rpC, sizeof(int32_t) * ((size_t)nA + 1)));
+  SP_HIP(hx_malloc((void**)&ub, sizeof(int64_t) * ((size_t)nA + 1)));
+  SP_HIP(hx_malloc((void**)&cap, sizeof(int32_t) * (size_t)nA));
+  SP_HIP(hx_malloc((void**)&cnt, sizeof(int32_t) * ((size_t)nA + 1)));
+  SP_HIP(hx_malloc((void**)&P->rpC, sizeof(int32_t) * ((size_t)nA + 1)));
   k_spgemm_ub<<<hx_grid(nA, 256), 256, 0, hx_s(s)>>>(nA, rpA, ciA, rpB, ncolsB, ub, cap);
   SP_HIP(hipGetLastError());
   // largest table, total list length
@@ -404,18 +404,18 @@ extern "C" int hx_spgemm_symbolic(hx_spgemm** out, int32_t nA, const int32_t* rp
   {
     size_t bytes = 0;
     int32_t* d_max = nullptr;
-    SP_HIP(hipMalloc((void**)&d_max, sizeof(int32_t)));
+    SP_HIP(hx_malloc((void**)&d_max, sizeof(int32_t)));
     e = hipcub::DeviceReduce::Max(nullptr, bytes, cap, d_max, nA, hx_s(s));
     void* t2 = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&t2, bytes ? bytes : 16);
+    if (e == hipSuccess) e = hx_malloc(&t2, bytes ? bytes : 16);
     if (e == hipSuccess) e = hipcub::DeviceReduce::Max(t2, bytes, cap, d_max, nA, hx_s(s));
     if (e == hipSuccess) e = hipMemcpyAsync(&cap_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, hx_s(s));
     if (e == hipSuccess) e = hipStreamSynchronize(hx_s(s));
-    (void)hipFree(t2); (void)hipFree(d_max);
+    (void)hx_free(t2); (void)hx_free(d_max);
     if (e != hipSuccess) return fail(HX_ERR_HIP, "hipcub::DeviceReduce::Max", hipGetErrorString(e));
   }
   SP_HIP(hipMemsetAsync(ub + nA, 0, sizeof(int64_t), hx_s(s)));
-  if ((rc = exclusive_scan_inplace(ub, (int64_t)nA + 1, hx_s(s)))) { cleanup(); (void)hipFree(P->rpC); delete P; return rc; }
+  if ((rc = exclusive_scan_inplace(ub, (int64_t)nA + 1, hx_s(s)))) { cleanup(); (void)hx_free(P->rpC); delete P; return rc; }
   int64_t total_ub = 0;
   SP_HIP(hipMemcpy(&total_ub, ub + nA, sizeof(int64_t), hipMemcpyDeviceToHost));
   // scratch tables: as many groups as fit 1 GiB, at most 8 groups per wave slot of the chip
@@ -424,27 +424,27 @@ extern "C" int hx_spgemm_symbolic(hx_spgemm** out, int32_t nA, const int32_t* rp
   n_groups = std::min<int64_t>(n_groups, ((int64_t)nA + 0));
   const int blocks = (int)std::max<int64_t>(1, (n_groups * SG + 255) / 256);
   n_groups = (int64_t)blocks * 256 / SG;
-  SP_HIP(hipMalloc((void**)&tables, sizeof(int32_t) * (size_t)n_groups * (size_t)cap_max));
-  SP_HIP(hipMalloc((void**)&lists, sizeof(int32_t) * (size_t)std::max<int64_t>(total_ub, 1)));
+  SP_HIP(hx_malloc((void**)&tables, sizeof(int32_t) * (size_t)n_groups * (size_t)cap_max));
+  SP_HIP(hx_malloc((void**)&lists, sizeof(int32_t) * (size_t)std::max<int64_t>(total_ub, 1)));
   SP_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)nA + 1), hx_s(s)));
   k_spgemm_symbolic<<<blocks, 256, 0, hx_s(s)>>>(nA, rpA, ciA, rpB, ciB, ub, cap, cap_max, tables, cnt, lists);
   SP_HIP(hipGetLastError());
   SP_HIP(hipMemcpyAsync(P->rpC, cnt, sizeof(int32_t) * ((size_t)nA + 1), hipMemcpyDeviceToDevice, hx_s(s)));
-  if ((rc = exclusive_scan_inplace(P->rpC, (int64_t)nA + 1, hx_s(s)))) { cleanup(); (void)hipFree(P->rpC); delete P; return rc; }
+  if ((rc = exclusive_scan_inplace(P->rpC, (int64_t)nA + 1, hx_s(s)))) { cleanup(); (void)hx_free(P->rpC); delete P; return rc; }
   int32_t nnz32 = 0;
   SP_HIP(hipMemcpy(&nnz32, P->rpC + nA, sizeof(int32_t), hipMemcpyDeviceToHost));
   if (nnz32 <= 0) return fail(HX_ERR_ARG, "hx_spgemm_symbolic", "empty product (or more than 2^31 entries)");
   P->nnzC = nnz32;
-  SP_HIP(hipMalloc((void**)&keys, sizeof(uint64_t) * (size_t)nnz32));
-  SP_HIP(hipMalloc((void**)&keys2, sizeof(uint64_t) * (size_t)nnz32));
-  SP_HIP(hipMalloc((void**)&P->ciC, sizeof(int32_t) * (size_t)nnz32));
+  SP_HIP(hx_malloc((void**)&keys, sizeof(uint64_t) * (size_t)nnz32));
+  SP_HIP(hx_malloc((void**)&keys2, sizeof(uint64_t) * (size_t)nnz32));
+  SP_HIP(hx_malloc((void**)&P->ciC, sizeof(int32_t) * (size_t)nnz32));
   k_spgemm_keys<<<blocks, 256, 0, hx_s(s)>>>(nA, P->rpC, ub, lists, keys);
   SP_HIP(hipGetLastError());
   int row_bits = 1;
   while ((1ll << row_bits) < (int64_t)nA) ++row_bits;
   size_t bytes = 0;
   SP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys, keys2, (int)nnz32, 0, 32 + row_bits, hx_s(s)));
-  SP_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  SP_HIP(hx_malloc(&tmp, bytes ? bytes : 16));
   SP_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, bytes, keys, keys2, (int)nnz32, 0, 32 + row_bits, hx_s(s)));
   k_spgemm_cols<<<hx_grid(nnz32, 256), 256, 0, hx_s(s)>>>(nnz32, keys2, P->ciC);
   SP_HIP(hipGetLastError());
@@ -502,7 +502,7 @@ extern "C" int hx_spgemm_numeric(const hx_spgemm* P, const int32_t* rpA, const i
 }
 extern "C" int hx_spgemm_destroy(hx_spgemm* P) {
   if (!P) return HX_OK;
-  (void)hipFree(P->rpC); (void)hipFree(P->ciC);
+  (void)hx_free(P->rpC); (void)hx_free(P->ciC);
   delete P;
   return HX_OK;
 }

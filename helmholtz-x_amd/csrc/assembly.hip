@@ -40,10 +40,10 @@ static int exclusive_scan_i32(int32_t* d_inout, int64_t count, hipStream_t s) {
   size_t bytes = 0;
   HX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_inout, d_inout, (int)count, s));
   void* tmp = nullptr;
-  HX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  HX_HIP(hx_malloc(&tmp, bytes ? bytes : 16));
   hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, bytes, d_inout, d_inout, (int)count, s);
   hipError_t e2 = hipStreamSynchronize(s);
-  (void)hipFree(tmp);
+  (void)hx_free(tmp);
   if (e != hipSuccess) return hx_fail(HX_ERR_HIP, "ExclusiveSum", hipGetErrorString(e));
   if (e2 != hipSuccess) return hx_fail(HX_ERR_HIP, "hipStreamSynchronize", hipGetErrorString(e2));
   return HX_OK;
@@ -65,12 +65,12 @@ extern "C" int hx_build_v2e(int32_t n_vert, int32_t n_ent, int k, const int32_t*
   if (rc) return rc;
   if (total == 0) return HX_OK;
   int32_t* cursor = nullptr;
-  HX_HIP(hipMalloc((void**)&cursor, sizeof(int32_t) * (size_t)n_vert));
+  HX_HIP(hx_malloc((void**)&cursor, sizeof(int32_t) * (size_t)n_vert));
   (void)hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_vert, s);
   k_fill_incidence<<<hx_grid(total, 256), 256, 0, s>>>(total, k, ents, v2e_ptr, cursor, v2e_idx);
   k_sort_lists<<<hx_grid(n_vert, 256), 256, 0, s>>>(n_vert, v2e_ptr, v2e_idx);
   hipError_t e = hipStreamSynchronize(s);
-  (void)hipFree(cursor);
+  (void)hx_free(cursor);
   if (e != hipSuccess) return hx_fail(HX_ERR_HIP, "hx_build_v2e", hipGetErrorString(e));
   HX_LAUNCH_CHECK("hx_build_v2e");
   return HX_OK;

@@ -141,7 +141,7 @@ extern "C" int hx_comm_create(hx_comm** out, int rank, int world, const void* id
 
 extern "C" int hx_comm_destroy(hx_comm* c) {
   if (!c) return HX_OK;
-  for (Plan& p : c->plans) { (void)hipFree(p.d_idx); (void)hipFree(p.stage); }
+  for (Plan& p : c->plans) { (void)hx_free(p.d_idx); (void)hx_free(p.stage); }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->cstream) (void)hipStreamDestroy(c->cstream);
@@ -174,7 +174,7 @@ extern "C" int hx_comm_set_plan(hx_comm* c, int plan, int ns, const int32_t* sen
   HX_REQUIRE(nr == 0 || (recv_peer && recv_off && recv_cnt), "missing receive ranges");
   if ((int)c->plans.size() <= plan) c->plans.resize(plan + 1);
   Plan& P = c->plans[plan];
-  (void)hipFree(P.d_idx); (void)hipFree(P.stage);
+  (void)hx_free(P.d_idx); (void)hx_free(P.stage);
   P = Plan();
   std::vector<int32_t> gathered;
   for (int q = 0; q < ns; ++q) {
@@ -196,9 +196,9 @@ extern "C" int hx_comm_set_plan(hx_comm* c, int plan, int ns, const int32_t* sen
   }
   P.n_gather = (int64_t)gathered.size();
   if (P.n_gather > 0) {
-    HX_HIP(hipMalloc((void**)&P.d_idx, sizeof(int32_t) * (size_t)P.n_gather));
+    HX_HIP(hx_malloc((void**)&P.d_idx, sizeof(int32_t) * (size_t)P.n_gather));
     HX_HIP(hipMemcpy(P.d_idx, gathered.data(), sizeof(int32_t) * (size_t)P.n_gather, hipMemcpyHostToDevice));
-    HX_HIP(hipMalloc(&P.stage, 16 * (size_t)P.n_gather));
+    HX_HIP(hx_malloc(&P.stage, 16 * (size_t)P.n_gather));
   }
   P.set = true;
   return HX_OK;

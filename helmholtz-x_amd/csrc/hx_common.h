@@ -31,6 +31,13 @@ static inline int hx_fail(int code, const char* what, const char* detail) {
 #define HX_REQUIRE(cond, msg) \
   do { if (!(cond)) return hx_fail(HX_ERR_ARG, __func__, msg); } while (0)
 
+// Device buffers of the library come from its pool (pool.hip): blocks of 1 MiB or more are kept on release and reused by the next
+// request of the same size -- the next fixed-point call builds the same objects again.
+hipError_t hx_pool_alloc(void** out, size_t bytes);
+hipError_t hx_pool_free(void* p);
+template <typename T> static inline hipError_t hx_malloc(T** p, size_t bytes) { return hx_pool_alloc((void**)p, bytes); }
+static inline hipError_t hx_free(void* p) { return hx_pool_free(p); }
+
 typedef double2 zc;  // complex128 as {re, im}: one 16-byte (dwordx4) access per element
 
 __device__ __forceinline__ zc zmul(zc a, zc b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }

@@ -214,9 +214,9 @@ __global__ void k_sell_ghost_flags(int32_t n_rows, int32_t n_slices, const int64
 
 extern "C" int hx_sell_destroy(hx_sell* h) {
   if (!h) return HX_OK;
-  (void)hipFree(h->slice_ptr); (void)hipFree(h->col); (void)hipFree(h->dcol); (void)hipFree(h->wide); (void)hipFree(h->val_z); (void)hipFree(h->val_c);
-  (void)hipFree(h->val_h); (void)hipFree(h->st_ptr); (void)hipFree(h->st_delta);
-  (void)hipFree(h->list_interior); (void)hipFree(h->list_boundary);
+  (void)hx_free(h->slice_ptr); (void)hx_free(h->col); (void)hx_free(h->dcol); (void)hx_free(h->wide); (void)hx_free(h->val_z); (void)hx_free(h->val_c);
+  (void)hx_free(h->val_h); (void)hx_free(h->st_ptr); (void)hx_free(h->st_delta);
+  (void)hx_free(h->list_interior); (void)hx_free(h->list_boundary);
   delete h;
   return HX_OK;
 }
@@ -240,19 +240,19 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     hipError_t e0 = hipMemcpyAsync(&nnz0, rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);
     if (e0 == hipSuccess && nnz0 > 0) {
-      e0 = hipMalloc((void**)&d_max, sizeof(int32_t));
+      e0 = hx_malloc((void**)&d_max, sizeof(int32_t));
       if (e0 == hipSuccess) e0 = hipcub::DeviceReduce::Max(nullptr, b0, col, d_max, nnz0, s);
-      if (e0 == hipSuccess) e0 = hipMalloc(&t0, b0 ? b0 : 16);
+      if (e0 == hipSuccess) e0 = hx_malloc(&t0, b0 ? b0 : 16);
       if (e0 == hipSuccess) e0 = hipcub::DeviceReduce::Max(t0, b0, col, d_max, nnz0, s);
       if (e0 == hipSuccess) e0 = hipMemcpyAsync(&cmax, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, s);
       if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);
-      (void)hipFree(t0); (void)hipFree(d_max);
+      (void)hx_free(t0); (void)hx_free(d_max);
     }
     if (e0 != hipSuccess) { delete h; return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e0)); }
     h->n_cols = cmax + 1 > n ? cmax + 1 : n;
     if (h->n_cols > (1 << 27)) { delete h; return hx_fail(HX_ERR_ARG, __func__, "more than 2^27 columns (32-bit byte offsets into x)"); }
   }
-  if (hipMalloc((void**)&h->slice_ptr, sizeof(int64_t) * np) != hipSuccess) { delete h; return hx_fail(HX_ERR_ALLOC, __func__, "slice_ptr"); }
+  if (hx_malloc((void**)&h->slice_ptr, sizeof(int64_t) * np) != hipSuccess) { delete h; return hx_fail(HX_ERR_ALLOC, __func__, "slice_ptr"); }
   {
     const hipError_t em = hipMemsetAsync(h->slice_ptr, 0, sizeof(int64_t) * np, s);
     if (em != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, "hx_sell_create: hipMemsetAsync", hipGetErrorString(em)); }
@@ -268,21 +268,21 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   int32_t* d_wu = nullptr;
   int32_t* d_tmpU = nullptr;
   if (allow_stencil && h->n_slices > 0 &&
-      hipMalloc((void**)&d_wu, sizeof(int32_t) * np) == hipSuccess &&
-      hipMalloc((void**)&d_tmpU, sizeof(int32_t) * 64 * (size_t)h->n_slices) == hipSuccess) {
+      hx_malloc((void**)&d_wu, sizeof(int32_t) * np) == hipSuccess &&
+      hx_malloc((void**)&d_tmpU, sizeof(int32_t) * 64 * (size_t)h->n_slices) == hipSuccess) {
     // (an allocation failure above only skips the stencil detection -- the format is complete without it; an error of
     // these launches is caught by the checked scan that follows on the same stream)
     if (hipMemsetAsync(d_wu, 0, sizeof(int32_t) * np, s) == hipSuccess) {
       k_sell_stencil_union<<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, h->slice_ptr, d_wu, d_tmpU);
       k_sell_stencil_sizes<<<hx_grid(h->n_slices, 256), 256, 0, s>>>(h->n_slices, d_wu, h->slice_ptr);
     }
-  } else { (void)hipFree(d_wu); (void)hipFree(d_tmpU); d_wu = nullptr; d_tmpU = nullptr; (void)hipGetLastError(); }
+  } else { (void)hx_free(d_wu); (void)hx_free(d_tmpU); d_wu = nullptr; d_tmpU = nullptr; (void)hipGetLastError(); }
   size_t bytes = 0;
   hipError_t e = hipGetLastError();               // the width / stencil launches above
   if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, h->slice_ptr, h->slice_ptr, (int)np, s);
   void* tmp = nullptr;
-  if (e != hipSuccess || hipMalloc(&tmp, bytes ? bytes : 16) != hipSuccess) {
-    (void)hipFree(d_wu); (void)hipFree(d_tmpU);
+  if (e != hipSuccess || hx_malloc(&tmp, bytes ? bytes : 16) != hipSuccess) {
+    (void)hx_free(d_wu); (void)hx_free(d_tmpU);
     hx_sell_destroy(h);
     return hx_fail(e != hipSuccess ? HX_ERR_HIP : HX_ERR_ALLOC, "hx_sell_create: slice scan", e != hipSuccess ? hipGetErrorString(e) : "workspace");
   }
@@ -290,34 +290,34 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   int64_t total = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&total, h->slice_ptr + h->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(tmp);
+  (void)hx_free(tmp);
   if (e == hipSuccess && d_wu) {        // st_ptr = exclusive scan of the union lengths; keep it only if some slice qualified
     size_t b2 = 0;
     void* t2 = nullptr;
     int32_t n_st = 0;
     e = hipcub::DeviceScan::ExclusiveSum(nullptr, b2, d_wu, d_wu, (int)np, s);
-    if (e == hipSuccess) e = hipMalloc(&t2, b2 ? b2 : 16);
+    if (e == hipSuccess) e = hx_malloc(&t2, b2 ? b2 : 16);
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(t2, b2, d_wu, d_wu, (int)np, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&n_st, d_wu + h->n_slices, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(t2);
-    if (e == hipSuccess && n_st > 0 && hipMalloc((void**)&h->st_delta, sizeof(int32_t) * (size_t)n_st) == hipSuccess) {
+    (void)hx_free(t2);
+    if (e == hipSuccess && n_st > 0 && hx_malloc((void**)&h->st_delta, sizeof(int32_t) * (size_t)n_st) == hipSuccess) {
       h->st_ptr = d_wu;
       d_wu = nullptr;
       h->n_stencil = n_st;
       k_sell_stencil_pack<<<grid, 256, 0, s>>>(h->n_slices, h->st_ptr, d_tmpU, h->st_delta);
       e = hipStreamSynchronize(s);
     }
-    (void)hipFree(d_wu); (void)hipFree(d_tmpU);
+    (void)hx_free(d_wu); (void)hx_free(d_tmpU);
     d_wu = nullptr; d_tmpU = nullptr;
   }
-  if (e != hipSuccess) { (void)hipFree(d_wu); (void)hipFree(d_tmpU); hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hx_free(d_wu); (void)hx_free(d_tmpU); hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
   h->padded = total;
   const size_t ne = (size_t)(total > 0 ? total : 1);
-  if (hipMalloc((void**)&h->col, sizeof(int32_t) * ne) != hipSuccess ||
-      (want_z && hipMalloc((void**)&h->val_z, sizeof(zc) * ne) != hipSuccess) ||
-      (want_c == 1 && hipMalloc((void**)&h->val_c, sizeof(cc) * ne) != hipSuccess) ||
-      (want_c == 2 && hipMalloc((void**)&h->val_h, sizeof(ch) * ne) != hipSuccess)) {
+  if (hx_malloc((void**)&h->col, sizeof(int32_t) * ne) != hipSuccess ||
+      (want_z && hx_malloc((void**)&h->val_z, sizeof(zc) * ne) != hipSuccess) ||
+      (want_c == 1 && hx_malloc((void**)&h->val_c, sizeof(cc) * ne) != hipSuccess) ||
+      (want_c == 2 && hx_malloc((void**)&h->val_h, sizeof(ch) * ne) != hipSuccess)) {
     hx_sell_destroy(h);
     return hx_fail(HX_ERR_ALLOC, __func__, "SELL arrays");
   }
@@ -330,7 +330,7 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     unsigned int* dmax = nullptr;
     unsigned int hmax = 0;
     int32_t nnz = 0;
-    e = hipMalloc((void**)&dmax, sizeof(unsigned int));
+    e = hx_malloc((void**)&dmax, sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemsetAsync(dmax, 0, sizeof(unsigned int), s);
     if (e == hipSuccess) e = hipMemcpyAsync(&nnz, rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -339,7 +339,7 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
       e = hipMemcpyAsync(&hmax, dmax, sizeof(unsigned int), hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(dmax);
+    (void)hx_free(dmax);
     if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
     float vmax;
     memcpy(&vmax, &hmax, sizeof(float));
@@ -354,19 +354,19 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   static const bool allow16 = !(getenv("HX_SELL_INDEX") && strcmp(getenv("HX_SELL_INDEX"), "i32") == 0);
   if (allow16 && total > 0) {
     int32_t* d_nw = nullptr;
-    bool ok = hipMalloc((void**)&h->dcol, sizeof(int16_t) * ne) == hipSuccess &&
-              hipMalloc((void**)&h->wide, (size_t)h->n_slices) == hipSuccess &&
-              hipMalloc((void**)&d_nw, sizeof(int32_t)) == hipSuccess;
+    bool ok = hx_malloc((void**)&h->dcol, sizeof(int16_t) * ne) == hipSuccess &&
+              hx_malloc((void**)&h->wide, (size_t)h->n_slices) == hipSuccess &&
+              hx_malloc((void**)&d_nw, sizeof(int32_t)) == hipSuccess;
     if (ok) {
       (void)hipMemsetAsync(d_nw, 0, sizeof(int32_t), s);
       k_sell_narrow<<<grid, 256, 0, s>>>(h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide, d_nw);
       ok = hipMemcpyAsync(&h->n_wide, d_nw, sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
            hipStreamSynchronize(s) == hipSuccess;
     }
-    (void)hipFree(d_nw);
+    (void)hx_free(d_nw);
     // not worth it when (nearly) every slice is wide: drop the narrow copy
     if (!ok || h->n_wide > h->n_slices / 2) {
-      (void)hipFree(h->dcol); (void)hipFree(h->wide);
+      (void)hx_free(h->dcol); (void)hx_free(h->wide);
       h->dcol = nullptr; h->wide = nullptr; h->n_wide = h->n_slices;
     }
     (void)hipGetLastError();
@@ -374,23 +374,23 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   if (h->n_cols > n && total > 0) {          // rectangular: a row-sharded local operator -> interior / boundary slice lists
     uint8_t* d_flag = nullptr;
     std::vector<uint8_t> hf((size_t)h->n_slices);
-    hipError_t ef = hipMalloc((void**)&d_flag, (size_t)h->n_slices);
+    hipError_t ef = hx_malloc((void**)&d_flag, (size_t)h->n_slices);
     if (ef == hipSuccess) {
       k_sell_ghost_flags<<<grid, 256, 0, s>>>(n, h->n_slices, h->slice_ptr, h->col, d_flag);
       ef = hipMemcpyAsync(hf.data(), d_flag, (size_t)h->n_slices, hipMemcpyDeviceToHost, s);
       if (ef == hipSuccess) ef = hipStreamSynchronize(s);
     }
-    (void)hipFree(d_flag);
+    (void)hx_free(d_flag);
     if (ef == hipSuccess) {
       std::vector<int32_t> li, lb;
       for (int32_t q = 0; q < h->n_slices; ++q) (hf[q] ? lb : li).push_back(q);
       if (!li.empty() && !lb.empty() &&
-          hipMalloc((void**)&h->list_interior, sizeof(int32_t) * li.size()) == hipSuccess &&
-          hipMalloc((void**)&h->list_boundary, sizeof(int32_t) * lb.size()) == hipSuccess &&
+          hx_malloc((void**)&h->list_interior, sizeof(int32_t) * li.size()) == hipSuccess &&
+          hx_malloc((void**)&h->list_boundary, sizeof(int32_t) * lb.size()) == hipSuccess &&
           hipMemcpy(h->list_interior, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice) == hipSuccess &&
           hipMemcpy(h->list_boundary, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice) == hipSuccess) {
         h->n_interior = (int32_t)li.size(); h->n_boundary = (int32_t)lb.size();
-      } else { (void)hipFree(h->list_interior); (void)hipFree(h->list_boundary); h->list_interior = h->list_boundary = nullptr; }
+      } else { (void)hx_free(h->list_interior); (void)hx_free(h->list_boundary); h->list_interior = h->list_boundary = nullptr; }
     }
     (void)hipGetLastError();
   }
@@ -410,14 +410,14 @@ extern "C" int hx_sell_stencil_slices(const hx_sell* h) {
   if (!h || !h->st_ptr) return 0;
   int32_t* d = nullptr;
   int32_t v = 0;
-  if (hipMalloc((void**)&d, sizeof(int32_t)) != hipSuccess) return -1;
+  if (hx_malloc((void**)&d, sizeof(int32_t)) != hipSuccess) return -1;
   hipError_t e = hipMemset(d, 0, sizeof(int32_t));
   if (e == hipSuccess) {
     k_count_stencil<<<hx_grid(h->n_slices, 256), 256>>>(h->n_slices, h->st_ptr, d);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(&v, d, sizeof(int32_t), hipMemcpyDeviceToHost);
-  (void)hipFree(d);
+  (void)hx_free(d);
   if (e != hipSuccess) { (void)hx_fail(HX_ERR_HIP, "hx_sell_stencil_slices", hipGetErrorString(e)); return -1; }
   return v;
 }

@@ -81,15 +81,15 @@ k_chain(int32_t l0, int32_t l1, const int32_t* __restrict__ level_ptr, const int
 
 template <typename T>
 static int upload(T** dst, const T* src, size_t count) {
-  HX_HIP(hipMalloc((void**)dst, std::max<size_t>(count, 1) * sizeof(T)));
+  HX_HIP(hx_malloc((void**)dst, std::max<size_t>(count, 1) * sizeof(T)));
   if (count) HX_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
   return HX_OK;
 }
 
 extern "C" int hx_sptrsv_destroy(hx_sptrsv* t) {
   if (!t) return HX_OK;
-  (void)hipFree(t->d_level_ptr); (void)hipFree(t->d_rows); (void)hipFree(t->d_rowptr);
-  (void)hipFree(t->d_col); (void)hipFree(t->d_val); (void)hipFree(t->d_inv_diag);
+  (void)hx_free(t->d_level_ptr); (void)hx_free(t->d_rows); (void)hx_free(t->d_rowptr);
+  (void)hx_free(t->d_col); (void)hx_free(t->d_val); (void)hx_free(t->d_inv_diag);
   delete t;
   return HX_OK;
 }

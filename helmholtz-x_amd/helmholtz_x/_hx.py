@@ -108,6 +108,9 @@ SIGNATURES = {
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
     "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_FN, HALO_END_FN]),
     "hx_amg_set_prolongator_ghost_rows": (C.c_int, [_vp, C.c_int]),
+    "hx_pool_trim": (C.c_int, []),
+    "hx_pool_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                C.POINTER(C.c_int64), C.c_int]),
     "hx_comm_halo_begin": (C.c_int, [_vp, _int, _vp, _int, _vp]),
     "hx_comm_halo_end": (C.c_int, [_vp, _int, _vp]),
     "hx_comm_overlapped": (_i64, [_vp]),

@@ -216,6 +216,7 @@ def _dev_filter(K, sign, theta, sd):
 
 
 _PINNED = {}
+AGG_TIMES = []        # (rows, graph entries, s device -> pinned host, s host pass) of the last aggregation passes (diagnostics)
 
 
 def _to_host_pinned(t, key):
@@ -233,15 +234,21 @@ def _to_host_pinned(t, key):
 def _dev_aggregate(Lf):
     """Greedy aggregation of the strength graph: the one sequential pass of the set-up, run on the host on the
     (pattern, |weight| as float32) of Lf -- the filtered graph is a fraction of K and K itself stays in HBM."""
+    import time
     n = Lf.shape[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     rp = _to_host_pinned(Lf.rowptr, "agg_rp")
     ci = _to_host_pinned(Lf.col, "agg_ci")
     w = _to_host_pinned(Lf.val.to(torch.float32), "agg_w")
     torch.cuda.synchronize()
+    t1 = time.perf_counter()
     agg = np.empty(n, dtype=np.int32)
     na = C.c_int32(0)
     _hx.check(_hx.lib.hx_host_aggregate_f32(n, C.c_void_p(rp.data_ptr()), C.c_void_p(ci.data_ptr()),
                                             C.c_void_p(w.data_ptr()), _hx.nptr(agg), C.byref(na)))
+    AGG_TIMES.append((n, int(Lf.nnz), round(t1 - t0, 4), round(time.perf_counter() - t1, 4)))
+    del AGG_TIMES[:-8]
     return agg, na.value
 
 
@@ -813,6 +820,8 @@ class AMGSolver:
         self.last = (0, 0.0)
         torch.cuda.synchronize()
         self.setup_s = time.perf_counter() - t_setup
+        self.agg_times = list(AGG_TIMES) if hierarchy is None else []
+        del AGG_TIMES[:]
         info("- AMG hierarchy: " + " -> ".join("%d" % lv["n"] for lv in levels)
              + "  (operator complexity %.2f)" % (sum(lv["K"].nnz for lv in levels) / levels[0]["K"].nnz))
 
@@ -940,7 +949,9 @@ class AMGSolver:
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
                     if self.sell else "csr",
                     stencil_slices=_hx.lib.hx_sell_stencil_slices(self.sell) if self.sell else 0, vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",
-                    setup_s=round(self.setup_s, 3), solves=self.n_solves,
+                    setup_s=round(self.setup_s, 3),
+                    setup_host_aggregation=[dict(rows=a, entries=b, copy_s=c, host_pass_s=d) for a, b, c, d in self.agg_times],
+                    solves=self.n_solves,
                     krylov="cocg" if self.use_cocg else "fgmres", cocg_solves=self.cocg_solves,
                     cocg_iters=self.cocg_iters, cocg_fallbacks=self.cocg_fallbacks,
                     attainable_stops=self.attainable_stops,

@@ -46,6 +46,7 @@ enum hx_status {
  * first call that consults it, and cached for the life of the process: set them before the first libhx call -- changing one
  * afterwards (e.g. from a test that monkey-patches os.environ mid-run) has no effect.
  *   HX_SELL_STENCIL=0 / HX_SELL_INDEX=i32 / HX_SELL_LDS=0|2   SELL-64 format and kernel variants (hx_sell_create, k_sell)
+ *   HX_POOL=0, HX_POOL_MAX_GIB, HX_POOL_MIN_BYTES                 device-buffer pool off / cap of the cached bytes / smallest pooled block
  *   HX_SELL_XCD=0|3, HX_SELL_ABLATE                            XCD-contiguous slice schedule never / always (default: by footprint); timing-only ablations
  *   HX_COCG_LAG=0                                             hx_cocg: wait for every residual norm (default: read one iteration late while far from the tolerance)
  *   HX_COCG_FUSE_REDUCTIONS=0                                  hx_cocg (read per solve): two-stage reductions on one GPU too
@@ -54,6 +55,16 @@ enum hx_status {
  *   HX_GMRES_TRACE=1                                          residual histories of hx_gmres / hx_cocg on stderr
  *   HX_HOST_THREADS                                           threads of the hx_host_* set-up passes
  *   HX_RCCL_LIB                                               librccl to bind in hx_comm_* (default: the loaded one / librccl.so.1) */
+/* Device-buffer pool (csrc/pool.hip): buffers of 1 MiB or more that a handle releases (hx_sell_destroy, hx_amg_destroy, the scratch
+ * of the set-up passes) are kept and handed to the next request of exactly the same size -- every fixed-point call of a driver
+ * builds the same objects again (the reference: E.destroy() and a new EPS per iteration, eigensolvers.py:161) -- instead of
+ * going through hipFree / hipMalloc, whose cost varies from milliseconds to tenths of a second with the load of the machine.
+ * HX_POOL=0 switches it off, HX_POOL_MAX_GIB caps the cached bytes (default 32), HX_POOL_MIN_BYTES the smallest pooled block.
+ * hx_pool_trim returns every cached block to the driver; hx_pool_stats: requests, requests served from the cache, calls that went to
+ * the driver and the seconds spent in them, bytes cached now (reset != 0 clears the counters). */
+int hx_pool_trim(void);
+int hx_pool_stats(int64_t* n_requests, int64_t* n_reused, int64_t* n_driver_calls, double* driver_seconds, int64_t* cached_bytes,
+                  int reset);
 int hx_version(void);
 const char* hx_last_error(void);
 /* SYNC. Device name, compute-unit count and HBM bytes of the current device. */

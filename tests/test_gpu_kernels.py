@@ -312,6 +312,42 @@ def test_sell64_products_match_csr(hx, n, density):
     hx.check(hx.lib.hx_sell_destroy(h))
 
 
+
+def test_device_buffer_pool_reuses_released_blocks(hx):
+    """csrc/pool.hip: the large buffers a destroyed SELL-64 operator releases are handed to the next operator of the same shape
+    without a driver call (every fixed-point call of a driver builds the same objects again); the product computed in reused
+    memory is right; hx_pool_trim gives everything back."""
+    rng = np.random.default_rng(3)
+    n = 200_000
+    M = sp.diags([1.0 + 0.5j, 4.0 - 1.0j, 0.7 + 0.2j], [-1, 0, 1], shape=(n, n), format="csr", dtype=np.complex128)
+    M.sort_indices()
+    rp, ci, va = _dev(M.indptr.astype(np.int32)), _dev(M.indices.astype(np.int32)), _dev(M.data.astype(np.complex128))
+    x = _rand_c(rng, n)
+    xd, yd = _dev(x), _dev(np.zeros(n, dtype=np.complex128))
+
+    def stats(reset=0):
+        a, b, c, e = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        d = C.c_double(0.0)
+        hx.check(hx.lib.hx_pool_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), reset))
+        return a.value, b.value, c.value, e.value
+
+    hx.check(hx.lib.hx_pool_trim())
+    stats(1)
+    for trip in range(2):
+        h = C.c_void_p()
+        hx.check(hx.lib.hx_sell_create(C.byref(h), n, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), 1, 1, hx.stream()))
+        hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(xd), hx.ptr(yd), hx.z2(1.0), hx.z2(0.0), hx.stream()))
+        assert np.max(np.abs(yd.cpu().numpy() - M @ x)) <= 1e-13 * np.max(np.abs(x)) * 6
+        hx.check(hx.lib.hx_sell_destroy(h))
+        requests, reused, driver, cached = stats()
+        if trip == 0:
+            assert reused == 0 and cached >= 16 * M.nnz            # (the complex128 value array alone)
+            first = requests
+        else:
+            assert reused > 0 and requests == 2 * first and cached >= 16 * M.nnz
+    hx.check(hx.lib.hx_pool_trim())
+    assert stats()[3] == 0
+
 @pytest.mark.parametrize("want", [(1, 0), (1, 1), (0, 2)])
 def test_sell64_stencil_slices(hx, want):
     """Slices whose rows share one list of column deltas are stored without per-entry indices (structured numberings):

@@ -72,20 +72,41 @@ class ShardContext:
         want = os.environ.get("HX_NATIVE_COMM")
         self.comm = None
         self.comm_library = None
-        if (self.backend == "nccl" and want != "0") or want == "1":
-            self._create_native_comm()
+        if (self.backend == "nccl" and want != "0") or want in ("1", "try"):
+            self._create_native_comm(required=(want == "1"))
 
     # ---- native communicator
-    def _create_native_comm(self):
-        ident = [None]
+    def _create_native_comm(self, required=False):
+        """The library's own RCCL communicator (hx_comm).  Collective: the ranks agree on the outcome -- if librccl cannot be bound
+        or ncclCommInitRank fails on ANY rank, every rank drops its communicator and the exchanges go through torch.distributed
+        (same plans, driven from Python: slower, same results), with a warning; ``required`` (HX_NATIVE_COMM=1) raises instead."""
+        ident, err, h = [None], None, None
         if self.rank == 0:
-            buf = (C.c_char * _hx.COMM_ID_BYTES)()
-            _hx.check(_hx.lib.hx_comm_unique_id(buf, _hx.COMM_ID_BYTES))
-            ident = [bytes(buf.raw)]
+            try:
+                buf = (C.c_char * _hx.COMM_ID_BYTES)()
+                _hx.check(_hx.lib.hx_comm_unique_id(buf, _hx.COMM_ID_BYTES))
+                ident = [bytes(buf.raw)]
+            except Exception as e:                        # (librccl not loadable, symbol missing, ...)
+                err = e
         dist.broadcast_object_list(ident, src=0, group=self.group)
-        h = C.c_void_p()
-        _hx.require_gpu()
-        _hx.check(_hx.lib.hx_comm_create(C.byref(h), self.rank, self.world, ident[0], _hx.COMM_ID_BYTES))
+        if ident[0] is not None:
+            try:
+                _hx.require_gpu()
+                h = C.c_void_p()
+                _hx.check(_hx.lib.hx_comm_create(C.byref(h), self.rank, self.world, ident[0], _hx.COMM_ID_BYTES))
+            except Exception as e:
+                err, h = e, None
+        ok = torch.tensor([1.0 if h is not None else 0.0], device=_hx.require_gpu() if self.backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if float(ok.item()) < 1.0:
+            if h is not None:
+                _hx.lib.hx_comm_destroy(h)
+            if required:
+                raise RuntimeError("HX_NATIVE_COMM=1: the library's RCCL communicator could not be created on every rank: %r" % (err,))
+            import sys
+            print("helmholtz_x.sharded: WARNING rank %d: no library-issued RCCL communicator (%r): the exchanges go through "
+                  "torch.distributed" % (self.rank, err), file=sys.stderr)
+            return
         self.comm = h
         self.comm_library = _hx.lib.hx_comm_library().decode()
 

@@ -385,6 +385,42 @@ def test_distributed_mesh_rows_halo_and_shift(world):
     assert len(out) == world and all(out.values())
 
 
+def _fallback_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd")]
+    os.environ["HX_NATIVE_COMM"] = "try"                       # ask for the library's communicator, do not insist
+    os.environ["HX_RCCL_LIB"] = "/nonexistent/librccl.so"      # ... which cannot be bound
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from helmholtz_x.sharded import ShardContext
+        ctx = ShardContext(1000)
+        t = torch.full((3,), float(rank + 1), dtype=torch.float64)
+        ctx.all_reduce_(t)
+        out[rank] = (ctx.comm is None, t.tolist(), ctx.counters()["issued_by"])
+        os.environ["HX_NATIVE_COMM"] = "1"                     # insisting on it is an error on every rank
+        try:
+            ShardContext(1000)
+            out[("raised", rank)] = False
+        except RuntimeError:
+            out[("raised", rank)] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_missing_rccl_library_falls_back_to_torch_distributed_on_every_rank():
+    """The library-issued RCCL path is an optimisation of the transport, not a requirement: when librccl cannot be bound the ranks
+    agree (one all-reduce of a flag) to drive the exchanges through torch.distributed instead -- no rank is left with a
+    communicator the others do not have -- and HX_NATIVE_COMM=1 turns that into an error."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_fallback_worker, args=(world, port, out), nprocs=world, join=True)
+    for rank in range(world):
+        no_comm, summed, issued = out[rank]
+        assert no_comm and summed == [3.0, 3.0, 3.0] and issued.startswith("torch.distributed")
+        assert out[("raised", rank)]
+
+
 def _rccl_one_rank_worker(rank, world, port, out):
     import ctypes as C
     import sys

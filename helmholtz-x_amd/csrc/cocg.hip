@@ -40,6 +40,7 @@ int hx_amg_vcycle_buffers(hx_amg*, hx_c64**, hx_c64**);
 int hx_amg_vcycle_c64(hx_amg*, hx_stream);
 int hx_panel_dot_blocks(int64_t n, int64_t* rows_per_block);
 int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* out, hx_stream s);
+int hx_sell_spmv_z_dot(const hx_sell* h, const hx_c128* x, hx_c128* y, hx_c128* dot, hx_stream s);
 
 static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0};
 
@@ -304,6 +305,7 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     return HX_OK;
   };
   static const bool trace = getenv("HX_GMRES_TRACE") != nullptr;
+  static const int pq_env = getenv("HX_COCG_PQ_IN_PRODUCT") ? atoi(getenv("HX_COCG_PQ_IN_PRODUCT")) : 1;
 
   // ---- once per harvested set: Cd = K Ut (Ut = the complex64-rounded U), E = Cd^T Ut (bilinear) and its inverse
   if (rec && !rec->have_E) {
@@ -522,13 +524,23 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       HX_LAUNCH_CHECK("k_cocg_direction");
       first = false;
       // q = K p ;  alpha = rho / p^T q ;  x += alpha p, r -= alpha q, |r|^2
-      if ((rc = Kx(p, q, ONE, ZERO))) return rc;
-      if ((rc = fuse ? hx_zpanel_bdot_partials(n, 0, nullptr, n, q, p, part, s)
-                     : hx_zpanel_bdot(n, 0, nullptr, n, q, p, sc, part, s))) return rc;
-      if ((rc = reduce(1))) return rc;
+      // single GPU with a SELL-64 operator of up to 2 M rows: p^T q comes out of the product itself (every wave leaves the sum of
+      // its slice, one block adds the slices): no pass over p and q -- 0.388 -> 0.377 ms per inner iteration at 1 M DOF.  At 5 M
+      // DOF the product is 5 us slower for it, one block needs 77 loads per thread for the 78 k slice sums, and the pass it
+      // replaces ran out of the Infinity Cache anyway: no gain (1.4445 vs 1.4474 ms per iteration), so larger operators keep
+      // the panel dot.  HX_COCG_PQ_IN_PRODUCT=0 / 2: never / at every size.
+      const bool pq_in_product = !sharded && Ksell && (pq_env == 2 || (pq_env == 1 && n <= 2000000));
+      if (pq_in_product) {
+        if ((rc = hx_sell_spmv_z_dot(Ksell, p, q, sc + CG_OUT, s))) return rc;
+      } else {
+        if ((rc = Kx(p, q, ONE, ZERO))) return rc;
+        if ((rc = fuse ? hx_zpanel_bdot_partials(n, 0, nullptr, n, q, p, part, s)
+                       : hx_zpanel_bdot(n, 0, nullptr, n, q, p, sc, part, s))) return rc;
+        if ((rc = reduce(1))) return rc;
+      }
       hx_c128* part_r = part + PD_NB;             // |r|^2 partials of the update: behind the p^T q partials it reads
       k_cocg_update<<<nblocks, 256, 0, hx_s(s)>>>(n, (const zc*)p, (const zc*)q, (zc*)x, (zc*)r, (cc*)r32, (const zc*)sc,
-                                                  (zc*)part_r, rpb, fuse ? (const zc*)part : nullptr, nblocks);
+                                                  (zc*)part_r, rpb, fuse && !pq_in_product ? (const zc*)part : nullptr, nblocks);
       HX_LAUNCH_CHECK("k_cocg_update");
       x_zero = false;
       double r2;

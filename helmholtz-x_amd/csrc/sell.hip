@@ -51,6 +51,7 @@ struct hx_sell {
   int32_t* list_interior = nullptr;
   int32_t* list_boundary = nullptr;
   int32_t n_interior = 0, n_boundary = 0;
+  zc* dot_ws = nullptr;              // one partial sum per slice (hx_sell_spmv_z_dot; allocated on first use)
 };
 typedef __half2 ch;
 __device__ __forceinline__ zc mload(const zc* p) { return *p; }
@@ -216,7 +217,7 @@ extern "C" int hx_sell_destroy(hx_sell* h) {
   if (!h) return HX_OK;
   (void)hx_free(h->slice_ptr); (void)hx_free(h->col); (void)hx_free(h->dcol); (void)hx_free(h->wide); (void)hx_free(h->val_z); (void)hx_free(h->val_c);
   (void)hx_free(h->val_h); (void)hx_free(h->st_ptr); (void)hx_free(h->st_delta);
-  (void)hx_free(h->list_interior); (void)hx_free(h->list_boundary);
+  (void)hx_free(h->list_interior); (void)hx_free(h->list_boundary); (void)hx_free(h->dot_ws);
   delete h;
   return HX_OK;
 }
@@ -640,7 +641,7 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
        const int32_t* __restrict__ st_delta, int32_t n_cols, const MV* __restrict__ val, const V* __restrict__ x, V* y,
        const V* yin, const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev, const SellOp<V> a,
-       const int32_t* __restrict__ slice_list, int32_t xcd_chunk) {
+       const int32_t* __restrict__ slice_list, int32_t xcd_chunk, V* __restrict__ dot_out /* MODE 0: x^T y per slice, or NULL */) {
   const int lane = threadIdx.x & 63;
   // n_slices counts the waves of this launch: all slices, or the entries of slice_list (interior / boundary part)
   // xcd_chunk > 0: workgroups are dealt round-robin to the eight XCDs, so workgroup g of XCD k = blockIdx.x % 8 takes the
@@ -662,6 +663,7 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
   if (live) {
     if (MODE == 0) {
       if (!a.beta_is_zero) rb = yin[row];
+      if (dot_out) rx = x[row];                                    // (the diagonal entry gathers the same line)
     } else {
       rb = b[row];
       rx = x[row];
@@ -682,12 +684,19 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
           : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t, G>(dcol + base, vb, lane, x, width, row)
                                    : sell_row_dot<V, MV, int32_t, G>(col + base, vb, lane, x, width, row);
   if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(a.vscale, acc);
-  if (!live) return;
   if (MODE == 0) {
     V r = zmul(a.alpha, acc);
     if (!a.beta_is_zero) zfma(r, a.beta, rb);
-    y[row] = r;
-  } else {
+    if (live) y[row] = r;
+    if (dot_out) {                 // bilinear x^T y of the slice's rows: shuffle tree over the wave, one partial per slice
+      V d = live ? zmul(rx, r) : czero<V>();
+      d = zreduce_sub<HX_WAVE>(d);
+      if (lane == 0) dot_out[slice] = d;
+    }
+    return;
+  }
+  if (!live) return;
+  {
     V xn = rx;
     zfma(xn, zscale(a.omega, rd), zsub(rb, acc));
     if (a.mom != 0) xn = zadd(xn, zscale(a.mom, xprev ? zsub(rx, rp) : rx));
@@ -700,7 +709,7 @@ static int sell_grid(int32_t n_slices) { return (n_slices + 3) / 4; }   // 4 wav
 template <typename V, int MODE, typename MV>
 static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alpha, V beta, int beta_is_zero, const V* dinv,
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
-                        typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr, int part = 0) {
+                        typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr, int part = 0, V* dot_out = nullptr) {
   static const int ablate = getenv("HX_SELL_ABLATE") ? atoi(getenv("HX_SELL_ABLATE")) : 0;
   const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale, MODE == 1 || sizeof(V) == 8 ? ablate : 0};
   // x windows of the stencil slices through LDS (HX_SELL_LDS=0: gathers everywhere; =2: also for complex128 values)
@@ -722,7 +731,7 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
                    (xcd_mode < 0 ? footprint <= 288e6 : (xcd_mode & (sizeof(V) == 8 ? 1 : 2)) != 0);
   const int32_t chunk = xcd ? (sell_grid(nw) + 7) / 8 : 0;
   kern<<<xcd ? 8 * chunk : sell_grid(nw), 256, 0, hx_s(s)>>>(h->n, nw, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
-                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list, chunk);
+                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list, chunk, dot_out);
 }
 
 
@@ -814,6 +823,35 @@ int hx_sell_spmv_z_part(const hx_sell* h, int part, const hx_c128* x, hx_c128* y
 extern "C" int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
                               hx_stream s) {
   return hx_sell_spmv_z_part(h, 0, x, y, alpha, beta, s);
+}
+// y = A x and, in the same pass, *dot = x^T y (bilinear; device scalar): the p^T K p of hx_cocg without a pass over p and q.
+// Every wave leaves the sum of its slice's rows, one block adds the slices in a fixed order (deterministic).
+__global__ void __launch_bounds__(1024)
+k_slice_dot_finish(int32_t n_slices, const zc* __restrict__ partials, zc* __restrict__ out) {
+  __shared__ zc red[1024 / HX_WAVE];
+  zc v = make_double2(0.0, 0.0);
+  for (int32_t i = threadIdx.x; i < n_slices; i += 1024) v = zadd(v, partials[i]);
+  v = zreduce_sub<HX_WAVE>(v);
+  if ((threadIdx.x & (HX_WAVE - 1)) == 0) red[threadIdx.x / HX_WAVE] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    zc t = red[0];
+    for (int w = 1; w < 1024 / HX_WAVE; ++w) t = zadd(t, red[w]);
+    out[0] = t;
+  }
+}
+int hx_sell_spmv_z_dot(const hx_sell* h, const hx_c128* x, hx_c128* y, hx_c128* dot, hx_stream s) {
+  HX_REQUIRE(h && h->val_z && x && y && dot && x != y, "bad argument");
+  hx_sell* m = const_cast<hx_sell*>(h);
+  if (!m->dot_ws) HX_HIP(hx_malloc((void**)&m->dot_ws, sizeof(zc) * (size_t)h->n_slices));
+  part_begin(0, h, 0, s);           // (in-situ timing of the operator product: this launch is one)
+  launch_sell<zc, 0, zc>(h, h->val_z, (const zc*)x, (zc*)y, make_double2(1.0, 0.0), make_double2(0.0, 0.0), 1, nullptr, nullptr,
+                         nullptr, 0.0, 0.0, 1.0, s, nullptr, 0, m->dot_ws);
+  part_end(0, 0, s);
+  HX_LAUNCH_CHECK("k_sell<c128,spmv+dot>");
+  k_slice_dot_finish<<<1, 1024, 0, hx_s(s)>>>(h->n_slices, m->dot_ws, (zc*)dot);
+  HX_LAUNCH_CHECK("k_slice_dot_finish");
+  return HX_OK;
 }
 int hx_sell_residual_c64_part(const hx_sell* h, int part, const hx_c64* x, const hx_c64* b, hx_c64* r, hx_stream s) {
   HX_REQUIRE(h && (h->val_c || h->val_h) && x && b && r && part >= 0 && part <= 2, "bad argument");

@@ -48,6 +48,7 @@ enum hx_status {
  *   HX_SELL_STENCIL=0 / HX_SELL_INDEX=i32 / HX_SELL_LDS=0|2   SELL-64 format and kernel variants (hx_sell_create, k_sell)
  *   HX_POOL=0, HX_POOL_MAX_GIB, HX_POOL_MIN_BYTES                 device-buffer pool off / cap of the cached bytes / smallest pooled block
  *   HX_SELL_XCD=0|3, HX_SELL_ABLATE                            XCD-contiguous slice schedule never / always (default: by footprint); timing-only ablations
+ *   HX_COCG_PQ_IN_PRODUCT=0|2                                 hx_cocg: p^T K p from the SELL-64 product itself never / at every size (default: up to 2 M rows)
  *   HX_COCG_LAG=0                                             hx_cocg: wait for every residual norm (default: read one iteration late while far from the tolerance)
  *   HX_COCG_FUSE_REDUCTIONS=0                                  hx_cocg (read per solve): two-stage reductions on one GPU too
  *   HX_CHEB_LO, HX_CHEB_KIND, HX_AMG_COARSE_EXTRA             Chebyshev bounds / kind, extra coarse smoothing steps

@@ -6,7 +6,7 @@
 // machine and many times that on a loaded one (hipFree also synchronises the device); the hierarchy set-up was measured between
 // 0.16 and 0.47 s for the same 5 M-DOF problem from process to process.  Blocks of HX_POOL_MIN_BYTES or more are therefore kept
 // on release and handed out again to the next request of EXACTLY the same size (the next call asks for the same sizes), up to
-// HX_POOL_MAX_GIB of cached memory (least recently released blocks go first); an allocation the driver refuses empties the
+// HX_POOL_MAX_GIB of cached memory (default: a quarter of the device's memory; least recently released blocks go first); an allocation the driver refuses empties the
 // cache and is tried once more.  Reuse is ordered like torch's caching allocator orders it: by the stream -- all libhx work of a
 // process runs on the caller's current stream, and handles are destroyed after their last solve has been read by the host.
 // HX_POOL=0 passes everything through.  hx_pool_trim() returns the cached blocks to the driver; hx_pool_stats() reports.
@@ -38,6 +38,11 @@ struct Pool {
     if (const char* e = getenv("HX_POOL")) on = atoi(e) != 0;
     if (const char* e = getenv("HX_POOL_MIN_BYTES")) min_bytes = (size_t)atoll(e);
     if (const char* e = getenv("HX_POOL_MAX_GIB")) max_cached = (size_t)(atof(e) * (double)((size_t)1 << 30));
+    else {                                                         // default: a quarter of the device's memory (72 GiB of 288)
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) max_cached = total_b / 4;
+      else (void)hipGetLastError();
+    }
   }
   void drop(std::list<Free>::iterator it) {                       // (lock held) cached block -> driver
     auto range = by_size.equal_range(it->bytes);

@@ -60,7 +60,7 @@ enum hx_status {
  * of the set-up passes) are kept and handed to the next request of exactly the same size -- every fixed-point call of a driver
  * builds the same objects again (the reference: E.destroy() and a new EPS per iteration, eigensolvers.py:161) -- instead of
  * going through hipFree / hipMalloc, whose cost varies from milliseconds to tenths of a second with the load of the machine.
- * HX_POOL=0 switches it off, HX_POOL_MAX_GIB caps the cached bytes (default 32), HX_POOL_MIN_BYTES the smallest pooled block.
+ * HX_POOL=0 switches it off, HX_POOL_MAX_GIB caps the cached bytes (default: a quarter of the device's memory), HX_POOL_MIN_BYTES the smallest pooled block.
  * hx_pool_trim returns every cached block to the driver; hx_pool_stats: requests, requests served from the cache, calls that went to
  * the driver and the seconds spent in them, bytes cached now (reset != 0 clears the counters). */
 int hx_pool_trim(void);

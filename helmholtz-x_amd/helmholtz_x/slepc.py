@@ -251,22 +251,27 @@ class WoodburySolver:
                 W_cache[key] = (self.W, self.VtW)
         # M^-1 = K^-1 - W (I + diag(c) V^T W)^-1 diag(c) V^T K^-1
         self.small = np.linalg.inv(np.eye(self.r) + self.coefs[:, None] * self.VtW) * self.coefs[None, :]
+        self.small_dev = to_device(np.ascontiguousarray(self.small))      # r x r: applied on the device, no host round trip per solve
 
-    def _vt(self, y):
-        """t_f = v_f^T y (bilinear, no conjugate) for all rank-1 pieces; returns a host array."""
+    def _vt_dev(self, y):
+        """t_f = v_f^T y (bilinear, no conjugate) for all rank-1 pieces, left in ``self.t_dev`` (summed over the ranks)."""
         _hx.check(_hx.lib.hx_zsparse_dots(self.r, _hx.ptr(self.v_ptr), _hx.ptr(self.v_idx), _hx.ptr(self.v_val),
                                           _hx.ptr(y), _hx.ptr(self.t_dev), _hx.stream()))
         if self.shard is not None:
             self.shard.all_reduce_(self.t_dev)
-        return self.t_dev.cpu().numpy().copy()
+        return self.t_dev
+
+    def _vt(self, y):
+        """The same as a host array (set-up: the r x r matrix V^T W)."""
+        return self._vt_dev(y).cpu().numpy().copy()
 
     def solve(self, b, x, relax=1.0):
         self.inner.solve(b, x, relax=relax)
         if not self.active:
             return
-        t = self._vt(x)
-        s = self.small @ t                                   # r x r host solve (tiny)
-        h = to_device(s)
+        # x -= W [(I + diag(c) V^T W)^-1 diag(c)] V^T x: the r sparse dots, the r x r product and the panel update stay on the
+        # device (was: dots -> host, numpy product, coefficients -> device: two synchronising copies per operator application)
+        h = torch.mv(self.small_dev, self._vt_dev(x))
         _hx.check(_hx.lib.hx_zpanel_sub(self.n, self.r, _hx.ptr(self.W), self.W.stride(0), _hx.ptr(h), _hx.ptr(x),
                                         _hx.stream()))
 

@@ -183,6 +183,17 @@ class WoodburySolver:
         dev = inner.tmp.device if hasattr(inner, "tmp") else _hx.require_gpu()
         # stack all rank-1 pieces: U (r x n dense rows), V packed sparse, coefficient per piece
         self.coefs = np.concatenate([np.full(lr.rank, c, dtype=np.complex128) for c, lr in terms])
+        key = None
+        if W_cache is not None:
+            key = (id(inner), tuple(id(lr) for _, lr in terms))
+        if key is not None and key in W_cache:
+            # the solves of one fixed-point call differ in the coefficients only (FTF(omega_k)): W = K^-1 U, V^T W and the packed
+            # right factors are built once (the dense rows of U alone are 16 x n x 16 bytes: 1.3 GB of traffic at 5 M DOF)
+            self.W, self.VtW, self.v_ptr, self.v_idx, self.v_val, self.t_dev = W_cache[key]
+            self.r = self.W.shape[0]
+            self.small = np.linalg.inv(np.eye(self.r) + self.coefs[:, None] * self.VtW) * self.coefs[None, :]
+            self.small_dev = to_device(np.ascontiguousarray(self.small))
+            return
         # row-sharded: factors assembled on a distributed mesh hold this rank's owned entries already (lr.local); factors
         # given on the global numbering are cut to the owned rows here
         U = torch.cat([lr.left_dense() if (shard is None or lr.local) else shard.own_slice(lr.left_dense()).contiguous()
@@ -202,53 +213,47 @@ class WoodburySolver:
         self.v_idx = to_device(np.concatenate(idxs).astype(np.int32) if off else np.zeros(1, np.int32))
         self.v_val = to_device(np.concatenate(vals).astype(np.complex128) if off else np.zeros(1, np.complex128))
         self.t_dev = torch.empty(self.r, dtype=torch.complex128, device=dev)
-        key = None
-        if W_cache is not None:
-            key = (id(inner), tuple(id(lr) for _, lr in terms))
-        if key is not None and key in W_cache:
-            self.W, self.VtW = W_cache[key]
-        else:
-            self.W = torch.empty_like(U)                         # rows: K^-1 u_f
-            # identical flames on a periodically numbered mesh: u_f is u_0 translated by s_f rows.  The translated solution
-            # of flame 0 is then the initial guess for flame f -- exact when K has the same periodicity (an annular
-            # combustor with identical burners), in which case the solve ends at its first residual check; a guess
-            # that is no good is dropped by the solver.  COCG route.  Row-sharded: the supports are compared on the GLOBAL
-            # numbering (gathered: a few hundred entries per flame) and the translate is a global cyclic shift of the
-            # row-sharded vector (segments travel point-to-point between the ranks that own source and destination).
-            shifts = None
-            if getattr(inner, "supports_x0", False) and self.r > 1 and W_WARM:
-                lefts = [u for _, lr in terms for (u, _) in lr.pairs]
-                if shard is None:
-                    shifts = translation_shifts(lefts, self.n)
-                else:
-                    if any(lr.local for _, lr in terms):
-                        import torch.distributed as dist
-                        mine = [(ui.astype(np.int64) + shard.r0, uv) for (ui, uv) in lefts]
-                        parts = [None] * shard.world
-                        dist.all_gather_object(parts, mine, group=shard.group)
-                        lefts = []
-                        for f in range(len(mine)):
-                            idx = np.concatenate([parts[p][f][0] for p in range(shard.world)])
-                            val = np.concatenate([parts[p][f][1] for p in range(shard.world)])
-                            order = np.argsort(idx, kind="stable")
-                            lefts.append((idx[order], val[order]))
-                    shifts = translation_shifts(lefts, shard.n_global)
-            self.warm_started = 0
-            for f in range(self.r):
-                # W only enters through the rank-r correction, whose weight in the eigenvalue is the flame's (a few
-                # per cent): a looser tolerance (W_RELAX) leaves the eigenvalues unchanged far below the parity bar
-                if shifts is not None and f > 0:
-                    self.W[f].copy_(torch.roll(self.W[0], shifts[f]) if shard is None
-                                    else shard.cyclic_shift(self.W[0], shifts[f]))
-                    inner.solve(U[f], self.W[f], relax=W_RELAX, x0=True)
-                    self.warm_started += 1
-                else:
-                    inner.solve(U[f], self.W[f], relax=W_RELAX)
-            self.VtW = np.empty((self.r, self.r), dtype=np.complex128)
-            for f in range(self.r):
-                self.VtW[:, f] = self._vt(self.W[f])
-            if key is not None:
-                W_cache[key] = (self.W, self.VtW)
+        self.W = torch.empty_like(U)                         # rows: K^-1 u_f
+        # identical flames on a periodically numbered mesh: u_f is u_0 translated by s_f rows.  The translated solution
+        # of flame 0 is then the initial guess for flame f -- exact when K has the same periodicity (an annular
+        # combustor with identical burners), in which case the solve ends at its first residual check; a guess
+        # that is no good is dropped by the solver.  COCG route.  Row-sharded: the supports are compared on the GLOBAL
+        # numbering (gathered: a few hundred entries per flame) and the translate is a global cyclic shift of the
+        # row-sharded vector (segments travel point-to-point between the ranks that own source and destination).
+        shifts = None
+        if getattr(inner, "supports_x0", False) and self.r > 1 and W_WARM:
+            lefts = [u for _, lr in terms for (u, _) in lr.pairs]
+            if shard is None:
+                shifts = translation_shifts(lefts, self.n)
+            else:
+                if any(lr.local for _, lr in terms):
+                    import torch.distributed as dist
+                    mine = [(ui.astype(np.int64) + shard.r0, uv) for (ui, uv) in lefts]
+                    parts = [None] * shard.world
+                    dist.all_gather_object(parts, mine, group=shard.group)
+                    lefts = []
+                    for f in range(len(mine)):
+                        idx = np.concatenate([parts[p][f][0] for p in range(shard.world)])
+                        val = np.concatenate([parts[p][f][1] for p in range(shard.world)])
+                        order = np.argsort(idx, kind="stable")
+                        lefts.append((idx[order], val[order]))
+                shifts = translation_shifts(lefts, shard.n_global)
+        self.warm_started = 0
+        for f in range(self.r):
+            # W only enters through the rank-r correction, whose weight in the eigenvalue is the flame's (a few
+            # per cent): a looser tolerance (W_RELAX) leaves the eigenvalues unchanged far below the parity bar
+            if shifts is not None and f > 0:
+                self.W[f].copy_(torch.roll(self.W[0], shifts[f]) if shard is None
+                                else shard.cyclic_shift(self.W[0], shifts[f]))
+                inner.solve(U[f], self.W[f], relax=W_RELAX, x0=True)
+                self.warm_started += 1
+            else:
+                inner.solve(U[f], self.W[f], relax=W_RELAX)
+        self.VtW = np.empty((self.r, self.r), dtype=np.complex128)
+        for f in range(self.r):
+            self.VtW[:, f] = self._vt(self.W[f])
+        if key is not None:
+            W_cache[key] = (self.W, self.VtW, self.v_ptr, self.v_idx, self.v_val, self.t_dev)
         # M^-1 = K^-1 - W (I + diag(c) V^T W)^-1 diag(c) V^T K^-1
         self.small = np.linalg.inv(np.eye(self.r) + self.coefs[:, None] * self.VtW) * self.coefs[None, :]
         self.small_dev = to_device(np.ascontiguousarray(self.small))      # r x r: applied on the device, no host round trip per solve

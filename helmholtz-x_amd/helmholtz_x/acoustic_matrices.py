@@ -73,8 +73,8 @@ class AcousticMatrices:
 
         info("- Passive matrices are assembling..")
         bc_dofs = np.unique(np.concatenate(self.bcs_Dirichlet)) if self.bcs_Dirichlet else None
-        if bc_dofs is not None and getattr(mesh, "part", None) is not None:
-            raise NotImplementedError("Dirichlet rows on a distributed mesh (no reference example uses them)")
+        # (distributed mesh: every rank sees the same boundary-condition dictionary, so bc_dofs is a list -- possibly empty, for a
+        # part that does not touch the boundary -- on all of them or on none: the flag exchange of apply_dirichlet is collective)
 
         c_dev = asm._field(self.c) if hasattr(asm, "_field") and degree == 1 else self.c    # one upload for A, C and B
         self._A, self._C = asm.stiffness_mass(c_dev)

@@ -446,11 +446,24 @@ class P1Assembler:
                 Mat.from_csr(self._csr(C_val)) if want_C else None)
 
     def apply_dirichlet(self, mat, dofs, diag=1.0):
-        flags = np.zeros(self.n, dtype=np.uint8)
-        flags[np.asarray(dofs, dtype=np.int64)] = 1
-        d_flags = to_device(flags)
+        """DOLFINx ``assemble_matrix(bcs=...)``: rows and columns of the listed dofs zeroed, ``diag`` on their diagonal.
+        Distributed mesh (``mesh.part``): the operator holds this rank's rows over [owned | ghost] columns; an owned
+        Dirichlet vertex is always known here (every tagged facet with an owned vertex is local), a ghost one may lie on
+        facets this rank does not hold -- its flag comes from its owner by one halo exchange (PETSc: the ghost update
+        ``MatZeroRowsColumns`` does for the reference)."""
         csr = mat.csr_part()
-        _hx.check(_hx.lib.hx_csr_apply_dirichlet(self.n, _hx.ptr(csr.rowptr), _hx.ptr(csr.col), _hx.ptr(csr.val),
+        n_rows, n_cols = csr.shape
+        flags = np.zeros(n_cols, dtype=np.uint8)
+        flags[np.asarray(dofs, dtype=np.int64)] = 1
+        part = getattr(self.mesh, "part", None)
+        if part is not None:
+            f = torch.zeros(n_cols, dtype=torch.int32, device=csr.val.device)
+            f[:part["n_own"]] = to_device(flags[:part["n_own"]].astype(np.int32))
+            self.mesh.shard.halo(f)
+            d_flags = f.to(torch.uint8)
+        else:
+            d_flags = to_device(flags)
+        _hx.check(_hx.lib.hx_csr_apply_dirichlet(n_rows, _hx.ptr(csr.rowptr), _hx.ptr(csr.col), _hx.ptr(csr.val),
                                                  _hx.ptr(d_flags), float(diag), _hx.stream()))
 
     def robin(self, facet_ids, coef_per_facet, c):

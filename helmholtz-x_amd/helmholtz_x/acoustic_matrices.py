@@ -47,9 +47,10 @@ class AcousticMatrices:
             if 'Neumann' in spec:
                 info("- Neumann boundaries on boundary " + str(boundary))
             if 'Dirichlet' in spec:
-                if degree != 1:
-                    raise NotImplementedError("Dirichlet rows are provided for degree 1 (no reference example uses them)")
-                self.bcs_Dirichlet.append(np.unique(mesh.facets[facets]))
+                if degree == 1:
+                    self.bcs_Dirichlet.append(np.unique(mesh.facets[facets]))
+                else:                      # quadratic space: the vertices and the edge midpoints of the boundary facets
+                    self.bcs_Dirichlet.append(np.unique(asm.facet_dofs(mesh.facets[facets])))
                 info("- Dirichlet boundary on boundary " + str(boundary))
             R = None
             if 'Robin' in spec:

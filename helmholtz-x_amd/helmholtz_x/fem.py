@@ -630,6 +630,15 @@ class P2Assembler:
         return (Mat.from_csr(self._csr(A_val)) if want_A else None,
                 Mat.from_csr(self._csr(C_val)) if want_C else None)
 
+    def apply_dirichlet(self, mat, dofs, diag=1.0):
+        """DOLFINx ``assemble_matrix(bcs=...)`` for the quadratic space: rows and columns of the listed dofs (vertices and edge
+        midpoints of the boundary facets: ``facet_dofs``) zeroed, ``diag`` on their diagonal."""
+        csr = mat.csr_part()
+        flags = np.zeros(self.n, dtype=np.uint8)
+        flags[np.asarray(dofs, dtype=np.int64)] = 1
+        _hx.check(_hx.lib.hx_csr_apply_dirichlet(self.n, _hx.ptr(csr.rowptr), _hx.ptr(csr.col), _hx.ptr(csr.val),
+                                                 _hx.ptr(to_device(flags)), float(diag), _hx.stream()))
+
     def facet_dofs(self, facets):
         """(nf, 6) global P2 dofs of boundary triangles: 3 vertices + the edges in TRI_EDGES order."""
         nv = self.mesh.num_vertices

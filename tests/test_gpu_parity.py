@@ -1334,6 +1334,13 @@ def test_p2_operators_match_oracle(golden_dir):
     ori, orv = fem.threshold_pack(fem_p2.distributed_right(x, cells, cd, n, rho.x.array, w.x.array), 1e-5)
     assert np.array_equal(li, oli) and _rel(lv, olv) < 1e-12
     assert np.array_equal(ri, ori) and _rel(rv, orv) < 1e-11
+    # Dirichlet boundary in the quadratic space (DOLFINx zeroes the rows and columns of the boundary's vertex AND edge dofs,
+    # unit diagonal: acoustic_matrices.py:43-50,101-103,121-123) against oracle.fem.apply_dirichlet on the oracle's P2 operators
+    Md = AcousticMatrices(mesh, facet_tags, {1: {'Neumann'}, 2: {'Dirichlet'}, 3: {'Robin': F.R_in}}, T, degree=2)
+    bc = np.unique(fem_p2.facet_dofs(nv, edges, mesh.facets[facet_tags.find(2)]))
+    assert bc.size > np.unique(mesh.facets[facet_tags.find(2)]).size           # edge dofs are among them
+    _csr_equal(Md.A, fem.apply_dirichlet(A.copy(), bc))
+    _csr_equal(Md.C, fem.apply_dirichlet(C.copy(), bc))
 
 
 def test_rijkeffd_degree2_fixed_point(ref_logs, golden_dir):

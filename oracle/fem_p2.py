@@ -12,7 +12,12 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates what DOLFINx/FFCx g
 
 All polynomial integrands are integrated exactly by a collapsed Gauss-Legendre rule (4 points per direction: exact to
 degree 5 on the simplex); the non-polynomial one with the same rule.  FFCx would use basix's degree-3 Xiao-Gimbutas
-rule there; the rule matters at the 1e-10 level only (measured for the degree-1 case: DESIGN.md section 8).
+rule there; the rule matters at the 1e-10 level only.
+
+PINNED to the reference (tests/test_oracle_goldens.py::test_rijkeffd_degree2_eigenpair_and_36_shape_derivatives_reference_goldens):
+on the mesh of the reference's own degree-2 run (recovered from Results/ShapeDerivatives/p_dir.h5) this module reproduces
+the stored 16-digit eigenvalue 1156.7431442242196+0.8682828502864666j to 1.6e-10, the logged trajectory and the vertex samples
+of the stored P2 modes to 1e-8.
 
 DOF numbering: the mesh vertices first (P1 numbering), then one DOF per edge, edges sorted lexicographically by their
 (low, high) vertex pair.  DOLFINx numbers differently; eigenvalues do not depend on it.

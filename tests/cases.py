@@ -182,3 +182,25 @@ class FlamedDuct:
     M1 = 1.1408306741423997e-2
     target_passive = 262 * 2 * np.pi
     target_active = 250 * 2 * np.pi
+
+
+def rijkeffd_shape_case(golden_dir):
+    """The mesh of the reference's degree-2 shape-derivative run (ShapeSensitivities/RijkeFFD/main_shape.py), recovered from
+    its result files (tests/golden/make_rijkeffd_shape_fixture.py), with the facet tags gmsh's ``occ.addCylinder`` gives its
+    three faces rebuilt by geometry: 1 = lateral surface (Neumann), 2 / 3 = the two end discs (both Robin with the SAME
+    reflection coefficient, params.py:27-28, so which disc is which does not matter).
+    Returns (x, cells, boundary facets (nf, 3), their cells, facet tags (nf,), goldens dict, npz with p_dir / p_adj)."""
+    import json
+    import os
+    from oracle import meshes
+    d = np.load(os.path.join(golden_dir, "rijkeffd_shape", "mesh_and_modes.npz"))
+    with open(os.path.join(golden_dir, "rijkeffd_shape", "goldens.json")) as fh:
+        g = json.load(fh)
+    x, cells = d["x"], d["cells"].astype(np.int32)
+    facets, fcell = meshes.boundary_facets(cells)
+    assert cells.shape[0] == g["cells"] and facets.shape[0] == g["facets"]          # results.log:1-2
+    z = x[facets][:, :, 2]
+    tags = np.full(facets.shape[0], 1, dtype=np.int32)
+    tags[(z == 1.0).all(axis=1)] = 2
+    tags[(z == 0.0).all(axis=1)] = 3
+    return x, cells, facets, fcell, tags, g, d

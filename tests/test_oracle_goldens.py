@@ -528,3 +528,69 @@ def test_shape_derivative_functional_patch(degree):
         got = shape.boundary_functional(x, mesh.topology.cells, mesh.facets[fids], mesh.facet_cells[fids], V1, x @ a + 0j, x @ b + 3.0,
                                         np.full(x.shape[0], 340.0 + 0j))
         assert abs(got - 340.0 ** 2 * np.dot(a, b)) < 1e-9 * abs(got)
+
+
+def test_rijkeffd_degree2_eigenpair_and_36_shape_derivatives_reference_goldens(golden_dir):
+    """ShapeSensitivities/RijkeFFD/main_shape.py, the reference's degree-2 + shape-derivative run, on the mesh of THAT run
+    (recovered from Results/ShapeDerivatives/p_dir.h5: 6,078 vertices / 25,246 cells, results.log:2).  Pins oracle/fem_p2.py
+    and oracle/shape.py to the reference's own numbers:
+      * direct eigenvalue 1156.7431442242196+0.8682828502864666j (eigenvalues.txt, 16 digits) to 1e-8 -- measured 1.6e-10,
+        the size of the quadrature difference in the non-polynomial flame form -- and the logged trajectory to 8 decimals;
+      * the vertex samples of the normalised P2 modes p_dir.h5 / p_adj.h5 to 1e-7 of the peak value;
+      * all 36 entries of ShapeDerivatives/normalized.txt (FFD lattice 2 x 4 x 9, outer ring of control points) to 1e-7:
+        normalize_adjoint with PETSc's conjugating dot, the boundary functional with P2 modes and the P1 sound speed
+        20.05 sqrt(T) of main_shape.py:71, the cylindrical lattice from the mesh nodes, radial surface normals."""
+    from cases import rijkeffd_shape_case
+    from oracle import fem_p2, shape
+    F = RijkeFFD
+    x, cells, facets, fcell, tags, g, d = rijkeffd_shape_case(golden_dir)
+    nv = x.shape[0]
+    cd, edges = fem_p2.p2_dofmap(nv, cells)
+    n = nv + len(edges)
+    T = fem.step_field(x, 3, F.x_f, F.T_in, F.T_out)
+    c = fem.sound_speed_variable_gamma(T)
+    A, C = fem_p2.assemble_A_C(x, cells, cd, n, c)
+    terms = [(facets[tags == t], fem_p2.facet_dofs(nv, edges, facets[tags == t]), fem.robin_Z(F.R_in), c) for t in (2, 3)]
+    B = fem_p2.assemble_B(x, n, terms)
+    h = fem.gaussian_function(x, cells, F.x_f, F.a_f)
+    w = fem.gaussian_function(x, cells, F.x_r, F.a_r)
+    rho = fem.density_step(x[:, 2], F.x_f[0][2], F.a_f, F.rho_d, F.rho_u)
+    a = fem_p2.distributed_left(x, cells, cd, n, F.gamma, h, F.q_0, F.u_b)
+    b = fem_p2.distributed_right(x, cells, cd, n, rho, w)
+    for v in (a, b):
+        v.real[np.abs(v.real) < 1e-5] = 0.0
+        v.imag[np.abs(v.imag) < 1e-5] = 0.0
+    ftf = eigen.NTau(F.n, F.tau)
+    E, hist = eigen.fixed_point_iteration_factored(A, B, C, eigen.FactoredFlame(a, b, ftf), F.target, nev=2, i=0)
+    gold = complex(*g["direct"])
+    omega = E.eigs[0]
+    assert abs(omega - gold) / abs(gold) < 1e-8, (omega, gold)
+    assert len(hist) - 1 == len(g["trajectory_direct"])
+    for zk, ref in zip(hist[1:], g["trajectory_direct"]):
+        assert abs(zk - complex(*ref)) < 2e-7, (zk, ref)              # (the flame form's quadrature rule: 1.8e-7 in Im)
+    p = eigen.normalize_eigenvector(E.vecs[:, 0], C)
+    assert sign_free_error(p[:nv], d["p_dir"]) < 1e-7
+    # adjoint problem: B^H, b a^T, conj(FTF(conj w)) (flame_matrices.py:96-115) -- same update rule
+    adj_ftf = lambda om: np.conj(ftf(np.conj(om)))                     # noqa: E731
+    Ea, _ = eigen.fixed_point_iteration_factored(A, B.conj().T.tocsr(), C, eigen.FactoredFlame(b, a, adj_ftf), F.target,
+                                                 nev=2, i=0)
+    gold_adj = complex(*g["adjoint"])
+    assert abs(Ea.eigs[0] - gold_adj) / abs(gold_adj) < 1e-8
+    pa = eigen.normalize_eigenvector(Ea.vecs[:, 0], C)
+    assert sign_free_error(pa[:nv], d["p_adj"]) < 1e-7
+    # shape derivatives (shape_derivatives.py:12-37)
+    q = np.conj(shape.normalize_adjoint(omega, p, pa, B, C, a, b, ftf.derivative))
+    lat = tags == 1
+    c_shape = 20.05 * np.sqrt(T)                                       # main_shape.py:71 sound_speed(T), NOT the operators' c
+    NW = shape.boundary_functional_weights(x, cells, facets[lat], fcell[lat], p, q, c_shape, degree=2, cell_dofs=cd)
+    l, m, nz = g["lattice_lmn"]
+    L = shape.CylindricalLattice(x, l, m, nz)
+    sv = np.unique(facets[lat])
+    der = np.array([[shape.boundary_functional(x, cells, facets[lat], fcell[lat],
+                                               shape.ffd_displacement_cylinder(x, sv, L, l - 1, j, k), p, q, c_shape, weights=NW)
+                     for j in range(m)] for k in range(nz)])
+    got = shape.nonaxisymmetric_normalize(der)
+    ref = np.array(g["normalized"])
+    ref = ref[..., 0] + 1j * ref[..., 1]
+    assert got.shape == ref.shape == (9, 4)
+    assert np.abs(got - ref).max() < 1e-7, np.abs(got - ref).max()

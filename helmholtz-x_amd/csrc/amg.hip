@@ -71,20 +71,23 @@ static int halo_level(hx_amg* h, int l, void* v, int elem_bytes, hx_stream s) {
 }
 
 // A product with the level's operator whose operand needs its ghost block: exchange first, then the whole product -- or, when
-// the split callbacks are set and the level's SELL-64 operator carries slice lists, start the exchange, run the INTERIOR slices
-// (they read no ghost column) while it travels, wait, run the boundary slices.  apply(part): 0 all, 1 interior, 2 boundary.
+// the split callbacks are set and the level's SELL-64 operator carries slice lists, start the exchange (on s), run the INTERIOR
+// slices (they read no ghost column) on the side stream the exchange hands out while it travels, join, run the boundary slices
+// on s.  apply(part, stream): part 0 all, 1 interior, 2 boundary.
 template <typename LT, typename F>
 static int with_halo(hx_amg* h, const LT& L, int l, void* v, int elem_bytes, hx_stream s, F&& apply) {
-  if (!h->sharded || l >= h->n_sharded) return apply(0);
+  if (!h->sharded || l >= h->n_sharded) return apply(0, s);
   int rc;
   if (h->halo_begin && h->halo_end && L.sell && hx_sell_has_parts(L.sell)) {
-    if (h->halo_begin(h->ctx, l, v, elem_bytes, s) != 0) return hx_fail(HX_ERR_COMM, __func__, "halo exchange (begin) failed");
-    if ((rc = apply(1))) return rc;
-    if (h->halo_end(h->ctx, l, s) != 0) return hx_fail(HX_ERR_COMM, __func__, "halo exchange (end) failed");
-    return apply(2);
+    hx_stream side = nullptr;
+    if (h->halo_begin(h->ctx, l, v, elem_bytes, s, &side) != 0) return hx_fail(HX_ERR_COMM, __func__, "halo exchange (begin) failed");
+    rc = apply(1, side);
+    if (h->halo_end(h->ctx, l, s) != 0) return hx_fail(HX_ERR_COMM, __func__, "halo exchange (end) failed");   // (joins the side stream also after an error)
+    if (rc) return rc;
+    return apply(2, s);
   }
   if ((rc = halo_level(h, l, v, elem_bytes, s))) return rc;
-  return apply(0);
+  return apply(0, s);
 }
 
 // ---- per-precision kernel dispatch
@@ -163,7 +166,7 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
   if (h->vexec) (void)hipGraphExecDestroy(h->vexec);
   if (h->ev_in) (void)hipEventDestroy(h->ev_in);
   if (h->ev_out) (void)hipEventDestroy(h->ev_out);
-  if (h->gstream) (void)hipStreamDestroy(h->gstream);
+  if (h->gstream) { (void)hipStreamSynchronize(h->gstream); hx_pool_register_stream(h->gstream, false); (void)hipStreamDestroy(h->gstream); }
   if (h->cg_pin) (void)hipHostFree(h->cg_pin);
   for (hipEvent_t e : h->cg_ev) if (e) (void)hipEventDestroy(e);
   delete h;
@@ -250,7 +253,11 @@ static int resize_ext(HierT<T>& H, int n_sharded, const int32_t* n_ext) {
     HX_HIP(hx_malloc((void**)&L.x2, bytes));
     HX_HIP(hx_malloc((void**)&L.x3, bytes));
     HX_HIP(hx_malloc((void**)&L.r, bytes));
-    HX_HIP(hipMemset(L.x, 0, bytes)); HX_HIP(hipMemset(L.x2, 0, bytes)); HX_HIP(hipMemset(L.x3, 0, bytes)); HX_HIP(hipMemset(L.r, 0, bytes));
+    // (blocks from the pool are idle when handed out; the fills run on the null stream and are awaited here, so that kernels of a
+    // non-blocking caller stream cannot overtake them)
+    HX_HIP(hipMemsetAsync(L.x, 0, bytes, nullptr)); HX_HIP(hipMemsetAsync(L.x2, 0, bytes, nullptr));
+    HX_HIP(hipMemsetAsync(L.x3, 0, bytes, nullptr)); HX_HIP(hipMemsetAsync(L.r, 0, bytes, nullptr));
+    HX_HIP(hipStreamSynchronize(nullptr));
     L.n_ext = n_ext[l];
   }
   return HX_OK;
@@ -280,7 +287,7 @@ extern "C" int hx_amg_set_prolongator_ghost_rows(hx_amg* h, int n_levels) {
   return HX_OK;
 }
 
-extern "C" int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_fn begin, hx_halo_end_fn end) {
+extern "C" int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_begin_fn begin, hx_halo_end_fn end) {
   HX_REQUIRE(h && ((begin && end) || (!begin && !end)), "both callbacks or none");
   h->halo_begin = begin; h->halo_end = end;
   return HX_OK;
@@ -370,13 +377,13 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
     for (int k = 1; k < n_pre; ++k) {
       T* nxt = other(cur, prev);
       // (for k = 1 the previous iterate of the Chebyshev recurrence is the zero start vector: prev == nullptr)
-      if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part) {
-            return cheb ? op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], s, part)
-                        : op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, s, part); }))) return rc;
+      if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part, hx_stream st) {
+            return cheb ? op_smooth(L, b, cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3], st, part)
+                        : op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, st, part); }))) return rc;
       prev = cur; cur = nxt;
     }
     // residual r = b - K x, restrict
-    if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part) { return op_residual(L, cur, b, L.r, s, part); }))) return rc;
+    if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part, hx_stream st) { return op_residual(L, cur, b, L.r, st, part); }))) return rc;
     if ((rc = restrict_from(L.r))) return rc;
   }
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
@@ -389,10 +396,10 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   const bool ghosts_current = sh && L.p_ghost_rows && n_pre > 0;
   for (int k = 0; k < n_post; ++k) {
     T* dst = (k == n_post - 1) ? xout : other(cur, prev);
-    auto step = [&](int part) {
-      return cheb ? op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, s, part)
-                  : op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, s, part); };
-    if ((rc = (k == 0 && ghosts_current) ? step(0) : with_halo(h, L, l, cur, EB, s, step))) return rc;
+    auto step = [&](int part, hx_stream st) {
+      return cheb ? op_smooth(L, b, cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0, st, part)
+                  : op_smooth(L, b, cur, dst, h->omega, nullptr, 0.0, st, part); };
+    if ((rc = (k == 0 && ghosts_current) ? step(0, s) : with_halo(h, L, l, cur, EB, s, step))) return rc;
     prev = cur; cur = dst;
   }
   if (n_post == 0)
@@ -426,7 +433,9 @@ int hx_amg_vcycle_c64(hx_amg* h, hx_stream s) {
   // on level 0 the residual buffer L0.r is consumed by the restriction before the last post-sweep writes it
   if (h->graph_state == 0 && !h->sharded) {                      // capture the cycle once (its buffers never change)
     bool ok = true;
-    if (!h->gstream) ok = hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess &&
+    if (!h->gstream && (ok = hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess))
+      hx_pool_register_stream(h->gstream, true);
+    if (ok && !h->ev_in) ok =
                           hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
                           hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
     hipGraph_t g = nullptr;
@@ -497,10 +506,11 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
     if (sharded) {   // stage the owned block, exchange the ghost block, multiply the local rows
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
       if (Ksell && M->halo_begin && M->halo_end && hx_sell_has_parts(Ksell)) {      // interior slices while the ghost entries travel
-        int rcx;
-        if (M->halo_begin(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange (begin) failed");
-        if ((rcx = hx_sell_spmv_z_part(Ksell, 1, xe, out, a, bt, s))) return rcx;
+        hx_stream side = nullptr;
+        if (M->halo_begin(M->ctx, 0, xe, 16, s, &side) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange (begin) failed");
+        const int rcx = hx_sell_spmv_z_part(Ksell, 1, xe, out, a, bt, side);
         if (M->halo_end(M->ctx, 0, s) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange (end) failed");
+        if (rcx) return rcx;
         return hx_sell_spmv_z_part(Ksell, 2, xe, out, a, bt, s);
       }
       if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_gmres", "halo exchange callback failed");

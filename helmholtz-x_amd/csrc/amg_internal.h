@@ -51,7 +51,7 @@ struct hx_amg {
   bool sharded = false;
   hx_halo_fn halo = nullptr;
   hx_allreduce_fn allreduce = nullptr;
-  hx_halo_fn halo_begin = nullptr;      // optional split form: the exchange overlaps the interior slices of the product
+  hx_halo_begin_fn halo_begin = nullptr;      // optional split form: the exchange overlaps the interior slices of the product
   hx_halo_end_fn halo_end = nullptr;
   void* ctx = nullptr;
   int n_sharded = 0;           // number of leading row-sharded levels

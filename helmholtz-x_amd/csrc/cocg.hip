@@ -263,10 +263,11 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     if (sharded) {
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
       if (split) {
-        int rcx;
-        if (M->halo_begin(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (begin) failed");
-        if ((rcx = hx_sell_spmv_z_part(Ksell, 1, xe, out, a, bt, s))) return rcx;
+        hx_stream side = nullptr;
+        if (M->halo_begin(M->ctx, 0, xe, 16, s, &side) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (begin) failed");
+        const int rcx = hx_sell_spmv_z_part(Ksell, 1, xe, out, a, bt, side);
         if (M->halo_end(M->ctx, 0, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (end) failed");
+        if (rcx) return rcx;
         return hx_sell_spmv_z_part(Ksell, 2, xe, out, a, bt, s);
       }
       if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
@@ -279,10 +280,11 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     if (sharded) {
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
       if (split) {
-        int rcx;
-        if (M->halo_begin(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (begin) failed");
-        if ((rcx = hx_sell_residual_z_part(Ksell, 1, xe, b, out, s))) return rcx;
+        hx_stream side = nullptr;
+        if (M->halo_begin(M->ctx, 0, xe, 16, s, &side) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (begin) failed");
+        const int rcx = hx_sell_residual_z_part(Ksell, 1, xe, b, out, side);
         if (M->halo_end(M->ctx, 0, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (end) failed");
+        if (rcx) return rcx;
         return hx_sell_residual_z_part(Ksell, 2, xe, b, out, s);
       }
       if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");

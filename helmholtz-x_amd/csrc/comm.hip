@@ -8,7 +8,11 @@
 //     neighbours; xGMI links are point-to-point, so this is the natural transport, not a ring collective);
 //   * allreduce: sum / max of a few scalars (Krylov inner products: <= 100 numbers, latency-bound) or of one coarse
 //     right-hand side.
-// Both are enqueued on the caller's stream: no host synchronisation, no Python frame per exchange.  hx_comm_halo /
+// Both are enqueued on the caller's stream: no host synchronisation, no Python frame per exchange.  EVERY call into the
+// communicator -- blocking halos, split halos, all-reduces -- is issued on that ONE stream, in program order, hence in the same
+// order on every rank: RCCL gives no ordering guarantee between operations of one communicator in flight on different
+// streams.  The split halo overlaps the other way round: the exchange stays on the caller's stream, the INTERIOR slices of the
+// product it feeds run on a side stream of the communicator (hx_comm_halo_begin hands it out), two events order the two.  hx_comm_halo /
 // hx_comm_allreduce have the hx_halo_fn / hx_allreduce_fn signatures and are handed to hx_amg_set_sharded with the
 // communicator as context, so hx_cocg_sharded / hx_gmres_sharded / the V-cycle run a whole solve inside the library.
 //
@@ -102,11 +106,32 @@ struct hx_comm {
   int rank = 0, world = 1;
   std::vector<Plan> plans;
   int64_t n_exchange = 0, n_allreduce = 0, n_overlapped = 0;
-  // split halo (hx_comm_halo_begin / _end): the exchange runs on the communicator's own stream, ordered against the compute
-  // stream by two events, so that the interior slices of a product run while the ghost entries travel
-  hipStream_t cstream = nullptr;
+  // split halo (hx_comm_halo_begin / _end): the exchange is enqueued on the caller's stream like every other operation of the
+  // communicator; the interior slices of the product run meanwhile on `istream`, ordered against the caller's stream by two
+  // events.  `pending`: a begin without its end (one exchange may be split at a time).
+  hipStream_t istream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  bool pending = false;
+  hipStream_t op_stream = nullptr;       // the stream the communicator's operations were last issued on (single-stream rule)
+  int64_t n_stream_switches = 0;         // times an operation arrived on another stream than the previous one
 };
+
+// Single-stream rule: operations of one communicator issued on different streams are ordered against each other here (the new
+// stream waits for everything the previous one holds), and counted -- the product path never switches (tests assert 0).
+static int same_stream(hx_comm* c, hx_stream s) {
+  hipStream_t st = hx_s(s);
+  if (c->op_stream == st) return HX_OK;
+  if (c->op_stream != nullptr || c->n_exchange + c->n_allreduce > 0) {
+    hipEvent_t ev;
+    HX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HX_HIP(hipEventRecord(ev, c->op_stream));
+    HX_HIP(hipStreamWaitEvent(st, ev, 0));
+    HX_HIP(hipEventDestroy(ev));
+    ++c->n_stream_switches;
+  }
+  c->op_stream = st;
+  return HX_OK;
+}
 
 // ---- gather of listed entries (4-, 8- or 16-byte elements) into the contiguous send buffer
 template <typename T>
@@ -141,10 +166,13 @@ extern "C" int hx_comm_create(hx_comm** out, int rank, int world, const void* id
 
 extern "C" int hx_comm_destroy(hx_comm* c) {
   if (!c) return HX_OK;
+  // nothing of this communicator may still be in flight when its staging buffers go back to the pool
+  if (c->istream) (void)hipStreamSynchronize(c->istream);
+  if (c->op_stream || c->n_exchange + c->n_allreduce > 0) (void)hipStreamSynchronize(c->op_stream);
   for (Plan& p : c->plans) { (void)hx_free(p.d_idx); (void)hx_free(p.stage); }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-  if (c->cstream) (void)hipStreamDestroy(c->cstream);
+  if (c->istream) { hx_pool_register_stream(c->istream, false); (void)hipStreamDestroy(c->istream); }
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   delete c;
   return HX_OK;
@@ -161,6 +189,8 @@ extern "C" int hx_comm_counters(const hx_comm* c, int64_t* n_exchange, int64_t* 
 }
 // number of halo exchanges that ran split (hx_comm_halo_begin / _end: overlapped with the interior slices of their product)
 extern "C" int64_t hx_comm_overlapped(const hx_comm* c) { return c ? c->n_overlapped : 0; }
+// times an operation of the communicator arrived on another stream than the one before it (0 on the product path)
+extern "C" int64_t hx_comm_stream_switches(const hx_comm* c) { return c ? c->n_stream_switches : 0; }
 
 // Exchange plan `plan` (>= 0; halo plans use the hierarchy level as their number).  HOST arrays:
 //   send_peer[ns], send_ptr[ns + 1] into send_idx (owned element indices, ascending per peer);
@@ -197,6 +227,8 @@ extern "C" int hx_comm_set_plan(hx_comm* c, int plan, int ns, const int32_t* sen
   P.n_gather = (int64_t)gathered.size();
   if (P.n_gather > 0) {
     HX_HIP(hx_malloc((void**)&P.d_idx, sizeof(int32_t) * (size_t)P.n_gather));
+    // (a pooled block may still be read by kernels of a non-blocking stream: hx_malloc orders the block against its last
+    // users; the copy itself is synchronous with respect to the host)
     HX_HIP(hipMemcpy(P.d_idx, gathered.data(), sizeof(int32_t) * (size_t)P.n_gather, hipMemcpyHostToDevice));
     HX_HIP(hx_malloc(&P.stage, 16 * (size_t)P.n_gather));
   }
@@ -211,6 +243,7 @@ extern "C" int hx_comm_exchange(hx_comm* c, int plan, const void* src, void* dst
   HX_REQUIRE(elem_bytes == 4 || elem_bytes == 8 || elem_bytes == 16, "element size must be 4, 8 or 16 bytes");
   Plan& P = c->plans[plan];
   const int ns = (int)P.send_peer.size(), nr = (int)P.recv_peer.size();
+  { const int rs = same_stream(c, s); if (rs) return rs; }
   ++c->n_exchange;
   if (ns == 0 && nr == 0) return HX_OK;
   const int64_t* stage_off = P.send_stage.data();
@@ -243,30 +276,36 @@ extern "C" int hx_comm_halo(void* ctx, int level, void* x_ext, int elem_bytes, h
   return hx_comm_exchange((hx_comm*)ctx, level, x_ext, x_ext, elem_bytes, s);
 }
 
-// Split form of the halo (hx_halo_fn / hx_halo_end_fn for hx_amg_set_halo_overlap): _begin orders the exchange after everything
-// enqueued on `s` so far and runs it on the communicator's stream; _end makes `s` wait for it.  Between the two the caller may
-// launch, on `s`, kernels that read only the OWNED block of x_ext (the interior slices of a row-sharded product).  One exchange
-// may be pending at a time.
-extern "C" int hx_comm_halo_begin(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s) {
+// Split form of the halo (hx_halo_begin_fn / hx_halo_end_fn for hx_amg_set_halo_overlap).  _begin enqueues the exchange on `s`
+// (after everything enqueued there so far) and hands out the communicator's side stream, made to wait for the same point of
+// `s`: the caller launches THERE the kernels that read only the OWNED block of x_ext (the interior slices of a row-sharded
+// product) -- they run while the ghost entries travel.  _end makes `s` wait for the side stream; the boundary slices then
+// follow on `s`, behind the exchange.  One exchange may be split at a time.
+extern "C" int hx_comm_halo_begin(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s, hx_stream* interior) {
   hx_comm* c = (hx_comm*)ctx;
-  HX_REQUIRE(c && x_ext, "bad argument");
-  if (!c->cstream) {
-    HX_HIP(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+  HX_REQUIRE(c && x_ext && interior, "bad argument");
+  HX_REQUIRE(!c->pending, "hx_comm_halo_begin: the previous split exchange was not ended");
+  if (!c->istream) {
+    HX_HIP(hipStreamCreateWithFlags(&c->istream, hipStreamNonBlocking));
+    hx_pool_register_stream(c->istream, true);
     HX_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     HX_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   }
   HX_HIP(hipEventRecord(c->ev_ready, hx_s(s)));
-  HX_HIP(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
-  const int rc = hx_comm_exchange(c, level, x_ext, x_ext, elem_bytes, (hx_stream)c->cstream);
-  if (rc) return rc;
-  HX_HIP(hipEventRecord(c->ev_done, c->cstream));
+  HX_HIP(hipStreamWaitEvent(c->istream, c->ev_ready, 0));
+  const int rc = hx_comm_exchange(c, level, x_ext, x_ext, elem_bytes, s);
+  if (rc) return rc;                         // (nothing was launched on the side stream yet: nothing to drain)
+  c->pending = true;
+  *interior = (hx_stream)c->istream;
   ++c->n_overlapped;
   return HX_OK;
 }
 extern "C" int hx_comm_halo_end(void* ctx, int level, hx_stream s) {
   hx_comm* c = (hx_comm*)ctx;
   (void)level;
-  HX_REQUIRE(c && c->ev_done, "no exchange pending");
+  HX_REQUIRE(c && c->pending, "hx_comm_halo_end: no split exchange pending");
+  c->pending = false;
+  HX_HIP(hipEventRecord(c->ev_done, c->istream));
   HX_HIP(hipStreamWaitEvent(hx_s(s), c->ev_done, 0));
   return HX_OK;
 }
@@ -275,6 +314,7 @@ extern "C" int hx_comm_halo_end(void* ctx, int level, hx_stream s) {
 extern "C" int hx_comm_allreduce(void* ctx, void* buf, int64_t count, int dtype, int op, hx_stream s) {
   hx_comm* c = (hx_comm*)ctx;
   HX_REQUIRE(c && buf && count >= 0 && (dtype == 0 || dtype == 1) && (op == 0 || op == 1), "bad argument");
+  { const int rs = same_stream(c, s); if (rs) return rs; }
   ++c->n_allreduce;
   if (count == 0 || c->world == 1) return HX_OK;
   HX_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, dtype ? ncclFloat64 : ncclFloat32, op ? ncclMax : ncclSum, c->comm,

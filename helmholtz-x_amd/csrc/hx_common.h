@@ -102,5 +102,12 @@ static inline int hx_grid(int64_t work_items, int block, int max_blocks = 256 * 
   if (g > max_blocks) g = max_blocks;
   return (int)g;
 }
-static inline hipStream_t hx_s(hx_stream s) { return (hipStream_t)s; }
+// every launch converts its stream argument here: the pool notes which caller streams may still touch a block it caches
+#include <atomic>
+extern std::atomic<hipStream_t> hx_last_stream;
+void hx_pool_register_stream(hipStream_t s, bool add);      // side streams of the library (see pool.hip)
+static inline hipStream_t hx_s(hx_stream s) {
+  hx_last_stream.store((hipStream_t)s, std::memory_order_relaxed);
+  return (hipStream_t)s;
+}
 static inline zc hx_z(const double a[2]) { return make_double2(a[0], a[1]); }

@@ -21,6 +21,7 @@ _dp = C.POINTER(C.c_double)
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p)                    # hx_halo_fn
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p)      # hx_allreduce_fn
 HALO_END_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)                                        # hx_halo_end_fn
+HALO_BEGIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p))  # hx_halo_begin_fn
 COMM_ID_BYTES = 128
 ERR_BREAKDOWN = -5
 
@@ -106,14 +107,16 @@ SIGNATURES = {
     "hx_gmres_hessenberg": (C.c_int, [_vp, C.POINTER(_int), _vp]),
     "hx_amg_set_recycle": (C.c_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
-    "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_FN, HALO_END_FN]),
+    "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_BEGIN_FN, HALO_END_FN]),
     "hx_amg_set_prolongator_ghost_rows": (C.c_int, [_vp, C.c_int]),
     "hx_pool_trim": (C.c_int, []),
+    "hx_pool_ordering_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hx_pool_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                 C.POINTER(C.c_int64), C.c_int]),
-    "hx_comm_halo_begin": (C.c_int, [_vp, _int, _vp, _int, _vp]),
+    "hx_comm_halo_begin": (C.c_int, [_vp, _int, _vp, _int, _vp, C.POINTER(_vp)]),
     "hx_comm_halo_end": (C.c_int, [_vp, _int, _vp]),
     "hx_comm_overlapped": (_i64, [_vp]),
+    "hx_comm_stream_switches": (_i64, [_vp]),
     "hx_comm_unique_id": (C.c_int, [_vp, _int]),
     "hx_comm_create": (C.c_int, [C.POINTER(_vp), _int, _int, C.c_char_p, _int]),
     "hx_comm_destroy": (C.c_int, [_vp]),
@@ -170,6 +173,27 @@ def require_gpu():
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_empty(shape, dtype, device=None):
+    """torch.empty on the GPU; when torch's allocator runs out of memory the blocks libhx keeps cached (which torch cannot see)
+    are returned to the driver and the allocation is tried once more."""
+    device = device if device is not None else require_gpu()
+    try:
+        return torch.empty(shape, dtype=dtype, device=device)
+    except torch.cuda.OutOfMemoryError:
+        check(lib.hx_pool_trim())
+        torch.cuda.empty_cache()
+        return torch.empty(shape, dtype=dtype, device=device)
+
+
+def shares_device():
+    """More local ranks than GPUs (rehearsals on a one-GPU box): caches are trimmed when solver objects are destroyed."""
+    import os
+    try:
+        return int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > max(torch.cuda.device_count(), 1)
+    except ValueError:
+        return False
 
 
 def ptr(t):

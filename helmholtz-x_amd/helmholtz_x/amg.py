@@ -789,8 +789,8 @@ class AMGSolver:
                 _hx.check(_hx.lib.hx_amg_set_prolongator_ghost_rows(h, n_pg))
             if shard.comm is not None and os.environ.get("HX_HALO_OVERLAP", "1") != "0":
                 # library-issued exchanges: split every halo around the interior slices of its product (exchange on the
-                # communicator's stream, ordered by events)
-                self._ov = (C.cast(_hx.lib.hx_comm_halo_begin, _hx.HALO_FN), C.cast(_hx.lib.hx_comm_halo_end, _hx.HALO_END_FN))
+                # compute stream like every other operation of the communicator, interior slices on its side stream)
+                self._ov = (C.cast(_hx.lib.hx_comm_halo_begin, _hx.HALO_BEGIN_FN), C.cast(_hx.lib.hx_comm_halo_end, _hx.HALO_END_FN))
                 _hx.check(_hx.lib.hx_amg_set_halo_overlap(h, self._ov[0], self._ov[1]))
             self._xe = shard.ext_vector(torch.complex128)
             self._hbuf = torch.zeros(max(self.params["restart"] + 2 + 32, 80), dtype=torch.complex128, device=dev)

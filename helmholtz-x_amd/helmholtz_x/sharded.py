@@ -160,6 +160,7 @@ class ShardContext:
             _hx.check(_hx.lib.hx_comm_counters(self.comm, C.byref(ne), C.byref(na), 0))
             out = {"halo_exchanges": out["halo_exchanges"] + ne.value, "all_reduces": na.value,
                    "halos_overlapped_with_interior_slices": int(_hx.lib.hx_comm_overlapped(self.comm)),
+                   "communicator_stream_switches": int(_hx.lib.hx_comm_stream_switches(self.comm)),
                    "issued_by": "libhx on the compute stream (%s)" % self.comm_library}
         return out
 

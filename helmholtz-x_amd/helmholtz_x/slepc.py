@@ -303,8 +303,8 @@ class DeviceBasis:
             if pool is not None:
                 pool.pop("basis", None)          # release a smaller pair before allocating the larger one
                 rows = max(m, min(int(pool.get("rows_hint", 0)), n))   # size once for the widest solve of the call
-            Va = torch.empty((rows, n), dtype=torch.complex128, device=dev)
-            Vb = torch.empty((rows, n), dtype=torch.complex128, device=dev)
+            Va = _hx.device_empty((rows, n), torch.complex128, dev)
+            Vb = _hx.device_empty((rows, n), torch.complex128, dev)
             if pool is not None:
                 pool["basis"] = (Va, Vb)
             self.V, self.V2 = Va[:m], Vb[:m]
@@ -678,6 +678,8 @@ class _EigenSolverBase:
 
     def destroy(self):
         self._basis = None
+        if _hx.shares_device():              # several ranks on one card: give cached blocks back for the others
+            _hx.check(_hx.lib.hx_pool_trim())
 
     def _finish(self, basis, sigma):
         ncv = self._ncv_used

@@ -60,10 +60,18 @@ enum hx_status {
  * of the set-up passes) are kept and handed to the next request of exactly the same size -- every fixed-point call of a driver
  * builds the same objects again (the reference: E.destroy() and a new EPS per iteration, eigensolvers.py:161) -- instead of
  * going through hipFree / hipMalloc, whose cost varies from milliseconds to tenths of a second with the load of the machine.
- * HX_POOL=0 switches it off, HX_POOL_MAX_GIB caps the cached bytes (default: a quarter of the device's memory), HX_POOL_MIN_BYTES the smallest pooled block.
- * hx_pool_trim returns every cached block to the driver; hx_pool_stats: requests, requests served from the cache, calls that went to
- * the driver and the seconds spent in them, bytes cached now (reset != 0 clears the counters). */
+ * HX_POOL=0 switches it off, HX_POOL_MAX_GIB caps the cached bytes (default: a quarter of the memory FREE on the device when the
+ * pool starts, divided among the local ranks sharing the device: LOCAL_WORLD_SIZE / device count), HX_POOL_MIN_BYTES the smallest
+ * pooled block.  Reuse is ordered: a released block records an event on every stream that may still touch it (the caller streams
+ * recently passed to the library and the library's own side streams) and the request that takes it out of the cache waits for
+ * them on the host -- the device-wide synchronisation hipFree used to provide, without the device-wide part.  (A caller that
+ * destroys a stream it passed to the library calls hx_pool_trim first.)
+ * hx_pool_trim returns every cached block to the driver (call it when another allocator of the process runs out of memory);
+ * hx_pool_stats: requests, requests served from the cache, calls that went to the driver and the seconds spent in them, bytes
+ * cached now (reset != 0 clears the counters); hx_pool_ordering_stats: events recorded on release, events waited for on reuse,
+ * the cap in bytes. */
 int hx_pool_trim(void);
+int hx_pool_ordering_stats(int64_t* n_events, int64_t* n_waits, int64_t* max_cached_bytes);
 int hx_pool_stats(int64_t* n_requests, int64_t* n_reused, int64_t* n_driver_calls, double* driver_seconds, int64_t* cached_bytes,
                   int reset);
 int hx_version(void);
@@ -385,14 +393,18 @@ typedef int (*hx_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype, i
  * handle re-allocates its level-l work vectors with that length. */
 int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext, hx_halo_fn halo, hx_allreduce_fn allreduce,
                        void* ctx);
-/* Optional split form of the halo exchange: begin(ctx, level, x_ext, elem_bytes, s) starts the exchange ordered after the work
- * enqueued on s and returns at once; end(ctx, level, s) makes s wait for it.  With both set, every product with a SELL-64
- * operator of a sharded level (smoother steps, residuals, the operator product of hx_cocg_sharded / hx_gmres_sharded) runs its
- * interior slices -- the ones that read no ghost column -- between the two and its boundary slices after: the exchange travels
- * over xGMI while most of the product streams from HBM.  hx_comm_halo_begin / hx_comm_halo_end implement it on the communicator's
- * own stream.  (PETSc overlaps the same way: VecScatterBegin, local part of MatMult, VecScatterEnd, off-diagonal part.) */
+/* Optional split form of the halo exchange.  begin(ctx, level, x_ext, elem_bytes, s, &interior) enqueues the exchange ON s,
+ * ordered after the work enqueued there, and hands out a side stream `interior` that waits for the same point of s;
+ * end(ctx, level, s) makes s wait for the side stream.  With both set, every product with a SELL-64 operator of a sharded level
+ * (smoother steps, residuals, the operator product of hx_cocg_sharded / hx_gmres_sharded) launches its interior slices -- the
+ * ones that read no ghost column -- on `interior` between the two and its boundary slices on s after: the exchange travels over
+ * xGMI while most of the product streams from HBM, and every operation of the communicator (split and blocking exchanges,
+ * all-reduces) stays on ONE stream in program order -- RCCL orders the operations of a communicator only within a stream.
+ * hx_comm_halo_begin / hx_comm_halo_end implement it.  (PETSc overlaps the same way: VecScatterBegin, local part of MatMult,
+ * VecScatterEnd, off-diagonal part.) */
+typedef int (*hx_halo_begin_fn)(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s, hx_stream* interior);
 typedef int (*hx_halo_end_fn)(void* ctx, int level, hx_stream s);
-int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_fn begin, hx_halo_end_fn end);
+int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_begin_fn begin, hx_halo_end_fn end);
 /* The prolongators of the first n_levels row-sharded levels were given with n_ext ROWS (behind this rank's rows the owners' rows of
  * its ghost vertices): the prolongation then also corrects the ghost block of the iterate, and the first post-smoothing step of a
  * cycle runs without an exchange -- one halo fewer per sharded level and cycle.  After hx_amg_set_sharded.  (PETSc: the ghost
@@ -419,9 +431,10 @@ int hx_comm_set_plan(hx_comm* c, int plan, int ns, const int32_t* send_peer, con
                      const int64_t* recv_cnt);
 int hx_comm_exchange(hx_comm* c, int plan, const void* src, void* dst, int elem_bytes, hx_stream s);
 int hx_comm_halo(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s);          /* an hx_halo_fn */
-int hx_comm_halo_begin(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s);    /* split form: an hx_halo_fn ... */
+int hx_comm_halo_begin(void* ctx, int level, void* x_ext, int elem_bytes, hx_stream s, hx_stream* interior); /* an hx_halo_begin_fn */
 int hx_comm_halo_end(void* ctx, int level, hx_stream s);                                   /* ... and its hx_halo_end_fn */
 int64_t hx_comm_overlapped(const hx_comm* c);   /* exchanges that ran split since the last counter reset */
+int64_t hx_comm_stream_switches(const hx_comm* c); /* operations that arrived on another stream than their predecessor (product path: 0) */
 int hx_comm_allreduce(void* ctx, void* buf, int64_t count, int dtype, int op, hx_stream s); /* an hx_allreduce_fn */
 int hx_comm_counters(const hx_comm* c, int64_t* n_exchange, int64_t* n_allreduce, int reset);
 /* hx_gmres on the row-sharded operator: K = local rows over [owned | ghost] columns, b / x / ws sized by n_own;

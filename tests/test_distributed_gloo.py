@@ -283,6 +283,9 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
         assert ("libhx" in counters["issued_by"]) == (transport == "fake_rccl"), counters
         if transport == "fake_rccl":      # most halos run split: interior slices of the product while the exchange is in flight
             assert counters["halos_overlapped_with_interior_slices"] > 0.5 * counters["halo_exchanges"], counters
+            # every operation of the communicator -- blocking and split halos, all-reduces -- was issued on ONE stream (RCCL
+            # orders the operations of a communicator only within a stream; the asynchronous stand-in fails a run that mixes)
+            assert counters["communicator_stream_switches"] == 0, counters
         nv_loc, nc_loc, nv, nc = r["local_mesh"]
         assert nv_loc < 0.6 * nv and nc_loc < 0.6 * nc            # a rank holds its half of the mesh + one ghost layer
     # both ranks hold identical (all-reduced) results
@@ -459,19 +462,27 @@ def _rccl_one_rank_worker(rank, world, port, out):
             want[20:24] = before[10:14]
             want[30:33] = before[torch.tensor([1, 7, 2], device="cuda")]
             assert torch.equal(x, want), dtype
-        # split form: the exchange runs on the communicator's own stream between two events; work enqueued on the compute
-        # stream between begin and end (here: an update of an entry the exchange does not touch) overlaps it
+        # split form: the exchange stays on the compute stream (every operation of the communicator does); begin hands out the
+        # communicator's side stream, ordered after the compute stream's work so far; work launched THERE between begin and end
+        # (here: an update of an entry the exchange does not touch) overlaps the exchange, end joins it
         x = torch.arange(40, device="cuda").to(torch.complex128)
         before = x.clone()
-        _hx.check(_hx.lib.hx_comm_halo_begin(ctx.comm, 5, _hx.ptr(x), 16, _hx.stream()))
-        x[39] = -1.0
+        side = C.c_void_p()
+        _hx.check(_hx.lib.hx_comm_halo_begin(ctx.comm, 5, _hx.ptr(x), 16, _hx.stream(), C.byref(side)))
+        assert side.value is not None and side.value != _hx.stream()
+        with torch.cuda.stream(torch.cuda.ExternalStream(side.value)):
+            x[39] = -1.0
+        rc = _hx.lib.hx_comm_halo_begin(ctx.comm, 5, _hx.ptr(x), 16, _hx.stream(), C.byref(C.c_void_p()))
+        assert rc != 0                               # a second begin before the end is refused
         _hx.check(_hx.lib.hx_comm_halo_end(ctx.comm, 5, _hx.stream()))
-        y = x * 2                                    # ordered after the exchange by the end event
+        assert _hx.lib.hx_comm_halo_end(ctx.comm, 5, _hx.stream()) != 0     # ... and so is an end without a begin
+        y = x * 2                                    # ordered after the exchange (stream order) and the side stream (end event)
         torch.cuda.synchronize()
         want = before.clone()
         want[20:24], want[30:33], want[39] = before[10:14], before[torch.tensor([1, 7, 2], device="cuda")], -1.0
         assert torch.equal(x, want) and torch.equal(y, 2 * want)
         assert _hx.lib.hx_comm_overlapped(ctx.comm) == 1
+        assert _hx.lib.hx_comm_stream_switches(ctx.comm) == 0          # everything above was issued on ONE stream
         ne, na = C.c_int64(0), C.c_int64(0)
         _hx.check(_hx.lib.hx_comm_counters(ctx.comm, C.byref(ne), C.byref(na), 0))
         out[0] = (ne.value, na.value, ctx.comm_library)
@@ -486,7 +497,8 @@ def test_library_issued_rccl_calls_on_one_rank():
     """The REAL librccl through libhx's run-time binding (csrc/comm.hip), as far as a one-GPU box can take it: communicator
     from an id drawn by the library, ncclAllReduce (sum, max) and a grouped ncclSend/ncclRecv exchange (in-place run +
     gathered list, three element sizes) issued by the library on torch's current stream -- with this rank as its own peer; and
-    the split form of the exchange (hx_comm_halo_begin / _end on the communicator's stream, ordered by events)."""
+    the split form of the exchange (hx_comm_halo_begin / _end: exchange on the compute stream, interior work on the communicator's
+    side stream, ordered by events; all operations of the communicator on one stream)."""
     port = _free_port()
     out = mp.Manager().dict()
     mp.spawn(_rccl_one_rank_worker, args=(1, port, out), nprocs=1, join=True)

@@ -312,8 +312,8 @@ extern "C" int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const in
 // Chebyshev coefficients for eigenvalues of D^-1 K in [lo, hi]: x_{k+1} = x_k + a_k D^-1 (b - K x_k) + c_k (x_k - x_{k-1})
 struct Cheb { double a[4], c[4]; };
 static Cheb cheb_coeffs(double rho) {
-  static const double lo_frac = getenv("HX_CHEB_LO") ? atof(getenv("HX_CHEB_LO")) : 0.1;   // experiment hook
-  static const int kind = getenv("HX_CHEB_KIND") ? atoi(getenv("HX_CHEB_KIND")) : 1;       // experiment hook
+  const double lo_frac = HX_OPT_DOUBLE("cheb_lo", 0.1);   // experiment hook
+  const int kind = (int)HX_OPT_INT("cheb_kind", 1);       // experiment hook
   const double hi = 1.1 * rho, lo = lo_frac * hi;
   Cheb C;
   if (kind == 4) {
@@ -345,7 +345,7 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   if (l == (int)H.L.size() - 1) return op_spmv(H.coarse_inv, b, xout, (T)1, (T)0, true, s);
   const bool cheb = L.rho > 0.0;
   const Cheb C = cheb ? cheb_coeffs(L.rho) : Cheb();
-  static const int extra = getenv("HX_AMG_COARSE_EXTRA") ? atoi(getenv("HX_AMG_COARSE_EXTRA")) : 0;   // experiment hook
+  const int extra = (int)HX_OPT_INT("amg_coarse_extra", 0);   // experiment hook
   const int n_pre = h->pre + (l > 0 ? extra : 0), n_post = h->post + (l > 0 ? extra : 0);
   T* bufs[3] = {L.x, L.x2, L.x3};
   auto other = [&](const T* a, const T* c) -> T* { for (T* q : bufs) if (q != a && q != c) return q; return nullptr; };
@@ -449,7 +449,7 @@ int hx_amg_vcycle_c64(hx_amg* h, hx_stream s) {
     h->graph_state = ok ? 1 : -1;                                // any failure: fall back to eager launches for good
   }
   if (h->graph_state == 1 && !h->sharded) {
-    static const bool hop = getenv("HX_AMG_GRAPH_PRIVATE_STREAM") != nullptr;     // (measured variant)
+    const bool hop = HX_OPT_SET("amg_graph_private_stream");     // (measured variant)
     if (hop) {
       HX_HIP(hipEventRecord(h->ev_in, hx_s(s)));                 // order the graph after the producer on the caller's stream
       HX_HIP(hipStreamWaitEvent(h->gstream, h->ev_in, 0));
@@ -549,7 +549,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
     return HX_OK;
   };
   int rc, it = 0, m_last = 0;
-  static const bool trace = getenv("HX_GMRES_TRACE") != nullptr;     // convergence history on stderr (diagnostics)
+  const bool trace = HX_OPT_SET("gmres_trace");     // convergence history on stderr (diagnostics)
   if (M) { M->last_backward = -1.0; M->x0_next = false; }     // (initial guesses are a feature of hx_cocg only)
   HX_HIP(hipMemsetAsync(x, 0, sizeof(hx_c128) * (size_t)n, hx_s(s)));
   if ((rc = dots(Pn, 0, b))) return rc;
@@ -836,12 +836,8 @@ extern "C" int hx_host_aggregate_f32(int32_t n, const int32_t* rp, const int32_t
 // Row-parallel helper for the host passes: contiguous row blocks, one std::thread each (HX_HOST_THREADS, default
 // min(16, hardware threads)); every row is produced by exactly one thread, so results do not depend on the count.
 static int host_threads() {
-  static const int nt = [] {
-    const char* e = getenv("HX_HOST_THREADS");
-    int v = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    return std::max(1, std::min(v, 64));
-  }();
-  return nt;
+  const int v = (int)HX_OPT_INT("host_threads", (long)std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+  return std::max(1, std::min(v, 64));
 }
 template <typename F> static void parallel_rows(int32_t n, F&& fn) {   // fn(thread, row_begin, row_end)
   int nt = host_threads();

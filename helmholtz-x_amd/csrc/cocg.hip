@@ -49,7 +49,8 @@ static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0};
 #define CG_OUT 0      // [0, 33): dot results
 #define CG_RHO 34     // r^T z of the current iterate
 #define CG_BETA 35
-#define CG_TMP 36      // [36, 40): scratch
+#define CG_TMP 36      // [36, 38): scratch
+#define CG_ALPHA 38    // single-reduction form: alpha of the previous iteration
 #define CG_T 40       // [40, 72): t = E^-1 C^T z
 #define CG_SCALARS 72
 #define CG_MAXK 32
@@ -177,6 +178,118 @@ k_cocg_start(int64_t n, int k, const PT* __restrict__ U, int64_t ldu, zc* __rest
   }
 }
 
+// ---- single-reduction (Chronopoulos-Gear) form of the deflated recurrence, used by the row-sharded solve: ONE all-reduce per
+// iteration instead of three.  With u = M r and v = K u (the product is applied to the preconditioned residual, not to the
+// direction), one fused pass leaves
+//     c = C^T u (k entries),  gamma = r^T u,  nu = v^T u,  |r|^2
+// and everything else follows from scalars:  t = E^-1 c,  the deflated quantities are u~ = u - U t and K u~ = v - C t (C = K U
+// holds to working precision, see the header), so  delta = (K u~)^T u~ = nu - t^T c  (K^T = K gives v^T U = c^T, and
+// t^T E t = t^T c),  beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old), and
+//     p = u~ + beta p,   s = K u~ + beta s (= K p by recurrence),   x += alpha p,   r -= alpha s.
+// Price: the vector s, and C is streamed twice (dots and update) -- per-rank vectors are short where this form is used and the
+// all-reduces it removes are pure latency (two of ~15-20 us per inner iteration of ~0.2 ms on eight ranks).
+template <typename UT, int JT>
+__global__ void __launch_bounds__(256)
+k_cocg_sr_dots(int64_t n, int k, const zc* __restrict__ Cd, int64_t ldc, const UT* __restrict__ u, const zc* __restrict__ r,
+               const zc* __restrict__ v, zc* __restrict__ partials, int64_t rows_per_block) {
+  __shared__ zc red[256 / HX_WAVE][JT];
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  const int lane = threadIdx.x & (HX_WAVE - 1), wv = threadIdx.x / HX_WAVE;
+  const int ncol = k + 3;                        // C_0 .. C_{k-1}, r, v (all bilinear with u), |r|^2
+  for (int j0 = 0; j0 < ncol; j0 += JT) {
+    zc acc[JT];
+#pragma unroll
+    for (int t = 0; t < JT; ++t) acc[t] = make_double2(0.0, 0.0);
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+      const zc ui = widen(u[i]);
+#pragma unroll
+      for (int t = 0; t < JT; ++t) {
+        const int j = j0 + t;
+        if (j < k) zfma(acc[t], Cd[(int64_t)j * ldc + i], ui);
+        else if (j == k) zfma(acc[t], r[i], ui);
+        else if (j == k + 1) zfma(acc[t], v[i], ui);
+        else if (j == k + 2) { const zc ri = r[i]; acc[t].x = fma(ri.x, ri.x, acc[t].x); acc[t].x = fma(ri.y, ri.y, acc[t].x); }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < JT; ++t) {
+      zc w = zreduce_sub<HX_WAVE>(acc[t]);
+      if (lane == 0) red[wv][t] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < JT && j0 + (int)threadIdx.x < ncol) {
+      zc w = red[0][threadIdx.x];
+      for (int q = 1; q < 256 / HX_WAVE; ++q) w = zadd(w, red[q][threadIdx.x]);
+      partials[(int64_t)blockIdx.x * ncol + j0 + threadIdx.x] = w;
+    }
+    __syncthreads();
+  }
+}
+
+// scalars of one iteration from the (all-)reduced [c ; gamma ; nu ; |r|^2] in sc[0 .. k+2]
+__global__ void __launch_bounds__(HX_WAVE)
+k_cocg_sr_small(int k, const zc* __restrict__ Einv, zc* __restrict__ sc, int first) {
+  const int i = threadIdx.x;
+  __shared__ zc s_c[CG_MAXK], s_t[CG_MAXK];
+  if (i < k) s_c[i] = sc[CG_OUT + i];
+  __syncthreads();
+  if (i < k) {
+    zc t = make_double2(0.0, 0.0);
+    for (int j = 0; j < k; ++j) zfma(t, Einv[i * k + j], s_c[j]);
+    s_t[i] = t;
+    sc[CG_T + i] = t;
+  }
+  __syncthreads();
+  if (i == 0) {
+    const zc gamma = sc[CG_OUT + k];
+    zc delta = sc[CG_OUT + k + 1];
+    for (int j = 0; j < k; ++j) { const zc tc = zmul(s_t[j], s_c[j]); delta = zsub(delta, tc); }
+    zc beta = make_double2(0.0, 0.0), alpha;
+    if (first) alpha = zdiv(gamma, delta);
+    else {
+      beta = zdiv(gamma, sc[CG_RHO]);
+      alpha = zdiv(gamma, zsub(delta, zdiv(zmul(beta, gamma), sc[CG_ALPHA])));
+    }
+    sc[CG_BETA] = beta;
+    sc[CG_ALPHA] = alpha;
+    sc[CG_RHO] = gamma;
+  }
+}
+
+// p = (u - U t) + beta p ;  s = (v - C t) + beta s ;  x += alpha p ;  r -= alpha s  (+ the complex64 copy of the new residual)
+template <typename UT>
+__global__ void __launch_bounds__(256)
+k_cocg_sr_update(int64_t n, int k, const cc* __restrict__ Uf, const zc* __restrict__ Cd, int64_t ld, const UT* __restrict__ u,
+                 const zc* __restrict__ v, zc* __restrict__ p, zc* __restrict__ sv, zc* __restrict__ x, zc* __restrict__ r,
+                 cc* __restrict__ r32, const zc* __restrict__ sc) {
+  __shared__ zc ts[CG_MAXK];
+  if ((int)threadIdx.x < k) ts[threadIdx.x] = sc[CG_T + threadIdx.x];
+  __syncthreads();
+  const zc beta = sc[CG_BETA], alpha = sc[CG_ALPHA];
+  const bool has_beta = beta.x != 0.0 || beta.y != 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    zc pn = widen(u[i]), sn = v[i];
+    for (int j = 0; j < k; ++j) {
+      const cc uf = Uf[(int64_t)j * ld + i];
+      const zc uj = make_double2((double)uf.x, (double)uf.y), cj = Cd[(int64_t)j * ld + i], tj = ts[j];
+      pn.x = fma(-uj.x, tj.x, pn.x); pn.x = fma(uj.y, tj.y, pn.x);
+      pn.y = fma(-uj.x, tj.y, pn.y); pn.y = fma(-uj.y, tj.x, pn.y);
+      sn.x = fma(-cj.x, tj.x, sn.x); sn.x = fma(cj.y, tj.y, sn.x);
+      sn.y = fma(-cj.x, tj.y, sn.y); sn.y = fma(-cj.y, tj.x, sn.y);
+    }
+    if (has_beta) { zfma(pn, beta, p[i]); zfma(sn, beta, sv[i]); }
+    p[i] = pn; sv[i] = sn;
+    zc xv = x[i], rv = r[i];
+    zfma(xv, alpha, pn);
+    rv.x = fma(-alpha.x, sn.x, rv.x); rv.x = fma(alpha.y, sn.y, rv.x);
+    rv.y = fma(-alpha.x, sn.y, rv.y); rv.y = fma(-alpha.y, sn.x, rv.y);
+    x[i] = xv; r[i] = rv;
+    if (r32) r32[i] = make_float2((float)rv.x, (float)rv.y);
+  }
+}
+
 // max_i sum_j |K_ij| (non-negative doubles order like their bit patterns)
 __global__ void k_csr_norm_inf(int32_t n, const int32_t* __restrict__ rp, const zc* __restrict__ val,
                                unsigned long long* __restrict__ out) {
@@ -276,6 +389,19 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     if (Ksell) return hx_sell_spmv_z(Ksell, in, out, a, bt, s);
     return hx_csr_spmv_z(n, nnz, rowptr, col, val, in, out, a, bt, 0, s);
   };
+  auto Kx_staged = [&](hx_c128* out) -> int {                        // out = K xe, the owned block of xe staged by the caller
+    if (split) {
+      hx_stream side = nullptr;
+      if (M->halo_begin(M->ctx, 0, xe, 16, s, &side) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (begin) failed");
+      const int rcx = hx_sell_spmv_z_part(Ksell, 1, xe, out, ONE, ZERO, side);
+      if (M->halo_end(M->ctx, 0, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange (end) failed");
+      if (rcx) return rcx;
+      return hx_sell_spmv_z_part(Ksell, 2, xe, out, ONE, ZERO, s);
+    }
+    if (M->halo(M->ctx, 0, xe, 16, s) != 0) return hx_fail(HX_ERR_COMM, "hx_cocg", "halo exchange callback failed");
+    if (Ksell) return hx_sell_spmv_z(Ksell, xe, out, ONE, ZERO, s);
+    return hx_csr_spmv_z(n, nnz, rowptr, col, val, xe, out, ONE, ZERO, 0, s);
+  };
   auto Kres = [&](const hx_c128* in, hx_c128* out) -> int {          // out = b - K in
     if (sharded) {
       HX_HIP(hipMemcpyAsync(xe, in, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
@@ -299,15 +425,18 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     return HX_OK;
   };
   cd host[CG_MAXK + 2];
-  const bool fuse = !sharded && getenv("HX_COCG_FUSE_REDUCTIONS") ? atoi(getenv("HX_COCG_FUSE_REDUCTIONS")) != 0 : !sharded;
+  const bool fuse = !sharded && HX_OPT_INT("cocg_fuse_reductions", 1) != 0;
   const int PD_NB = 1024;                       // PD_MAXBLOCKS of vecops.hip: room of one column of partials
   auto fetch = [&](int count) -> int {        // first `count` scalars -> host (SYNC)
     HX_HIP(hipMemcpyAsync(host, sc, sizeof(cd) * (size_t)count, hipMemcpyDeviceToHost, hx_s(s)));
     HX_HIP(hipStreamSynchronize(hx_s(s)));
     return HX_OK;
   };
-  static const bool trace = getenv("HX_GMRES_TRACE") != nullptr;
-  static const int pq_env = getenv("HX_COCG_PQ_IN_PRODUCT") ? atoi(getenv("HX_COCG_PQ_IN_PRODUCT")) : 1;
+  const bool trace = HX_OPT_SET("gmres_trace");
+  // single-reduction form of the recurrence (see k_cocg_sr_dots): row-sharded solves (1, default), never (0), also on one GPU (2)
+  const int sr_opt = (int)HX_OPT_INT("cocg_single_reduction", 1);
+  const bool single = (sr_opt == 2 || (sr_opt == 1 && sharded)) && k + 3 <= 33;
+  const int pq_env = (int)HX_OPT_INT("cocg_pq_in_product", 1);
 
   // ---- once per harvested set: Cd = K Ut (Ut = the complex64-rounded U), E = Cd^T Ut (bilinear) and its inverse
   if (rec && !rec->have_E) {
@@ -346,8 +475,12 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   bool converged = false, x_zero = true;
   M->last_backward = -1.0;
   auto true_residual = [&]() -> int {        // r = b - K x, relres = |r| / |b|  (SYNC)
-    if (x_zero) HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
-    else if ((rc = Kres(x, r))) return rc;   // one pass, no copy of b first
+    if (x_zero) {                            // r = b: the norm is |b| itself -- no pass, no reduction, no host round trip
+      HX_HIP(hipMemcpyAsync(r, b, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+      relres = 1.0;
+      return HX_OK;
+    }
+    if ((rc = Kres(x, r))) return rc;        // one pass, no copy of b first
     if ((rc = hx_zpanel_dot(n, 0, nullptr, n, r, sc, part, s))) return rc;
     if ((rc = reduce(1))) return rc;
     if ((rc = fetch(1))) return rc;
@@ -418,6 +551,7 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       if ((rc = backward_error(relres))) return rc;
       if (M->last_backward <= BE_FLOOR) { converged = true; break; }
     }
+    bool need_r0 = false;
     if (k > 0) {     // Galerkin correction on span(U): x += U E^-1 U^T r, so that U^T r = 0 again
       if ((rc = hx_zpanel_bdot_c64(n, k, (const hx_c64*)rec->Uf, n, r, r, sc, part, s))) return rc;   // U^T r (entry k unused)
       if ((rc = reduce(k))) return rc;
@@ -431,10 +565,13 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
         k_cocg_start<zc, +1><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, (const zc*)rec->Cd, n, (zc*)r, (const zc*)sc);
         HX_LAUNCH_CHECK("k_cocg_start<r>");
         x_zero = false;
-        if ((rc = hx_zpanel_dot(n, 0, nullptr, n, r, sc, part, s))) return rc;
-        if ((rc = reduce(1))) return rc;
-        if ((rc = fetch(1))) return rc;
-        relres = std::sqrt(host[0].real()) / bnorm;
+        if (single) need_r0 = true;          // |r_0| arrives with the first fused reduction of the recurrence
+        else {
+          if ((rc = hx_zpanel_dot(n, 0, nullptr, n, r, sc, part, s))) return rc;
+          if ((rc = reduce(1))) return rc;
+          if ((rc = fetch(1))) return rc;
+          relres = std::sqrt(host[0].real()) / bnorm;
+        }
       } else {
         x_zero = false;
         if ((rc = true_residual())) return rc;
@@ -475,7 +612,7 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
     // (42 us per inner iteration at 1 M DOF).  None of the rules can fire on |r_j| in that regime except "converged" after a
     // single-step drop by more than LAG_MARGIN; the recurrence then simply ends one (converged) iteration later.  Closer to the
     // tolerance every norm is awaited as before.  HX_COCG_LAG=0: always wait.
-    static const int lag_env = getenv("HX_COCG_LAG") ? atoi(getenv("HX_COCG_LAG")) : 1;
+    const int lag_env = (int)HX_OPT_INT("cocg_lag", 1);
     const double LAG_MARGIN = 1e4;
     const bool may_lag = lag_env != 0 && !trace;
     if (!M->cg_pin) {
@@ -493,6 +630,91 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       *r2 = lane[0];
       return HX_OK;
     };
+    if (single) {
+      // ---- single-reduction form: per iteration one V-cycle, one product (of the preconditioned residual), ONE all-reduce
+      // of k + 3 scalars; |r_j|^2 rides with it, so the norm of the residual the iteration STARTED from is known before its
+      // update is queued -- far from the tolerance it is read one iteration late (the queue does not drain), near it the host
+      // waits and leaves before the update (x_j and r_j stay consistent; the V-cycle and the product of that last iteration
+      // are the price of not sending the norm on its own).
+      hx_c128* sv = q;                           // s = K p by recurrence
+      hx_c128* v = tmp;                          // v = K u
+      auto arrived_sr = [&](int slot, double* r2) -> int {
+        HX_HIP(hipEventSynchronize(M->cg_ev[slot]));
+        *r2 = ((const cd*)M->cg_pin + (size_t)slot * PD_NB)[0].real();
+        return HX_OK;
+      };
+      int queued = it, upd = 0, pending = -1;
+      while (queued < max_it) {
+        if (r32) { if ((rc = hx_amg_vcycle_c64(M, s))) return rc; }
+        else if ((rc = hx_amg_vcycle(M, r, z, s))) return rc;
+        // v = K u
+        if (sharded) {
+          if (r32) { if ((rc = hx_cast_c2z(n, (const float*)z32, xe, s))) return rc; }
+          else HX_HIP(hipMemcpyAsync(xe, z, sizeof(hx_c128) * (size_t)n, hipMemcpyDeviceToDevice, hx_s(s)));
+          if ((rc = Kx_staged(v))) return rc;
+        } else {
+          if (r32) { if ((rc = hx_cast_c2z(n, (const float*)z32, z, s))) return rc; }
+          if ((rc = Kx(z, v, ONE, ZERO))) return rc;
+        }
+        if (r32) k_cocg_sr_dots<cc, 8><<<nblocks, 256, 0, hx_s(s)>>>(n, k, rec ? (const zc*)rec->Cd : nullptr, n, (const cc*)z32,
+                                                                     (const zc*)r, (const zc*)v, (zc*)part, rpb);
+        else k_cocg_sr_dots<zc, 8><<<nblocks, 256, 0, hx_s(s)>>>(n, k, rec ? (const zc*)rec->Cd : nullptr, n, (const zc*)z,
+                                                                 (const zc*)r, (const zc*)v, (zc*)part, rpb);
+        HX_LAUNCH_CHECK("k_cocg_sr_dots");
+        if ((rc = hx_panel_dot_finish(nblocks, k + 2, part, sc, s))) return rc;
+        if ((rc = reduce(k + 3))) return rc;
+        const int slot = upd & 1;
+        if (upd > 0 || need_r0) {
+          HX_HIP(hipMemcpyAsync((cd*)M->cg_pin + (size_t)slot * PD_NB, sc + k + 2, sizeof(cd), hipMemcpyDeviceToHost, hx_s(s)));
+          HX_HIP(hipEventRecord(M->cg_ev[slot], hx_s(s)));
+        }
+        k_cocg_sr_small<<<1, HX_WAVE, 0, hx_s(s)>>>(k, rec ? (const zc*)rec->Einv : nullptr, (zc*)sc, first ? 1 : 0);
+        HX_LAUNCH_CHECK("k_cocg_sr_small");
+        double r2;
+        if (need_r0) {                 // residual of the Galerkin start: known only now (no update has been counted yet)
+          need_r0 = false;
+          if ((rc = arrived_sr(slot, &r2))) return rc;
+          relres = std::sqrt(r2) / bnorm;
+          if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "non-finite residual");
+          if (trace) fprintf(stderr, "[hx_cocg] start  relres %.3e\n", relres);
+          best = prev = relres;
+          if (relres <= rtol) break;   // (the next cycle measures the true residual and accepts it)
+        }
+        if (pending >= 0) {            // the norm the previous iteration left unread
+          if ((rc = arrived_sr(pending, &r2))) return rc;
+          pending = -1;
+          if ((rc = judge(r2))) return rc;
+          if (leave) {                 // (a drop by more than LAG_MARGIN in one step) x is one update further: judge that one too, stop
+            if ((rc = arrived_sr(slot, &r2))) return rc;
+            if ((rc = judge(r2))) return rc;
+            leave = true;
+            break;
+          }
+        }
+        if (upd > 0) {
+          const bool lag = may_lag && relres > LAG_MARGIN * rtol && since_best <= 3 && queued + 1 < max_it;
+          if (lag) pending = slot;
+          else {
+            if ((rc = arrived_sr(slot, &r2))) return rc;
+            if ((rc = judge(r2))) return rc;
+            if (leave) break;          // r_j meets the stopping rule: x_j is the iterate that goes with it
+          }
+        }
+        if (r32) k_cocg_sr_update<cc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, rec ? (const cc*)rec->Uf : nullptr,
+            rec ? (const zc*)rec->Cd : nullptr, n, (const cc*)z32, (const zc*)v, (zc*)p, (zc*)sv, (zc*)x, (zc*)r, (cc*)r32, (const zc*)sc);
+        else k_cocg_sr_update<zc><<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, k, rec ? (const cc*)rec->Uf : nullptr,
+            rec ? (const zc*)rec->Cd : nullptr, n, (const zc*)z, (const zc*)v, (zc*)p, (zc*)sv, (zc*)x, (zc*)r, (cc*)r32, (const zc*)sc);
+        HX_LAUNCH_CHECK("k_cocg_sr_update");
+        first = false;
+        x_zero = false;
+        ++queued; ++upd;
+      }
+      if (pending >= 0) {
+        double r2;
+        if ((rc = arrived_sr(pending, &r2))) return rc;
+        if ((rc = judge(r2))) return rc;
+      }
+    } else {
     int queued = it;                 // iterations queued (it = iterations judged)
     int pending = -1;                // landing area of a queued, not yet judged iteration
     int carry = -1;                  // row-sharded: landing area of an iteration whose |r|^2 is still to be all-reduced
@@ -590,6 +812,7 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       double r2;
       if ((rc = arrived(pending, &r2))) return rc;
       if ((rc = judge(r2))) return rc;
+    }
     }
   }
   if (!converged) {                           // iteration / cycle limit: report the true residual of what we have

@@ -111,3 +111,25 @@ static inline hipStream_t hx_s(hx_stream s) {
   return (hipStream_t)s;
 }
 static inline zc hx_z(const double a[2]) { return make_double2(a[0], a[1]); }
+
+// ---- run-time options (options.hip): hx_set_option overrides, else the environment variable HX_<NAME>, else the default.
+// A call site keeps a static HxOpt: the value is looked up again only when the registry's generation changed.
+extern std::atomic<int> hx_option_generation;
+long hx_option_lookup_int(const char* name, long dflt);
+double hx_option_lookup_double(const char* name, double dflt);
+bool hx_option_lookup_is(const char* name, const char* value);
+bool hx_option_lookup_set(const char* name);
+struct HxOpt { int gen = -1; long i = 0; double d = 0.0; };
+#define HX_OPT_INT(name, dflt)                                                                   \
+  ([]() -> long { static HxOpt o_; const int g_ = hx_option_generation.load(std::memory_order_relaxed);  \
+                  if (o_.gen != g_) { o_.i = hx_option_lookup_int(name, dflt); o_.gen = g_; } return o_.i; }())
+#define HX_OPT_DOUBLE(name, dflt)                                                                \
+  ([]() -> double { static HxOpt o_; const int g_ = hx_option_generation.load(std::memory_order_relaxed); \
+                    if (o_.gen != g_) { o_.d = hx_option_lookup_double(name, dflt); o_.gen = g_; } return o_.d; }())
+#define HX_OPT_IS(name, value)                                                                   \
+  ([]() -> bool { static HxOpt o_; const int g_ = hx_option_generation.load(std::memory_order_relaxed);   \
+                  if (o_.gen != g_) { o_.i = hx_option_lookup_is(name, value) ? 1 : 0; o_.gen = g_; } return o_.i != 0; }())
+#define HX_OPT_SET(name)                                                                         \
+  ([]() -> bool { static HxOpt o_; const int g_ = hx_option_generation.load(std::memory_order_relaxed);   \
+                  if (o_.gen != g_) { o_.i = hx_option_lookup_set(name) ? 1 : 0; o_.gen = g_; } return o_.i != 0; }())
+static inline long hx_option_int(const char* name, long dflt) { return hx_option_lookup_int(name, dflt); }

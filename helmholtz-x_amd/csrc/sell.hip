@@ -265,7 +265,7 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     if (el != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, "k_sell_widths", hipGetErrorString(el)); }
   }
   // stencil slices (HX_SELL_STENCIL=0 switches the detection off)
-  static const bool allow_stencil = !(getenv("HX_SELL_STENCIL") && atoi(getenv("HX_SELL_STENCIL")) == 0);
+  const bool allow_stencil = HX_OPT_INT("sell_stencil", 1) != 0;
   int32_t* d_wu = nullptr;
   int32_t* d_tmpU = nullptr;
   if (allow_stencil && h->n_slices > 0 &&
@@ -352,7 +352,7 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
   if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
   HX_LAUNCH_CHECK("hx_sell_create");
   // 16-bit column deltas, slice by slice (HX_SELL_INDEX=i32 keeps the 32-bit columns everywhere)
-  static const bool allow16 = !(getenv("HX_SELL_INDEX") && strcmp(getenv("HX_SELL_INDEX"), "i32") == 0);
+  const bool allow16 = !HX_OPT_IS("sell_index", "i32");
   if (allow16 && total > 0) {
     int32_t* d_nw = nullptr;
     bool ok = hx_malloc((void**)&h->dcol, sizeof(int16_t) * ne) == hipSuccess &&
@@ -710,10 +710,10 @@ template <typename V, int MODE, typename MV>
 static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alpha, V beta, int beta_is_zero, const V* dinv,
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
                         typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr, int part = 0, V* dot_out = nullptr) {
-  static const int ablate = getenv("HX_SELL_ABLATE") ? atoi(getenv("HX_SELL_ABLATE")) : 0;
+  const int ablate = (int)HX_OPT_INT("sell_ablate", 0);
   const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale, MODE == 1 || sizeof(V) == 8 ? ablate : 0};
   // x windows of the stencil slices through LDS (HX_SELL_LDS=0: gathers everywhere; =2: also for complex128 values)
-  static const int lds_mode = getenv("HX_SELL_LDS") ? atoi(getenv("HX_SELL_LDS")) : 1;
+  const int lds_mode = (int)HX_OPT_INT("sell_lds", 1);
   const bool use_lds = h->st_ptr && (lds_mode == 2 || (lds_mode == 1 && sizeof(MV) == 4));
   auto kern = use_lds ? k_sell<V, MODE, MV, 8, true> : k_sell<V, MODE, MV, 8, false>;
   // part 0: every slice; 1 / 2: the interior / boundary slices of a row-sharded local operator (hx_sell::list_*)
@@ -725,7 +725,7 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
   // (1.9 M rows: smoother step 35.4 -> 29.0 us, residual 33.5 -> 26.1; 1 M rows: operator product 45.4 -> 41.5 us).  Beyond
   // that size the pass streams from HBM, the refetches come from the cache beside it and the interleaved schedule is as fast or
   // faster (5 M rows: 95 vs 98 us).  HX_SELL_XCD = 0 / 3: never / always (bit 0 complex64 kernels, bit 1 complex128).
-  static const int xcd_mode = getenv("HX_SELL_XCD") ? atoi(getenv("HX_SELL_XCD")) : -1;
+  const int xcd_mode = (int)HX_OPT_INT("sell_xcd", -1);
   const double footprint = (double)h->padded * sizeof(MV) + (double)h->n * sizeof(V) * (MODE == 1 ? 5 : 3);
   const bool xcd = sell_grid(nw) >= 64 &&
                    (xcd_mode < 0 ? footprint <= 288e6 : (xcd_mode & (sizeof(V) == 8 ? 1 : 2)) != 0);

@@ -109,6 +109,8 @@ SIGNATURES = {
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
     "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_BEGIN_FN, HALO_END_FN]),
     "hx_amg_set_prolongator_ghost_rows": (C.c_int, [_vp, C.c_int]),
+    "hx_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "hx_get_option": (C.c_int, [C.c_char_p, C.c_char_p, _int]),
     "hx_pool_trim": (C.c_int, []),
     "hx_pool_ordering_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hx_pool_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -173,6 +175,16 @@ def require_gpu():
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def set_option(name, value=None):
+    """Run-time option of libhx (include/hx.h: "Run-time options"); value None removes the override."""
+    check(lib.hx_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name, default=None):
+    buf = C.create_string_buffer(256)
+    return buf.value.decode() if lib.hx_get_option(name.encode(), buf, 256) == 0 else default
 
 
 def device_empty(shape, dtype, device=None):

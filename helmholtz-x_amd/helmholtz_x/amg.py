@@ -882,10 +882,19 @@ class AMGSolver:
         repeats the solve with GMRES; after three such solves COCG is switched off for this operator)."""
         K = self.K
         if self.shard is not None:
+            native = self.shard.comm is not None
+            if native:                      # exchanges issued inside this solve (library-issued path: counted by the communicator)
+                ne0, na0 = C.c_int64(0), C.c_int64(0)
+                _hx.check(_hx.lib.hx_comm_counters(self.shard.comm, C.byref(ne0), C.byref(na0), 0))
             rc = _hx.lib.hx_cocg_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                          self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
                                          _hx.ptr(self.ws), _hx.ptr(self._xe),
                                          _hx.ptr(self._hbuf), C.byref(it), C.byref(rr), _hx.stream())
+            if native:
+                ne1, na1 = C.c_int64(0), C.c_int64(0)
+                _hx.check(_hx.lib.hx_comm_counters(self.shard.comm, C.byref(ne1), C.byref(na1), 0))
+                self.cocg_halos = getattr(self, "cocg_halos", 0) + ne1.value - ne0.value
+                self.cocg_allreduces = getattr(self, "cocg_allreduces", 0) + na1.value - na0.value
             if rc != 0 and self.shard.callback_error():
                 raise RuntimeError("exchange callback failed inside hx_cocg_sharded:\n" + self.shard.callback_error())
         else:
@@ -958,7 +967,8 @@ class AMGSolver:
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1),
                     harmonic_ritz=[round(float(t), 3) for t in getattr(self, "harmonic_ritz", [])],
-                    warm_starts=getattr(self, "warm_starts", 0))
+                    warm_starts=getattr(self, "warm_starts", 0),
+                    cocg_halos=getattr(self, "cocg_halos", 0), cocg_allreduces=getattr(self, "cocg_allreduces", 0))
 
     def destroy(self):
         if getattr(self, "handle", None):

@@ -42,20 +42,31 @@ enum hx_status {
   HX_ERR_COMM = -6       /* an exchange callback of the row-sharded mode reported failure */
 };
 
-/* Environment switches of the library (experiment / diagnostics hooks; none is needed for normal use).  Each is read ONCE, at the
- * first call that consults it, and cached for the life of the process: set them before the first libhx call -- changing one
- * afterwards (e.g. from a test that monkey-patches os.environ mid-run) has no effect.
+/* Switches of the library (experiment / diagnostics hooks; none is needed for normal use).  Each can be given as an environment
+ * variable or, at run time, through hx_set_option (below), which takes precedence; the environment is consulted again whenever
+ * an option is set or removed.
  *   HX_SELL_STENCIL=0 / HX_SELL_INDEX=i32 / HX_SELL_LDS=0|2   SELL-64 format and kernel variants (hx_sell_create, k_sell)
  *   HX_POOL=0, HX_POOL_MAX_GIB, HX_POOL_MIN_BYTES                 device-buffer pool off / cap of the cached bytes / smallest pooled block
  *   HX_SELL_XCD=0|3, HX_SELL_ABLATE                            XCD-contiguous slice schedule never / always (default: by footprint); timing-only ablations
  *   HX_COCG_PQ_IN_PRODUCT=0|2                                 hx_cocg: p^T K p from the SELL-64 product itself never / at every size (default: up to 2 M rows)
  *   HX_COCG_LAG=0                                             hx_cocg: wait for every residual norm (default: read one iteration late while far from the tolerance)
- *   HX_COCG_FUSE_REDUCTIONS=0                                  hx_cocg (read per solve): two-stage reductions on one GPU too
+ *   HX_COCG_FUSE_REDUCTIONS=0                                  hx_cocg: two-stage reductions on one GPU too
+ *   HX_COCG_SINGLE_REDUCTION=0|2                               single-reduction (Chronopoulos-Gear) recurrence never / also on one GPU (default: row-sharded solves)
  *   HX_CHEB_LO, HX_CHEB_KIND, HX_AMG_COARSE_EXTRA             Chebyshev bounds / kind, extra coarse smoothing steps
  *   HX_AMG_GRAPH_PRIVATE_STREAM                               hipGraph replay of the V-cycle on a private stream
  *   HX_GMRES_TRACE=1                                          residual histories of hx_gmres / hx_cocg on stderr
  *   HX_HOST_THREADS                                           threads of the hx_host_* set-up passes
  *   HX_RCCL_LIB                                               librccl to bind in hx_comm_* (default: the loaded one / librccl.so.1) */
+/* Run-time options (csrc/options.hip).  Every switch listed above is ALSO an option: its name is the environment variable's
+ * without the HX_ prefix, in lower case ("sell_stencil", "cocg_lag", "cocg_single_reduction", ...).  hx_set_option(name, value)
+ * overrides the environment from the next library call on (value NULL or "" removes the override); nothing is latched at first
+ * use any more, so a test or a driver can switch a kernel variant between two calls of one process.  hx_get_option returns the
+ * value in force as text (HX_ERR_ARG when neither an override nor the environment variable exists).  The pool's start-up
+ * parameters (HX_POOL*) and HX_RCCL_LIB are read once, when the pool / the RCCL binding is first used.
+ * replaces: nothing in the reference (its solver options are set in code, eigensolvers.py:43-60); PETSc's options database is the
+ * analogue. */
+int hx_set_option(const char* name, const char* value);
+int hx_get_option(const char* name, char* out, int out_len);
 /* Device-buffer pool (csrc/pool.hip): buffers of 1 MiB or more that a handle releases (hx_sell_destroy, hx_amg_destroy, the scratch
  * of the set-up passes) are kept and handed to the next request of exactly the same size -- every fixed-point call of a driver
  * builds the same objects again (the reference: E.destroy() and a new EPS per iteration, eigensolvers.py:161) -- instead of

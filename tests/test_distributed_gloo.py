@@ -286,6 +286,12 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
             # every operation of the communicator -- blocking and split halos, all-reduces -- was issued on ONE stream (RCCL
             # orders the operations of a communicator only within a stream; the asynchronous stand-in fails a run that mixes)
             assert counters["communicator_stream_switches"] == 0, counters
+            # single-reduction COCG: ONE all-reduce of k + 3 scalars per inner iteration (+ one inside the V-cycle: the
+            # restriction onto the first replicated level) and three per solve (|b|, the Galerkin start, the closing true
+            # residual); round 3 needed 3.9 per inner iteration
+            st = r["distributed"]["stats"]
+            assert st["cocg_allreduces"] <= 2 * st["cocg_iters"] + 2 * st["cocg_solves"] + 3 * st["cocg_solves"], st
+            assert st["cocg_allreduces"] / st["cocg_iters"] < 2.7, st
         nv_loc, nc_loc, nv, nc = r["local_mesh"]
         assert nv_loc < 0.6 * nv and nc_loc < 0.6 * nc            # a rank holds its half of the mesh + one ghost layer
     # both ranks hold identical (all-reduced) results

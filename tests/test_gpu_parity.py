@@ -560,51 +560,70 @@ def test_amg_gmres_inner_solver_matches_direct(overrides):
     assert solver.stats()["vcycle_graph"] == ("graph_max_rows" in overrides)      # hipGraph replay of the V-cycle
 
 
-_COCG_AB_SCRIPT = r"""
-import hashlib, json, os, sys
-sys.path[:0] = [os.environ["HX_TEST_ROOT"], os.path.join(os.environ["HX_TEST_ROOT"], "helmholtz-x_amd")]
-os.environ.setdefault("HX_QUIET", "1")
-import numpy as np, torch
-import bench
-from helmholtz_x.acoustic_matrices import AcousticMatrices
-from helmholtz_x.amg import AMGSolver
-from helmholtz_x.petsc import combine_csr, to_device
-case = bench.build_case((10, 128, 12))
-P = case["P"]
-M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
-K = combine_csr(M.A.shape, M.A.csr_terms + [(P.target * c, m) for c, m in M.B.csr_terms]
-                + [(P.target ** 2 * c, m) for c, m in M.C.csr_terms])
-solver = AMGSolver(K, cocg_min_rows=0, recycle_min_rows=0, sell_min_rows=0)
-rng = np.random.default_rng(5)
-out = []
-for k in range(4):
-    b = to_device(rng.standard_normal(K.shape[0]) + 1j * rng.standard_normal(K.shape[0]))
-    x = torch.empty_like(b)
-    solver.solve(b, x, relax=1.0 if k < 3 else 1e3)
-    out.append([int(solver.last[0]), float(solver.last[1]), hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest()])
-print("RESULT " + json.dumps(out))
-"""
+def _cocg_ab_runs(options):
+    """Four solves with one hierarchy (the first one harvests with GMRES, the others run hx_cocg) under the given libhx options
+    (hx_set_option: effective from the next call -- nothing is latched per process any more): [(iterations, relres, sha256(x))]."""
+    import hashlib
+    import torch
+    import bench
+    from helmholtz_x import _hx
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.amg import AMGSolver
+    from helmholtz_x.petsc import combine_csr, to_device
+    for name, value in options.items():
+        _hx.set_option(name, value)
+    try:
+        case = bench.build_case((10, 128, 12))
+        P = case["P"]
+        M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+        K = combine_csr(M.A.shape, M.A.csr_terms + [(P.target * c, m) for c, m in M.B.csr_terms]
+                        + [(P.target ** 2 * c, m) for c, m in M.C.csr_terms])
+        solver = AMGSolver(K, cocg_min_rows=0, recycle_min_rows=0, sell_min_rows=0)
+        rng = np.random.default_rng(5)
+        out, xs = [], []
+        for k in range(4):
+            b = to_device(rng.standard_normal(K.shape[0]) + 1j * rng.standard_normal(K.shape[0]))
+            x = torch.empty_like(b)
+            solver.solve(b, x, relax=1.0 if k < 3 else 1e3)
+            r = torch.empty_like(b)
+            K.spmv(x, r)
+            true_rel = float(torch.linalg.norm(b - r) / torch.linalg.norm(b))
+            out.append([int(solver.last[0]), float(solver.last[1]), hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest()])
+            xs.append((x.clone(), true_rel))
+        return out, xs
+    finally:
+        for name in options:
+            _hx.set_option(name, None)
 
 
 def test_cocg_fused_reductions_and_lagged_norm_reads_leave_the_solve_bitwise_unchanged():
     """The single-GPU short cuts of hx_cocg -- consumers summing the stage-1 partials of the three reductions, |r_j| read while
     iteration j + 1 is queued -- change neither an iterate nor a stopping decision: same iteration counts, residuals and
-    solution BITS as the two-stage, wait-for-every-norm form (HX_COCG_FUSE_REDUCTIONS=0 HX_COCG_LAG=0), in separate processes
-    (the switches are read once per process)."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    runs = []
-    for env_extra in ({}, {"HX_COCG_LAG": "0"}, {"HX_COCG_LAG": "0", "HX_COCG_FUSE_REDUCTIONS": "0"}):
-        env = dict(os.environ, HX_TEST_ROOT=root, **env_extra)
-        p = subprocess.run([sys.executable, "-c", _COCG_AB_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
-        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
-        runs.append(json.loads(line[len("RESULT "):]))
+    solution BITS as the two-stage, wait-for-every-norm form (options cocg_lag = 0, cocg_fuse_reductions = 0, switched IN
+    PROCESS through hx_set_option: round 3 needed one process per setting because the switches were latched)."""
+    runs = [_cocg_ab_runs(opts)[0] for opts in ({}, {"cocg_lag": 0}, {"cocg_lag": 0, "cocg_fuse_reductions": 0})]
     assert runs[0] == runs[1] == runs[2]
     assert all(its > 3 for its, _, _ in runs[0][1:])          # (solve 0 is the harvested GMRES run; the others are COCG)
+
+
+def test_cocg_single_reduction_form_solves_to_the_same_tolerance_in_the_same_iterations():
+    """The single-reduction (Chronopoulos-Gear) form of the deflated COCG recurrence -- what the row-sharded solve runs so that an
+    inner iteration needs ONE all-reduce of k + 3 scalars instead of three reductions -- forced on one GPU
+    (cocg_single_reduction = 2): same solutions to the solver's tolerance, iteration counts within one of the classic form's
+    (the recurrences are algebraically equivalent; s = K p by recurrence and the alpha recurrence change rounding only),
+    true residuals at the requested level."""
+    import torch
+    classic, xc = _cocg_ab_runs({})
+    single, xs = _cocg_ab_runs({"cocg_single_reduction": 2})
+    assert classic[0] == single[0]                             # the GMRES solve that harvests the deflation pairs is untouched
+    for k in range(1, 4):
+        assert abs(classic[k][0] - single[k][0]) <= 1, (classic, single)
+        xa, ra = xc[k]
+        xb, rb = xs[k]
+        tol = 1e-11 * (1.0 if k < 3 else 1e3)
+        assert ra < 20 * tol and rb < 20 * tol, (k, ra, rb)
+        assert float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xa)) < 1e-7 * (1.0 if k < 3 else 1e3)
+    assert sum(r[0] for r in single[1:]) <= 1.02 * sum(r[0] for r in classic[1:]) + 1
 
 
 def test_cocg_initial_guess_is_used_checked_and_dropped():

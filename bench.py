@@ -254,6 +254,7 @@ def spmv_roofline(K, reps=50, in_situ=None, pmc=None):
                 avg_launch_ms=round(ms, 5),
                 timing="in situ: HIP events around %d launches of the timed region" % in_situ[0]
                 if (in_situ is not None and in_situ[0] > 0) else "back-to-back loop",
+                in_situ_launches_not_timed=(in_situ[2] if in_situ is not None and len(in_situ) > 2 else None),
                 back_to_back_loop_ms=round(loop_ms, 5),
                 csr_kernel={"kernel": "k_spmv<8, 0, c128> (hx_csr_spmv_z)", "avg_launch_ms": round(ms_csr, 5),
                             "achieved": round(alg_bytes / (ms_csr * 1e-3) / 1e9, 1),
@@ -557,8 +558,9 @@ def read_in_situ():
     _hx.check(_hx.lib.hx_profile_sell_spmv_read(C.byref(n_launch), C.byref(tot_ms)))
     n_sm, sm_ms = C.c_int64(0), C.c_double(0.0)
     _hx.check(_hx.lib.hx_profile_sell_read(1, C.byref(n_sm), C.byref(sm_ms)))
+    skipped = (int(_hx.lib.hx_profile_sell_skipped(0)), int(_hx.lib.hx_profile_sell_skipped(1)))
     _hx.check(_hx.lib.hx_profile_sell_spmv(0, 0))
-    return (n_launch.value, tot_ms.value), (n_sm.value, sm_ms.value)
+    return (n_launch.value, tot_ms.value, skipped[0]), (n_sm.value, sm_ms.value, skipped[1])
 
 
 def run_sharded(args, case, shape, rank, world, backend, n_dev, barrier):

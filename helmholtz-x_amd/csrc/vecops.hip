@@ -382,3 +382,135 @@ extern "C" int hx_zthreshold_pack(int64_t n, const hx_c128* x, double tol, int32
   HX_LAUNCH_CHECK("k_threshold_pack");
   return HX_OK;
 }
+
+// ---------------------------------------------------------------- small dense helpers of the solve path (were torch calls)
+// y = A x for a small row-major m x n matrix on the device (the r x r Woodbury coefficient matrix of the flame term,
+// r = number of flames <= 64): one block, one thread per row.
+__global__ void __launch_bounds__(64)
+k_small_gemv(int m, int n, const zc* __restrict__ A, const zc* __restrict__ x, zc* __restrict__ y) {
+  __shared__ zc xs[64];
+  if ((int)threadIdx.x < n) xs[threadIdx.x] = x[threadIdx.x];
+  __syncthreads();
+  const int i = threadIdx.x;
+  if (i < m) {
+    zc acc = make_double2(0.0, 0.0);
+    for (int j = 0; j < n; ++j) zfma(acc, A[i * n + j], xs[j]);
+    y[i] = acc;
+  }
+}
+extern "C" int hx_zsmall_gemv(int m, int n, const hx_c128* A, const hx_c128* x, hx_c128* y, hx_stream s) {
+  HX_REQUIRE(m >= 1 && m <= 64 && n >= 1 && n <= 64 && A && x && y && x != y, "bad argument (m, n <= 64)");
+  k_small_gemv<<<1, 64, 0, hx_s(s)>>>(m, n, (const zc*)A, (const zc*)x, (zc*)y);
+  HX_LAUNCH_CHECK("k_small_gemv");
+  return HX_OK;
+}
+
+// dst[(i + shift) mod n] = src[i]: cyclic shift (the translated Woodbury column of identical flames on a periodic numbering)
+__global__ void k_zroll(int64_t n, int64_t shift, const zc* __restrict__ src, zc* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t j = i + shift;
+    if (j >= n) j -= n;
+    dst[j] = src[i];
+  }
+}
+extern "C" int hx_zroll(int64_t n, int64_t shift, const hx_c128* src, hx_c128* dst, hx_stream s) {
+  HX_REQUIRE(n > 0 && src && dst && src != dst, "bad argument");
+  shift %= n;
+  if (shift < 0) shift += n;
+  k_zroll<<<hx_grid(n, 256), 256, 0, hx_s(s)>>>(n, shift, (const zc*)src, (zc*)dst);
+  HX_LAUNCH_CHECK("k_zroll");
+  return HX_OK;
+}
+
+// ---- in-place inverse of a dense n x n complex128 matrix (row-major) by Gauss-Jordan elimination with partial pivoting: the
+// coarsest operator of the V-cycle (n <= ~1000; applied as a dense product afterwards).  Per column: one single-block kernel finds
+// the pivot, swaps the two rows, scales the pivot row; one grid-wide kernel eliminates the column from every other row.  The
+// column permutation the row swaps imply is undone at the end, one thread per row.  2 n + 1 launches: ~10 ms at n = 1000 --
+// once per hierarchy, where a LAPACK call on the host (round 1) or rocSOLVER through torch (round 3) stood.
+__global__ void __launch_bounds__(256)
+k_gj_pivot(int n, int k, zc* __restrict__ A, int32_t* __restrict__ piv, int* __restrict__ singular) {
+  __shared__ double best[256];
+  __shared__ int where[256];
+  double b = -1.0;
+  int w = k;
+  for (int i = k + threadIdx.x; i < n; i += 256) {
+    const zc v = A[(int64_t)i * n + k];
+    const double a = v.x * v.x + v.y * v.y;
+    if (a > b) { b = a; w = i; }
+  }
+  best[threadIdx.x] = b; where[threadIdx.x] = w;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double c = best[threadIdx.x + o];
+      const int cw = where[threadIdx.x + o];
+      if (c > best[threadIdx.x] || (c == best[threadIdx.x] && cw < where[threadIdx.x])) { best[threadIdx.x] = c; where[threadIdx.x] = cw; }
+    }
+    __syncthreads();
+  }
+  const int p = where[0];
+  if (threadIdx.x == 0) { piv[k] = p; if (!(best[0] > 0.0)) *singular = 1; }
+  if (!(best[0] > 0.0)) return;
+  __shared__ zc dinv;
+  if (threadIdx.x == 0) dinv = zdiv(make_double2(1.0, 0.0), A[(int64_t)p * n + k]);
+  __syncthreads();
+  const zc d = dinv;
+  // swap rows k and p, then scale row k by 1/pivot with the pivot entry itself replaced by 1 (in-place Gauss-Jordan)
+  for (int j = threadIdx.x; j < n; j += 256) {
+    zc rk = A[(int64_t)p * n + j];
+    if (p != k) A[(int64_t)p * n + j] = A[(int64_t)k * n + j];
+    if (j == k) rk = make_double2(1.0, 0.0);
+    A[(int64_t)k * n + j] = zmul(rk, d);
+  }
+}
+__global__ void __launch_bounds__(256)
+k_gj_eliminate(int n, int k, zc* __restrict__ A, const int* __restrict__ singular) {
+  if (*singular) return;
+  const int i = blockIdx.x;                    // one block per row
+  if (i == k) return;
+  __shared__ zc f_s;
+  if (threadIdx.x == 0) { f_s = A[(int64_t)i * n + k]; }
+  __syncthreads();
+  const zc f = f_s;
+  if (f.x == 0.0 && f.y == 0.0) return;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    zc a = j == k ? make_double2(0.0, 0.0) : A[(int64_t)i * n + j];
+    const zc r = A[(int64_t)k * n + j];
+    a.x = fma(-f.x, r.x, a.x); a.x = fma(f.y, r.y, a.x);
+    a.y = fma(-f.x, r.y, a.y); a.y = fma(-f.y, r.x, a.y);
+    A[(int64_t)i * n + j] = a;
+  }
+}
+__global__ void k_gj_unpermute(int n, zc* __restrict__ A, const int32_t* __restrict__ piv, const int* __restrict__ singular) {
+  if (*singular) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = n - 1; k >= 0; --k) {
+    const int p = piv[k];
+    if (p != k) { const zc t = A[(int64_t)i * n + k]; A[(int64_t)i * n + k] = A[(int64_t)i * n + p]; A[(int64_t)i * n + p] = t; }
+  }
+}
+// SYNC (reads the singularity flag).  A: n x n row-major, overwritten by its inverse.
+extern "C" int hx_zdense_inverse(int n, hx_c128* A, hx_stream s) {
+  HX_REQUIRE(n >= 1 && n <= 4096 && A, "bad argument (n <= 4096)");
+  int32_t* piv = nullptr;
+  HX_HIP(hx_malloc(&piv, sizeof(int32_t) * (size_t)(n + 1)));
+  int* flag = (int*)(piv + n);
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), hx_s(s));
+  for (int k = 0; k < n && e == hipSuccess; ++k) {
+    k_gj_pivot<<<1, 256, 0, hx_s(s)>>>(n, k, (zc*)A, piv, flag);
+    k_gj_eliminate<<<n, 256, 0, hx_s(s)>>>(n, k, (zc*)A, flag);
+    if ((k & 63) == 63) e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    k_gj_unpermute<<<(n + 255) / 256, 256, 0, hx_s(s)>>>(n, (zc*)A, piv, flag);
+    e = hipGetLastError();
+  }
+  int h_flag = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, hx_s(s));
+  if (e == hipSuccess) e = hipStreamSynchronize(hx_s(s));
+  (void)hx_free(piv);
+  if (e != hipSuccess) return hx_fail(HX_ERR_HIP, "hx_zdense_inverse", hipGetErrorString(e));
+  if (h_flag) return hx_fail(HX_ERR_BREAKDOWN, "hx_zdense_inverse", "singular matrix");
+  return HX_OK;
+}

@@ -56,6 +56,7 @@ SIGNATURES = {
     "hx_sell_smooth_c64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, C.c_float, _vp]),
     "hx_sell_destroy": (C.c_int, [_vp]),
     "hx_profile_sell_spmv": (C.c_int, [_int, _i32]),
+    "hx_profile_sell_skipped": (_i64, [_int]),
     "hx_profile_sell_spmv_read": (C.c_int, [C.POINTER(_i64), C.POINTER(C.c_double)]),
     "hx_profile_sell_read": (C.c_int, [_int, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "hx_build_v2e": (C.c_int, [_i32, _i32, _int, _vp, _vp, _vp, _vp]),
@@ -109,6 +110,9 @@ SIGNATURES = {
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
     "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_BEGIN_FN, HALO_END_FN]),
     "hx_amg_set_prolongator_ghost_rows": (C.c_int, [_vp, C.c_int]),
+    "hx_zsmall_gemv": (C.c_int, [_int, _int, _vp, _vp, _vp, _vp]),
+    "hx_zroll": (C.c_int, [_i64, _i64, _vp, _vp, _vp]),
+    "hx_zdense_inverse": (C.c_int, [_int, _vp, _vp]),
     "hx_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "hx_get_option": (C.c_int, [C.c_char_p, C.c_char_p, _int]),
     "hx_pool_trim": (C.c_int, []),

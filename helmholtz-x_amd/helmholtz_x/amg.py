@@ -761,14 +761,16 @@ class AMGSolver:
                 _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), None, 0, 0, None,
                                     None, None, 0, None, None, None))
                 if isinstance(lv["K"], DevCSR):
-                    # dense inverse of the coarsest operator in HBM (rocSOLVER through torch.linalg.inv: plain dense LAPACK
-                    # work, as the host's np.linalg.inv was), handed to the V-cycle as a dense CSR
+                    # dense inverse of the coarsest operator in HBM (hx_zdense_inverse: Gauss-Jordan with partial pivoting on
+                    # the device; rocSOLVER through torch.linalg.inv in round 3, np.linalg.inv on the host before), handed to
+                    # the V-cycle as a dense CSR
                     Kc, nc = lv["K"], lv["n"]
                     dense = torch.zeros((nc, nc), dtype=torch.complex128, device=dev)
                     lens = (Kc.rowptr[1:] - Kc.rowptr[:-1]).long()
                     rows = torch.repeat_interleave(torch.arange(nc, device=dev), lens)
                     dense[rows, Kc.col.long()] = Kc.val
-                    inv = torch.linalg.inv(dense)
+                    _hx.check(_hx.lib.hx_zdense_inverse(nc, _hx.ptr(dense), _hx.stream()))
+                    inv = dense
                     crp = torch.arange(0, nc * nc + 1, nc, dtype=torch.int32, device=dev)
                     cci = torch.arange(nc, dtype=torch.int32, device=dev).repeat(nc)
                     cva = inv.reshape(-1).to(cdt).contiguous()
@@ -826,6 +828,13 @@ class AMGSolver:
              + "  (operator complexity %.2f)" % (sum(lv["K"].nnz for lv in levels) / levels[0]["K"].nnz))
 
     supports_x0 = True
+
+    def set_rtol(self, rtol):
+        """Relative tolerance of the inner solves (default 1e-11).  The eigen-solver lowers it when the caller asks the fixed
+        point for more digits than 1e-11 solves leave in the eigenvalue (``fixed_point_iteration(tol=1e-8)`` at |omega| ~ 10^3 is a
+        relative 6e-12: the reference's direct solve delivers it; see eigensolvers._inner_rtol)."""
+        self.params["rtol"] = float(rtol)
+        self.krylov_tol_floor = 10.0 * self.params["rtol"]
 
     def solve(self, b, x, relax=1.0, x0=False):
         """``relax`` >= 1 multiplies the relative tolerance (inexact-Krylov relaxation decided by the eigen-solver).

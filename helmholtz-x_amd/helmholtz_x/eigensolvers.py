@@ -94,6 +94,16 @@ def _fmt(tol):
     return "{{:+.{}f}}".format(digits)
 
 
+def _inner_rtol(tol, target):
+    """Relative tolerance the iterative inner solves need so that the eigenvalue noise stays an order of magnitude below the
+    stopping tolerance ``tol`` of the fixed point (an ABSOLUTE tolerance on omega, eigensolvers.py:155,223).  The reference's
+    direct solve (PCLU) leaves ~1e-15; the default 1e-11 is enough down to tol/|omega| = 1e-10 and is tightened below that, to at
+    most 1e-13 -- FlamedDuct's default call (tol = 1e-8 at |omega| = 1650, i.e. 6e-12 relative) then stops at the same
+    iteration as the reference's log instead of one later on 1e-8 worth of solver noise."""
+    rel = tol / max(abs(target), 1e-300)
+    return min(1e-11, max(1e-13, 0.1 * rel))
+
+
 def _flame_matrix(D, omega, problem_type):
     D.assemble_matrix(omega, problem_type)
     if problem_type == 'direct':
@@ -152,7 +162,7 @@ def fixed_point_iteration_eps(operators, D, target, nev=2, i=0, tol=1e-8, maxite
                               problem_type='direct', two_sided=False, st_type=None, history=None, shard=None):
     A, C = operators.A, operators.C
     B = operators.B_adj if problem_type == 'adjoint' else operators.B
-    caches = ({}, {}, {})       # inner solvers, Woodbury W, warm-start vector + counters
+    caches = ({}, {}, {"inner_rtol": _inner_rtol(tol, target)})       # inner solvers, Woodbury W, warm-start vector + counters
     s = _fmt(tol)
     info("--> Fixed point iteration started.\n")
 
@@ -178,7 +188,7 @@ def fixed_point_iteration_pep(operators, D, target, nev=2, i=0, tol=1e-8, maxite
                               problem_type='direct', st_type=None, history=None, shard=None):
     A, C = operators.A, operators.C
     B = operators.B_adj if problem_type == 'adjoint' else operators.B
-    caches = ({}, {}, {})       # inner solvers, Woodbury W, warm-start vector + counters
+    caches = ({}, {}, {"inner_rtol": _inner_rtol(tol, target)})       # inner solvers, Woodbury W, warm-start vector + counters
     s = _fmt(tol)
 
     def passive(nev_req):

@@ -191,6 +191,7 @@ class WoodburySolver:
             # right factors are built once (the dense rows of U alone are 16 x n x 16 bytes: 1.3 GB of traffic at 5 M DOF)
             self.W, self.VtW, self.v_ptr, self.v_idx, self.v_val, self.t_dev = W_cache[key]
             self.r = self.W.shape[0]
+            self.h_dev = torch.empty_like(self.t_dev)
             self.small = np.linalg.inv(np.eye(self.r) + self.coefs[:, None] * self.VtW) * self.coefs[None, :]
             self.small_dev = to_device(np.ascontiguousarray(self.small))
             return
@@ -213,6 +214,7 @@ class WoodburySolver:
         self.v_idx = to_device(np.concatenate(idxs).astype(np.int32) if off else np.zeros(1, np.int32))
         self.v_val = to_device(np.concatenate(vals).astype(np.complex128) if off else np.zeros(1, np.complex128))
         self.t_dev = torch.empty(self.r, dtype=torch.complex128, device=dev)
+        self.h_dev = torch.empty_like(self.t_dev)
         self.W = torch.empty_like(U)                         # rows: K^-1 u_f
         # identical flames on a periodically numbered mesh: u_f is u_0 translated by s_f rows.  The translated solution
         # of flame 0 is then the initial guess for flame f -- exact when K has the same periodicity (an annular
@@ -243,8 +245,10 @@ class WoodburySolver:
             # W only enters through the rank-r correction, whose weight in the eigenvalue is the flame's (a few
             # per cent): a looser tolerance (W_RELAX) leaves the eigenvalues unchanged far below the parity bar
             if shifts is not None and f > 0:
-                self.W[f].copy_(torch.roll(self.W[0], shifts[f]) if shard is None
-                                else shard.cyclic_shift(self.W[0], shifts[f]))
+                if shard is None:
+                    _hx.check(_hx.lib.hx_zroll(self.n, int(shifts[f]), _hx.ptr(self.W[0]), _hx.ptr(self.W[f]), _hx.stream()))
+                else:
+                    self.W[f].copy_(shard.cyclic_shift(self.W[0], shifts[f]))
                 inner.solve(U[f], self.W[f], relax=W_RELAX, x0=True)
                 self.warm_started += 1
             else:
@@ -276,7 +280,12 @@ class WoodburySolver:
             return
         # x -= W [(I + diag(c) V^T W)^-1 diag(c)] V^T x: the r sparse dots, the r x r product and the panel update stay on the
         # device (was: dots -> host, numpy product, coefficients -> device: two synchronising copies per operator application)
-        h = torch.mv(self.small_dev, self._vt_dev(x))
+        t = self._vt_dev(x)
+        if self.r <= 64:
+            _hx.check(_hx.lib.hx_zsmall_gemv(self.r, self.r, _hx.ptr(self.small_dev), _hx.ptr(t), _hx.ptr(self.h_dev), _hx.stream()))
+            h = self.h_dev
+        else:                                   # (more than 64 rank-1 pieces: no example of the reference has them)
+            h = torch.mv(self.small_dev, t)
         _hx.check(_hx.lib.hx_zpanel_sub(self.n, self.r, _hx.ptr(self.W), self.W.stride(0), _hx.ptr(h), _hx.ptr(x),
                                         _hx.stream()))
 
@@ -693,10 +702,10 @@ class _EigenSolverBase:
         self._basis = basis
         if self.state is not None:
             kc = max(1, min(res.nconv, self._nev))
-            self.state["start"] = basis.V[:kc].sum(dim=0)                       # next lean solve: converged pairs only
+            self.state["start"] = _row_sum(basis.V, kc)                         # next lean solve: converged pairs only
             self._remember(basis, kc)
             k = min(len(res.theta), kc + n_extra)
-            self.state["start_wide"] = basis.V[:k].sum(dim=0) if k > kc else None  # a following solve that wants more pairs
+            self.state["start_wide"] = _row_sum(basis.V, k) if k > kc else None    # a following solve that wants more pairs
             self.state["krylov_ops"] = self.state.get("krylov_ops", 0) + basis.n_ops
             self.state["restarts"] = self.state.get("restarts", 0) + res.its
             self.state["eig_solves"] = self.state.get("eig_solves", 0) + 1
@@ -719,6 +728,9 @@ class _EigenSolverBase:
         if self.inner_cache is not None and key in self.inner_cache:
             return self.inner_cache[key]
         solver = make_inner_solver(K, st_type=self.st_type, shard=self.shard)
+        rtol = None if self.state is None else self.state.get("inner_rtol")
+        if rtol is not None and hasattr(solver, "set_rtol"):
+            solver.set_rtol(rtol)            # (the direct route ignores it: its solves are exact to rounding)
         if self.inner_cache is not None:
             self.inner_cache[key] = solver
         return solver
@@ -788,6 +800,15 @@ class _EigenSolverBase:
         cf = (C.c_double * 4)((1 + t).real, (1 + t).imag, (-t).real, (-t).imag)
         _hx.check(_hx.lib.hx_zlincomb(x1.numel(), 2, cf, arr, _hx.ptr(out), _hx.stream()))
         return out
+
+
+def _row_sum(V, k):
+    """V[0] + ... + V[k-1] of a row-major panel (hx_zpanel_mul with a column of ones)."""
+    n = V.shape[1]
+    out = torch.empty(n, dtype=torch.complex128, device=V.device)
+    ones = to_device(np.ones(k, dtype=np.complex128))
+    _hx.check(_hx.lib.hx_zpanel_mul(n, k, 1, _hx.ptr(V), V.stride(0), _hx.ptr(ones), _hx.ptr(out), n, _hx.stream()))
+    return out
 
 
 def _term_key(mat):

@@ -128,6 +128,14 @@ int hx_zpanel_sub_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx_
 /* Vout[:, :kout] = V[:, :m] Q,  Q (m x kout) column-major on the device (Krylov-Schur restart). */
 int hx_zpanel_mul(int64_t n, int m, int kout, const hx_c128* V, int64_t ldv, const hx_c128* Q,
                   hx_c128* Vout, int64_t ldvout, hx_stream s);
+/* Small dense helpers of the solve path (round 4: these were torch calls).  hx_zsmall_gemv: y = A x for a row-major m x n matrix
+ * on the device, m, n <= 64 (the r x r coefficient matrix of the Woodbury update of the flame term, flame_matrices.py:170-177 keeps
+ * r = number of flames).  hx_zroll: dst[(i + shift) mod n] = src[i].  hx_zdense_inverse (SYNC): in-place inverse of a row-major
+ * n x n matrix, n <= 4096, Gauss-Jordan with partial pivoting -- the coarsest operator of the V-cycle; HX_ERR_BREAKDOWN if singular.
+ * replaces: the coarse LU inside the reference's PCLU (eigensolvers.py:50,103 via MUMPS) for that level. */
+int hx_zsmall_gemv(int m, int n, const hx_c128* A, const hx_c128* x, hx_c128* y, hx_stream s);
+int hx_zroll(int64_t n, int64_t shift, const hx_c128* src, hx_c128* dst, hx_stream s);
+int hx_zdense_inverse(int n, hx_c128* A, hx_stream s);
 /* Sparse dots t[f] = sum_i vals[ptr[f]+i] * y[idx[ptr[f]+i]]  (the b_f^T y of the rank-1 flame
  * operator kept factored; replaces the explicit D of flame_matrices.py:91-92,176,233). */
 int hx_zsparse_dots(int nvec, const int32_t* ptr, const int32_t* idx, const hx_c128* vals,
@@ -182,13 +190,15 @@ int hx_sell_smooth_c64(const hx_sell* h, const hx_c64* dinv, const hx_c64* b, co
                        float omega, const hx_c64* xprev, float mom, hx_stream s);
 int hx_sell_destroy(hx_sell* h);
 /* In-situ timing of hx_sell_spmv_z (the operator product = the roofline kernel): once enabled, every launch on an operator
- * with at least min_rows rows is bracketed by HIP events on its launch stream (up to 16384 launches, no synchronisation);
- * the read-out waits for the recorded events and returns their count and summed duration. */
+ * with at least min_rows rows is bracketed by HIP events on its launch stream (up to 262144 launches, events created in
+ * chunks as needed, no synchronisation); the read-out waits for the recorded events and returns their count and summed
+ * duration; hx_profile_sell_skipped: launches that qualified but were not bracketed (cap reached, or inside a graph capture). */
 int hx_profile_sell_spmv(int enable, int32_t min_rows);
 int hx_profile_sell_spmv_read(int64_t* launches, double* total_ms);
 /* the same for kind 0 = hx_sell_spmv_z, kind 1 = hx_sell_smooth_c64 (the V-cycle smoother step, the kernel with the largest
  * share of the run time) on operators with at least min_rows rows */
 int hx_profile_sell_read(int kind, int64_t* launches, double* total_ms);
+int64_t hx_profile_sell_skipped(int kind);
 
 /* ------------------------------------------------------------------ P1 assembly (DOLFINx assemble_*)
  * Vertex-centric "owner computes" assembly: one CSR row per vertex, gathered from the cells incident

@@ -26,6 +26,10 @@ def _rand_c(rng, *shape):
     return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
 
 
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(np.asarray(b))), 1e-300))
+
+
 @pytest.mark.parametrize("n,density", [(1, 1.0), (257, 0.05), (5000, 0.003), (20000, 0.0008)])
 def test_spmv_random_all_lane_widths(hx, n, density):
     from helmholtz_x.petsc import CSR
@@ -701,3 +705,82 @@ def test_shape_derivative_functional_kernel(degree):
                                     cd.x.array, degree=degree, cell_dofs=cell_dofs, c_is_cellwise=True)
     got = boundary_functional(mesh, tags, 6, V2, p2, q2, cd, degree=degree)
     assert abs(got - ref) < 1e-12 * abs(ref)
+
+
+def test_small_dense_helpers_of_the_solve_path():
+    """hx_zsmall_gemv, hx_zroll, hx_zdense_inverse (round 4: the r x r Woodbury product, the translated Woodbury column and the
+    coarsest-level inverse were torch calls) against NumPy; the inverse with a matrix that NEEDS its row pivoting, and a
+    singular one is reported."""
+    import torch
+    from helmholtz_x import _hx
+    from helmholtz_x.petsc import to_device
+    rng = np.random.default_rng(3)
+    for m, n in ((16, 16), (1, 5), (64, 64), (7, 3)):
+        A, x = _rand_c(rng, m * n).reshape(m, n), _rand_c(rng, n)
+        y = torch.empty(m, dtype=torch.complex128, device="cuda")
+        Ad, xd = to_device(A), to_device(x)           # (named: the device copies must outlive the launch)
+        _hx.check(_hx.lib.hx_zsmall_gemv(m, n, _hx.ptr(Ad), _hx.ptr(xd), _hx.ptr(y), _hx.stream()))
+        assert _rel(y.cpu().numpy(), A @ x) < 1e-14
+    assert _hx.lib.hx_zsmall_gemv(65, 4, None, None, None, _hx.stream()) != 0
+    for n, shift in ((1000, 17), (1000, -17), (5, 12), (64, 0)):
+        x = _rand_c(rng, n)
+        dst = torch.empty(n, dtype=torch.complex128, device="cuda")
+        xd = to_device(x)
+        _hx.check(_hx.lib.hx_zroll(n, shift, _hx.ptr(xd), _hx.ptr(dst), _hx.stream()))
+        assert np.array_equal(dst.cpu().numpy(), np.roll(x, shift))
+    for n in (1, 2, 37, 300, 1000):
+        A = _rand_c(rng, n * n).reshape(n, n) + 0.1 * np.eye(n)
+        if n > 2:
+            A[0, 0] = 0.0                     # a zero on the diagonal: elimination without row exchanges would stop here
+            A[[1, n - 1]] = A[[n - 1, 1]]
+        d = to_device(A.copy())
+        _hx.check(_hx.lib.hx_zdense_inverse(n, _hx.ptr(d), _hx.stream()))
+        inv = d.cpu().numpy()
+        assert np.max(np.abs(inv @ A - np.eye(n))) < 1e-10 * np.linalg.cond(A) / max(n, 10) + 1e-11, n
+        assert _rel(inv, np.linalg.inv(A)) < 1e-9
+    Sd = to_device(np.ones((6, 6), dtype=complex))
+    assert _hx.lib.hx_zdense_inverse(6, _hx.ptr(Sd), _hx.stream()) == _hx.ERR_BREAKDOWN
+    # options registry: an override is visible at once and removable
+    _hx.set_option("cocg_lag", 0)
+    assert _hx.get_option("cocg_lag") == "0"
+    _hx.set_option("cocg_lag", None)
+    assert _hx.get_option("cocg_lag", "unset") in ("unset", __import__("os").environ.get("HX_COCG_LAG", "unset"))
+
+
+def test_pool_orders_the_reuse_of_cached_blocks_across_streams():
+    """Device-buffer pool: a block released while a kernel of a NON-DEFAULT (non-blocking) torch stream still writes
+    it is handed to the next request of the same size only after that kernel has finished -- the release records events on the
+    caller's streams, the reuse waits for them.  Checked with a long-running fill on a side stream followed at once by a release
+    and a re-allocation through the library (SELL-64 handles are pooled blocks)."""
+    import ctypes as C
+    import torch
+    from helmholtz_x import _hx
+    ev0, w0 = C.c_int64(0), C.c_int64(0)
+    _hx.check(_hx.lib.hx_pool_ordering_stats(C.byref(ev0), C.byref(w0), None))
+    import scipy.sparse as sp
+    from helmholtz_x.petsc import CSR
+    n = 400_000
+    A = sp.diags([np.full(n, 2.0 + 1j), np.full(n - 1, -1.0 + 0j), np.full(n - 1, -1.0 + 0j)], [0, 1, -1]).tocsr()
+    K = CSR.from_scipy(A)
+    side = torch.cuda.Stream()
+    x = torch.ones(n, dtype=torch.complex128, device="cuda")
+    y = torch.empty_like(x)
+    one, zero = _hx.z2(1.0), _hx.z2(0.0)
+    results = []
+    for rep in range(3):
+        h = C.c_void_p()
+        with torch.cuda.stream(side):
+            _hx.check(_hx.lib.hx_sell_create(C.byref(h), n, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val), 1, 0, _hx.stream()))
+            for _ in range(20):
+                _hx.check(_hx.lib.hx_sell_spmv_z(h, _hx.ptr(x), _hx.ptr(y), one, zero, _hx.stream()))
+            results.append(y.clone())
+            _hx.lib.hx_sell_destroy(h)         # its blocks go to the cache while the side stream may still be running
+    torch.cuda.synchronize()
+    ref = A @ np.ones(n)
+    for r in results:
+        assert _rel(r.cpu().numpy(), ref) < 1e-14
+    ev1, w1, cap = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    _hx.check(_hx.lib.hx_pool_ordering_stats(C.byref(ev1), C.byref(w1), C.byref(cap)))
+    assert ev1.value > ev0.value and w1.value > w0.value       # releases recorded events, reuses waited for them
+    free_b, total_b = torch.cuda.mem_get_info()
+    assert 0 < cap.value <= total_b // 4

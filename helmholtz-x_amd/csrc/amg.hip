@@ -58,6 +58,15 @@ int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
 int hx_csr_norm_inf(int32_t, const int32_t*, const hx_c128*, void*, double*, hx_stream);
 int hx_cast_c2z(int64_t, const float*, hx_c128*, hx_stream);
 
+// block kernels (block.hip)
+extern "C" int hx_block_width(void);
+int hx_sell_spmm_c64(const hx_sell*, const hx_c64*, hx_c64*, float, float, const hx_c64*, hx_stream);
+int hx_sell_smooth_blk_c64(const hx_sell*, const hx_c64*, const hx_c64*, const hx_c64*, hx_c64*, float, const hx_c64*, float, hx_stream);
+int hx_csr_spmm_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, bool, const float*, float*, float, float, const float*, hx_stream);
+int hx_csr_smooth_blk_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, float*, float,
+                        const float*, float, hx_stream);
+int hx_cdiag_scale_blk(int64_t, float, const float*, const float*, float*, hx_stream);
+
 static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0}, MONE[2] = {-1.0, 0.0};
 
 static void drop_graph(hx_amg* h) {
@@ -161,6 +170,7 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
   };
   for (auto& l : h->D.L) release(l);
   for (auto& l : h->S.L) release(l);
+  for (auto& l : h->blk) release(l);
   (void)hx_free(h->rec.U); (void)hx_free(h->rec.CV); (void)hx_free(h->rec.CVf);
   (void)hx_free(h->rec.Uf); (void)hx_free(h->rec.Cd); (void)hx_free(h->rec.Einv);
   if (h->vexec) (void)hipGraphExecDestroy(h->vexec);
@@ -462,6 +472,83 @@ int hx_amg_vcycle_c64(hx_amg* h, hx_stream s) {
     return HX_OK;
   }
   return vcycle<float>(h, h->S, 0, L0.b, L0.r, s);
+}
+
+// ---- the complex64 V-cycle on a BLOCK of hx_block_width() interleaved right-hand sides (single GPU): the same cycle as
+// vcycle<float> -- same smoother polynomials, same transfers, same coarse inverse -- with every pass shared by the block.
+static int vcycle_blk(hx_amg* h, int l, const float* b, float* xout, hx_stream s) {
+  HierT<float>& H = h->S;
+  LevelT<float>& L = H.L[l];
+  int rc;
+  if (l == (int)H.L.size() - 1)
+    return hx_csr_spmm_c(H.coarse_inv.rows, H.coarse_inv.nnz, H.coarse_inv.rp, H.coarse_inv.ci, H.coarse_inv.va, H.coarse_inv.real_vals,
+                         b, xout, 1.f, 0.f, nullptr, s);
+  const bool cheb = L.rho > 0.0;
+  const Cheb C = cheb ? cheb_coeffs(L.rho) : Cheb();
+  const int extra = (int)HX_OPT_INT("amg_coarse_extra", 0);
+  const int n_pre = h->pre + (l > 0 ? extra : 0), n_post = h->post + (l > 0 ? extra : 0);
+  hx_amg::BlkBuf& W = h->blk[l];
+  hx_amg::BlkBuf& Wc = h->blk[l + 1];
+  float* bufs[3] = {W.x, W.x2, W.x3};
+  auto other = [&](const float* a, const float* c) -> float* { for (float* q : bufs) if (q != a && q != c) return q; return nullptr; };
+  auto smooth = [&](const float* xin, float* out, double w, const float* xprev, double mom) -> int {
+    if (L.sell) return hx_sell_smooth_blk_c64(L.sell, (const hx_c64*)L.dinv, (const hx_c64*)b, (const hx_c64*)xin, (hx_c64*)out, (float)w,
+                                              (const hx_c64*)xprev, (float)mom, s);
+    return hx_csr_smooth_blk_c(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, xin, out, (float)w, xprev, (float)mom, s);
+  };
+  float* cur = W.x;
+  float* prev = nullptr;
+  LevelT<float>& Lc = H.L[l + 1];
+  if (n_pre == 0) {
+    if ((rc = hx_csr_spmm_c(L.R.rows, L.R.nnz, L.R.rp, L.R.ci, L.R.va, L.R.real_vals, b, Wc.b, 1.f, 0.f, nullptr, s))) return rc;
+  } else {
+    if ((rc = hx_cdiag_scale_blk(L.n, (float)(cheb ? C.a[0] : h->omega), L.dinv, b, cur, s))) return rc;
+    for (int k = 1; k < n_pre; ++k) {
+      float* nxt = other(cur, prev);
+      if ((rc = cheb ? smooth(cur, nxt, C.a[k < 4 ? k : 3], prev, C.c[k < 4 ? k : 3]) : smooth(cur, nxt, h->omega, nullptr, 0.0))) return rc;
+      prev = cur; cur = nxt;
+    }
+    if (L.sell) { if ((rc = hx_sell_spmm_c64(L.sell, (const hx_c64*)cur, (hx_c64*)W.r, -1.f, 1.f, (const hx_c64*)b, s))) return rc; }
+    else if ((rc = hx_csr_spmm_c(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, false, cur, W.r, -1.f, 1.f, b, s))) return rc;
+    if ((rc = hx_csr_spmm_c(L.R.rows, L.R.nnz, L.R.rp, L.R.ci, L.R.va, L.R.real_vals, W.r, Wc.b, 1.f, 0.f, nullptr, s))) return rc;
+  }
+  float* ec = Wc.r;
+  if ((rc = vcycle_blk(h, l + 1, Wc.b, ec, s))) return rc;
+  (void)Lc;
+  if ((rc = hx_csr_spmm_c(L.P.rows, L.P.nnz, L.P.rp, L.P.ci, L.P.va, L.P.real_vals, ec, cur, 1.f, n_pre == 0 ? 0.f : 1.f, nullptr, s))) return rc;
+  prev = nullptr;
+  for (int k = 0; k < n_post; ++k) {
+    float* dst = (k == n_post - 1) ? xout : other(cur, prev);
+    if ((rc = cheb ? smooth(cur, dst, C.a[k < 4 ? k : 3], k ? prev : nullptr, k ? C.c[k < 4 ? k : 3] : 0.0)
+                   : smooth(cur, dst, h->omega, nullptr, 0.0))) return rc;
+    prev = cur; cur = dst;
+  }
+  if (n_post == 0)
+    HX_HIP(hipMemcpyAsync(xout, cur, 2 * sizeof(float) * (size_t)L.n * hx_block_width(), hipMemcpyDeviceToDevice, hx_s(s)));
+  return HX_OK;
+}
+// input / output buffers of the block cycle (level 0: b and r, as for the single-vector cycle); allocates the block work vectors
+int hx_amg_vcycle_blk_buffers(hx_amg* h, hx_c64** b, hx_c64** z) {
+  HX_REQUIRE(h && b && z && h->single && !h->sharded && h->S.coarse_inv.rp && !h->S.L.empty() && h->S.L[0].n > 0,
+             "the block cycle needs the complex64 hierarchy on one GPU");
+  if (h->blk.empty()) {
+    h->blk.resize(h->S.L.size());
+    const size_t nb = (size_t)hx_block_width();
+    for (size_t l = 0; l < h->S.L.size(); ++l) {
+      const size_t bytes = 2 * sizeof(float) * (size_t)h->S.L[l].n * nb;
+      hx_amg::BlkBuf& W = h->blk[l];
+      HX_HIP(hx_malloc(&W.b, bytes));
+      HX_HIP(hx_malloc(&W.r, bytes));
+      if (l + 1 < h->S.L.size()) { HX_HIP(hx_malloc(&W.x, bytes)); HX_HIP(hx_malloc(&W.x2, bytes)); HX_HIP(hx_malloc(&W.x3, bytes)); }
+    }
+  }
+  *b = (hx_c64*)h->blk[0].b;
+  *z = (hx_c64*)h->blk[0].r;
+  return HX_OK;
+}
+int hx_amg_vcycle_blk(hx_amg* h, hx_stream s) {
+  HX_REQUIRE(h && !h->blk.empty(), "hx_amg_vcycle_blk_buffers first");
+  return vcycle_blk(h, 0, h->blk[0].b, h->blk[0].r, s);
 }
 
 extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream s) {

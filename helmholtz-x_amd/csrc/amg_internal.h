@@ -72,4 +72,8 @@ struct hx_amg {
   // so that the host can read the norm of iteration j while iteration j + 1 is already queued
   void* cg_pin = nullptr;
   hipEvent_t cg_ev[2] = {nullptr, nullptr};
+  // work vectors of the BLOCK V-cycle (block.hip / hx_amg_vcycle_blk: hx_block_width() interleaved complex64 vectors per level),
+  // allocated at the first block cycle
+  struct BlkBuf { float *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr; };
+  std::vector<BlkBuf> blk;
 };

@@ -110,6 +110,12 @@ SIGNATURES = {
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
     "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_BEGIN_FN, HALO_END_FN]),
     "hx_amg_set_prolongator_ghost_rows": (C.c_int, [_vp, C.c_int]),
+    "hx_block_width": (C.c_int, []),
+    "hx_zblock_pack": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp]),
+    "hx_zblock_unpack": (C.c_int, [_i64, _int, _vp, _vp, _i64, _vp]),
+    "hx_sell_spmm_z": (C.c_int, [_vp, _vp, _vp, _dp, _dp, _vp]),
+    "hx_cocg_block_ws": (C.c_size_t, [_i64]),
+    "hx_cocg_block": (C.c_int, [_vp, _i32, _vp, _int, _vp, _vp, C.c_double, _int, _vp, C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_zsmall_gemv": (C.c_int, [_int, _int, _vp, _vp, _vp, _vp]),
     "hx_zroll": (C.c_int, [_i64, _i64, _vp, _vp, _vp]),
     "hx_zdense_inverse": (C.c_int, [_int, _vp, _vp]),

@@ -871,6 +871,55 @@ class AMGSolver:
             raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
                                   % (rr.value, it.value))
 
+    # ---- blocks of right-hand sides (csrc/cocg_block.hip)
+    def block_ready(self):
+        """The batched route: single GPU, SELL-64 fine level with complex128 values, complex64 V-cycle, COCG in use and its
+        deflation pairs prepared by an earlier solve (or none wanted)."""
+        return (self.shard is None and self.sell is not None and self.use_cocg and self.params["precision"] == "mixed"
+                and os.environ.get("HX_BLOCK_SOLVES", "1") != "0"
+                and (self.recycle_k == 0 or (self.recycled and self.cocg_solves > 0)))
+
+    def solve_block(self, B, X, relax=1.0):
+        """K X[c] = B[c] for the rows of the row-major panels B, X (nb x n): groups of hx_block_width() columns run side by side
+        (hx_cocg_block); a column the batched recurrence leaves above the acceptance band is finished by ``solve`` from where it
+        stands.  Falls back to one ``solve`` per row when the batched route is not available."""
+        import time
+        nb = B.shape[0]
+        if not self.block_ready():
+            for c in range(nb):
+                self.solve(B[c], X[c], relax=relax)
+            return
+        t0 = time.perf_counter()
+        w = _hx.lib.hx_block_width()
+        rtol = self.params["rtol"] * max(float(relax), 1.0)
+        if getattr(self, "_blk_ws", None) is None:
+            self._blk_ws = _hx.device_empty(int(_hx.lib.hx_cocg_block_ws(self.n)), torch.complex128, B.device)
+            self._blk_b = _hx.device_empty(self.n * w, torch.complex128, B.device)
+            self._blk_x = _hx.device_empty(self.n * w, torch.complex128, B.device)
+        its, rrs = (C.c_int * w)(), (C.c_double * w)()
+        redo = []
+        for c0 in range(0, nb, w):
+            m = min(w, nb - c0)
+            _hx.check(_hx.lib.hx_zblock_pack(self.n, m, _hx.ptr(B[c0]), B.stride(0), _hx.ptr(self._blk_b), _hx.stream()))
+            rc = _hx.lib.hx_cocg_block(self.handle, self.n, self.sell, m, _hx.ptr(self._blk_b), _hx.ptr(self._blk_x), rtol,
+                                       self.params["max_it"], _hx.ptr(self._blk_ws), its, rrs, _hx.stream())
+            if rc == _hx.ERR_BREAKDOWN:                  # a recurrence broke down: the whole group goes the single-vector way
+                redo += [(c, False) for c in range(c0, c0 + m)]
+                continue
+            _hx.check(rc)
+            _hx.check(_hx.lib.hx_zblock_unpack(self.n, m, _hx.ptr(self._blk_x), _hx.ptr(X[c0]), X.stride(0), _hx.stream()))
+            self.block_solves = getattr(self, "block_solves", 0) + 1
+            self.block_columns = getattr(self, "block_columns", 0) + m
+            self.block_iters = getattr(self, "block_iters", 0) + max(its[c] for c in range(m))
+            for c in range(m):
+                self.total_iters += its[c]
+                self.n_solves += 1
+                if not (rrs[c] <= 10 * rtol):
+                    redo.append((c0 + c, True))
+        self.solve_s += time.perf_counter() - t0
+        for c, warm in redo:
+            self.solve(B[c], X[c], relax=relax, x0=warm)
+
     def _solve_gmres(self, b, x, rtol, it, rr):
         K = self.K
         if self.shard is not None:
@@ -977,7 +1026,9 @@ class AMGSolver:
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1),
                     harmonic_ritz=[round(float(t), 3) for t in getattr(self, "harmonic_ritz", [])],
                     warm_starts=getattr(self, "warm_starts", 0),
-                    cocg_halos=getattr(self, "cocg_halos", 0), cocg_allreduces=getattr(self, "cocg_allreduces", 0))
+                    cocg_halos=getattr(self, "cocg_halos", 0), cocg_allreduces=getattr(self, "cocg_allreduces", 0),
+                    block_solves=getattr(self, "block_solves", 0), block_columns=getattr(self, "block_columns", 0),
+                    block_iters=getattr(self, "block_iters", 0))
 
     def destroy(self):
         if getattr(self, "handle", None):

@@ -241,7 +241,14 @@ class WoodburySolver:
                         lefts.append((idx[order], val[order]))
                 shifts = translation_shifts(lefts, shard.n_global)
         self.warm_started = 0
-        for f in range(self.r):
+        if shifts is None and self.r > 1 and getattr(inner, "block_ready", lambda: False)():
+            # flames that are NOT translates of each other (every unstructured mesh): the r columns share the operator, so
+            # they are solved in blocks -- each pass over the matrix serves hx_block_width() columns
+            inner.solve_block(U, self.W, relax=W_RELAX)
+            todo = ()
+        else:
+            todo = range(self.r)
+        for f in todo:
             # W only enters through the rank-r correction, whose weight in the eigenvalue is the flame's (a few
             # per cent): a looser tolerance (W_RELAX) leaves the eigenvalues unchanged far below the parity bar
             if shifts is not None and f > 0:

@@ -394,6 +394,24 @@ int hx_cocg_backward_error(const hx_amg* M, double* out);
 int hx_cocg(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
             const hx_sell* Ksell, const hx_c128* b, hx_c128* x, double rtol, int max_it, hx_c128* ws, int* h_iters,
             double* h_relres, hx_stream s);
+/* ---- Blocks of right-hand sides (csrc/block.hip, csrc/cocg_block.hip; single GPU).  What the reference gets from its direct
+ * factorisation -- one MatSolve serves any number of right-hand sides (eigensolvers.py:50,103; the flame columns of
+ * flame_matrices.py:170-177 are 16 solves with one operator) -- the iterative route gets by running hx_block_width() (= 4)
+ * INDEPENDENT deflated COCG recurrences side by side: the vectors of a block are interleaved row by row (X[row * 4 + c]), every
+ * matrix entry is loaded once per pass and multiplies four adjacent operands (V-cycle smoother: 60 + 40 -> 15 + 40 bytes per
+ * row and vector; gathers of 32 / 64 contiguous bytes per lane).  hx_zblock_pack / _unpack convert between nb <= 4 rows of a
+ * row-major panel and the interleaved block (missing columns: zero).  hx_sell_spmm_z: Y = alpha K X + beta Y on blocks.
+ * hx_cocg_block: K X = B for the first ncols columns; needs a handle whose complex64 V-cycle and SELL-64 fine level are set and
+ * whose deflation pairs (if any) were prepared by an earlier hx_cocg solve; h_iters / h_relres: 4 entries (iterations and TRUE
+ * relative residual per column -- a column above 10 rtol is reported as it is, the caller decides); ws: hx_cocg_block_ws(n)
+ * complex128 entries. */
+int hx_block_width(void);
+int hx_zblock_pack(int64_t n, int nb, const hx_c128* panel, int64_t ld, hx_c128* blk, hx_stream s);
+int hx_zblock_unpack(int64_t n, int nb, const hx_c128* blk, hx_c128* panel, int64_t ld, hx_stream s);
+int hx_sell_spmm_z(const hx_sell* h, const hx_c128* X, hx_c128* Y, const double alpha[2], const double beta[2], hx_stream s);
+size_t hx_cocg_block_ws(int64_t n);
+int hx_cocg_block(hx_amg* M, int32_t n, const hx_sell* Ksell, int ncols, const hx_c128* B, hx_c128* X, double rtol, int max_it,
+                  hx_c128* ws, int* h_iters, double* h_relres, hx_stream s);
 /* ---- Row-sharded mode (one process per GPU).  Replaces what the reference gets from PETSc's
  * parallel Mat / KSP / PC under mpirun (eigensolvers.py:43-62 with a distributed A; run lines
  * numerical_examples/AnnularCombustor/Micca/fullAnnulus/runAll.sh:9-10): the first `n_sharded` levels of the hierarchy

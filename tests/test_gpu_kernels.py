@@ -784,3 +784,88 @@ def test_pool_orders_the_reuse_of_cached_blocks_across_streams():
     assert ev1.value > ev0.value and w1.value > w0.value       # releases recorded events, reuses waited for them
     free_b, total_b = torch.cuda.mem_get_info()
     assert 0 < cap.value <= total_b // 4
+
+
+@pytest.mark.parametrize("fmt", ["stencil", "i16", "i32"])
+def test_block_products_and_block_cocg_match_the_single_vector_path(fmt):
+    """Blocks of right-hand sides (csrc/block.hip, cocg_block.hip): the SELL-64 block product on the three index formats equals
+    four single-vector products; hx_cocg_block (four deflated COCG recurrences side by side, block V-cycle) returns the
+    solutions of four hx_cocg solves to the solver's tolerance in about the same number of iterations; a zero column and a
+    partial block (3 of 4 columns) are handled; AMGSolver.solve_block falls back cleanly when the batched route is off."""
+    import torch
+    import bench
+    from helmholtz_x import _hx
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.amg import AMGSolver
+    from helmholtz_x.petsc import combine_csr, to_device
+    if fmt == "i32":
+        _hx.set_option("sell_index", "i32")
+    if fmt != "stencil":
+        _hx.set_option("sell_stencil", 0)
+    try:
+        case = bench.build_case((10, 128, 12), "native" if fmt == "stencil" else "rcm", 0.0 if fmt == "stencil" else 0.2)
+        P = case["P"]
+        M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+        K = combine_csr(M.A.shape, M.A.csr_terms + [(P.target * c, m) for c, m in M.B.csr_terms]
+                        + [(P.target ** 2 * c, m) for c, m in M.C.csr_terms])
+        n = K.shape[0]
+        solver = AMGSolver(K, cocg_min_rows=0, recycle_min_rows=0, sell_min_rows=0)
+        st = solver.stats()
+        assert st["fine_format"].startswith("sell64")
+        assert (st["stencil_slices"] > 0) == (fmt == "stencil")
+        assert st["fine_format"].endswith("i32" if fmt == "i32" else "i16")
+        rng = np.random.default_rng(7)
+        w = _hx.lib.hx_block_width()
+        assert w == 4
+        # block product against single-vector products
+        Xp = to_device(_rand_c(rng, w, n))
+        blk, yblk = torch.empty(n * w, dtype=torch.complex128, device="cuda"), torch.empty(n * w, dtype=torch.complex128, device="cuda")
+        _hx.check(_hx.lib.hx_zblock_pack(n, w, _hx.ptr(Xp), n, _hx.ptr(blk), _hx.stream()))
+        assert torch.equal(blk.reshape(n, w).t().contiguous(), Xp)
+        al, be = _hx.z2(0.7 - 0.3j), _hx.z2(0.0)
+        _hx.check(_hx.lib.hx_sell_spmm_z(solver.sell, _hx.ptr(blk), _hx.ptr(yblk), al, be, _hx.stream()))
+        Yp = torch.empty_like(Xp)
+        _hx.check(_hx.lib.hx_zblock_unpack(n, w, _hx.ptr(yblk), _hx.ptr(Yp), n, _hx.stream()))
+        for c in range(w):
+            y1 = torch.empty(n, dtype=torch.complex128, device="cuda")
+            _hx.check(_hx.lib.hx_sell_spmv_z(solver.sell, _hx.ptr(Xp[c]), _hx.ptr(y1), al, be, _hx.stream()))
+            assert float(torch.linalg.norm(Yp[c] - y1) / torch.linalg.norm(y1)) < 1e-14
+        # solves: the first one harvests (GMRES), the second prepares the deflation pairs (hx_cocg)
+        B = to_device(_rand_c(rng, 7, n))
+        B[5].zero_()                                        # a zero right-hand side inside a block
+        Xs = torch.zeros_like(B)
+        assert not solver.block_ready()
+        for c in range(2):
+            solver.solve(B[c], Xs[c])
+        assert solver.block_ready()
+        its_single = []
+        for c in range(7):
+            solver.solve(B[c], Xs[c])
+            its_single.append(solver.last[0])
+        Xb = torch.full_like(B, 7.0)
+        solver.solve_block(B, Xb)                           # 4 + 3 columns
+        stb = solver.stats()
+        assert stb["block_solves"] == 2 and stb["block_columns"] == 7
+        for c in range(7):
+            if c == 5:
+                assert float(torch.abs(Xb[c]).max()) == 0.0
+                continue
+            r = torch.empty(n, dtype=torch.complex128, device="cuda")
+            K.spmv(Xb[c], r)
+            assert float(torch.linalg.norm(B[c] - r) / torch.linalg.norm(B[c])) < 1e-10
+            assert float(torch.linalg.norm(Xb[c] - Xs[c]) / torch.linalg.norm(Xs[c])) < 1e-8
+        nz = [c for c in range(7) if c != 5]
+        assert stb["block_iters"] <= max(its_single[c] for c in nz[:4]) + max(its_single[c] for c in nz[4:]) + 4
+        # batched route switched off: the same call goes vector by vector
+        import os
+        os.environ["HX_BLOCK_SOLVES"] = "0"
+        try:
+            Xc = torch.zeros_like(B)
+            solver.solve_block(B[:2], Xc[:2])
+            assert solver.stats()["block_solves"] == 2
+            assert float(torch.linalg.norm(Xc[0] - Xs[0]) / torch.linalg.norm(Xs[0])) < 1e-8
+        finally:
+            del os.environ["HX_BLOCK_SOLVES"]
+    finally:
+        _hx.set_option("sell_index", None)
+        _hx.set_option("sell_stencil", None)

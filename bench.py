@@ -643,6 +643,7 @@ def run_sharded(args, case, shape, rank, world, backend, n_dev, barrier):
                     "contiguous row ranges of the RCM numbering" if shape[0] == "real" else "theta-slabs", sh.n_own,
                     sh.n_ext - sh.n_own),
                 "setup": case.get("setup_mode"),
+                "partition": case.get("partition"),
                 "inner_solver": getattr(inner, "name", None),
                 "inner_stats": inner.stats() if inner is not None else None,
                 "krylov": {k: v for k, v in (E.state or {}).items() if not k.startswith(("start", "_"))},

@@ -14,6 +14,16 @@ Differences, on purpose:
   * the rank-r flame operator stays factored: blochify() of a low-rank ``Mat`` transforms the factors
     (u' = NB u, v' = BN^T v) instead of materialising a (x) b.
   * ``B_adj`` is provided (the reference leaves it None, :25,88-90, so its Bloch + Robin adjoint cannot run).
+
+Row-sharded runs (round 4; BASELINE config 5 names four GPUs; the reference runs its Bloch case serially, Micca/README.md:29):
+``Blochifier(geometry, ..., global_geometry=G)`` with ``geometry`` holding this rank's part of the sector mesh
+(``ShardContext.distribute``) and ``G`` the whole sector mesh + tags that every rank holds as host arrays anyway.  The sector
+must be partitioned so that every master/slave pair is RANK-LOCAL -- slabs in z or r of a numbering that is contiguous in that
+direction (``sector_slab_numbering``), not theta-slabs.  The master/slave pairing is computed on the global arrays (integer host
+work, identical on every rank); every rank then forms ITS rows of NB M BN from its own rows of M by the same two device sparse
+products, over the [owned | ghost] columns of the REDUCED numbering (a ghost master column folds onto its slave partner, which
+joins the ghost set), and ``self.shard`` is the ShardContext of the reduced problem (what ``fixed_point_iteration(..., shard=)``
+takes).  The reduced operators are not complex symmetric, so the inner solver is the row-sharded flexible GMRES (hx_gmres_sharded).
 """
 import numpy as np
 import scipy.sparse as sp
@@ -25,7 +35,14 @@ from .solver_utils import info
 class Blochifier:
 
     def __init__(self, geometry, boundary_conditions, N, passive_matrices, active_matrix=None, pairing="geometric",
-                 index_order=None):
+                 index_order=None, global_geometry=None):
+        self.shard = None
+        if getattr(geometry.mesh, "part", None) is not None:
+            if global_geometry is None:
+                raise ValueError("a Bloch reduction on a distributed mesh needs global_geometry= (the whole sector mesh and its "
+                                 "facet tags, which every rank holds as host arrays)")
+            self._init_distributed(geometry, global_geometry, boundary_conditions, N, passive_matrices, active_matrix)
+            return
         self.passive_matrices = passive_matrices
         self.active_matrix = active_matrix
         self.b = 1.0                                  # Bloch wave number
@@ -77,6 +94,88 @@ class Blochifier:
             self._B_adj.conjugate()
         self._C = self.blochify(passive_matrices.C)
         info("- Bloch reduction: %d -> %d DOFs (%d master/slave pairs)" % (n, keep.size, dofs_master.size))
+
+    # ------------------------------------------------------------------ row-sharded reduction
+    def _init_distributed(self, geometry, G, boundary_conditions, N, passive_matrices, active_matrix):
+        import torch
+        from .sharded import ShardContext
+        self.passive_matrices, self.active_matrix = passive_matrices, active_matrix
+        self.b = 1.0
+        self.f_b = np.exp(self.b * 1j * 2 * np.pi / N)
+        self.mesh, self.facet_tags, self.V = geometry.mesh, geometry.facet_tags, passive_matrices.V
+        self._A = self._B = self._B_adj = self._C = self._D = None
+        part = self.mesh.part
+        full = self.mesh.shard                       # ShardContext of the full (unreduced) numbering
+        n_g, n_own, l2g = part["n_global"], part["n_own"], np.asarray(part["local_to_global"], dtype=np.int64)
+        ranges = part["ranges"]
+        # global pairing: integer host work on arrays every rank holds (identical result on every rank)
+        master_tag = list(boundary_conditions.keys())[list(boundary_conditions.values()).index("Master")]
+        slave_tag = list(boundary_conditions.keys())[list(boundary_conditions.values()).index("Slave")]
+        gm = np.unique(G.mesh.facets[G.facet_tags.find(master_tag)])
+        gs = np.unique(G.mesh.facets[G.facet_tags.find(slave_tag)])
+        assert len(gm) == len(gs)
+        x_keep, self.mesh = self.mesh, G.mesh        # (_pair_by_rotation reads self.mesh.geometry.x)
+        try:
+            gs = self._pair_by_rotation(gm, gs, 2 * np.pi / N)
+        finally:
+            self.mesh = x_keep
+        starts = np.array([r[0] for r in ranges] + [ranges[-1][1]])
+        owner = lambda ids: np.searchsorted(starts, ids, side="right") - 1          # noqa: E731
+        if not np.array_equal(owner(gm), owner(gs)):
+            raise ValueError("Bloch reduction on a distributed mesh: every master/slave pair must be owned by ONE rank -- partition "
+                             "the sector in slabs along z or r (bloch_operator.sector_slab_numbering), not along theta")
+        slave_of = np.full(n_g, -1, dtype=np.int64)
+        slave_of[gm] = gs
+        is_master = slave_of >= 0
+        red_id = np.full(n_g, -1, dtype=np.int64)                                      # full id -> reduced id (kept dofs, order kept)
+        red_id[~is_master] = np.arange(int((~is_master).sum()))
+        ranges_red = []
+        for (a, b) in ranges:
+            kept = np.flatnonzero(~is_master[a:b])
+            lo = int(red_id[a + kept[0]]) if kept.size else (ranges_red[-1][1] if ranges_red else 0)
+            ranges_red.append((lo, lo + int(kept.size)))
+        R0, R1 = ranges_red[part["rank"]]
+        self.N = n_g
+        # reduced column each local full column folds onto (a master: its slave partner's), and the reduced ghost set
+        tgt = np.where(is_master[l2g], red_id[np.where(is_master[l2g], slave_of[l2g], 0)], red_id[l2g])
+        ghost_red = np.unique(tgt[(tgt < R0) | (tgt >= R1)])
+        n_keep_own, n_ext_red = R1 - R0, (R1 - R0) + ghost_red.size
+        loc_red = np.where((tgt >= R0) & (tgt < R1), tgt - R0, n_keep_own + np.searchsorted(ghost_red, tgt))
+        n_ext_full = l2g.size
+        vals = np.where(is_master[l2g], self.f_b, 1.0 + 0j)
+        self.BN_csr = sp.csr_matrix((vals, (np.arange(n_ext_full), loc_red)), shape=(n_ext_full, n_ext_red))
+        own_full = np.arange(n_own)
+        # NB: rows = owned reduced dofs, columns = owned full dofs (both partners of a pair are owned)
+        assert np.all(loc_red[:n_own] < n_keep_own)
+        nb_vals = np.where(is_master[l2g[:n_own]], 1 / self.f_b, 1.0 + 0j)
+        self.NB_csr = sp.csr_matrix((nb_vals, (loc_red[:n_own], own_full)), shape=(n_keep_own, n_own))
+        self.dofs_master = np.flatnonzero(is_master[l2g[:n_own]])                       # local (owned) ids
+        self.dofs_slave = np.array([int(np.flatnonzero(l2g[:n_own] == slave_of[l2g[m]])[0]) for m in self.dofs_master], dtype=np.int64) \
+            if self.dofs_master.size else np.zeros(0, np.int64)
+        # remapper: owned full entries from OWNED reduced entries (a master's slave is owned)
+        self._BN_own = sp.csr_matrix((vals[:n_own], (own_full, loc_red[:n_own])), shape=(n_own, n_keep_own))
+        self._BN = Mat.from_csr(CSR.from_scipy(self._BN_own))
+        self._NB_dev = self._BN_dev = None
+        self.shard = ShardContext(int((~is_master).sum()), group=full.group, ranges=ranges_red)
+        self.shard.set_ghosts(ghost_red)
+        self.full_shard = full
+        self._A = self.blochify(passive_matrices.A)
+        if passive_matrices.B:
+            self._B = self.blochify(passive_matrices.B)
+            # adjoint: (NB B BN)^H = BN^H B^H NB^H needs rows of other ranks in general; B is a boundary mass matrix (complex
+            # symmetric up to the scalar i c / Z, acoustic_matrices.py:107-119), so B^H = conj(B) and the reduction commutes:
+            # NB conj(B) BN with the conjugated phases = conj of (conj(NB) B conj(BN)) -- formed the same way from local rows
+            self._B_adj = self._blochify_conj(passive_matrices.B)
+        self._C = self.blochify(passive_matrices.C)
+        info("- Bloch reduction (rank %d of %d): %d -> %d owned DOFs (%d master/slave pairs), %d reduced ghost columns"
+             % (part["rank"], len(ranges), n_own, n_keep_own, self.dofs_master.size, ghost_red.size))
+
+    def _blochify_conj(self, matrix):
+        """(NB M BN)^H for a complex SYMMETRIC M, from local rows: (NB M BN)^H = BN^H conj(M) NB^H, and with NB = BN^H (|f_b| = 1)
+        this is NB' conj(M) BN' with NB' = BN^H = NB, BN' = NB^H = BN: the same reduction applied to conj(M)."""
+        m = matrix.copy()
+        m.conjugate()
+        return self.blochify(m)
 
     def _pair_by_rotation(self, dofs_master, dofs_slave, angle):
         """For every master DOF the slave DOF at the same (r, z), one sector pitch further (either sense)."""
@@ -135,6 +234,24 @@ class Blochifier:
         m = self.NB_csr.shape[0]
         csr_terms, lr_terms = [], []
         K = matrix.csr_part()
+        if self.shard is not None:
+            # this rank's rows of the reduced operator over the [owned | ghost] reduced columns
+            if K is not None:
+                red = self._triple_product_device(K)
+                red.local = True
+                csr_terms.append((1.0, red))
+            n_own = self.NB_csr.shape[1]
+            for coef, lr in matrix.lr_terms:
+                if not lr.local:
+                    raise ValueError("flame factors of a distributed Bloch run must be assembled on the distributed mesh")
+                pairs = []
+                for (ui, uv), (vi, vv) in lr.pairs:
+                    u = self.NB_csr @ sp.csr_matrix((uv, (ui, np.zeros_like(ui))), shape=(n_own, 1))
+                    v = self._BN_own.T @ sp.csr_matrix((vv, (vi, np.zeros_like(vi))), shape=(n_own, 1))
+                    u, v = u.tocoo(), v.tocoo()
+                    pairs.append(((u.row.astype(np.int32), u.data), (v.row.astype(np.int32), v.data)))
+                lr_terms.append((coef, LowRank(m, pairs, local=True)))
+            return Mat((m, self.BN_csr.shape[1]), csr_terms, lr_terms)
         if K is not None:
             import os
             if os.environ.get("HX_BLOCH_HOST", "0") != "0":
@@ -151,3 +268,20 @@ class Blochifier:
                 pairs.append(((u.row.astype(np.int32), u.data), (v.row.astype(np.int32), v.data)))
             lr_terms.append((coef, LowRank(m, pairs)))
         return Mat((m, m), csr_terms, lr_terms)
+
+
+def sector_slab_numbering(mesh, axis="z"):
+    """perm[old] = new vertex id of a sector mesh such that the numbering runs slab by slab along ``axis`` ("z" or "r"):
+    contiguous row ranges are then z- (r-) slabs, and every master/slave pair of a Bloch sector -- two vertices with equal (r, z)
+    -- lies in ONE range when the cuts fall between the planes (``ShardContext(align=...)`` / equal keys never split: the sort is
+    stable and the returned ``plane_starts`` lists the first id of every plane).  Use with ``mesh.renumbered(perm)``."""
+    x = mesh.geometry.x
+    key = x[:, 2] if axis == "z" else np.hypot(x[:, 0], x[:, 1])
+    scale = max(float(np.ptp(key)), 1e-300)
+    q = np.round((key - key.min()) / scale * 1e9).astype(np.int64)          # planes: equal keys up to rounding
+    order = np.argsort(q, kind="stable")                                    # order[new] = old
+    perm = np.empty(order.size, dtype=np.int64)
+    perm[order] = np.arange(order.size)
+    qs = q[order]
+    plane_starts = np.flatnonzero(np.concatenate([[True], qs[1:] != qs[:-1]]))
+    return perm, plane_starts

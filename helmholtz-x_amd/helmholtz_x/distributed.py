@@ -28,6 +28,83 @@ def partition_rows(n, world, align=1):
     return [(cuts[p], cuts[p + 1]) for p in range(world)]
 
 
+def rcb_parts(x, world):
+    """Recursive coordinate bisection of points into ``world`` parts of (nearly) equal size: every split cuts the current set along
+    the LONGEST axis of its bounding box at the weighted median (part counts need not be powers of two: a set destined for p parts
+    is cut in the proportion floor(p/2) : ceil(p/2)).  part[i] in [0, world); deterministic (stable sorts, ties by index).
+    What the reference gets from DOLFINx's graph partitioner when it reads a mesh on N ranks (io_utils.py:149-155); METIS / SCOTCH
+    are not available here, and a geometric partition of a FEM mesh has compact parts with few neighbours, which is what the halo
+    exchange wants (point-to-point over xGMI, one message per neighbour)."""
+    x = np.asarray(x, dtype=np.float64)
+    part = np.zeros(x.shape[0], dtype=np.int32)
+    stack = [(np.arange(x.shape[0]), 0, int(world))]
+    while stack:
+        ids, first, p = stack.pop()
+        if p <= 1 or ids.size == 0:
+            part[ids] = first
+            continue
+        pl = p // 2
+        box = x[ids].max(axis=0) - x[ids].min(axis=0)
+        axis = int(np.argmax(box))
+        order = ids[np.argsort(x[ids, axis], kind="stable")]
+        cut = int(round(ids.size * pl / p))
+        stack.append((order[:cut], first, pl))
+        stack.append((order[cut:], first + pl, p - pl))
+    return part
+
+
+def rcb_renumbering(mesh, world, local_order="rcm"):
+    """(perm, ranges): perm[old] = new vertex id such that part p of ``rcb_parts`` owns the contiguous range ranges[p] -- the form
+    ShardContext / distribute_mesh take -- and, inside every part, the vertices follow the reverse Cuthill-McKee order of the
+    part's own sub-graph (``local_order="rcm"``: neighbouring rows have neighbouring columns, which the SELL-64 kernels and their
+    16-bit column deltas rely on) or keep their relative order (``"keep"``).  Integer host work at ingestion, identical on every
+    rank.  Use with ``mesh.renumbered(perm)``."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    x = mesh.geometry.x
+    n = x.shape[0]
+    part = rcb_parts(x, world)
+    counts = np.bincount(part, minlength=world)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    ranges = [(int(starts[p]), int(starts[p + 1])) for p in range(world)]
+    order = np.argsort(part, kind="stable")                       # order[new] = old, parts contiguous, relative order kept
+    if local_order == "rcm":
+        cells = np.asarray(mesh.topology.cells, dtype=np.int64)
+        k = cells.shape[1]
+        rows = np.repeat(cells, k, axis=1).ravel()
+        cols = np.tile(cells, (1, k)).ravel()
+        same = part[rows] == part[cols]                           # edges inside a part only
+        G = sp.coo_matrix((np.ones(int(same.sum()), np.int8), (rows[same], cols[same])), shape=(n, n)).tocsr()
+        del rows, cols
+        for p in range(world):
+            ids = order[starts[p]:starts[p + 1]]
+            if ids.size > 1:
+                sub = G[ids][:, ids]
+                order[starts[p]:starts[p + 1]] = ids[reverse_cuthill_mckee(sub, symmetric_mode=True)]
+    elif local_order != "keep":
+        raise ValueError("local_order must be 'rcm' or 'keep'")
+    perm = np.empty(n, dtype=np.int64)
+    perm[order] = np.arange(n)
+    return perm, ranges
+
+
+def partition_quality(cells, ranges):
+    """Per rank of a contiguous-range partition: ghost vertices (columns owned elsewhere that its rows touch) and neighbour ranks
+    -- the size and the number of the messages of one halo exchange.  Host arrays; for bench records and tests."""
+    cells = np.asarray(cells, dtype=np.int64)
+    starts = np.array([r[0] for r in ranges] + [ranges[-1][1]])
+    owner = np.searchsorted(starts, cells, side="right") - 1     # (nc, k)
+    out = []
+    for p in range(len(ranges)):
+        touch = (owner == p).any(axis=1)
+        v = cells[touch]
+        o = owner[touch]
+        ghost = np.unique(v[o != p])
+        nb = np.unique(o[o != p])
+        out.append(dict(rows=int(ranges[p][1] - ranges[p][0]), ghosts=int(ghost.size), neighbours=int(nb.size)))
+    return out
+
+
 def shard_mesh(x, cells, r0, r1):
     """Local mesh of the rank owning vertices [r0, r1).
 

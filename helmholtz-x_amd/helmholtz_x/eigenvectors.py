@@ -26,10 +26,21 @@ def normalize_eigenvector(mesh, obj, i, absolute=False, degree=1, which='right',
         omega = obj.getEigenpair(i, vr, vi)
     else:
         raise TypeError("expected an EPS or PEP solver object")
-    if BlochRemapper:
+    shard = getattr(obj, "shard", None)
+    if BlochRemapper and shard is not None and getattr(mesh, "shard", None) is not None:
+        # row-sharded Bloch run: the solver lives on the REDUCED numbering (obj.shard); the remapper gives this rank's owned
+        # entries of the full vector from its owned reduced entries (both partners of a master/slave pair are owned by one
+        # rank), and the normalisation below runs on the full distributed mesh
+        from .petsc import Vec
+        full = mesh.shard
+        x_red, x_own = Vec(vr.t[:shard.n_own].clone()), Vec.zeros(full.n_own)
+        BlochRemapper.mult(x_red, x_own)
+        vr = Vec.zeros(full.n_ext)
+        vr.t[:full.n_own].copy_(x_own.t)
+        shard = full
+    elif BlochRemapper:
         vr = matrix_vector(BlochRemapper, vr)
     V = matrices.V if matrices else FunctionSpace(mesh, "CG", degree)
-    shard = getattr(obj, "shard", None)
     if shard is not None:
         return omega, _normalize_distributed(mesh, shard, V, vr, omega, absolute, print_eigs)
     FixSign(vr)

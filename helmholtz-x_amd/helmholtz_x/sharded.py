@@ -362,12 +362,42 @@ def distributed_case(case, group=None):
         return d
     mesh = case["mesh"]
     x = mesh.geometry.x
-    plane = 1
+    world = dist.get_world_size(group)
+    sub, ft, c = case["subdomains"], case["facet_tags"], case["c"]
     if case.get("numbering", "native") == "native":
+        # the generator's theta-major numbering: theta-slabs cut between mesh planes (two neighbours per rank)
         th = np.arctan2(x[:, 1], x[:, 0])
-        plane = max(int(np.argmax(np.abs(th - th[0]) > 1e-12)), 1)     # rows per theta-plane: cut the slabs between planes
-    shard = ShardContext(mesh.num_vertices, group=group, align=plane)
-    local, sub_l, ft_l, (c_l,) = shard.distribute(mesh, case["subdomains"], case["facet_tags"], [case["c"]])
+        plane = max(int(np.argmax(np.abs(th - th[0]) > 1e-12)), 1)     # rows per theta-plane
+        shard = ShardContext(mesh.num_vertices, group=group, align=plane)
+        kind = "theta-slabs of the generator's numbering"
+    else:
+        # any other mesh: recursive coordinate bisection, reverse Cuthill-McKee inside every part (what DOLFINx's graph
+        # partitioner + dof reordering do for the reference, io_utils.py:149-155); HX_PARTITION=rows keeps contiguous row ranges
+        # of the numbering as it is (strips of the global RCM order: fewer neighbours, 2-3 x more ghost rows)
+        from .distributed import rcb_renumbering
+        from .fem import Function, FunctionSpace, MeshTags
+        if os.environ.get("HX_PARTITION", "rcb") == "rcb":
+            perm, ranges = rcb_renumbering(mesh, world)
+            old = mesh
+            mesh = old.renumbered(perm)
+            sub = MeshTags(mesh, sub.dim, sub.indices, sub.values)
+            ft = MeshTags(mesh, ft.dim, ft.indices, ft.values)
+            if c.function_space.kind != "DG0":               # nodal field: follows its vertices
+                c2 = Function(FunctionSpace(mesh, "CG", 1), c.name)
+                c2.x.array[perm] = c.x.array
+                c = c2
+            else:
+                c2 = Function(FunctionSpace(mesh, "DG", 0), c.name)
+                c2.x.array[:] = c.x.array
+                c = c2
+            shard = ShardContext(mesh.num_vertices, group=group, ranges=ranges)
+            kind = "recursive coordinate bisection + reverse Cuthill-McKee inside the parts"
+        else:
+            shard = ShardContext(mesh.num_vertices, group=group)
+            kind = "contiguous row ranges of the mesh numbering"
+    from .distributed import partition_quality
+    case["partition"] = dict(kind=kind, per_rank=partition_quality(mesh.topology.cells, shard.ranges))
+    local, sub_l, ft_l, (c_l,) = shard.distribute(mesh, sub, ft, [c])
     local.assembler()                                  # local mesh arrays -> HBM
     c_l.resident()
     h_l = Q_multiple(local, sub_l, case["P"].N_sector).resident()

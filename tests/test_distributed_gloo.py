@@ -841,3 +841,185 @@ def test_micca_newton_solver_distributed_over_two_ranks(ref_logs, golden_dir):
             assert abs(re_ - rr) < 0.011 and abs(im_ - ri) < 0.011
             assert abs(dom - rd) <= 0.011 * rd
         assert abs(r["omega"] - final) / abs(final) < 1e-9, (r["omega"], final)
+
+
+def _bloch_sharded_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
+    os.environ["HX_QUIET"] = "1"
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import contextlib
+        import io
+        from scipy.io import loadmat
+        from cases import Micca
+        from helmholtz_x.acoustic_matrices import AcousticMatrices
+        from helmholtz_x.bloch_operator import Blochifier, sector_slab_numbering
+        from helmholtz_x.eigensolvers import fixed_point_iteration
+        from helmholtz_x.eigenvectors import normalize_eigenvector
+        from helmholtz_x.fem import MeshTags
+        from helmholtz_x.flame_matrices import PointwiseFlameMatrix
+        from helmholtz_x.flame_transfer_function import stateSpace
+        from helmholtz_x.parameters_utils import Q_multiple
+        from helmholtz_x.sharded import ShardContext
+        from helmholtz_x.synthetic import annulus, micca_sound_speed
+        half = np.pi / 16
+
+        class Geometry:
+            pass
+
+        mesh0, sub0, ft0 = annulus(12, 12, 48, n_flames=1, sector=(-half, half))
+        perm, planes = sector_slab_numbering(mesh0, "z")             # numbering that runs z-plane by z-plane
+        G = Geometry()
+        G.mesh = mesh0.renumbered(perm)
+        G.facet_tags = MeshTags(G.mesh, ft0.dim, ft0.indices, ft0.values)
+        sub = MeshTags(G.mesh, sub0.dim, sub0.indices, sub0.values)
+        bcs = {11: 'Neumann', 12: 'Master', 13: 'Slave'}
+        mat = loadmat(os.path.join(root, "tests", "golden", "micca_ftf.mat"))
+        FTF = stateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+        x_r = np.array([[Micca.r_r, 0.0, Micca.z_r]])
+        c = micca_sound_speed(G.mesh)
+        res = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            # one GPU, same numbering
+            M = AcousticMatrices(G.mesh, G.facet_tags, bcs, c)
+            bloch = Blochifier(G, bcs, 16, M)
+            D = PointwiseFlameMatrix(G.mesh, sub, x_r, Q_multiple(G.mesh, sub, 1), Micca.rho_amb, Micca.q_0, Micca.u_b, FTF, bloch_object=bloch)
+            D.assemble_submatrices('direct')
+            D.blochify('direct')
+            hist = []
+            E = fixed_point_iteration(bloch, D, Micca.target, i=0, nev=2, tol=1e-3, history=hist)
+            w1, p1 = normalize_eigenvector(G.mesh, E, 0, BlochRemapper=bloch.remapper, print_eigs=False)
+            res["single"] = dict(eig=E.getEigenvalue(0), hist=list(hist), p=p1.x.array.copy())
+            # two ranks: z-slabs cut between two planes, so that every master/slave pair is rank-local
+            n = G.mesh.num_vertices
+            cuts = [0] + [int(planes[np.argmin(np.abs(planes - (q * n) // world))]) for q in range(1, world)] + [n]
+            ranges = [(cuts[q], cuts[q + 1]) for q in range(world)]
+            ctx = ShardContext(n, ranges=ranges)
+            local, sub_l, ft_l, (c_l,) = ctx.distribute(G.mesh, sub, G.facet_tags, [c])
+            L = Geometry()
+            L.mesh, L.facet_tags = local, ft_l
+            M_l = AcousticMatrices(local, ft_l, bcs, c_l)
+            bloch_l = Blochifier(L, bcs, 16, M_l, global_geometry=G)
+            D_l = PointwiseFlameMatrix(local, sub_l, x_r, Q_multiple(local, sub_l, 1), Micca.rho_amb, Micca.q_0, Micca.u_b, FTF,
+                                       bloch_object=bloch_l)
+            D_l.assemble_submatrices('direct')
+            D_l.blochify('direct')
+            hist_l = []
+            E_l = fixed_point_iteration(bloch_l, D_l, Micca.target, i=0, nev=2, tol=1e-3, history=hist_l, shard=bloch_l.shard)
+            w2, p2 = normalize_eigenvector(local, E_l, 0, BlochRemapper=bloch_l.remapper, print_eigs=False)
+            D_l.assemble_submatrices('adjoint')
+            D_l.blochify('adjoint')
+            E_a = fixed_point_iteration(bloch_l, D_l, Micca.target.conjugate(), i=0, nev=2, tol=1e-3, problem_type='adjoint',
+                                        shard=bloch_l.shard)
+            inner = [v for v in E_l.inner_cache.values() if hasattr(v, "stats")][0]
+            l2g = local.part["local_to_global"]
+            n_own = local.part["n_own"]
+            res["sharded"] = dict(eig=E_l.getEigenvalue(0), hist=list(hist_l), adj=E_a.getEigenvalue(0), stats=inner.stats(),
+                                  p_own=p2.x.array[:n_own].copy(), own_ids=np.asarray(l2g[:n_own]), pairs=int(bloch_l.dofs_master.size),
+                                  n_red=(bloch_l.shard.n_own, bloch_l.shard.n_ext, bloch_l.shard.n_global),
+                                  f_b=bloch_l.f_b, pm=p2.x.array[bloch_l.dofs_master].copy(), ps=p2.x.array[bloch_l.dofs_slave].copy())
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bloch_sector_row_sharded_over_two_ranks_matches_single_gpu():
+    """BASELINE config 5 on the row-sharded path (round 4): the Bloch-reduced sector problem distributed over two ranks in
+    z-slabs (every master/slave pair rank-local), each rank forming ITS rows of NB M BN with the device sparse products over the
+    [owned | ghost] columns of the reduced numbering, the non-symmetric reduced operator solved collectively by
+    hx_gmres_sharded.  The fixed-point trajectory and the eigenvalue equal the single-GPU Bloch run to 1e-8, the adjoint
+    eigenvalue is the conjugate of the direct one to 1e-8 (bloch_operator.py:104-111; Micca/bloch/active.py), the remapped
+    eigenvector satisfies p(master) = f_b p(slave) and matches the single-GPU mode up to its sign."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_bloch_sharded_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    n_pairs = 0
+    for rank in range(world):
+        s, d = out[rank]["single"], out[rank]["sharded"]
+        assert len(s["hist"]) == len(d["hist"])
+        for a, b in zip(s["hist"], d["hist"]):
+            assert abs(a - b) / abs(a) < 1e-8, (a, b)
+        assert abs(s["eig"] - d["eig"]) / abs(s["eig"]) < 1e-8
+        assert abs(d["adj"] - np.conj(d["eig"])) / abs(d["eig"]) < 1e-8, (d["adj"], d["eig"])
+        assert d["stats"]["krylov"] == "fgmres" and len(d["stats"]["sharded_levels"]) >= 1
+        n_own_red, n_ext_red, n_glob_red = d["n_red"]
+        assert n_ext_red > n_own_red and n_glob_red < len(s["p"])
+        n_pairs += d["pairs"]
+        assert np.max(np.abs(d["pm"] - d["f_b"] * d["ps"])) < 1e-12 * np.max(np.abs(d["ps"]))
+        ref = s["p"][d["own_ids"]]
+        err = min(np.max(np.abs(d["p_own"] - ref)), np.max(np.abs(d["p_own"] + ref))) / np.max(np.abs(ref))
+        assert err < 1e-6, err
+    assert n_pairs == 13 * 49                       # every pair of the (12 + 1) x (48 + 1) periodic face is owned by exactly one rank
+    assert out[0]["sharded"]["eig"] == out[1]["sharded"]["eig"]
+
+
+def _rcb_worker(rank, world, port, out, golden_dir):
+    """RCB partition of the reference's real (unstructured) MICCA mesh over `world` ranks: distribute, exchange, check."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
+    os.environ["HX_QUIET"] = "1"
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        import contextlib
+        import io
+        from helmholtz_x.distributed import distribute_mesh, partition_quality, partition_rows, rcb_renumbering
+        from helmholtz_x.fem import MeshTags
+        from helmholtz_x.io_utils import XDMFReader
+        from helmholtz_x.sharded import ShardContext
+        with contextlib.redirect_stdout(io.StringIO()):
+            mesh, sub, ft = XDMFReader(os.path.join(golden_dir, "meshes", "micca_full", "mesh")).getAll()
+        n = mesh.num_vertices
+        perm, ranges = rcb_renumbering(mesh, world)
+        assert np.array_equal(np.sort(perm), np.arange(n)) and ranges[0][0] == 0 and ranges[-1][1] == n
+        m2 = mesh.renumbered(perm)
+        ft2 = MeshTags(m2, ft.dim, ft.indices, ft.values)
+        sub2 = MeshTags(m2, sub.dim, sub.indices, sub.values)
+        local, sub_l, ft_l, _ = distribute_mesh(m2, ranges, rank, sub2, ft2, [])
+        part = local.part
+        n_own, l2g = part["n_own"], np.asarray(part["local_to_global"])
+        r0, r1 = ranges[rank]
+        assert n_own == r1 - r0 and abs(n_own - n / world) <= 1
+        ctx = ShardContext(n, ranges=ranges)
+        ctx.set_ghosts(l2g[n_own:])
+        v = torch.zeros(ctx.n_ext, dtype=torch.float64)
+        v[:n_own] = torch.from_numpy(m2.geometry.x[r0:r1, 2].copy())          # the owners' z coordinates travel to the ghosts
+        ctx.halo(v)
+        assert np.array_equal(v[n_own:].numpy(), m2.geometry.x[l2g[n_own:], 2])
+        owned_cells = torch.tensor([float(part["cell_owned"].sum())], dtype=torch.float64)
+        dist.all_reduce(owned_cells)
+        assert int(owned_cells[0]) == mesh.num_cells
+        q_rcb = partition_quality(m2.topology.cells, ranges)
+        assert q_rcb[rank]["ghosts"] == l2g.size - n_own                      # the plan's ghost block IS the partition's cut
+        m3 = mesh.locality_renumbered("rcm")
+        q_rows = partition_quality(m3.topology.cells, partition_rows(n, world))
+        out[rank] = (q_rcb, q_rows, len(ctx.plan.recv_from))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rcb_partition_of_the_real_micca_mesh_over_eight_ranks(golden_dir):
+    """a geometric partitioner for unstructured meshes (METIS is not installed; the reference partitions through
+    DOLFINx, io_utils.py:149-155).  Recursive coordinate bisection + reverse Cuthill-McKee inside the parts on the reference's
+    real MICCA mesh, world 8 (gloo, CPU): balanced parts, every cell owned once, the exchange plan built from the local mesh
+    delivers the owners' values to the ghosts -- and the cut is less than half of what contiguous strips of the global RCM
+    numbering (the round-3 partition) give: 4.4 k against 10.6 k ghost rows in total, at 5 instead of 2 neighbours per rank
+    (point-to-point messages to different peers travel over different xGMI links)."""
+    world, port = 8, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_rcb_worker, args=(world, port, out, golden_dir), nprocs=world, join=True)
+    assert len(out) == world
+    q_rcb, q_rows, _ = out[0]
+    g_rcb, g_rows = sum(d["ghosts"] for d in q_rcb), sum(d["ghosts"] for d in q_rows)
+    assert g_rcb < 0.5 * g_rows, (g_rcb, g_rows)
+    assert max(d["neighbours"] for d in q_rcb) <= 7               # (one xGMI link per peer on an 8-GPU node)
+    for rank in range(world):
+        assert out[rank][2] == q_rcb[rank]["neighbours"]
+    assert max(d["rows"] for d in q_rcb) - min(d["rows"] for d in q_rcb) <= 1

@@ -563,3 +563,33 @@ def test_resident_field_is_frozen_until_released():
     assert f.x.array[0] == 5.0 and complex(f._dev[0].item()) == 5.0
     with pytest.raises(ValueError):
         f.x.array[:] = 1.0
+
+
+def test_sector_slab_numbering_keeps_bloch_pairs_in_one_row_range():
+    """bloch_operator.sector_slab_numbering: renumbered z-plane by z-plane, a contiguous row partition cut between planes owns both
+    vertices of every master/slave pair of a Bloch sector (equal r and z) -- the precondition of the row-sharded Bloch reduction;
+    theta-slabs of the generator's numbering do not."""
+    from helmholtz_x.bloch_operator import sector_slab_numbering
+    from helmholtz_x.fem import MeshTags
+    from helmholtz_x.synthetic import annulus
+    half = np.pi / 16
+    mesh, sub, ft = annulus(4, 6, 10, n_flames=1, sector=(-half, half))
+    n = mesh.num_vertices
+    perm, planes = sector_slab_numbering(mesh, "z")
+    assert np.array_equal(np.sort(perm), np.arange(n)) and len(planes) == 11 and planes[0] == 0
+    m2 = mesh.renumbered(perm)
+    z = m2.geometry.x[:, 2]
+    assert np.all(np.diff(z) >= -1e-12)
+    ft2 = MeshTags(m2, ft.dim, ft.indices, ft.values)
+    master = np.unique(m2.facets[ft2.find(12)])
+    slave = np.unique(m2.facets[ft2.find(13)])
+    cut = int(planes[5])
+    x = m2.geometry.x
+    key = lambda ids: np.round(np.stack([np.hypot(x[ids, 0], x[ids, 1]), x[ids, 2]], axis=1), 9)      # noqa: E731
+    km, ks = key(master), key(slave)
+    own_m, own_s = master < cut, slave < cut
+    assert {tuple(r) for r in km[own_m]} == {tuple(r) for r in ks[own_s]}        # the same (r, z) set on either side of the cut
+    # the generator's theta-major numbering: master plane first, slave plane last -> a two-way row split separates every pair
+    m_old = np.unique(mesh.facets[ft.find(12)])
+    s_old = np.unique(mesh.facets[ft.find(13)])
+    assert m_old.max() < n // 2 <= s_old.min()

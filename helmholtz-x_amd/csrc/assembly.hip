@@ -879,3 +879,47 @@ extern "C" int hx_assemble_p2_load(int kind, int32_t n_dof, const double* x, con
   HX_LAUNCH_CHECK("k_p2_load");
   return HX_OK;
 }
+
+// Pointwise flames on the quadratic space (PointwiseFlameMatrix(degree = 2), flame_matrices.py:139-141):
+//   out_j = scale * sum over the cells tagged `tag` of  h_cell * int_cell phi_j dx      (h: DG0, one value per cell)
+// one thread per dof over its incident cells, like k_p2_load.
+__global__ void __launch_bounds__(128)
+k_p2_load_cells(int32_t n_dof, const double* __restrict__ x, const int32_t* __restrict__ cells, const int32_t* __restrict__ cdofs,
+                const int32_t* __restrict__ d2c_ptr, const int32_t* __restrict__ d2c_idx, const zc* __restrict__ h_cell,
+                const int32_t* __restrict__ cell_tag, int32_t tag, zc scale, int nq, const double* __restrict__ quad,
+                zc* __restrict__ out) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_dof; i += gridDim.x * blockDim.x) {
+    zc acc = make_double2(0, 0);
+    for (int32_t p = d2c_ptr[i]; p < d2c_ptr[i + 1]; ++p) {
+      const int32_t cell = d2c_idx[p];
+      if (cell_tag[cell] != tag) continue;
+      const int32_t* v = cells + (int64_t)cell * 4;
+      const int32_t* dofs = cdofs + (int64_t)cell * 10;
+      int j = 0;
+      for (int t = 0; t < 10; ++t) if (dofs[t] == i) j = t;
+      double G[4][3], vol;
+      p1_geometry<3>(x, v, G, vol);
+      double integral = 0.0;
+      for (int q = 0; q < nq; ++q) {
+        const double* lam = quad + 5 * q;
+        double dl[4];
+        integral += lam[4] * vol * p2_basis<4>(j, lam, dl);
+      }
+      const zc hc = h_cell[cell];
+      acc.x += integral * hc.x;
+      acc.y += integral * hc.y;
+    }
+    out[i] = zmul(scale, acc);
+  }
+}
+extern "C" int hx_assemble_p2_load_cells(int32_t n_dof, const double* x, const int32_t* cells, const int32_t* cell_dofs,
+                                         const int32_t* d2c_ptr, const int32_t* d2c_idx, const hx_c128* h_cell,
+                                         const int32_t* cell_tag, int32_t tag, const double scale[2], int nq, const double* quad,
+                                         hx_c128* out, hx_stream s) {
+  HX_REQUIRE(n_dof > 0 && x && cells && cell_dofs && d2c_ptr && d2c_idx && h_cell && cell_tag && scale && nq > 0 && quad && out,
+             "bad argument");
+  k_p2_load_cells<<<hx_grid(n_dof, 128), 128, 0, hx_s(s)>>>(n_dof, x, cells, cell_dofs, d2c_ptr, d2c_idx, (const zc*)h_cell, cell_tag,
+                                                           tag, hx_z(scale), nq, quad, (zc*)out);
+  HX_LAUNCH_CHECK("k_p2_load_cells");
+  return HX_OK;
+}

@@ -70,6 +70,7 @@ SIGNATURES = {
     "hx_assemble_p2_stiff_mass": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "hx_assemble_p2_robin": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "hx_assemble_p2_load": (C.c_int, [_int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dp, _int, _vp, _vp, _vp]),
+    "hx_assemble_p2_load_cells": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _dp, _int, _vp, _vp, _vp]),
     "hx_p1_cell_volumes": (C.c_int, [_int, _i32, _vp, _vp, _vp, _vp]),
     "hx_p1_locate_points": (C.c_int, [_int, _i32, _vp, _vp, _int, _vp, C.c_double, _vp, _vp]),
     "hx_sptrsv_create": (C.c_int, [C.POINTER(_vp), _i32, _int, _vp, _vp, _vp, _vp]),

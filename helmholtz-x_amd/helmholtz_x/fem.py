@@ -667,6 +667,16 @@ class P2Assembler:
                                                self.quad2.shape[0], _hx.ptr(self.quad2), _hx.ptr(val), _hx.stream()))
         return Mat.from_csr(CSR((self.n, self.n), rowptr, col, val))
 
+    def load_cells(self, h_cell, cell_tag, tag, scale=1.0):
+        """scale * sum over the cells tagged ``tag`` of h_cell int phi_j dx (h: DG0 array; cell_tag: device int32 per cell)."""
+        h_t = h_cell if isinstance(h_cell, torch.Tensor) else to_device(np.asarray(h_cell, dtype=np.complex128))
+        out = torch.empty(self.n, dtype=torch.complex128, device=self.x.device)
+        _hx.check(_hx.lib.hx_assemble_p2_load_cells(self.n, _hx.ptr(self.x), _hx.ptr(self.cells), _hx.ptr(self.cdofs),
+                                                    _hx.ptr(self.d2c_ptr), _hx.ptr(self.d2c_idx), _hx.ptr(h_t), _hx.ptr(cell_tag),
+                                                    int(tag), _hx.z2(scale), self.quad3.shape[0], _hx.ptr(self.quad3),
+                                                    _hx.ptr(out), _hx.stream()))
+        return out
+
     def load(self, kind, fa, fb, scale=1.0):
         """kind 1: scale * int fa fb phi_j dx; kind 2: scale * int (d phi_j / dz) fb / fa dx (fa, fb: P1 nodal arrays)."""
         fa_t = to_device(np.asarray(fa, dtype=np.complex128))

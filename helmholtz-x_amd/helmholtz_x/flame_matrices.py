@@ -134,9 +134,10 @@ class PointwiseFlameMatrix(FlameMatrix):
         reference's answer is whatever cell DOLFINx's point-ownership search returns first (flame_matrices.py:144-152);
         by default the lowest-index containing cell is used."""
         super().__init__(mesh, h, q_0, u_b, FTF, degree, bloch_object, tol)
-        if degree != 1:
-            raise NotImplementedError("pointwise flames are provided for degree 1 (the reference's degree-2 run uses "
-                                      "DistributedFlameMatrix)")
+        if degree not in (1, 2):
+            raise NotImplementedError("pointwise flames: degree 1 or 2")
+        if degree == 2 and (mesh.topology.dim != 3 or getattr(mesh, "part", None) is not None):
+            raise NotImplementedError("degree-2 pointwise flames are provided on undistributed tetrahedral meshes")
         self.subdomains = subdomains
         self.x_r = x_r
         self.rho_u = rho_u
@@ -206,9 +207,40 @@ class PointwiseFlameMatrix(FlameMatrix):
         ok[ok] = part["cell_ids"][pos[ok]] == chosen[ok]
         return np.where(ok, pos, -1)
 
+    def _assemble_vectors_p2(self, flame):
+        """Degree 2 (the reference's signature accepts it, flame_matrices.py:131): left = the P2 load vector of the DG0 heat release
+        on the cells of flame f (hx_assemble_p2_load_cells), right = grad(phi_k).n_r / rho_u of the TEN quadratic basis functions of
+        the cell that holds x_r, at x_r (:144-156: Expression(grad(TestFunction)) evaluated at the pulled-back point)."""
+        asm = self.V.assembler()
+        p1 = self.mesh.assembler()
+        h_dev = p1._field(self.h)[0]
+        left = self.indices_and_values(asm.load_cells(h_dev, p1.cell_tag_array(self.subdomains), flame,
+                                                      scale=(self.gamma - 1) * self.q_0 / self.u_b))
+        if getattr(self, "_x_r_cells", None) is None:
+            self._x_r_cells = p1.locate_points(self.x_r)
+        c = int(self._x_r_cells[flame])
+        G = _cell_gradients(self.mesh, c)                        # rows: grad lambda_m
+        X = self.mesh.geometry.x[self.mesh.topology.cells[c]]
+        l123 = np.linalg.solve((X[1:] - X[0]).T, np.asarray(self.x_r[flame], dtype=float).reshape(-1)[:3] - X[0])
+        lam = np.concatenate([[1.0 - l123.sum()], l123])
+        from .fem import TET_EDGES
+        grad = np.zeros((10, 3))
+        for m in range(4):
+            grad[m] = (4 * lam[m] - 1) * G[m]
+        for e, (a, b) in enumerate(TET_EDGES):
+            grad[4 + e] = 4 * (lam[a] * G[b] + lam[b] * G[a])
+        right = (self.V.cell_dofs[c].astype(np.int32), (grad @ self.n_r) / self.rho_u + 0j)
+        return left, right
+
     def assemble_submatrices(self, problem_type='direct'):
         info("- Generating matrix D..")
         pairs = []
+        if self.degree == 2:
+            for flame, point in enumerate(self.x_r):
+                pairs.append(self._assemble_vectors_p2(flame))
+                info("- Matrix contribution of flame " + str(flame) + " is computed.")
+            self._store(pairs, problem_type)
+            return
         lefts = self._left_vectors_batched()
         part = getattr(self.mesh, "part", None)
         for flame, point in enumerate(self.x_r):

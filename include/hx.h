@@ -280,6 +280,11 @@ int hx_assemble_p2_robin(int32_t n_dof, const double* x, const int32_t* facets, 
 int hx_assemble_p2_load(int kind, int32_t n_dof, const double* x, const int32_t* cells, const int32_t* cell_dofs,
                         const int32_t* d2c_ptr, const int32_t* d2c_idx, const hx_c128* fa, const hx_c128* fb,
                         const double scale[2], int nq, const double* quad, hx_c128* out, hx_stream s);
+/* Pointwise flames on the quadratic space: out_j = scale * sum_{cells with cell_tag == tag} h_cell int_cell phi_j dx  (h DG0).
+ * replaces: flame_matrices.py:139-141 -- assemble_vector(form((gamma - 1) q_0 / u_b inner(h, phi_j) dx(flame))) with degree = 2 */
+int hx_assemble_p2_load_cells(int32_t n_dof, const double* x, const int32_t* cells, const int32_t* cell_dofs, const int32_t* d2c_ptr,
+                              const int32_t* d2c_idx, const hx_c128* h_cell, const int32_t* cell_tag, int32_t tag,
+                              const double scale[2], int nq, const double* quad, hx_c128* out, hx_stream s);
 
 /* ------------------------------------------------------------------ sparse triangular solves (MatSolve)
  * replaces: KSP(preonly)+PC(LU) MatSolve inside ST sinvert (eigensolvers.py:49-50,102-103 -> :62,:113).

@@ -160,3 +160,32 @@ def distributed_right(x, cells, cell_dofs, n_dof, rho, w_field):
     b = np.zeros(n_dof, dtype=complex)
     np.add.at(b, cell_dofs.ravel(), loc.ravel())
     return b
+
+
+# ----------------------------------------------------------------------------- pointwise flames (flame_matrices.py:139-160, degree 2)
+def pointwise_left(x, cells, cell_dofs, n_dof, cell_tags, flame, h_cell, gamma, q_0, u_b):
+    """a_j = (gamma-1) q0/u_b int_{Omega_f} h phi_j dx with h DG0 and phi_j quadratic (flame_matrices.py:141): on a tetrahedron
+    int phi_vertex = -|K|/20, int phi_edge = |K|/5 -- integrated here with the rule of the other forms."""
+    _, vol = fem.cell_geometry(x, cells)
+    lam, w = collapsed_gauss(3)
+    phi, _ = p2_basis(lam, TET_EDGES)
+    ints = np.einsum('q,qj->j', w, phi)                        # reference integrals of the 10 basis functions (sum to 1)
+    m = np.flatnonzero(np.asarray(cell_tags) == flame)
+    loc = (gamma - 1) * q_0 / u_b * np.asarray(h_cell, dtype=complex)[m, None] * vol[m, None] * ints[None, :]
+    a = np.zeros(n_dof, dtype=complex)
+    np.add.at(a, cell_dofs[m].ravel(), loc.ravel())
+    return a
+
+
+def pointwise_right(x, cells, cell_dofs, point, rho_u, cell=None):
+    """b_k = (grad phi_k . e_z)(x_r) / rho_u on the 10 dofs of the cell holding x_r (flame_matrices.py:144-156, degree 2):
+    (dofs (10,), values (10,)).  ``cell``: the owner cell (default: lowest index containing the point)."""
+    c = fem.locate_cell(x, cells, point) if cell is None else int(cell)
+    G, _ = fem.cell_geometry(x, cells[c:c + 1])                # G[0, m, :] = grad lambda_m
+    X = x[cells[c]]
+    J = (X[1:] - X[0]).T
+    l123 = np.linalg.solve(J, np.asarray(point, dtype=float).reshape(-1)[:3] - X[0])
+    lam = np.concatenate([[1 - l123.sum()], l123])[None, :]
+    _, dphi = p2_basis(lam, TET_EDGES)                         # d phi_j / d lambda_m at the point: (1, 10, 4)
+    grad = dphi[0] @ G[0]                                      # (10, 3)
+    return cell_dofs[c].astype(np.int32), (grad[:, 2] / rho_u).astype(complex)

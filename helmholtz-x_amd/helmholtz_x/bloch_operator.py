@@ -150,8 +150,9 @@ class Blochifier:
         nb_vals = np.where(is_master[l2g[:n_own]], 1 / self.f_b, 1.0 + 0j)
         self.NB_csr = sp.csr_matrix((nb_vals, (loc_red[:n_own], own_full)), shape=(n_keep_own, n_own))
         self.dofs_master = np.flatnonzero(is_master[l2g[:n_own]])                       # local (owned) ids
-        self.dofs_slave = np.array([int(np.flatnonzero(l2g[:n_own] == slave_of[l2g[m]])[0]) for m in self.dofs_master], dtype=np.int64) \
-            if self.dofs_master.size else np.zeros(0, np.int64)
+        r0 = int(ranges[part["rank"]][0])                                               # owned vertices: local id = global id - r0
+        assert n_own == 0 or (l2g[0] == r0 and l2g[n_own - 1] == r0 + n_own - 1)
+        self.dofs_slave = (slave_of[l2g[self.dofs_master]] - r0).astype(np.int64)
         # remapper: owned full entries from OWNED reduced entries (a master's slave is owned)
         self._BN_own = sp.csr_matrix((vals[:n_own], (own_full, loc_red[:n_own])), shape=(n_own, n_keep_own))
         self._BN = Mat.from_csr(CSR.from_scipy(self._BN_own))

@@ -419,19 +419,19 @@ def _select_columns(A, c0, c1):
 
 def _localize_columns(A, c0, c1, ghost_sorted, n_own):
     """Global column ids -> [owned | ghost] numbering: owned [c0, c1) -> col - c0, others -> n_own + position in the
-    ascending ghost list (device int64 tensor)."""
+    ascending ghost list (device int64 tensor).  Returns (operator, number of columns found OUTSIDE owned + ghost set): the
+    caller sums that count over the ranks before it raises, so that all of them raise together (a rank that raised alone
+    would leave the others blocked in their next exchange)."""
     col = A.col.long()
     own = (col >= c0) & (col < c1)
     if ghost_sorted.numel():
         pos = torch.searchsorted(ghost_sorted, col).clamp(max=int(ghost_sorted.numel()) - 1)
-        if not bool(torch.all(own | (ghost_sorted[pos] == col))):
-            raise ValueError("column outside the ghost set of the level")
+        n_bad = int((~(own | (ghost_sorted[pos] == col))).sum())
     else:
         pos = torch.zeros_like(col)
-        if not bool(torch.all(own)):
-            raise ValueError("off-rank column but the ghost set is empty")
+        n_bad = int((~own).sum())
     lcol = torch.where(own, col - c0, n_own + pos).to(torch.int32).contiguous()
-    return DevCSR((A.shape[0], n_own + int(ghost_sorted.numel())), A.rowptr, lcol, A.val)
+    return DevCSR((A.shape[0], n_own + int(ghost_sorted.numel())), A.rowptr, lcol, A.val), n_bad
 
 
 # row-sharded levels: prolongators with the ghost vertices' rows (one halo fewer per level and cycle); HX_AMG_GHOST_P=0: owned rows only
@@ -578,10 +578,13 @@ def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["
             cols = torch.cat([Kc.col.long(), P_lvl.col.long()])
             ghost_c = torch.unique(cols[(cols < c0) | (cols >= c1)])
             shard.set_level_plan(l + 1, c_ranges, ghost_c.cpu().numpy())
-            level["P"] = _localize_columns(P_lvl, c0, c1, ghost_c, na)
+            level["P"], bad_p = _localize_columns(P_lvl, c0, c1, ghost_c, na)
             level["p_ghost_rows"] = PARAMS_GHOST_P
             level["coarse_sharded"] = True
-            Kl = _localize_columns(Kc, c0, c1, ghost_c, na)
+            Kl, bad_k = _localize_columns(Kc, c0, c1, ghost_c, na)
+            (n_bad,) = _host_sum(shard, bad_p + bad_k)                     # (collective: every rank raises or none)
+            if n_bad:
+                raise ValueError("row-sharded AMG: %d column(s) of level %d lie outside the ghost set of their rank" % (n_bad, l + 1))
             ranges, n_glob, l = c_ranges, na_glob, l + 1
             continue
         # level l + 1 is replicated: P keeps global columns, the restriction is the transpose of MY prolongator rows (the

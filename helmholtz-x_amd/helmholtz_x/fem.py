@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _hx
-from .petsc import CSR, Mat, to_device
+from .petsc import CSR, Mat, new_pattern_id, to_device
 
 
 # ----------------------------------------------------------------------------- host-side objects
@@ -372,7 +372,7 @@ class P1Assembler:
         self.cells = to_device(mesh.topology.cells)
         self.v2c_ptr, self.v2c_idx = self._adjacency(self.cells, self.nc, self.dim + 1)
         self.rowptr, self.col = self._pattern(self.cells, self.nc, self.dim + 1, self.v2c_ptr, self.v2c_idx)
-        self.pattern_id = id(self)
+        self.pattern_id = new_pattern_id()
         self._h_pattern = None
         self.device = dev
 
@@ -542,8 +542,7 @@ class P1Assembler:
         """Recompute adjacency and CSR pattern from the resident mesh arrays (what a fresh assembly pays)."""
         self.v2c_ptr, self.v2c_idx = self._adjacency(self.cells, self.nc, self.dim + 1)
         self.rowptr, self.col = self._pattern(self.cells, self.nc, self.dim + 1, self.v2c_ptr, self.v2c_idx)
-        self.pattern_id = object()
-        self.pattern_id = id(self.rowptr)
+        self.pattern_id = new_pattern_id()
 
     def lumped(self):
         """m_j = int phi_j dx, so that int f dx = m . f for nodal P1 f."""
@@ -603,7 +602,7 @@ class P2Assembler:
         self.quad2 = to_device(collapsed_gauss(2))
         self.d2c_ptr, self.d2c_idx = self._adjacency(self.cdofs, self.nc, 10)
         self.rowptr, self.col = self._pattern(self.cdofs, self.nc, 10, self.d2c_ptr, self.d2c_idx)
-        self.pattern_id = id(self)
+        self.pattern_id = new_pattern_id()
 
     _adjacency = P1Assembler._adjacency
     _pattern = P1Assembler._pattern

@@ -121,6 +121,13 @@ class _SerialComm:
 
 
 _ws_cache = {}
+_PATTERN_IDS = __import__("itertools").count(1)
+
+
+def new_pattern_id():
+    """Identity of a sparsity pattern: a process-wide counter, never reused (an ``id()`` would be once its object is freed, so
+    caches keyed by it had to keep whole operators -- values included -- alive)."""
+    return next(_PATTERN_IDS)
 
 
 def panel_dot(V, k, w):
@@ -144,7 +151,8 @@ class CSR:
         self.shape = (int(shape[0]), int(shape[1]))
         self.rowptr, self.col, self.val = rowptr, col, val
         self._h_rowptr, self._h_col = h_rowptr, h_col
-        self.pattern_id = pattern_id if pattern_id is not None else id(self)
+        self.pattern_id = pattern_id if pattern_id is not None else new_pattern_id()
+        self.value_id = new_pattern_id()                # identity of this set of VALUES (caches of objects built from them)
         self.nnz = int(col.numel())
 
     @classmethod
@@ -220,14 +228,21 @@ class LowRank:
             self._rp = (to_device(ptr), to_device(idx), to_device(val))
         return self._rp
 
+    def left_packed(self):
+        """[(device int32 indices, device complex128 values)] of the left factors u_f: their supports are a few hundred entries."""
+        if not hasattr(self, "_lp"):
+            self._lp = [(to_device(ui), to_device(uv)) for (ui, uv), _ in self.pairs]
+        return self._lp
+
     def left_dense(self):
-        """(rank, n) device tensor whose rows are the dense u_f."""
-        if not hasattr(self, "_ld"):
-            U = torch.zeros((self.rank, self.n), dtype=torch.complex128, device=_dev())
-            for f, ((ui, uv), _) in enumerate(self.pairs):
-                U[f, torch.from_numpy(ui.astype(np.int64)).to(U.device)] = to_device(uv)
-            self._ld = U
-        return self._ld
+        """(rank, n) device tensor whose rows are the dense u_f: right-hand sides of the Woodbury columns.  Built on every call
+        and owned by the caller (16 flames x 5 M rows are 1.2 GiB: until round 4 the tensor was cached here for the lifetime
+        of the flame matrix)."""
+        U = torch.zeros((self.rank, self.n), dtype=torch.complex128, device=_dev())
+        for f, (ui, uv) in enumerate(self.left_packed()):
+            if ui.numel():
+                U[f, ui.long()] = uv
+        return U
 
 
 class Mat:
@@ -394,10 +409,12 @@ class Mat:
                                               _hx.ptr(t), _hx.stream()))
             if shard is not None and lr.local:   # v_f^T x: the ranks hold their owned entries of v_f
                 shard.all_reduce_(t)
-            h = (-coef) * t                      # y -= U (-(coef) t)
-            U = lr.left_dense()
-            _hx.check(_hx.lib.hx_zpanel_sub(lr.n, lr.rank, _hx.ptr(U), U.stride(0), _hx.ptr(h), _hx.ptr(y.t),
-                                            _hx.stream()))
+            h = (coef * t).cpu().numpy()         # y += coef * sum_f (v_f^T x) u_f: r scatters over the supports of the u_f
+            for f, (ui, uv) in enumerate(lr.left_packed()):
+                if ui.numel() == 0:
+                    continue
+                _hx.check(_hx.lib.hx_zscatter_axpy(int(ui.numel()), _hx.z2(complex(h[f])), _hx.ptr(uv), _hx.ptr(ui), _hx.ptr(y.t),
+                                                   _hx.stream()))
 
     def getValuesCSR(self):
         """Explicit CSR including the outer-product blocks -- what the reference stores (small cases / tests only)."""
@@ -418,7 +435,8 @@ class Mat:
 
 from collections import OrderedDict
 
-_SLOT_CACHE = OrderedDict()     # (base pattern id, other pattern id) -> (device slot map, base, other); bounded LRU
+_SLOT_CACHE = OrderedDict()     # (base pattern id, other pattern id) -> device slot map; LRU bounded in entries and bytes
+_SLOT_CACHE_MAX_BYTES = 64 << 20
 
 
 def clear_caches():
@@ -473,7 +491,7 @@ def combine_csr(shape, terms):
     others = [m for _, m in terms if m.pattern_id != base.pattern_id]
     slot_maps = {}
     if others and all((base.pattern_id, m.pattern_id) in _SLOT_CACHE for m in others):
-        slot_maps = {m.pattern_id: _SLOT_CACHE[(base.pattern_id, m.pattern_id)][0] for m in others}
+        slot_maps = {m.pattern_id: _SLOT_CACHE[(base.pattern_id, m.pattern_id)] for m in others}
         others = []
     if others:
         n = shape[0]
@@ -498,9 +516,11 @@ def combine_csr(shape, terms):
                 continue
             f = found[m.pattern_id]
             slot_maps[m.pattern_id] = f if isinstance(f, torch.Tensor) else to_device(f)
-            if not need_union:
-                _SLOT_CACHE[(base.pattern_id, m.pattern_id)] = (slot_maps[m.pattern_id], base, m)   # keep ids alive
-                while len(_SLOT_CACHE) > 8:
+            if not need_union and 4 * m.nnz <= _SLOT_CACHE_MAX_BYTES // 4:
+                # (pattern ids are never reused: the cache holds the small maps only, no operator -- it used to keep up to
+                # eight (base, other) operator pairs with their values alive across fixed-point calls, 1.4 GiB each at 5 M DOF)
+                _SLOT_CACHE[(base.pattern_id, m.pattern_id)] = slot_maps[m.pattern_id]
+                while len(_SLOT_CACHE) > 8 or sum(4 * v.numel() for v in _SLOT_CACHE.values()) > _SLOT_CACHE_MAX_BYTES:
                     _SLOT_CACHE.popitem(last=False)
     same = [(c, m) for c, m in terms if m.pattern_id == base.pattern_id and m.val is not None]
     out = None

@@ -39,6 +39,7 @@ W_WARM = __import__("os").environ.get("HX_WOODBURY_WARM", "1") != "0"      # tra
 # the 38th column; a restart there (when the last pair misses the tolerance by a hair) costs five more shift-invert
 # applications of ~45 ms each at 5 M DOF, eight spare columns cost 1.3 GB of HBM.
 NCV_EXTRA = int(__import__("os").environ.get("HX_NCV_EXTRA", "8"))
+ROTATE_SLABS = 8                 # DeviceBasis.rotate: the panel is rotated in this many slabs of positions (scratch = panel / 8)
 RELAX_CAP = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP", "1e4"))     # 1 switches the relaxation off
 RELAX_CAP_MULTI = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP_MULTI", "30"))  # cap for nev > 1 (see set_inner_accuracy)
 
@@ -308,22 +309,24 @@ class DeviceBasis:
         self.shard, self.blocks = shard, blocks
         self.n, self.m = n, m
         self.start = start
-        # The two panels are the largest allocations of the path (m x n complex128 each: 2 x 6 GB for the 5 M-DOF
-        # companion vectors); consecutive solves of one fixed-point call reuse them through ``pool``.  Rows are always
-        # written (set_start / expand / rotate) before they are read, so no zero fill is needed.
+        # The panel is the largest allocation of the path (m x n complex128: 7 GB for the 5 M-DOF companion vectors);
+        # consecutive solves of one fixed-point call reuse it through ``pool``.  Rows are always written (set_start / expand /
+        # rotate) before they are read, so no zero fill is needed.  (Until round 4 a second panel of the same size served as the
+        # target of the restart rotation; the rotation now runs slab by slab through a scratch an eighth of that size.)
         got = None if pool is None else pool.get("basis")
         if got is not None and got[0].shape[1] == n and got[0].shape[0] >= m and got[0].device == dev:
-            self.V, self.V2 = got[0][:m], got[1][:m]
+            self._panel, self._scratch = got
         else:
             rows = m
             if pool is not None:
-                pool.pop("basis", None)          # release a smaller pair before allocating the larger one
+                pool.pop("basis", None)          # release a smaller panel before allocating the larger one
                 rows = max(m, min(int(pool.get("rows_hint", 0)), n))   # size once for the widest solve of the call
-            Va = _hx.device_empty((rows, n), torch.complex128, dev)
-            Vb = _hx.device_empty((rows, n), torch.complex128, dev)
+            self._panel = _hx.device_empty((rows, n), torch.complex128, dev)
+            slab = min(n, max(-(-n // ROTATE_SLABS), 65536))
+            self._scratch = _hx.device_empty((rows, slab), torch.complex128, dev)
             if pool is not None:
-                pool["basis"] = (Va, Vb)
-            self.V, self.V2 = Va[:m], Vb[:m]
+                pool["basis"] = (self._panel, self._scratch)
+        self.V = self._panel[:m]
         self.apply_op = apply_op
         self.seed = seed
         self.h_dev = torch.empty(m + 1, dtype=torch.complex128, device=dev)
@@ -393,13 +396,20 @@ class DeviceBasis:
         return h1 + h2, beta
 
     def rotate(self, Q, k):
+        """columns[0:k] = columns[0:mact] @ Q, residual column mact -> column k.  In place: every position i of the vectors is a
+        small product of its own (out[j, i] = sum_a Q[a, j] V[a, i]), so the panel is processed in slabs of positions -- product
+        into the scratch, rows copied back -- and no second panel is needed (one extra pass over k rows per rotation)."""
         mact = Q.shape[0]
         Qd = to_device(np.ascontiguousarray(np.asarray(Q, dtype=np.complex128).T))   # column-major (mact x k)
-        _hx.check(_hx.lib.hx_zpanel_mul(self.n, mact, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(Qd),
-                                        _hx.ptr(self.V2), self.V2.stride(0), _hx.stream()))
+        slab = self._scratch.shape[1]
+        for off in range(0, self.n, slab):
+            ln = min(slab, self.n - off)
+            src = self.V[:, off:off + ln]
+            _hx.check(_hx.lib.hx_zpanel_mul(ln, mact, k, _hx.ptr(src), self.V.stride(0), _hx.ptr(Qd),
+                                            _hx.ptr(self._scratch), self._scratch.stride(0), _hx.stream()))
+            self.V[:k, off:off + ln].copy_(self._scratch[:k, :ln])
         if mact < self.m:
-            self.V2[k].copy_(self.V[mact])
-        self.V, self.V2 = self.V2, self.V
+            self.V[k].copy_(self.V[mact])
 
 
 class CompactBasis:
@@ -819,7 +829,7 @@ def _row_sum(V, k):
 
 
 def _term_key(mat):
-    return tuple((c, m.pattern_id, id(m.val)) for c, m in mat.csr_terms)
+    return tuple((c, m.pattern_id, getattr(m, "value_id", id(m.val))) for c, m in mat.csr_terms)
 
 
 class EPS(_EigenSolverBase):

@@ -282,6 +282,7 @@ def smoother_roofline(inner, n, in_situ, numbering="native"):
     gbs = nbytes / (ms * 1e-3) / 1e9
     traffic = measured_traffic(n, None, numbering, kernel="k_sell<c64,1,half>")
     return dict(kernel="k_sell<c64, 1, half> (hx_sell_smooth_c64, fine level)", launches=in_situ[0],
+                timing="in situ: HIP events around every 8th launch of the timed region (the roofline kernel above: every launch)",
                 avg_launch_ms=round(ms, 5), bytes_per_launch=nbytes,
                 bytes_model="stored SELL-64 entries * 4 + indexed entries * index bytes + 5 complex64 vectors",
                 achieved=round(gbs, 1), unit="GB/s",
@@ -493,6 +494,11 @@ def main(argv=None):
         for _ in range(args.warmup):
             hot_path(case, args.st_type)
             gc.collect()
+        # What is alive now -- the imported modules, the case -- leaves the collector's generations: the full collections inside the
+        # timed region (the explicit one per step and the automatic ones) then walk the objects of the calls only.  Measured
+        # (tools/step_time_drift.py): releasing a call's objects 42-77 ms -> 0.7 ms, 1 M DOF 0.625 -> 0.58 s per call, 5 M DOF
+        # 2.41 -> 2.36 s.  A long-running driver of the library does the same after its set-up (gc.freeze(), Python >= 3.7).
+        gc.freeze()
         from helmholtz_x import _hx
         import ctypes as C
         # in-situ HIP-event timing of the roofline kernel (operator product on the fine operator) over the timed region
@@ -611,6 +617,7 @@ def run_sharded(args, case, shape, rank, world, backend, n_dev, barrier):
                 E.destroy()
                 E = _m = None
                 gc.collect()
+            gc.freeze()                                   # (as in the single-GPU leg: modules and the case leave the collector)
             from helmholtz_x import sharded as shd
             sh = shd.distributed_case(case)["shard"]      # partition + this rank's mesh part in HBM (outside the timed region)
             n_loc = sh.n_own

@@ -705,6 +705,7 @@ struct SpmvProfile {
   std::vector<hipEvent_t> ev;          // 2 per launch
   size_t used = 0;
   int64_t skipped = 0;
+  int64_t seen = 0;                    // (kind 1: launches offered to the sampling)
 } g_prof[2];
 // events are created in chunks as the launches come (a driver-length run of the 5 M-DOF bench records ~45,000 products; round 3
 // stopped at 16,384 and timed the first 11 of 20 steps only); launches beyond the cap are counted in `skipped` and reported
@@ -724,7 +725,7 @@ extern "C" int hx_profile_sell_spmv(int enable, int32_t min_rows) {
     if (enable && P.ev.empty() && !prof_grow(P)) return hx_fail(HX_ERR_HIP, "hx_profile_sell_spmv", "hipEventCreate failed");
     P.on = enable != 0;
     P.min_rows = min_rows;
-    if (enable) { P.used = 0; P.skipped = 0; }
+    if (enable) { P.used = 0; P.skipped = 0; P.seen = 0; }
   }
   return HX_OK;
 }
@@ -746,6 +747,14 @@ extern "C" int hx_profile_sell_read(int kind, int64_t* launches, double* total_m
 extern "C" int hx_profile_sell_spmv_read(int64_t* launches, double* total_ms) { return hx_profile_sell_read(0, launches, total_ms); }
 static bool prof_begin(int kind, int32_t n, hx_stream s) {
   SpmvProfile& P = g_prof[kind];
+  // The operator product (the roofline kernel) is timed at EVERY launch; the smoother step (bench.py's dominant_by_time, 2.7 times as
+  // many launches) at every 8th: an event pair costs ~10 us of a launch-bound call (1 M DOF: +9 % per call with both kernels timed
+  // at every launch, measured with tools/step_time_drift.py; attaching the pair to the dispatch with hipExtLaunchKernelGGL costs the
+  // same).  Launches passed over by the sampling are not `skipped` (that counts launches that could not be timed).
+  if (kind == 1 && P.on && n >= P.min_rows) {
+    const long every = HX_OPT_INT("sell_profile_smoother_every", 8);
+    if (every > 1 && (P.seen++ % every) != 0) return false;
+  }
   bool rec = P.on && n >= P.min_rows && (P.used + 2 <= P.ev.size() || prof_grow(P));
   if (rec) {      // launches that are being captured into a hipGraph (V-cycle replay) cannot be bracketed by events
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

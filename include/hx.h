@@ -196,7 +196,9 @@ int hx_sell_destroy(hx_sell* h);
 int hx_profile_sell_spmv(int enable, int32_t min_rows);
 int hx_profile_sell_spmv_read(int64_t* launches, double* total_ms);
 /* the same for kind 0 = hx_sell_spmv_z, kind 1 = hx_sell_smooth_c64 (the V-cycle smoother step, the kernel with the largest
- * share of the run time) on operators with at least min_rows rows */
+ * share of the run time) on operators with at least min_rows rows.  Kind 1 is SAMPLED: every 8th qualifying launch carries the
+ * event pair (option "sell_profile_smoother_every"; an event pair costs ~10 us of a launch-bound call and the smoother is launched
+ * 2.7 times as often as the product) -- launches passed over by the sampling do not count as skipped. */
 int hx_profile_sell_read(int kind, int64_t* launches, double* total_ms);
 int64_t hx_profile_sell_skipped(int kind);
 

@@ -517,6 +517,19 @@ def test_in_situ_spmv_profile_counts_launches(hx):
         hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(x), hx.ptr(y), one, zero, hx.stream()))
     hx.check(hx.lib.hx_profile_sell_spmv_read(C.byref(cnt), C.byref(ms)))
     assert cnt.value == 7 and 0.0 < ms.value < 50.0
+    # the smoother step (kind 1) is SAMPLED: every 8th launch carries an event pair (launches 0, 8, 16 of 20)
+    h2 = C.c_void_p()                                           # (a handle that carries the complex64 copy of the values)
+    hx.check(hx.lib.hx_sell_create(C.byref(h2), n, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), 0, 1, hx.stream()))
+    d32 = _dev((1.0 / M.diagonal()).astype(np.complex64))
+    b32, x32 = _dev(_rand_c(rng, n).astype(np.complex64)), _dev(_rand_c(rng, n).astype(np.complex64))
+    o32 = torch.empty_like(x32)
+    for _ in range(20):
+        hx.check(hx.lib.hx_sell_smooth_c64(h2, hx.ptr(d32), hx.ptr(b32), hx.ptr(x32), hx.ptr(o32), 0.6, None, 0.0, hx.stream()))
+    hx.check(hx.lib.hx_profile_sell_read(1, C.byref(cnt), C.byref(ms)))
+    assert cnt.value == 3 and 0.0 < ms.value < 50.0 and hx.lib.hx_profile_sell_skipped(1) == 0
+    hx.check(hx.lib.hx_sell_destroy(h2))
+    hx.check(hx.lib.hx_profile_sell_spmv_read(C.byref(cnt), C.byref(ms)))
+    assert cnt.value == 7                                       # (the product's records are its own)
     hx.check(hx.lib.hx_profile_sell_spmv(0, 0))
     hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(x), hx.ptr(y), one, zero, hx.stream()))
     hx.check(hx.lib.hx_profile_sell_spmv_read(C.byref(cnt), C.byref(ms)))

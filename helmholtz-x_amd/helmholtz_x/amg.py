@@ -1045,6 +1045,12 @@ class AMGSolver:
         for shl in getattr(self, "coarse_sells", []):
             _hx.lib.hx_sell_destroy(shl)
         self.coarse_sells = []
+        # the device arrays the handles pointed into: released with them, not at the next garbage collection
+        for name in ("ws", "tmp", "_blk_ws", "_blk_b", "_blk_x", "_xe", "_hbuf", "K", "_keep"):
+            if hasattr(self, name):
+                setattr(self, name, None)
+        if getattr(self, "levels", None):
+            self.levels = [{k: v for k, v in lv.items() if isinstance(v, (int, float, bool, str))} for lv in self.levels]
 
     def __del__(self):
         try:

@@ -155,6 +155,7 @@ def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history, stat
     if lean < nev:
         E.destroy()
         E, _ = solve_active(omega[k], nev) if k >= 0 else solve_passive(nev)
+    E._owns_caches = True          # the returned solver owns the call's caches: its destroy() releases them (see slepc.py)
     return E
 
 

@@ -395,6 +395,12 @@ class DeviceBasis:
         _hx.check(_hx.lib.hx_zscal(self.n, _hx.z2(1.0 / beta), _hx.ptr(w), _hx.stream()))
         return h1 + h2, beta
 
+    def close(self):
+        """Drop the panel and the operator closure (which captures this object: a reference cycle only the garbage collector
+        would break).  Called by the solver's destroy()."""
+        self.apply_op = None
+        self.V = self._panel = self._scratch = self.start = None
+
     def rotate(self, Q, k):
         """columns[0:k] = columns[0:mact] @ Q, residual column mact -> column k.  In place: every position i of the vectors is a
         small product of its own (out[j, i] = sum_a Q[a, j] V[a, i]), so the panel is processed in slabs of positions -- product
@@ -703,7 +709,28 @@ class _EigenSolverBase:
         return float(self._result.resid[i])
 
     def destroy(self):
+        """E.destroy() of the reference (eigensolvers.py:161,179,244).  The intermediate solvers of a fixed-point call share its
+        caches (inner solvers with their hierarchies, Woodbury columns, the Krylov panel) and only drop their own basis; the
+        solver the call RETURNS owns them and releases them here -- device memory comes back at destroy(), not at the next
+        garbage collection (the objects sit in reference cycles)."""
+        if self._basis is not None and hasattr(self._basis, "close"):
+            self._basis.close()
         self._basis = None
+        if self._left is not None:               # two-sided mode: the solver of the transposed pencil goes with this one
+            self._left.destroy()
+            self._left = None
+        if getattr(self, "_owns_caches", False):
+            self._owns_caches = False
+            for cache in (self.inner_cache, self.W_cache):
+                if cache:
+                    for v in list(cache.values()):
+                        d = getattr(v, "destroy", None)
+                        if callable(d):
+                            d()
+                    cache.clear()
+            if self.state is not None:
+                for key in [k for k, v in self.state.items() if k == "_pool" or torch.is_tensor(v)]:
+                    self.state.pop(key, None)
         if _hx.shares_device():              # several ranks on one card: give cached blocks back for the others
             _hx.check(_hx.lib.hx_pool_trim())
 

@@ -58,33 +58,6 @@ def live_tensors(top=14):
 
 
 
-workload = sys.argv[1] if len(sys.argv) > 1 else "annulus-5M"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-census("process start")
-case = bench.build_case(bench.WORKLOADS[workload])
-case["mesh"].assembler()
-census("case resident")
-import contextlib  # noqa: E402
-E = None
-for k in range(steps):
-    if E is not None:
-        E.destroy()
-    E = matrices = None
-    gc.collect()
-    with contextlib.redirect_stdout(sys.stderr):
-        E, matrices = bench.hot_path(case)
-    census("after call %d (solver objects alive)" % (k + 1))
-print(json.dumps({"listing": "largest device tensors while the solver objects of the last call are alive"}))
-live_tensors(40)
-E.destroy()
-E = matrices = None
-gc.collect()
-census("solver objects destroyed")
-
-
-live_tensors()
-
-
 def who_holds(cls_name, depth=8):
     """Referrer chains (type names; dict keys where they help) of every live instance of a class: what keeps it alive."""
     me = sys._getframe()
@@ -116,6 +89,38 @@ def who_holds(cls_name, depth=8):
             skip.add(id(r))
             cur = r
         print(json.dumps({"instance": cls_name, "shape": getattr(o, "shape", None), "held_through": chain}), flush=True)
+
+
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "annulus-5M"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+census("process start")
+case = bench.build_case(bench.WORKLOADS[workload])
+case["mesh"].assembler()
+census("case resident")
+import contextlib  # noqa: E402
+E = None
+for k in range(steps):
+    if E is not None:
+        E.destroy()
+    E = matrices = None
+    gc.collect()
+    with contextlib.redirect_stdout(sys.stderr):
+        E, matrices = bench.hot_path(case)
+    census("after call %d (solver objects alive)" % (k + 1))
+print(json.dumps({"listing": "largest device tensors while the solver objects of the last call are alive"}))
+live_tensors(40)
+E.destroy()
+census("E.destroy() alone (no garbage collection yet)")
+for cls in ("DeviceBasis", "AMGSolver", "WoodburySolver"):
+    who_holds(cls)
+E = matrices = None
+census("references dropped (no garbage collection yet)")
+gc.collect()
+census("solver objects destroyed")
+
+
+live_tensors()
 
 
 who_holds("CSR")

@@ -583,6 +583,11 @@ extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream 
 extern "C" size_t hx_gmres_ws(int64_t n, int restart) {      // (room for up to 32 recycled rows in the dot workspace)
   return (size_t)(2 * restart + 2) * (size_t)n + hx_panel_dot_ws(restart + 1 + 32) + (size_t)restart + 2 + 32;
 }
+// the same for a handle with the recycling workspace (hx_amg_enable_recycling): the Arnoldi vectors then live in the handle's
+// [C; V] panel and the workspace holds the Z panel, the residual and the reduction scratch only -- (restart + 1) x n less
+extern "C" size_t hx_gmres_ws_recycling(int64_t n, int restart) {
+  return (size_t)(restart + 1) * (size_t)n + hx_panel_dot_ws(restart + 1 + 32) + (size_t)restart + 2 + 32;
+}
 
 
 // xe / hbuf: row-sharded mode only (xe: owned + ghost staging vector for the K products, hbuf: inner products, all-reduced);
@@ -621,7 +626,7 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
   // Gram-Schmidt panel: rows [0, kc) = recycled C, rows kc + j = v_j.  Without recycling it lives in ws as before.
   hx_c128* Pn = rec ? rec->CV : ws;
   hx_c128* V = Pn + (size_t)kc * n;                  // (restart+1) x n, row j = v_j
-  hx_c128* Z = ws + (size_t)(restart + 1) * n;       // restart x n,   row j = M^-1 v_j
+  hx_c128* Z = rec ? ws : ws + (size_t)(restart + 1) * n;       // restart x n,   row j = M^-1 v_j  (hx_gmres_ws / _recycling)
   hx_c128* r = Z + (size_t)restart * n;
   hx_c128* part = r + n;
   const int kmax = rec ? rec->kmax : 0;
@@ -832,7 +837,7 @@ extern "C" int hx_amg_set_recycle(hx_amg* h, int k, const hx_c128* Ucoef, const 
   const int m = R.m_last;
   HX_REQUIRE(R.kmax > 0 && k >= 1 && k <= R.kmax && m >= k, "nothing to harvest from");
   const int64_t n = R.n;
-  hx_c128* Z = ws + (size_t)(R.restart + 1) * n;
+  hx_c128* Z = ws;                                    // (layout of a handle with the recycling workspace: hx_gmres_ws_recycling)
   hx_c128* coef = nullptr;
   HX_HIP(hx_malloc((void**)&coef, sizeof(hx_c128) * (size_t)(m + 1) * k));
   int rc;

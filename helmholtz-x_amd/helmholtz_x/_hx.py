@@ -95,6 +95,7 @@ SIGNATURES = {
     "hx_amg_vcycle": (C.c_int, [_vp, _vp, _vp, _vp]),
     "hx_amg_destroy": (C.c_int, [_vp]),
     "hx_gmres_ws": (C.c_size_t, [_i64, _int]),
+    "hx_gmres_ws_recycling": (C.c_size_t, [_i64, _int]),
     "hx_gmres": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _int, _int, _vp,
                            C.POINTER(_int), C.POINTER(C.c_double), _vp]),
     "hx_cocg_ws": (C.c_size_t, [_i64]),

@@ -805,8 +805,6 @@ class AMGSolver:
         gmax = int(os.environ.get("HX_AMG_GRAPH_MAX_ROWS", self.params["graph_max_rows"]))
         if mixed and shard is None and len(levels) > 1 and self.n <= gmax:
             _hx.check(_hx.lib.hx_amg_enable_graph(h, 1))
-        self.ws = torch.empty(max(_hx.lib.hx_gmres_ws(self.n, self.params["restart"]), _hx.lib.hx_cocg_ws(self.n)),
-                              dtype=torch.complex128, device=dev)
         self.tmp = torch.empty(self.n, dtype=torch.complex128, device=dev)
         # subspace recycling (all solves of a fixed-point call share K): the harvest keeps the modes the spectrum asks for (3 on
         # the small synthetic annuli, 6 on the reference's MICCA mesh, 6-8 from 1 M DOF on).  Rounds 1-2 enabled it from 1e5 rows;
@@ -820,6 +818,9 @@ class AMGSolver:
         self.recycled = 0
         if self.recycle_k > 0:
             _hx.check(_hx.lib.hx_amg_enable_recycling(h, self.n, self.recycle_k, self.params["restart"]))
+        # Krylov workspace: with the recycling workspace in the handle the Arnoldi vectors live there (51 x n entries less here)
+        gmres_ws = (_hx.lib.hx_gmres_ws_recycling if self.recycle_k > 0 else _hx.lib.hx_gmres_ws)(self.n, self.params["restart"])
+        self.ws = torch.empty(max(gmres_ws, _hx.lib.hx_cocg_ws(self.n)), dtype=torch.complex128, device=dev)
         self.krylov_tol_floor = 10.0 * self.params["rtol"]
         self.total_iters = 0
         self.n_solves = 0

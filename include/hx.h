@@ -360,6 +360,9 @@ int hx_amg_destroy(hx_amg* h);
 /* FLEXIBLE right-preconditioned restarted GMRES on K x = b (x0 = 0), CGS2 with the fused panel kernels; M may be NULL.
  * ws: hx_gmres_ws(n, restart) complex numbers.  SYNC (one small D2H per orthogonalisation pass). */
 size_t hx_gmres_ws(int64_t n, int restart);
+/* workspace of hx_gmres / hx_gmres_sharded / hx_amg_set_recycle for a handle with hx_amg_enable_recycling: the Arnoldi vectors
+ * live in the handle's [C; V] panel, so the workspace is (restart + 1) x n entries smaller (3.8 GiB at 5 M rows, restart 50) */
+size_t hx_gmres_ws_recycling(int64_t n, int restart);
 int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col,
              const hx_c128* val, const hx_sell* Ksell /* optional SELL-64 companion of the same K */,
              const hx_c128* b, hx_c128* x, double rtol, int max_it, int restart,

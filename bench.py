@@ -48,7 +48,8 @@ for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
 
 WORKLOADS = {
     # name: (nr, ntheta, nz)  -> DOFs = (nr+1)*ntheta*(nz+1)
-    "annulus-20M": (88, 2816, 76),     # 19,298,048 DOF: capacity point (one GPU, ~170 GB of HBM), not a BASELINE config
+    "annulus-25M": (96, 3072, 83),     # 25,030,656 DOF: capacity point after the round-4 memory work (one GPU), not a BASELINE config
+    "annulus-20M": (88, 2816, 76),     # 19,298,048 DOF: capacity point (one GPU, 155 GiB of HBM), not a BASELINE config
     "annulus-5M": (56, 1792, 48),      # 5,005,056 DOF (BASELINE configs[3], the metric's headline size)
     "annulus-5M-iso": (42, 666, 176),  # 5,068,926 DOF with near-cubic cells (h = 1.65 mm in r, theta, z): what an unstructured
                                        # mesher produces; the headline grid above has 10:1 cells (0.6 x 1.25 x 6 mm)

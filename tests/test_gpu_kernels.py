@@ -882,3 +882,54 @@ def test_block_products_and_block_cocg_match_the_single_vector_path(fmt):
     finally:
         _hx.set_option("sell_index", None)
         _hx.set_option("sell_stencil", None)
+
+
+def test_krylov_basis_rotation_in_place_and_destroy_releases_memory():
+    """Round 4: DeviceBasis.rotate runs IN PLACE through a slab scratch (the second panel is gone) -- one slab and several slabs
+    against NumPy, thick-restart shape (k kept columns + the residual column) and final shape (k == active columns); and
+    E.destroy() of the solver a fixed-point call returns gives the device memory back without a garbage collection."""
+    import gc
+    import torch
+    from helmholtz_x import slepc
+    rng = np.random.default_rng(11)
+    for n in (5000, 300_000):                      # (scratch slab: max(n / 8, 65536) positions -> 1 and 5 slabs)
+        m = 12
+        basis = slepc.DeviceBasis(n, m + 1, apply_op=None)
+        V0 = _rand_c(rng, (m + 1) * n).reshape(m + 1, n)
+        basis.V.copy_(_dev(V0))
+        assert basis._scratch.shape[1] == min(n, max(-(-n // slepc.ROTATE_SLABS), 65536))
+        for mact, k in ((m, 5), (7, 7)):           # thick restart: 12 active -> 5 kept; final Ritz vectors: 7 of 7 active
+            Vin = basis.V.cpu().numpy().copy()
+            Q = _rand_c(rng, mact * k).reshape(mact, k)
+            basis.rotate(Q, k)
+            Vout = basis.V.cpu().numpy()
+            ref = Q.T @ Vin[:mact]
+            assert np.max(np.abs(Vout[:k] - ref)) <= 1e-13 * np.max(np.abs(ref))
+            assert np.array_equal(Vout[k], Vin[mact])                       # residual column moved behind the kept ones
+        basis.close()
+        assert basis.V is None and basis._panel is None
+    # ---- destroy() releases: a small fixed-point call, then memory with the collector switched off
+    import bench
+    case = bench.build_case(bench.WORKLOADS["annulus-16k"])
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        E, matrices = bench.hot_path(case)          # warm-up: pools, pinned buffers, the case's device arrays
+        E.destroy()
+        del E, matrices
+        gc.collect()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        gc.disable()
+        try:
+            E, matrices = bench.hot_path(case)
+            held = torch.cuda.memory_allocated() - base
+            E.destroy()
+            del E, matrices
+            left = torch.cuda.memory_allocated() - base
+        finally:
+            gc.enable()
+    assert held > 20e6                              # the call did hold device memory (basis, hierarchy, operators) ...
+    assert left <= 0.05 * held, (held, left)        # ... and destroy() + dropping the references gave it back, no collection needed
+    from helmholtz_x import petsc
+    assert all(torch.is_tensor(v) for v in petsc._SLOT_CACHE.values())     # the slot cache holds maps, never operators

@@ -73,6 +73,12 @@ static void drop_graph(hx_amg* h) {
   if (h->vexec) { (void)hipGraphExecDestroy(h->vexec); h->vexec = nullptr; }
   if (h->graph_state == 1) h->graph_state = 0;          // re-capture with the new set-up
 }
+// block work vectors are sized from the levels' row counts when the first block solve asks for them: a level that is set again
+// (hx_amg_set_level*, hx_amg_set_coarse*, hx_amg_set_sharded) invalidates them -- the next block solve allocates afresh
+static void drop_blk(hx_amg* h) {
+  for (auto& l : h->blk) { (void)hx_free(l.x); (void)hx_free(l.x2); (void)hx_free(l.x3); (void)hx_free(l.b); (void)hx_free(l.r); }
+  h->blk.clear();
+}
 // ghost block of a sharded level's iterate must be current before K (or a transfer operator) is applied to it
 static int halo_level(hx_amg* h, int l, void* v, int elem_bytes, hx_stream s) {
   if (!h->sharded || l >= h->n_sharded) return HX_OK;
@@ -170,7 +176,7 @@ extern "C" int hx_amg_destroy(hx_amg* h) {
   };
   for (auto& l : h->D.L) release(l);
   for (auto& l : h->S.L) release(l);
-  for (auto& l : h->blk) release(l);
+  drop_blk(h);
   (void)hx_free(h->rec.U); (void)hx_free(h->rec.CV); (void)hx_free(h->rec.CVf);
   (void)hx_free(h->rec.Uf); (void)hx_free(h->rec.Cd); (void)hx_free(h->rec.Einv);
   if (h->vexec) (void)hipGraphExecDestroy(h->vexec);
@@ -215,6 +221,7 @@ extern "C" int hx_amg_set_level(hx_amg* h, int l, int32_t n, int64_t nnzK, const
                                 const int32_t* rpR, const int32_t* ciR, const hx_c128* vaR) {
   HX_REQUIRE(h, "null handle");
   h->normK_val = nullptr;      // new operator values: the cached |K|_inf of the backward-error test is stale
+  drop_blk(h);
   return set_level<double>(h->real_transfers, h->D, l, n, nnzK, rpK, ciK, (const double*)vaK, (const double*)dinv, n_coarse, nnzP, rpP, ciP,
                            (const double*)vaP, nnzR, rpR, ciR, (const double*)vaR);
 }
@@ -226,6 +233,7 @@ extern "C" int hx_amg_set_level_c(hx_amg* h, int l, int32_t n, int64_t nnzK, con
   h->single = true;
   h->normK_val = nullptr;
   drop_graph(h);
+  drop_blk(h);
   return set_level<float>(h->real_transfers, h->S, l, n, nnzK, rpK, ciK, (const float*)vaK, (const float*)dinv, n_coarse, nnzP, rpP, ciP,
                           (const float*)vaP, nnzR, rpR, ciR, (const float*)vaR);
 }
@@ -279,6 +287,7 @@ extern "C" int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext
   const size_t nl = h->single ? h->S.L.size() : h->D.L.size();
   HX_REQUIRE(n_sharded >= 1 && (size_t)n_sharded < nl, "row-sharded mode needs at least one replicated coarse level");
   drop_graph(h);
+  drop_blk(h);
   h->sharded = true; h->halo = halo; h->allreduce = allreduce; h->ctx = ctx; h->n_sharded = n_sharded;
   return h->single ? resize_ext<float>(h->S, n_sharded, n_ext) : resize_ext<double>(h->D, n_sharded, n_ext);
 }
@@ -318,6 +327,7 @@ extern "C" int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_begin_fn begin, hx_hal
 extern "C" int hx_amg_set_coarse(hx_amg* h, int32_t n_c, int64_t nnz, const int32_t* rp, const int32_t* ci,
                                  const hx_c128* va) {
   HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->D.L.back().n == n_c, "bad argument");
+  drop_blk(h);
   h->D.coarse_inv.rows = n_c; h->D.coarse_inv.nnz = nnz; h->D.coarse_inv.rp = rp; h->D.coarse_inv.ci = ci;
   h->D.coarse_inv.va = (const double*)va;
   return HX_OK;
@@ -326,6 +336,7 @@ extern "C" int hx_amg_set_coarse_c(hx_amg* h, int32_t n_c, int64_t nnz, const in
                                    const hx_c64* va) {
   HX_REQUIRE(h && n_c > 0 && rp && ci && va && h->S.L.back().n == n_c, "bad argument");
   drop_graph(h);
+  drop_blk(h);
   h->S.coarse_inv.rows = n_c; h->S.coarse_inv.nnz = nnz; h->S.coarse_inv.rp = rp; h->S.coarse_inv.ci = ci;
   h->S.coarse_inv.va = (const float*)va;
   return HX_OK;

@@ -106,9 +106,14 @@ static inline int hx_grid(int64_t work_items, int block, int max_blocks = 256 * 
 #include <atomic>
 extern std::atomic<hipStream_t> hx_last_stream;
 void hx_pool_register_stream(hipStream_t s, bool add);      // side streams of the library (see pool.hip)
+void hx_pool_note_stream(hipStream_t s);                    // (slow path: takes the pool's lock)
 static inline hipStream_t hx_s(hx_stream s) {
-  hx_last_stream.store((hipStream_t)s, std::memory_order_relaxed);
-  return (hipStream_t)s;
+  hipStream_t st = (hipStream_t)s;
+  if (hx_last_stream.load(std::memory_order_relaxed) != st) {   // a stream other than the previous call's: remember it where it is USED
+    hx_last_stream.store(st, std::memory_order_relaxed);
+    hx_pool_note_stream(st);
+  }
+  return st;
 }
 static inline zc hx_z(const double a[2]) { return make_double2(a[0], a[1]); }
 

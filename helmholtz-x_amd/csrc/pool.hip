@@ -12,13 +12,16 @@
 // ORDERING OF REUSE.  hipFree used to synchronise the device; a cached block does not go through it, and libhx launches on more
 // than one stream (the caller's stream -- possibly a non-blocking torch side stream --, the communicator's side stream for interior
 // slices, the graph-replay stream).  On release a block therefore records one event on every stream that may still touch it
-// (the recently seen caller streams, noted by hx_s(), and the registered internal streams); the request that takes the block out
+// (the caller streams seen since the last hx_pool_trim -- hx_s() notes a stream whenever it differs from the previous call's, up
+// to 8 of them, most recent last -- and the registered internal streams); the request that takes the block out
 // of the cache waits for those events on the HOST before it hands the block out, so whatever stream uses it next -- including the
 // null stream of a hipMemset / hipMemcpy -- finds it idle.  Released blocks usually sit in the cache for a whole fixed-point call:
 // the waits return at once.  HX_POOL=0 passes everything through.  hx_pool_trim() returns the cached blocks to the driver;
-// hx_pool_stats() reports.
+// hx_pool_stats() reports.  A caller that DESTROYS a stream it has passed to the library calls hx_pool_trim() first (the set of
+// noted streams is cleared there; an event must not be recorded on a dead handle).
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <list>
 #include <map>
@@ -29,7 +32,8 @@
 #include "hx_common.h"
 
 // the caller streams recently passed to the library (hx_s notes them) and the library's own side streams
-std::atomic<hipStream_t> hx_last_stream{nullptr};
+static hipStream_t const HX_NO_STREAM = (hipStream_t)(intptr_t)-1;    // "none seen yet" (nullptr is the null stream, a real one)
+std::atomic<hipStream_t> hx_last_stream{(hipStream_t)(intptr_t)-1};
 
 namespace {
 struct Pool {
@@ -37,18 +41,18 @@ struct Pool {
   std::unordered_map<void*, size_t> live;                         // pooled blocks handed out: size
   struct Free { void* p; size_t bytes; std::vector<hipEvent_t> ev; };
   std::vector<hipEvent_t> spare_events;
-  std::vector<hipStream_t> caller_streams;                        // up to 4 distinct caller streams, most recent last
+  std::vector<hipStream_t> caller_streams;                        // up to 8 distinct caller streams, most recent last
   std::vector<hipStream_t> internal_streams;
   int64_t n_events = 0, n_waits = 0;
-  void note_caller() {                                            // (lock held)
-    hipStream_t s = hx_last_stream.load(std::memory_order_relaxed);
+  void note(hipStream_t s) {                                      // (lock held)
+    if (s == HX_NO_STREAM) return;
     for (size_t i = 0; i < caller_streams.size(); ++i)
       if (caller_streams[i] == s) { caller_streams.erase(caller_streams.begin() + i); break; }
     caller_streams.push_back(s);
-    if (caller_streams.size() > 4) caller_streams.erase(caller_streams.begin());
+    if (caller_streams.size() > 8) caller_streams.erase(caller_streams.begin());
   }
   void mark(Free& f) {                                            // (lock held) one event per stream that may still use the block
-    note_caller();
+    note(hx_last_stream.load(std::memory_order_relaxed));
     auto rec = [&](hipStream_t st) {
       hipEvent_t e = nullptr;
       if (!spare_events.empty()) { e = spare_events.back(); spare_events.pop_back(); }
@@ -78,25 +82,38 @@ struct Pool {
   double driver_s = 0.0;
   bool on = true;
   size_t min_bytes = (size_t)1 << 20, max_cached = (size_t)32 << 30;
-  bool init = false;
+  bool init = false, cap_from_env = false;
+  size_t free_at_start = 0;
   void setup() {
     if (init) return;
     init = true;
     if (const char* e = getenv("HX_POOL")) on = atoi(e) != 0;
     if (const char* e = getenv("HX_POOL_MIN_BYTES")) min_bytes = (size_t)atoll(e);
-    if (const char* e = getenv("HX_POOL_MAX_GIB")) max_cached = (size_t)(atof(e) * (double)((size_t)1 << 30));
+    if (const char* e = getenv("HX_POOL_MAX_GIB")) { max_cached = (size_t)(atof(e) * (double)((size_t)1 << 30)); cap_from_env = true; }
     else {
       // default: a quarter of what is FREE now, shared between the local ranks that use this device (rehearsals run several
-      // ranks per card; torch's allocator and the other ranks' pools cannot see this cache)
+      // ranks per card; torch's allocator and the other ranks' pools cannot see this cache).  The GUESS made here -- local ranks /
+      // visible devices -- is wrong in one direction only when a launcher isolates one GPU per rank (ROCR_ / HIP_VISIBLE_DEVICES:
+      // 8 ranks, 1 visible device each, nobody shares): a process that sees ONE device through such a mask counts as alone on
+      // it.  Python's ShardContext replaces the guess by the count of local ranks with the same PCI bus id (hx_pool_set_sharing).
       size_t free_b = 0, total_b = 0;
       int ndev = 1;
       if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { (void)hipGetLastError(); ndev = 1; }
       int local_world = 1;
       if (const char* e = getenv("LOCAL_WORLD_SIZE")) local_world = atoi(e) > 0 ? atoi(e) : 1;
-      const int sharing = (local_world + ndev - 1) / ndev;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) max_cached = free_b / 4 / (size_t)(sharing > 0 ? sharing : 1);
-      else (void)hipGetLastError();
+      int sharing = (local_world + ndev - 1) / ndev;
+      const bool masked = getenv("ROCR_VISIBLE_DEVICES") || getenv("HIP_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES");
+      if (ndev == 1 && masked && !getenv("HX_POOL_ASSUME_SHARED")) sharing = 1;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+        free_at_start = free_b;
+        max_cached = free_b / 4 / (size_t)(sharing > 0 ? sharing : 1);
+      } else (void)hipGetLastError();
+      log_cap(sharing);
     }
+  }
+  void log_cap(int sharing) {
+    if (getenv("HX_POOL_VERBOSE"))
+      fprintf(stderr, "[hx pool] cache cap %.2f GiB (%d rank(s) on this device)\n", (double)max_cached / (double)((size_t)1 << 30), sharing);
   }
   void drop(std::list<Free>::iterator it) {                       // (lock held) cached block -> driver
     auto range = by_size.equal_range(it->bytes);
@@ -173,6 +190,12 @@ hipError_t hx_pool_free(void* p) {
   return hipSuccess;
 }
 
+void hx_pool_note_stream(hipStream_t s) {
+  Pool& P = g_pool;
+  std::lock_guard<std::mutex> lock(P.mu);
+  P.note(s);
+}
+
 // A side stream of the library (communicator: interior slices; hierarchy: graph replay) that may touch pooled blocks
 void hx_pool_register_stream(hipStream_t s, bool add) {
   Pool& P = g_pool;
@@ -182,7 +205,7 @@ void hx_pool_register_stream(hipStream_t s, bool add) {
   if (add) P.internal_streams.push_back(s);
   else {                                                         // a destroyed stream must not be recorded on: drop caller entries too
     hipStream_t cur = s;
-    hx_last_stream.compare_exchange_strong(cur, nullptr);
+    hx_last_stream.compare_exchange_strong(cur, HX_NO_STREAM);
     for (size_t i = 0; i < P.caller_streams.size(); ++i)
       if (P.caller_streams[i] == s) { P.caller_streams.erase(P.caller_streams.begin() + i); break; }
   }
@@ -198,12 +221,26 @@ extern "C" int hx_pool_ordering_stats(int64_t* n_events, int64_t* n_waits, int64
   return HX_OK;
 }
 
+// The number of ranks that really share THIS device (the caller counted equal PCI bus ids over the local ranks): replaces the
+// start-up guess unless HX_POOL_MAX_GIB fixed the cap.
+extern "C" int hx_pool_set_sharing(int ranks_on_this_device) {
+  HX_REQUIRE(ranks_on_this_device >= 1, "ranks_on_this_device must be >= 1");
+  Pool& P = g_pool;
+  std::lock_guard<std::mutex> lock(P.mu);
+  P.setup();
+  if (P.cap_from_env || P.free_at_start == 0) return HX_OK;
+  P.max_cached = P.free_at_start / 4 / (size_t)ranks_on_this_device;
+  P.log_cap(ranks_on_this_device);
+  while (P.cached > P.max_cached && !P.lru.empty()) P.drop(P.lru.begin());
+  return HX_OK;
+}
+
 extern "C" int hx_pool_trim(void) {
   Pool& P = g_pool;
   std::lock_guard<std::mutex> lock(P.mu);
   while (!P.lru.empty()) P.drop(P.lru.begin());
   P.caller_streams.clear();                                       // (a caller about to destroy its stream: forget it)
-  hx_last_stream.store(nullptr);
+  hx_last_stream.store(HX_NO_STREAM);
   return HX_OK;
 }
 

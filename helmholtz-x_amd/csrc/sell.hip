@@ -395,9 +395,9 @@ template <> __device__ __forceinline__ int32_t cidx<int32_t>(int32_t c, int32_t)
 template <> __device__ __forceinline__ int32_t cidx<int16_t>(int16_t c, int32_t row) { return row + (int32_t)c; }
 
 // acc += v * x with v in its storage type (complex-half: the conversions ride inside mixed-precision multiply-adds)
-__device__ __forceinline__ void mfma_acc(zc& acc, zc v, zc x) { zfma(acc, v, x); }
-__device__ __forceinline__ void mfma_acc(cc& acc, cc v, cc x) { zfma(acc, v, x); }
-__device__ __forceinline__ void mfma_acc(cc& acc, ch v, cc x) {
+__device__ __forceinline__ void cmul_acc(zc& acc, zc v, zc x) { zfma(acc, v, x); }
+__device__ __forceinline__ void cmul_acc(cc& acc, cc v, cc x) { zfma(acc, v, x); }
+__device__ __forceinline__ void cmul_acc(cc& acc, ch v, cc x) {
   const float vr = __low2float(v), vi = __high2float(v);
   acc.x = fmaf(vr, x.x, acc.x);
   acc.y = fmaf(vr, x.y, acc.y);
@@ -434,7 +434,7 @@ __device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cb, const MV* _
 #pragma unroll
     for (int j = 0; j < G; ++j) xv[j] = ld32<V>(x, (uint32_t)cidx<IT>(ci[j], row) * (uint32_t)sizeof(V));
 #pragma unroll
-    for (int j = 0; j < G; ++j) mfma_acc(acc[j & 3], v[j], xv[j]);
+    for (int j = 0; j < G; ++j) cmul_acc(acc[j & 3], v[j], xv[j]);
   }
   if (k0 < width) {
     IT ci[G];
@@ -449,7 +449,7 @@ __device__ __forceinline__ V sell_row_dot(const IT* __restrict__ cb, const MV* _
 #pragma unroll
     for (int j = 0; j < G; ++j) xv[j] = ld32<V>(x, (uint32_t)cidx<IT>(ci[j], row) * (uint32_t)sizeof(V));
 #pragma unroll
-    for (int j = 0; j < G; ++j) mfma_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv[j]));
+    for (int j = 0; j < G; ++j) cmul_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv[j]));
   }
   return zadd(zadd(acc[0], acc[1]), zadd(acc[2], acc[3]));
 }
@@ -473,7 +473,7 @@ __device__ __forceinline__ V sell_row_dot_stencil(int32_t u, const MV* __restric
       xv[j] = ld32<V>(x, (uint32_t)clampi(row + __builtin_amdgcn_readlane(u, k0 + j), n - 1) * (uint32_t)sizeof(V));
     }
 #pragma unroll
-    for (int j = 0; j < G; ++j) mfma_acc(acc[j & 3], v[j], xv[j]);
+    for (int j = 0; j < G; ++j) cmul_acc(acc[j & 3], v[j], xv[j]);
   }
   if (k0 < width) {
     MV v[G];
@@ -485,7 +485,7 @@ __device__ __forceinline__ V sell_row_dot_stencil(int32_t u, const MV* __restric
       xv[j] = ld32<V>(x, (uint32_t)clampi(row + __builtin_amdgcn_readlane(u, k), n - 1) * (uint32_t)sizeof(V));
     }
 #pragma unroll
-    for (int j = 0; j < G; ++j) mfma_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv[j]));
+    for (int j = 0; j < G; ++j) cmul_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv[j]));
   }
   return zadd(zadd(acc[0], acc[1]), zadd(acc[2], acc[3]));
 }
@@ -564,7 +564,7 @@ __device__ __forceinline__ bool sell_row_dot_stencil_lds(int32_t u, int32_t stw,
   for (int j = 0; j < G; ++j) {
     const int k = min(j, width - 1);
     const V xv = lds[__builtin_amdgcn_readlane(lofs, k) + lane];
-    mfma_acc(acc[j & 3], v0[j], zscale((R)(j < width ? 1 : 0), xv));
+    cmul_acc(acc[j & 3], v0[j], zscale((R)(j < width ? 1 : 0), xv));
   }
   for (int k0 = G; k0 < width; k0 += G) {
     MV v[G];
@@ -574,7 +574,7 @@ __device__ __forceinline__ bool sell_row_dot_stencil_lds(int32_t u, int32_t stw,
     for (int j = 0; j < G; ++j) {
       const int k = min(k0 + j, width - 1);
       const V xv = lds[__builtin_amdgcn_readlane(lofs, k) + lane];
-      mfma_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv));
+      cmul_acc(acc[j & 3], v[j], zscale((R)(k0 + j < width ? 1 : 0), xv));
     }
   }
   result = zadd(zadd(acc[0], acc[1]), zadd(acc[2], acc[3]));

@@ -356,6 +356,32 @@ extern "C" int hx_zsparse_dots(int nvec, const int32_t* ptr, const int32_t* idx,
   return HX_OK;
 }
 
+// ---------------------------------------------------------------- sparse updates y += coef * sum_f t[f] u_f (left factors of the flame term)
+// One block per vector f of the range [f0, f1): y[idx[p]] += coef * t[f] * vals[p] for its packed entries.  The coefficients
+// t stay on the device (they come out of hx_zsparse_dots / an all-reduce): no host round trip per product.  Indices are unique
+// inside a vector; vectors with DISJOINT supports (flames in separate regions) go in one launch, overlapping ones are issued
+// one vector per launch by the caller (stream order = a fixed summation order: deterministic, no atomics).
+__global__ void k_sparse_axpys(int f0, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, const zc* __restrict__ vals,
+                               const zc* __restrict__ t, zc coef, zc* __restrict__ y) {
+  const int f = f0 + blockIdx.x;
+  const zc a = zmul(coef, t[f]);
+  for (int p = ptr[f] + threadIdx.x; p < ptr[f + 1]; p += blockDim.x) {
+    const int32_t i = idx[p];
+    zc v = y[i];
+    zfma(v, a, vals[p]);
+    y[i] = v;
+  }
+}
+extern "C" int hx_zsparse_axpys(int nvec, const int32_t* ptr, const int32_t* idx, const hx_c128* vals, const hx_c128* t,
+                                const double coef[2], hx_c128* y, int disjoint, hx_stream s) {
+  HX_REQUIRE(nvec >= 0 && ptr && t && coef && y, "bad argument");
+  if (nvec == 0) return HX_OK;
+  HX_REQUIRE(idx && vals, "bad argument");
+  if (disjoint) k_sparse_axpys<<<nvec, 256, 0, hx_s(s)>>>(0, ptr, idx, (const zc*)vals, (const zc*)t, hx_z(coef), (zc*)y);
+  else for (int f = 0; f < nvec; ++f) k_sparse_axpys<<<1, 256, 0, hx_s(s)>>>(f, ptr, idx, (const zc*)vals, (const zc*)t, hx_z(coef), (zc*)y);
+  HX_LAUNCH_CHECK("k_sparse_axpys");
+  return HX_OK;
+}
 
 // ---------------------------------------------------------------- threshold + compaction of a load vector
 // flame_matrices.py:66-72: zero |Re| < tol and |Im| < tol separately, keep the non-zeros as (index, value) pairs.

@@ -42,6 +42,7 @@ SIGNATURES = {
     "hx_zpanel_sub_c64": (C.c_int, [_i64, _int, _vp, _i64, _vp, _vp, _vp]),
     "hx_zpanel_mul": (C.c_int, [_i64, _int, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
     "hx_zsparse_dots": (C.c_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hx_zsparse_axpys": (C.c_int, [_int, _vp, _vp, _vp, _vp, _dp, _vp, _int, _vp]),
     "hx_zthreshold_pack": (C.c_int, [_i64, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp]),
     "hx_csr_spmv_z": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _dp, _dp, _int, _vp]),
     "hx_sell_create": (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _vp, _int, _int, _vp]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "hx_zsmall_gemv": (C.c_int, [_int, _int, _vp, _vp, _vp, _vp]),
     "hx_zroll": (C.c_int, [_i64, _i64, _vp, _vp, _vp]),
     "hx_zdense_inverse": (C.c_int, [_int, _vp, _vp]),
+    "hx_pool_set_sharing": (C.c_int, [_int]),
     "hx_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "hx_get_option": (C.c_int, [C.c_char_p, C.c_char_p, _int]),
     "hx_pool_trim": (C.c_int, []),
@@ -211,9 +213,33 @@ def device_empty(shape, dtype, device=None):
         return torch.empty(shape, dtype=dtype, device=device)
 
 
+_SHARING = None          # ranks of the process group that use THIS rank's device (count_device_sharing)
+
+
+def count_device_sharing(group=None):
+    """How many ranks of ``group`` run on the device of this rank: every rank publishes (host, PCI domain:bus:device of its
+    current device) and counts its equals.  Collective; tells the device-buffer pool (hx_pool_set_sharing) -- a launcher that
+    masks one GPU per rank (ROCR_VISIBLE_DEVICES) leaves LOCAL_WORLD_SIZE / visible devices = 8 although nobody shares."""
+    global _SHARING
+    import socket
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()):
+        return 1
+    p = torch.cuda.get_device_properties(torch.cuda.current_device())
+    mine = (socket.gethostname(), getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", torch.cuda.current_device()),
+            getattr(p, "pci_device_id", 0))
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, mine, group=group)
+    _SHARING = max(1, sum(1 for e in everyone if tuple(e) == mine))
+    check(lib.hx_pool_set_sharing(_SHARING))
+    return _SHARING
+
+
 def shares_device():
-    """More local ranks than GPUs (rehearsals on a one-GPU box): caches are trimmed when solver objects are destroyed."""
+    """More ranks than GPUs (rehearsals on a one-GPU box): caches are trimmed when solver objects are destroyed."""
     import os
+    if _SHARING is not None:
+        return _SHARING > 1
     try:
         return int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > max(torch.cuda.device_count(), 1)
     except ValueError:

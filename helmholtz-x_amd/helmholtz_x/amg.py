@@ -281,13 +281,19 @@ def _dev_spgemm(A, B):
 
 
 def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"], coarse_size=PARAMS["coarse_size"],
-                           level_offset=0):
+                           level_offset=0, graph=None):
     """Same smoothed-aggregation hierarchy as ``build_hierarchy``, built in HBM: K (petsc.CSR / DevCSR on the device) is
     never copied to the host.  Device passes (amg_setup.hip): diagonal, strength filter, power iteration, smoothed
     prolongator, transpose, Galerkin product as R (K P).  Host: the greedy aggregation of the filtered graph and the
-    dense inverse of the coarsest operator (a few hundred unknowns).  Returns level dicts whose K / P / R are DevCSR."""
+    dense inverse of the coarsest operator (a few hundred unknowns).  Returns level dicts whose K / P / R are DevCSR.
+
+    ``graph`` (CSR on K's pattern, e.g. the stiffness part A of K = A + sigma B + sigma^2 C): strength of connection, aggregation
+    and prolongator smoothing are taken from IT on every level (G_{l+1} = R G_l P is carried down beside K_{l+1} = R K_l P) -- the
+    transfer operators are then those of the Laplacian whatever the shift does to the signs and sizes of K's entries (at high
+    frequency sigma^2 C outweighs A on the coarse levels and the "Laplacian-like part of K" is no Laplacian any more)."""
     levels = []
     Kl = DevCSR(K.shape, K.rowptr, K.col, K.val)
+    Gl = None if graph is None else DevCSR(graph.shape, graph.rowptr, graph.col, graph.val)
     dev = K.val.device
     # (level_offset > 0: continuation of a row-sharded set-up below its last sharded level -- theta was halved per level)
     th = float(os.environ.get("HX_AMG_THETA", theta)) if level_offset == 0 else float(theta)
@@ -305,15 +311,22 @@ def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_leve
                 raise ArithmeticError("AMG hierarchy still has %d unknowns after %d levels" % (n, len(levels) + 1))
             levels.append(level)
             break
-        sgn = -1.0 if 2 * int((diag.real < 0).sum()) > n else 1.0
+        Sl = Kl if Gl is None else Gl              # the operator whose real part plays the Laplacian
+        if Gl is None:
+            sgn = -1.0 if 2 * int((diag.real < 0).sum()) > n else 1.0
+        else:
+            gd = torch.empty(n, dtype=torch.complex128, device=dev)
+            _hx.check(_hx.lib.hx_csr_diagonal_z(n, _hx.ptr(Gl.rowptr), _hx.ptr(Gl.col), _hx.ptr(Gl.val), _hx.ptr(gd), _hx.stream()))
+            sgn = -1.0 if 2 * int((gd.real < 0).sum()) > n else 1.0
+            del gd
         sd = torch.empty(n, dtype=torch.float64, device=dev)
-        Lf = _dev_filter(Kl, sgn, th, sd)
+        Lf = _dev_filter(Sl, sgn, th, sd)
         agg, na = _dev_aggregate(Lf)
         for _ in range(3):                         # too few couplings count as strong: relax the threshold and retry
             if na < 0.8 * n:
                 break
             th *= 0.25
-            Lf = _dev_filter(Kl, sgn, th, sd)
+            Lf = _dev_filter(Sl, sgn, th, sd)
             agg, na = _dev_aggregate(Lf)
         if na >= 0.8 * n:                          # coarsening stalled for good: this level becomes the coarsest one
             if n > MAX_DENSE_COARSE:
@@ -346,6 +359,8 @@ def build_hierarchy_device(K, theta=PARAMS["theta"], max_levels=PARAMS["max_leve
         levels.append(level)
         del Lf, sd, v, w
         Kl = _dev_spgemm(R, _dev_spgemm(Kl, P))
+        if Gl is not None:
+            Gl = _dev_spgemm(R, _dev_spgemm(Gl, P))
         th *= 0.5
     return levels
 
@@ -626,35 +641,102 @@ class AMGSolver:
 
     name = "amg"
 
-    def __init__(self, K_csr, hierarchy=None, shard=None, **overrides):
+    def __init__(self, K_csr, hierarchy=None, shard=None, shifted=None, graph=None, label=None, **overrides):
         """``shard`` (sharded.ShardContext): K_csr holds this rank's rows over [owned | ghost] columns (distributed assembly;
         a global operator is cut to them first), the hierarchy is built and kept row-sharded on its large levels and the
-        solve is collective (hx_cocg_sharded / hx_gmres_sharded)."""
-        import time
-        t_setup = time.perf_counter()
-        self.params = dict(PARAMS, **overrides)
+        solve is collective (hx_cocg_sharded / hx_gmres_sharded).
+
+        Escalation ladder (``LADDER``): a solve that stalls does not end the call -- the solver moves to its next rung, stays there
+        for the rest of its life and repeats the solve; ``stats()['ladder']`` logs every step with its reason.  The rungs beyond the
+        first need ``shifted(beta)`` -> CSR of K + i beta sigma^2 C (the complex-shifted operator the hierarchy is then built on:
+        a damped Helmholtz problem every coarse grid can represent; the Krylov method still solves K x = b to the same tolerance)
+        and ``graph()`` -> CSR of the Laplacian-like part A on K's pattern (strength of connection and prolongator smoothing
+        are then taken from A at every level, whatever the frequency does to the sign of K's entries).  Both are supplied by
+        slepc.EPS / PEP; without them the ladder ends after its second rung.  ``label``: text naming the operator in errors."""
         import os
-        for key in ("pre", "post", "restart"):            # experiment hooks (tools/): HX_AMG_PRE / HX_AMG_POST / HX_AMG_RESTART
+        self.params = dict(PARAMS, **overrides)
+        for key in ("pre", "post", "restart", "max_it"):    # experiment hooks (tools/): HX_AMG_PRE / _POST / _RESTART / _MAX_IT
             if os.environ.get("HX_AMG_" + key.upper()):
                 self.params[key] = int(os.environ["HX_AMG_" + key.upper()])
         self.shard = shard
+        self._K_in, self._hierarchy_in = K_csr, hierarchy
+        self._shifted, self._graph, self.label = shifted, graph, label
+        self.cocg_solves = self.cocg_fallbacks = self.cocg_iters = self.attainable_stops = 0
+        self.backward_stable = False
+        self.total_iters = 0
+        self.n_solves = 0
+        self.solve_s = 0.0
+        self.setup_s = 0.0
+        self.last = (0, 0.0)
+        self.ladder = []                              # [{rung, after_solve, reason}]: the steps taken so far
+        self.rung = int(os.environ.get("HX_AMG_RUNG", "0"))      # (experiment hook: start on a later rung)
+        self._apply_rung()
+        self._build()
+
+    # ---- escalation ladder: what changes from rung to rung (everything else stays as PARAMS has it)
+    #   default          V(2,2) on the hierarchy of K itself, deflated COCG / FGMRES(50), at most 200 iterations per solve
+    #   long             the same hierarchy, three times the iteration budget (a solve that was converging slowly: nothing is rebuilt)
+    #   shifted          hierarchy of K + i 0.5 sigma^2 C with transfers from the Laplacian part, FGMRES / COCG on K itself
+    #   shifted-strong   the same with beta = 1 and one more smoothing step on each side
+    LADDER = (dict(name="default"),
+              dict(name="long", max_it_factor=3),
+              dict(name="shifted", max_it_factor=3, beta=0.5, graph=True),
+              dict(name="shifted-strong", max_it_factor=4, beta=1.0, graph=True, sweeps=3))
+
+    def _apply_rung(self):
+        import os
+        r = self.LADDER[self.rung]
+        self.beta = float(os.environ.get("HX_AMG_SHIFT_BETA", r.get("beta", 0.0)))
+        self.use_graph = bool(int(os.environ.get("HX_AMG_GRAPH_FROM_A", int(bool(r.get("graph"))))))
+        self._max_it = int(self.params["max_it"] * r.get("max_it_factor", 1))
+        self._sweeps = r.get("sweeps")
+        if self.beta and self._shifted is None:
+            raise ArithmeticError("rung %r needs the complex-shifted operator, which this caller did not supply" % r["name"])
+
+    def _escalate(self, reason):
+        """Next rung (rebuilding the hierarchy where the rung asks for another one).  Returns False at the end of the ladder.
+        Row-sharded: the decision rests on all-reduced residual norms, so every rank takes the same step."""
+        nxt = self.rung + 1
+        if nxt >= len(self.LADDER) or (self.LADDER[nxt].get("beta") and self._shifted is None):
+            return False
+        rebuild = any(self.LADDER[nxt].get(k) != self.LADDER[self.rung].get(k) for k in ("beta", "graph", "sweeps"))
+        self.rung = nxt
+        self.ladder.append(dict(rung=self.LADDER[nxt]["name"], after_solve=self.n_solves, reason=reason))
+        info("! inner solver: %s -- moving to rung %r of the escalation ladder" % (reason, self.LADDER[nxt]["name"]))
+        self._apply_rung()
+        if rebuild:
+            self._teardown()
+            self._build()
+        return True
+
+    def _build(self):
+        import os
+        import time
+        t_setup = time.perf_counter()
+        K_csr, hierarchy, shard = self._K_in, self._hierarchy_in, self.shard
+        if self._sweeps:
+            self.params["pre"] = self.params["post"] = int(self._sweeps)
         dev = K_csr.val.device
+        # the operator the HIERARCHY is built on: K itself, or its complex-shifted companion (same pattern)
+        Kp = K_csr if not self.beta else self._shifted(self.beta)
+        G = self._graph() if (self.use_graph and self._graph is not None) else None
         if shard is not None:
             # row-sharded: K_csr is this rank's rows (distributed assembly) or the global operator (cut to the rank's rows
             # here); either way the hierarchy is BUILT sharded -- every rank its slab of every large level
             K_csr = shard.localize(K_csr)
+            Kp = K_csr if Kp is self._K_in else shard.localize(Kp)
             levels = hierarchy if hierarchy is not None else build_hierarchy_sharded(
-                K_csr, shard, self.params["theta"], self.params["max_levels"], self.params["coarse_size"],
+                Kp, shard, self.params["theta"], self.params["max_levels"], self.params["coarse_size"],
                 self.params["replicate_max_rows"])
             n_rows = shard.n_global
         elif hierarchy is not None:
             levels = hierarchy
         elif os.environ.get("HX_AMG_SETUP", self.params["setup"]) == "host":      # round-1 host passes (comparison / tests)
-            levels = build_hierarchy(K_csr.to_scipy(), self.params["theta"], self.params["max_levels"],
+            levels = build_hierarchy(Kp.to_scipy(), self.params["theta"], self.params["max_levels"],
                                      self.params["coarse_size"])
         else:
-            levels = build_hierarchy_device(K_csr, self.params["theta"], self.params["max_levels"],
-                                            self.params["coarse_size"])
+            levels = build_hierarchy_device(Kp, self.params["theta"], self.params["max_levels"],
+                                            self.params["coarse_size"], graph=G)
         self.levels = levels
         self.n_sharded = sum(1 for lv in levels if lv.get("sharded"))
         # Krylov method of the inner solve: complex symmetric K (every shifted operator of the path except the
@@ -671,8 +753,6 @@ class AMGSolver:
             kry == "cocg" or (kry == "auto" and n_rows >= self.params["cocg_min_rows"]
                               and (_is_complex_symmetric(K_csr) if shard is None
                                    else _is_complex_symmetric_sharded(K_csr, shard))))
-        self.cocg_solves = self.cocg_fallbacks = self.cocg_iters = self.attainable_stops = 0
-        self.backward_stable = False
         if shard is not None and len(levels) < 2:
             raise ValueError("row-sharded AMG needs at least one coarse level (problem too small to shard)")
         self.n = K_csr.shape[0]
@@ -715,7 +795,7 @@ class AMGSolver:
             return M.val if isinstance(M, DevCSR) else to_device(sp.csr_matrix(M).data.astype(np.complex128))
 
         # SELL-64 companion of the fine operator (complex128 for K z in GMRES, working precision for the V-cycle)
-        self.sell = None
+        self.sell = self.sell_pre = None
         self.coarse_sells = []
         # (threshold: CSR with several lanes per row wins below ~1e5 rows -- 66 k DOF 0.20 s per call against 0.24 s with SELL-64,
         # 260 k DOF 0.39 against 0.35; row-sharded levels are judged by their GLOBAL size and keep SELL-64, whose slice lists the
@@ -727,17 +807,29 @@ class AMGSolver:
             # when the cycle runs in complex64 (8 instead of 12 bytes per entry; same GMRES iteration counts measured)
             half = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
             self.fine_values = "fp16" if half else ("c64" if mixed else "c128")
-            _hx.check(_hx.lib.hx_sell_create(C.byref(sh), self.n, _hx.ptr(K_csr.rowptr), _hx.ptr(K_csr.col),
-                                             _hx.ptr(K_csr.val), 1, 2 if half else int(mixed), _hx.stream()))
-            self.sell = sh
-            _hx.check(_hx.lib.hx_amg_set_level_sell(h, 0, sh))
+            if Kp is K_csr:
+                _hx.check(_hx.lib.hx_sell_create(C.byref(sh), self.n, _hx.ptr(K_csr.rowptr), _hx.ptr(K_csr.col),
+                                                 _hx.ptr(K_csr.val), 1, 2 if half else int(mixed), _hx.stream()))
+                self.sell = sh
+                _hx.check(_hx.lib.hx_amg_set_level_sell(h, 0, sh))
+            else:
+                # hierarchy of the complex-shifted companion: the Krylov method multiplies by K (complex128 copy only), the
+                # V-cycle smooths with K + i beta sigma^2 C (working-precision copy only) -- two SELL-64 objects, same pattern
+                _hx.check(_hx.lib.hx_sell_create(C.byref(sh), self.n, _hx.ptr(K_csr.rowptr), _hx.ptr(K_csr.col),
+                                                 _hx.ptr(K_csr.val), 1, 0, _hx.stream()))
+                self.sell = sh
+                sp_ = C.c_void_p()
+                _hx.check(_hx.lib.hx_sell_create(C.byref(sp_), self.n, _hx.ptr(Kp.rowptr), _hx.ptr(Kp.col), _hx.ptr(Kp.val),
+                                                 int(not mixed), (2 if half else int(mixed)), _hx.stream()))
+                self.sell_pre = sp_
+                _hx.check(_hx.lib.hx_amg_set_level_sell(h, 0, sp_))
         # coarse SELL levels take the same storage (5 M DOF: iterations unchanged, 8.38 -> 8.27 s)
         half_coarse = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
         for l, lv in enumerate(levels):
             if l == 0:
-                k0 = K_csr.val.to(cdt) if mixed else K_csr.val
+                k0 = Kp.val.to(cdt) if mixed else Kp.val
                 self._keep.append(k0)
-                (krp, kci, kva), knnz = (K_csr.rowptr, K_csr.col, k0), K_csr.nnz
+                (krp, kci, kva), knnz = (Kp.rowptr, Kp.col, k0), Kp.nnz
             else:
                 (krp, kci, kva), knnz = dev_csr(lv["K"])
                 # (one lane per row only pays for short rows: measured 33 us per SELL smoothing step on 88 k rows of
@@ -822,12 +914,8 @@ class AMGSolver:
         gmres_ws = (_hx.lib.hx_gmres_ws_recycling if self.recycle_k > 0 else _hx.lib.hx_gmres_ws)(self.n, self.params["restart"])
         self.ws = torch.empty(max(gmres_ws, _hx.lib.hx_cocg_ws(self.n)), dtype=torch.complex128, device=dev)
         self.krylov_tol_floor = 10.0 * self.params["rtol"]
-        self.total_iters = 0
-        self.n_solves = 0
-        self.solve_s = 0.0
-        self.last = (0, 0.0)
         torch.cuda.synchronize()
-        self.setup_s = time.perf_counter() - t_setup
+        self.setup_s += time.perf_counter() - t_setup
         self.agg_times = list(AGG_TIMES) if hierarchy is None else []
         del AGG_TIMES[:]
         info("- AMG hierarchy: " + " -> ".join("%d" % lv["n"] for lv in levels)
@@ -842,10 +930,31 @@ class AMGSolver:
         self.params["rtol"] = float(rtol)
         self.krylov_tol_floor = 10.0 * self.params["rtol"]
 
+    def set_max_it(self, max_it):
+        """Iteration limit of one inner solve on the first rung (-st_ksp_max_it); later rungs multiply it."""
+        self.params["max_it"] = int(max_it)
+        self._apply_rung()
+
     def solve(self, b, x, relax=1.0, x0=False):
         """``relax`` >= 1 multiplies the relative tolerance (inexact-Krylov relaxation decided by the eigen-solver).
         ``x0``: x holds an initial guess (a related solution); used by the COCG route only, and dropped by the solver when
-        it does not bring the residual below a tenth of |b| (hx_amg_next_solve_uses_x)."""
+        it does not bring the residual below a tenth of |b| (hx_amg_next_solve_uses_x).
+        A solve that ends above 100x its tolerance (and not at a rounding-level backward error) moves the solver up its
+        escalation ladder and is repeated there; only the last rung raises -- with the operator's label in the message."""
+        while True:
+            it, rr = self._solve_once(b, x, relax, x0)
+            rtol = self.params["rtol"] * max(float(relax), 1.0)
+            if not (rr > 100 * rtol and not getattr(self, "backward_stable", False)):
+                return
+            reason = "inner solve %d stalled at relative residual %.2e after %d iterations" % (self.n_solves, rr, it)
+            x0 = False
+            if not self._escalate(reason):
+                raise ArithmeticError("%s on the last rung (%r) of the escalation ladder%s; steps taken: %s"
+                                      % (reason, self.LADDER[self.rung]["name"],
+                                         " -- operator: %s" % self.label if self.label else "",
+                                         [st["rung"] for st in self.ladder] or "none"))
+
+    def _solve_once(self, b, x, relax, x0):
         import time
         t0 = time.perf_counter()
         it, rr = C.c_int(0), C.c_double(0.0)
@@ -873,9 +982,7 @@ class AMGSolver:
         self.last = (it.value, rr.value)
         if os.environ.get("HX_AMG_LOG_ITS"):
             print("[amg] solve %d: %d its, relres %.2e" % (self.n_solves, it.value, rr.value), file=__import__("sys").stderr)
-        if rr.value > 100 * rtol and not getattr(self, "backward_stable", False):
-            raise ArithmeticError("inner GMRES stalled at relative residual %.2e after %d iterations"
-                                  % (rr.value, it.value))
+        return it.value, rr.value
 
     # ---- blocks of right-hand sides (csrc/cocg_block.hip)
     def block_ready(self):
@@ -908,7 +1015,7 @@ class AMGSolver:
             m = min(w, nb - c0)
             _hx.check(_hx.lib.hx_zblock_pack(self.n, m, _hx.ptr(B[c0]), B.stride(0), _hx.ptr(self._blk_b), _hx.stream()))
             rc = _hx.lib.hx_cocg_block(self.handle, self.n, self.sell, m, _hx.ptr(self._blk_b), _hx.ptr(self._blk_x), rtol,
-                                       self.params["max_it"], _hx.ptr(self._blk_ws), its, rrs, _hx.stream())
+                                       self._max_it, _hx.ptr(self._blk_ws), its, rrs, _hx.stream())
             if rc == _hx.ERR_BREAKDOWN:                  # a recurrence broke down: the whole group goes the single-vector way
                 redo += [(c, False) for c in range(c0, c0 + m)]
                 continue
@@ -930,7 +1037,7 @@ class AMGSolver:
         K = self.K
         if self.shard is not None:
             rc = _hx.lib.hx_gmres_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
-                                          self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
+                                          self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self._max_it,
                                           self.params["restart"], _hx.ptr(self.ws), _hx.ptr(self._xe),
                                           _hx.ptr(self._hbuf), C.byref(it), C.byref(rr), _hx.stream())
             if rc != 0 and self.shard.callback_error():
@@ -938,7 +1045,7 @@ class AMGSolver:
             _hx.check(rc)
         else:
             _hx.check(_hx.lib.hx_gmres(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
-                                       self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
+                                       self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self._max_it,
                                        self.params["restart"], _hx.ptr(self.ws), C.byref(it), C.byref(rr), _hx.stream()))
 
     def _solve_cocg(self, b, x, rtol, it, rr):
@@ -951,7 +1058,7 @@ class AMGSolver:
                 ne0, na0 = C.c_int64(0), C.c_int64(0)
                 _hx.check(_hx.lib.hx_comm_counters(self.shard.comm, C.byref(ne0), C.byref(na0), 0))
             rc = _hx.lib.hx_cocg_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
-                                         self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"],
+                                         self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self._max_it,
                                          _hx.ptr(self.ws), _hx.ptr(self._xe),
                                          _hx.ptr(self._hbuf), C.byref(it), C.byref(rr), _hx.stream())
             if native:
@@ -963,7 +1070,7 @@ class AMGSolver:
                 raise RuntimeError("exchange callback failed inside hx_cocg_sharded:\n" + self.shard.callback_error())
         else:
             rc = _hx.lib.hx_cocg(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
-                                 self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self.params["max_it"], _hx.ptr(self.ws),
+                                 self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self._max_it, _hx.ptr(self.ws),
                                  C.byref(it), C.byref(rr), _hx.stream())
         be = C.c_double(-1.0)
         if rc == 0 and rr.value > 10 * rtol:
@@ -1016,7 +1123,9 @@ class AMGSolver:
         self.harmonic_ritz = theta
 
     def stats(self):
-        return dict(recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)),
+        return dict(rung=self.LADDER[self.rung]["name"], ladder=list(self.ladder), shift_beta=self.beta,
+                    transfers_from="A" if (self.use_graph and self._graph is not None) else "K",
+                    recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)),
                     levels=[lv.get("n_global", lv["n"]) for lv in self.levels],
                     sharded_levels=[[lv["n"], lv["n_ext"] - lv["n"]] for lv in self.levels if lv.get("sharded")],
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
@@ -1036,13 +1145,15 @@ class AMGSolver:
                     block_solves=getattr(self, "block_solves", 0), block_columns=getattr(self, "block_columns", 0),
                     block_iters=getattr(self, "block_iters", 0))
 
-    def destroy(self):
+    def _teardown(self):
+        """Handles and device arrays of the current hierarchy (destroy(); also between two rungs of the ladder)."""
         if getattr(self, "handle", None):
             _hx.lib.hx_amg_destroy(self.handle)
             self.handle = None
-        if getattr(self, "sell", None):
-            _hx.lib.hx_sell_destroy(self.sell)
-            self.sell = None
+        for name in ("sell", "sell_pre"):
+            if getattr(self, name, None):
+                _hx.lib.hx_sell_destroy(getattr(self, name))
+                setattr(self, name, None)
         for shl in getattr(self, "coarse_sells", []):
             _hx.lib.hx_sell_destroy(shl)
         self.coarse_sells = []
@@ -1052,6 +1163,10 @@ class AMGSolver:
                 setattr(self, name, None)
         if getattr(self, "levels", None):
             self.levels = [{k: v for k, v in lv.items() if isinstance(v, (int, float, bool, str))} for lv in self.levels]
+
+    def destroy(self):
+        self._teardown()
+        self._K_in = self._hierarchy_in = self._shifted = self._graph = None
 
     def __del__(self):
         try:

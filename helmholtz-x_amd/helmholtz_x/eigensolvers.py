@@ -54,9 +54,9 @@ def eps_solver(A, C, target, nev, two_sided=False, print_results=False, st_type=
     E.setTwoSided(two_sided)
     E.setDimensions(nev, DECIDE)
     E.setTolerances(1e-15)
-    E.setFromOptions()
     E.st_type = st_type
     E.shard = shard
+    E.setFromOptions()          # -eps_* / -st_* overrides from the options database (slepc.py)
     if _caches is not None:
         E.inner_cache, E.W_cache, E.state = _caches
     info("- EPS solver started.")
@@ -76,9 +76,9 @@ def pep_solver(A, B, C, target, nev, print_results=False, st_type=None, _caches=
     Q.setWhichEigenpairs(PEP.Which.TARGET_MAGNITUDE)
     Q.setDimensions(nev, DECIDE)
     Q.setTolerances(1e-15)
-    Q.setFromOptions()
     Q.st_type = st_type
     Q.shard = shard
+    Q.setFromOptions()          # -pep_* / -st_* overrides from the options database (slepc.py)
     if _caches is not None:
         Q.inner_cache, Q.W_cache, Q.state = _caches
     info("- PEP solver started.")

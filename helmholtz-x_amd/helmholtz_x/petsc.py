@@ -112,6 +112,97 @@ class Vec:
         self.t = None
 
 
+class Options:
+    """``PETSc.Options``-shaped view of ONE process-wide options database (petsc4py: ``PETSc.Options()``; the reference's solver
+    set-up ends in ``E.setFromOptions()`` / ``Q.setFromOptions()``, eigensolvers.py:60,109, so that ``-eps_nev 6 -eps_tol 1e-10
+    -st_pc_type lu ...`` on the command line of a driver, or ``PETSC_OPTIONS`` in the environment, override what the code set).
+    The database is seeded once from ``PETSC_OPTIONS`` and ``sys.argv`` (what ``petsc4py.init(sys.argv)`` does); names are stored
+    without the leading dash.  ``slepc.EPS/PEP.setFromOptions`` maps the ``eps_* / pep_* / st_*`` names it knows onto the setters
+    of the device solvers and ``hx_<name>`` onto the library's own registry (hx_set_option)."""
+
+    _db = None
+
+    def __init__(self, prefix=None):
+        self.prefix = (prefix or "").lstrip("-")
+        if Options._db is None:
+            Options._db = {}
+            import os
+            import shlex
+            import sys
+            Options._parse(shlex.split(os.environ.get("PETSC_OPTIONS", "")))
+            Options._parse(sys.argv[1:])
+
+    @staticmethod
+    def _is_name(tok):
+        """An option name starts with a dash followed by a letter (``-1e-3`` or ``-0.5`` are values)."""
+        return len(tok) > 1 and tok[0] == "-" and (tok[1].isalpha() or (tok[1] == "-" and len(tok) > 2 and tok[2].isalpha()))
+
+    @classmethod
+    def _parse(cls, tokens):
+        i = 0
+        while i < len(tokens):
+            tok = tokens[i]
+            if cls._is_name(tok):
+                val = ""
+                if i + 1 < len(tokens) and not cls._is_name(tokens[i + 1]):
+                    val = tokens[i + 1]
+                    i += 1
+                cls._db[tok.lstrip("-")] = val
+            i += 1
+
+    def _key(self, name):
+        return self.prefix + str(name).lstrip("-")
+
+    # --- petsc4py surface
+    def setValue(self, name, value):
+        Options._db[self._key(name)] = "" if value is None else (("1" if value else "0") if isinstance(value, bool) else str(value))
+
+    __setitem__ = setValue
+
+    def delValue(self, name):
+        Options._db.pop(self._key(name), None)
+
+    __delitem__ = delValue
+
+    def hasName(self, name):
+        return self._key(name) in Options._db
+
+    __contains__ = hasName
+
+    def getString(self, name, default=None):
+        return Options._db.get(self._key(name), default)
+
+    def __getitem__(self, name):
+        return Options._db[self._key(name)]
+
+    def getInt(self, name, default=None):
+        v = self.getString(name)
+        return default if v in (None, "") else int(float(v))
+
+    def getReal(self, name, default=None):
+        v = self.getString(name)
+        return default if v in (None, "") else float(v)
+
+    def getScalar(self, name, default=None):
+        v = self.getString(name)
+        return default if v in (None, "") else complex(v.replace("i", "j").replace(" ", ""))
+
+    def getBool(self, name, default=None):
+        v = self.getString(name)
+        if v is None:
+            return default
+        return v.lower() in ("", "1", "true", "yes", "on")
+
+    def getAll(self):
+        n = len(self.prefix)
+        return {k[n:]: v for k, v in Options._db.items() if k.startswith(self.prefix)}
+
+    def clear(self):
+        for k in [k for k in Options._db if k.startswith(self.prefix)]:
+            del Options._db[k]
+        return self
+
+
 class _SerialComm:
     def getRank(self):
         return 0
@@ -231,8 +322,24 @@ class LowRank:
     def left_packed(self):
         """[(device int32 indices, device complex128 values)] of the left factors u_f: their supports are a few hundred entries."""
         if not hasattr(self, "_lp"):
-            self._lp = [(to_device(ui), to_device(uv)) for (ui, uv), _ in self.pairs]
+            self._lp = [(to_device(np.asarray(ui, dtype=np.int32)), to_device(np.asarray(uv, dtype=np.complex128)))
+                        for (ui, uv), _ in self.pairs]
         return self._lp
+
+    def left_packed_all(self):
+        """(ptr, idx, val, disjoint) of ALL left factors, packed like ``right_packed``: one scatter launch per product
+        (hx_zsparse_axpys).  ``disjoint``: no row index occurs in two factors."""
+        if not hasattr(self, "_lpa"):
+            lens = [len(u[0]) for u, _ in self.pairs]
+            ptr = np.zeros(self.rank + 1, np.int32)
+            ptr[1:] = np.cumsum(lens)
+            idx = np.concatenate([np.asarray(u[0], dtype=np.int32) for u, _ in self.pairs]) if self.rank else np.zeros(0, np.int32)
+            val = np.concatenate([np.asarray(u[1], dtype=np.complex128) for u, _ in self.pairs]) if self.rank else np.zeros(0, np.complex128)
+            disjoint = int(np.unique(idx).size == idx.size)
+            if idx.size == 0:
+                idx, val = np.zeros(1, np.int32), np.zeros(1, np.complex128)
+            self._lpa = (to_device(ptr), to_device(idx), to_device(val), disjoint)
+        return self._lpa
 
     def left_dense(self):
         """(rank, n) device tensor whose rows are the dense u_f: right-hand sides of the Woodbury columns.  Built on every call
@@ -409,12 +516,11 @@ class Mat:
                                               _hx.ptr(t), _hx.stream()))
             if shard is not None and lr.local:   # v_f^T x: the ranks hold their owned entries of v_f
                 shard.all_reduce_(t)
-            h = (coef * t).cpu().numpy()         # y += coef * sum_f (v_f^T x) u_f: r scatters over the supports of the u_f
-            for f, (ui, uv) in enumerate(lr.left_packed()):
-                if ui.numel() == 0:
-                    continue
-                _hx.check(_hx.lib.hx_zscatter_axpy(int(ui.numel()), _hx.z2(complex(h[f])), _hx.ptr(uv), _hx.ptr(ui), _hx.ptr(y.t),
-                                                   _hx.stream()))
+            # y += coef * sum_f (v_f^T x) u_f: ONE scatter launch over the supports of the u_f, coefficients read on the device
+            # (until round 5: coefficients to the host -- a stream synchronisation per product -- and one launch per flame)
+            uptr, uidx, uval, disjoint = lr.left_packed_all()
+            _hx.check(_hx.lib.hx_zsparse_axpys(lr.rank, _hx.ptr(uptr), _hx.ptr(uidx), _hx.ptr(uval), _hx.ptr(t), _hx.z2(coef),
+                                               _hx.ptr(y.t), disjoint, _hx.stream()))
 
     def getValuesCSR(self):
         """Explicit CSR including the outer-product blocks -- what the reference stores (small cases / tests only)."""
@@ -545,3 +651,18 @@ def combine_csr(shape, terms):
             _hx.check(_hx.lib.hx_zscatter_axpy(m.nnz, _hx.z2(c), _hx.ptr(m.val), _hx.ptr(slot_maps[m.pattern_id]),
                                                _hx.ptr(out), _hx.stream()))
     return base.with_values(out)
+
+
+class PETSc:
+    """Namespace with the names a driver written against ``from petsc4py import PETSc`` touches on the hot path
+    (``PETSc.ScalarType(+1000)`` in active_modes.py:42, ``PETSc.Mat().create``, ``PETSc.InsertMode.ADD_VALUES``, ``PETSc.Options()``)."""
+    Mat = Mat
+    Vec = Vec
+    Options = Options
+    ScalarType = np.complex128
+    IntType = np.int32
+    DECIDE = -1
+
+    class InsertMode:
+        INSERT_VALUES = INSERT = "insert"
+        ADD_VALUES = ADD = "add"

@@ -60,6 +60,7 @@ class ShardContext:
         if min(b - a for a, b in self.ranges) <= 0:
             raise ValueError("every rank must own at least one row")
         self.backend = dist.get_backend(group)
+        self.ranks_on_device = _hx.count_device_sharing(group)      # (collective) sizes the device-buffer pool's cap
         self.plans = {}             # level -> HaloPlan
         self.level_n = {0: (self.n_own, self.n_own)}      # level -> (n_own, n_ext)
         self.level_ranges = {0: self.ranges}

@@ -117,14 +117,15 @@ class LUSolver:
             pass
 
 
-def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=None):
+def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=None, shifted=None, graph=None, label=None):
+    """``shifted`` / ``graph`` / ``label``: what the iterative solver's escalation ladder needs (amg.AMGSolver)."""
     st = st_type or DEFAULTS["st_type"]
     n = K_csr.shape[0]
     if shard is not None:
         if st == "lu":
             raise NotImplementedError("the direct inner solver is single-GPU; the row-sharded path uses st_type='amg'")
         from .amg import AMGSolver
-        return AMGSolver(K_csr, hierarchy=hierarchy, shard=shard)
+        return AMGSolver(K_csr, hierarchy=hierarchy, shard=shard, shifted=shifted, label=label)
     if st == "auto":
         # measured (MI355X, round 1): 2-D 103 k DOF PEP solve 3.8 s with LU (host SuperLU 2.5 s + latency-bound
         # triangular solves) vs 0.29 s with AMG-GMRES; 3-D 34 k DOF fixed point 20.8 s vs < 3 s.  Round 3, with COCG at every
@@ -135,8 +136,16 @@ def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=
         return LUSolver(K_csr)
     if st == "amg":
         from .amg import AMGSolver
-        return AMGSolver(K_csr, hierarchy=hierarchy)
+        return AMGSolver(K_csr, hierarchy=hierarchy, shifted=shifted, graph=graph, label=label)
     raise ValueError("unknown st_type %r" % st)
+
+
+def _shift_sign(sigma2, sigma):
+    """Sign of the imaginary shift that ADDS to the damping the operator already has: that of Im(sigma^2) when the target is
+    complex, else that of Re(sigma) (a passive boundary contributes sigma B with Im B > 0: acoustic_matrices.py:108)."""
+    if abs(sigma2.imag) > 1e-12 * abs(sigma2):
+        return 1.0 if sigma2.imag > 0 else -1.0
+    return 1.0 if sigma.real >= 0 else -1.0
 
 
 def translation_shifts(lefts, n, rtol=1e-9):
@@ -665,8 +674,57 @@ class _EigenSolverBase:
         if max_it is not None:
             self._max_it = max_it
 
+    options_prefix = "eps_"
+
     def setFromOptions(self):
-        pass
+        """Run-time overrides from the options database (petsc.Options: ``PETSC_OPTIONS`` + the command line), read where the
+        reference reads them (``E.setFromOptions()`` / ``Q.setFromOptions()``, eigensolvers.py:60,109).  Names follow SLEPc/PETSc:
+
+          -eps_nev/-pep_nev, -eps_ncv, -eps_mpd (accepted, unused), -eps_tol, -eps_max_it, -eps_target, -eps_two_sided,
+          -eps_type krylovschur | -pep_type toar|linear   (the methods on this path; anything else raises like an unknown ST)
+          -st_type sinvert, -st_shift (same as the target under sinvert)
+          -st_pc_type lu|cholesky (direct: host factorisation + device triangular solves) | gamg|mg|hypre|ml (device AMG + Krylov),
+          -st_ksp_type preonly (direct) | gmres|fgmres|cg|... (iterative), -st_pc_factor_mat_solver_type <any> (direct),
+          -st_ksp_rtol, -st_ksp_max_it  (inner tolerance / iteration limit of the iterative route)
+          -hx_<name> <value>   any switch of the library's own registry (hx_set_option), e.g. -hx_cocg_single_reduction 1
+        """
+        from .petsc import Options
+        db = Options()
+        pre = self.options_prefix
+        nev = db.getInt(pre + "nev")
+        ncv = db.getInt(pre + "ncv")
+        if nev is not None or ncv is not None:
+            self.setDimensions(self._nev if nev is None else nev, self._ncv if ncv is None else ncv)
+        tol, max_it = db.getReal(pre + "tol"), db.getInt(pre + "max_it")
+        if tol is not None or max_it is not None:
+            self.setTolerances(tol, max_it)
+        if db.hasName(pre + "target"):
+            self.setTarget(db.getScalar(pre + "target"))
+        if db.hasName(pre + "two_sided"):
+            self.setTwoSided(db.getBool(pre + "two_sided"))
+        typ = db.getString(pre + "type")
+        if typ:
+            allowed = ("krylovschur",) if pre == "eps_" else ("toar", "linear")
+            if typ not in allowed:
+                raise NotImplementedError("-%stype %s: this path provides %s" % (pre, typ, " / ".join(allowed)))
+        st = db.getString("st_type")
+        if st:
+            self.setType(st)
+        if db.hasName("st_shift"):
+            self.setTarget(db.getScalar("st_shift"))
+        pc, ksp = db.getString("st_pc_type"), db.getString("st_ksp_type")
+        if pc in ("lu", "cholesky") or db.hasName("st_pc_factor_mat_solver_type") or (ksp == "preonly" and pc is None):
+            self.st_type = "lu"
+        elif pc in ("gamg", "mg", "hypre", "ml", "amg") or (ksp not in (None, "", "preonly")):
+            self.st_type = "amg"
+        elif pc:
+            raise NotImplementedError("-st_pc_type %s: the inner solve of this path is lu (direct) or gamg/mg/hypre (device AMG)" % pc)
+        rtol, kmax = db.getReal("st_ksp_rtol"), db.getInt("st_ksp_max_it")
+        if rtol is not None or kmax is not None:
+            self._ksp_opts = dict(rtol=rtol, max_it=kmax)
+        for name, value in db.getAll().items():
+            if name.startswith("hx_"):
+                _hx.set_option(name[3:], value)
 
     # --- results
     def getConverged(self):
@@ -766,15 +824,22 @@ class _EigenSolverBase:
         self._ncv_used = max(min(ncv, n - 1), self._nev + 1)
         return self._ncv_used
 
-    def _inner(self, K, key):
+    def _inner(self, K, key, shifted=None, graph=None):
         """Inner solver for the sparse part of the shifted operator; cached across fixed-point iterations when
         the caller supplies ``inner_cache`` (K does not depend on omega_k when the target is fixed)."""
         if self.inner_cache is not None and key in self.inner_cache:
             return self.inner_cache[key]
-        solver = make_inner_solver(K, st_type=self.st_type, shard=self.shard)
+        t = self._target
+        label = "%s shift-invert at target %s" % (self.options_prefix[:3].upper(), ("%g%+gj" % (t.real, t.imag)) if t.imag else "%g" % t.real)
+        solver = make_inner_solver(K, st_type=self.st_type, shard=self.shard, shifted=shifted, graph=graph, label=label)
         rtol = None if self.state is None else self.state.get("inner_rtol")
+        ksp = getattr(self, "_ksp_opts", None) or {}
+        if ksp.get("rtol") is not None:      # -st_ksp_rtol (setFromOptions) wins over the fixed point's own choice
+            rtol = ksp["rtol"]
         if rtol is not None and hasattr(solver, "set_rtol"):
             solver.set_rtol(rtol)            # (the direct route ignores it: its solves are exact to rounding)
+        if ksp.get("max_it") is not None and hasattr(solver, "set_max_it"):
+            solver.set_max_it(ksp["max_it"])
         if self.inner_cache is not None:
             self.inner_cache[key] = solver
         return solver
@@ -877,7 +942,12 @@ class EPS(_EigenSolverBase):
             K = combine_csr(A.shape, A.csr_terms + [(-sigma * c, m) for c, m in M.csr_terms])   # A - sigma M
             if self.inner_cache is not None:
                 self.inner_cache[("ops",) + key] = K
-        inner = self._inner(K, key)
+        sgn = _shift_sign(sigma, sigma)
+
+        def shifted(beta):          # A - sigma (1 + i beta) M: the damped companion the escalated hierarchy is built on
+            return combine_csr(A.shape, A.csr_terms + [(-sigma * (1 + 1j * sgn * beta) * c, m) for c, m in M.csr_terms])
+
+        inner = self._inner(K, key, shifted, A.csr_part)
         self._tol_floor = getattr(inner, "krylov_tol_floor", 0.0)
         sh = self.shard
         solver = WoodburySolver(inner, A.lr_terms, self.W_cache, shard=sh)
@@ -929,6 +999,8 @@ class EPS(_EigenSolverBase):
 class PEP(_EigenSolverBase):
     """Quadratic problem (A + lambda B + lambda^2 C) x = 0 (eigensolvers.py:96-99)."""
 
+    options_prefix = "pep_"
+
     def getType(self):
         return "toar"
 
@@ -964,7 +1036,13 @@ class PEP(_EigenSolverBase):
         else:
             K, BsC = ops
         Ccsr = Cm.csr_part()
-        inner = self._inner(K, key)
+        sgn = _shift_sign(sigma ** 2, sigma)
+
+        def shifted(beta):          # A + sigma B + (1 + i beta) sigma^2 C
+            return combine_csr(A.shape, A.csr_terms + [(sigma * c, m) for c, m in b_terms]
+                               + [(sigma ** 2 * (1 + 1j * sgn * beta) * c, m) for c, m in Cm.csr_terms])
+
+        inner = self._inner(K, key, shifted, A.csr_part)
         self._tol_floor = getattr(inner, "krylov_tol_floor", 0.0)
         sh = self.shard
         solver = WoodburySolver(inner, A.lr_terms, self.W_cache, shard=sh)

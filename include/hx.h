@@ -72,9 +72,9 @@ int hx_get_option(const char* name, char* out, int out_len);
  * builds the same objects again (the reference: E.destroy() and a new EPS per iteration, eigensolvers.py:161) -- instead of
  * going through hipFree / hipMalloc, whose cost varies from milliseconds to tenths of a second with the load of the machine.
  * HX_POOL=0 switches it off, HX_POOL_MAX_GIB caps the cached bytes (default: a quarter of the memory FREE on the device when the
- * pool starts, divided among the local ranks sharing the device: LOCAL_WORLD_SIZE / device count), HX_POOL_MIN_BYTES the smallest
+ * pool starts, divided among the local ranks sharing the device: hx_pool_set_sharing), HX_POOL_MIN_BYTES the smallest
  * pooled block.  Reuse is ordered: a released block records an event on every stream that may still touch it (the caller streams
- * recently passed to the library and the library's own side streams) and the request that takes it out of the cache waits for
+ * passed to the library since the last hx_pool_trim -- up to 8 -- and the library's own side streams) and the request that takes it out of the cache waits for
  * them on the host -- the device-wide synchronisation hipFree used to provide, without the device-wide part.  (A caller that
  * destroys a stream it passed to the library calls hx_pool_trim first.)
  * hx_pool_trim returns every cached block to the driver (call it when another allocator of the process runs out of memory);
@@ -82,6 +82,11 @@ int hx_get_option(const char* name, char* out, int out_len);
  * cached now (reset != 0 clears the counters); hx_pool_ordering_stats: events recorded on release, events waited for on reuse,
  * the cap in bytes. */
 int hx_pool_trim(void);
+/* The number of local ranks that share THIS device (counted by the caller, e.g. equal PCI bus ids over the node's ranks): the
+ * cap becomes (free memory at start) / 4 / that number.  Without it the pool guesses LOCAL_WORLD_SIZE / visible devices, and a
+ * process that sees ONE device through ROCR_/HIP_VISIBLE_DEVICES counts as alone on it.  No effect when HX_POOL_MAX_GIB is set.
+ * HX_POOL_VERBOSE=1 prints the cap chosen.  replaces: nothing in the reference (PETSc allocates through the host malloc). */
+int hx_pool_set_sharing(int ranks_on_this_device);
 int hx_pool_ordering_stats(int64_t* n_events, int64_t* n_waits, int64_t* max_cached_bytes);
 int hx_pool_stats(int64_t* n_requests, int64_t* n_reused, int64_t* n_driver_calls, double* driver_seconds, int64_t* cached_bytes,
                   int reset);
@@ -140,6 +145,12 @@ int hx_zdense_inverse(int n, hx_c128* A, hx_stream s);
  * operator kept factored; replaces the explicit D of flame_matrices.py:91-92,176,233). */
 int hx_zsparse_dots(int nvec, const int32_t* ptr, const int32_t* idx, const hx_c128* vals,
                     const hx_c128* y, hx_c128* out, hx_stream s);
+/* The other half of a product with the factored flame term: y[idx[p]] += coef * t[f] * vals[p] over the packed entries of the
+ * left factors a_f (same packing as hx_zsparse_dots), the coefficients t[f] = b_f^T x read from DEVICE memory.  disjoint != 0:
+ * the supports of the nvec vectors do not overlap (one launch); 0: one launch per vector in order (deterministic sums).
+ * replaces: the rows of the explicit D in MatMult (flame_matrices.py:91-92,176,233 + petsc4py_utils.py:85). */
+int hx_zsparse_axpys(int nvec, const int32_t* ptr, const int32_t* idx, const hx_c128* vals, const hx_c128* t,
+                     const double coef[2], hx_c128* y, int disjoint, hx_stream s);
 
 /* Threshold + pack a load vector (flame_matrices.py:66-72): entries with |Re| < tol / |Im| < tol zeroed separately,
  * surviving (index, value) pairs written to idx/val (capacity cap) in arbitrary order, *count = number found

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -73,10 +74,30 @@ struct fakeComm {
   size_t map_bytes;
   bool registered = false;
   char name[64];
-  void barrier() {
+  // Sense-reversing barrier WITH A DEADLINE (HX_FAKE_RCCL_TIMEOUT_S, default 60 s): it runs inside a host function on the
+  // stream, so a rank that raised or exited before enqueueing the matching operation would otherwise leave the other ranks'
+  // streams -- and every hipDeviceSynchronize / pool wait behind them -- blocked for good.  On expiry the communicator is
+  // marked failed (every later operation reports ncclInternalError), the rank says what it was waiting in, and the stream drains.
+  bool barrier(const char* what = "operation") {
+    if (hdr->failed.load()) return false;
     const int gen = hdr->generation.load();
-    if (hdr->arrived.fetch_add(1) + 1 == world) { hdr->arrived.store(0); hdr->generation.fetch_add(1); }
-    else while (hdr->generation.load() == gen) sched_yield();
+    if (hdr->arrived.fetch_add(1) + 1 == world) { hdr->arrived.store(0); hdr->generation.fetch_add(1); return true; }
+    static const double limit = getenv("HX_FAKE_RCCL_TIMEOUT_S") ? atof(getenv("HX_FAKE_RCCL_TIMEOUT_S")) : 60.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (hdr->generation.load() == gen) {
+      sched_yield();
+      if ((++spins & 1023u) == 0) {
+        if (hdr->failed.load()) return false;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+          fprintf(stderr, "[fake_rccl] rank %d: barrier of %s timed out after %.0f s (%d of %d ranks arrived): a peer never enqueued "
+                          "the matching operation\n", rank, what, limit, hdr->arrived.load(), world);
+          hdr->failed.store(1);
+          return false;
+        }
+      }
+    }
+    return true;
   }
   char* outbox(int r) { return box + (size_t)r * OUTBOX; }
 };
@@ -103,7 +124,7 @@ static void run_job(Job* j) {
   H->count[c->rank] = j->kind ? j->count * (size_t)(j->dtype ? 8 : 4) : 0;
   H->n_msg[c->rank] = (int)j->sends.size();
   for (size_t q = 0; q < j->sends.size(); ++q) H->msg[c->rank][q] = j->sends[q];
-  c->barrier();
+  if (!c->barrier(j->kind ? "an all-reduce" : "a send/receive group")) return;     // failed or timed out: no copies, the stream drains
   // every rank must be in the same kind of operation (a group meeting an all-reduce = operations issued in different orders,
   // or two operations of this communicator racing on two streams)
   for (int r = 0; r < c->world; ++r)
@@ -137,7 +158,7 @@ static void run_job(Job* j) {
         for (size_t i = 0; i < n; ++i) a[i] = j->op == 0 ? a[i] + b[i] : (a[i] > b[i] ? a[i] : b[i]); }
     }
   }
-  c->barrier();       // outboxes and tables may be reused
+  (void)c->barrier(j->kind ? "an all-reduce (release)" : "a send/receive group (release)");       // outboxes and tables may be reused
 }
 static void host_fn(void* p) { Job* j = (Job*)p; run_job(j); delete j; }
 
@@ -218,9 +239,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
     if (!c->registered) { (void)hipGetLastError(); fprintf(stderr, "[fake_rccl] rank %d: pinned staging unavailable, synchronous transport\n", rank); }
   }
   if (!c->registered) c->inbox = (char*)malloc(OUTBOX);
-  c->barrier();
-  if (rank == 0) shm_unlink(c->name);      // every rank has it mapped: the name can go
-  c->barrier();
+  const bool met = c->barrier("ncclCommInitRank");
+  if (rank == 0) shm_unlink(c->name);      // every rank has it mapped (or gave up): the name can go
+  if (!met || !c->barrier("ncclCommInitRank (release)")) return ncclSystemError;
   *out = c;
   return ncclSuccess;
 }

@@ -933,3 +933,92 @@ def test_krylov_basis_rotation_in_place_and_destroy_releases_memory():
     assert left <= 0.05 * held, (held, left)        # ... and destroy() + dropping the references gave it back, no collection needed
     from helmholtz_x import petsc
     assert all(torch.is_tensor(v) for v in petsc._SLOT_CACHE.values())     # the slot cache holds maps, never operators
+
+
+def test_pool_notes_every_caller_stream_where_it_is_used():
+    """a block whose last kernels ran on caller stream A must get an event on A even if the caller made a libhx launch
+    on stream B before the handle was destroyed -- hx_s() notes a stream when it is USED (not only the last one at release).
+    Two non-blocking caller streams: long product chain on A, one short launch on B, release, re-allocate, overwrite."""
+    import ctypes as C
+    import torch
+    from helmholtz_x import _hx
+    from helmholtz_x.petsc import CSR
+    n = 400_000
+    A = sp.diags([np.full(n, 2.0 + 1j), np.full(n - 1, -1.0 + 0j), np.full(n - 1, -1.0 + 0j)], [0, 1, -1]).tocsr()
+    K = CSR.from_scipy(A)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.ones(n, dtype=torch.complex128, device="cuda")
+    ya, yb = torch.empty_like(x), torch.empty_like(x)
+    one, zero = _hx.z2(1.0), _hx.z2(0.0)
+    torch.cuda.synchronize()
+    _hx.check(_hx.lib.hx_pool_trim())                      # forget earlier streams: the set starts empty
+    ev0 = C.c_int64(0)
+    _hx.check(_hx.lib.hx_pool_ordering_stats(C.byref(ev0), None, None))
+    h = C.c_void_p()
+    with torch.cuda.stream(sa):
+        _hx.check(_hx.lib.hx_sell_create(C.byref(h), n, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val), 1, 0, _hx.stream()))
+        for _ in range(40):
+            _hx.check(_hx.lib.hx_sell_spmv_z(h, _hx.ptr(x), _hx.ptr(ya), one, zero, _hx.stream()))
+    with torch.cuda.stream(sb):                            # the LAST stream the library sees before the release is B
+        K.spmv(x, yb)
+    _hx.lib.hx_sell_destroy(h)                             # released while stream A may still be reading the block
+    ev1 = C.c_int64(0)
+    _hx.check(_hx.lib.hx_pool_ordering_stats(C.byref(ev1), None, None))
+    # one event per noted caller stream and pooled block: with A forgotten there would be half as many
+    h2 = C.c_void_p()
+    _hx.check(_hx.lib.hx_sell_create(C.byref(h2), n, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr((2.0 * K.val).contiguous()), 1, 0, _hx.stream()))
+    torch.cuda.synchronize()
+    assert _rel(ya.cpu().numpy(), A @ np.ones(n)) < 1e-14          # A's products never saw the re-used block's new values
+    y2 = torch.empty_like(x)
+    _hx.check(_hx.lib.hx_sell_spmv_z(h2, _hx.ptr(x), _hx.ptr(y2), one, zero, _hx.stream()))
+    assert _rel(y2.cpu().numpy(), 2.0 * (A @ np.ones(n))) < 1e-14
+    _hx.lib.hx_sell_destroy(h2)
+    n_blocks_events = ev1.value - ev0.value
+    assert n_blocks_events >= 2 and n_blocks_events % 2 == 0, n_blocks_events     # events on BOTH streams for every released block
+    torch.cuda.synchronize()
+    _hx.check(_hx.lib.hx_pool_trim())
+
+
+def test_factored_flame_term_scatter_with_device_coefficients(hx):
+    """hx_zsparse_axpys: y += coef * sum_f t[f] u_f over packed left factors, t on the device -- disjoint supports in one launch,
+    overlapping supports one launch per factor (fixed order); and Mat.mult with a low-rank term against the explicit matrix."""
+    import torch
+    from helmholtz_x.petsc import CSR, LowRank, Mat, Vec
+    rng = np.random.default_rng(5)
+    n, r = 5000, 7
+    for overlapping in (False, True):
+        pool = rng.permutation(n)
+        sup = [np.sort(pool[300 * f:300 * f + 200 + 13 * f]) for f in range(r)]
+        if overlapping:
+            sup[3] = np.sort(np.unique(np.concatenate([sup[3][:50], sup[2][:80], sup[5][10:40]])))
+        vals = [_rand_c(rng, len(s)) for s in sup]
+        ptr = np.zeros(r + 1, np.int32)
+        ptr[1:] = np.cumsum([len(s) for s in sup])
+        idx = np.concatenate(sup).astype(np.int32)
+        t = _rand_c(rng, r)
+        y0 = _rand_c(rng, n)
+        coef = 0.3 - 1.7j
+        ref = y0.copy()
+        for f in range(r):
+            ref[sup[f]] += coef * t[f] * vals[f]
+        y = _dev(y0)
+        hx.check(hx.lib.hx_zsparse_axpys(r, hx.ptr(_dev(ptr)), hx.ptr(_dev(idx)), hx.ptr(_dev(np.concatenate(vals))), hx.ptr(_dev(t)),
+                                         hx.z2(coef), hx.ptr(y), int(not overlapping), hx.stream()))
+        assert _rel(y.cpu().numpy(), ref) < 1e-14
+        # the petsc4py-shaped product: (S + coef * sum_f u_f v_f^T) x
+        S = sp.random(n, n, density=0.001, random_state=rng, format="csr") + sp.eye(n)
+        S = sp.csr_matrix(S.astype(np.complex128))
+        rsup = [np.sort(rng.choice(n, 4, replace=False)).astype(np.int32) for _ in range(r)]
+        rval = [_rand_c(rng, 4) for _ in range(r)]
+        lr = LowRank(n, [((sup[f].astype(np.int32), vals[f]), (rsup[f], rval[f])) for f in range(r)])
+        assert lr.left_packed_all()[3] == int(not overlapping)
+        M = Mat((n, n), [(1.0, CSR.from_scipy(S))], [(coef, lr)])
+        xv = _rand_c(rng, n)
+        out = Vec.zeros(n)
+        M.mult(Vec(xv), out)
+        D = np.zeros((n, n), dtype=np.complex128) if n <= 6000 else None
+        expl = S @ xv
+        for f in range(r):
+            expl[sup[f]] += coef * vals[f] * (rval[f] @ xv[rsup[f]])
+        assert _rel(out.array, expl) < 1e-13
+        del D

@@ -593,3 +593,46 @@ def test_sector_slab_numbering_keeps_bloch_pairs_in_one_row_range():
     m_old = np.unique(mesh.facets[ft.find(12)])
     s_old = np.unique(mesh.facets[ft.find(13)])
     assert m_old.max() < n // 2 <= s_old.min()
+
+
+def test_set_from_options_maps_the_reference_option_names(monkeypatch):
+    """E.setFromOptions() / Q.setFromOptions() (reference: eigensolvers.py:60,109) read -eps_* / -pep_* / -st_* from the options
+    database (PETSC_OPTIONS + the command line, as petsc4py.init(sys.argv) does) and -hx_* for the library's own registry."""
+    import sys
+    from helmholtz_x import _hx
+    from helmholtz_x.petsc import Options, PETSc
+    from helmholtz_x.slepc import EPS, PEP
+    monkeypatch.setattr(Options, "_db", None)                   # re-seed the process-wide database for this test
+    monkeypatch.setenv("PETSC_OPTIONS", "-eps_nev 6 -eps_tol 1e-9 -st_pc_type lu")
+    monkeypatch.setattr(sys, "argv", ["driver.py", "-nopopup", "-target", "1000", "-eps_ncv", "40", "-eps_max_it", "7",
+                                      "-pep_nev", "3", "-pep_type", "toar", "-st_ksp_rtol", "1e-12", "-eps_target", "-1.5e3+2i",
+                                      "-hx_cocg_single_reduction", "2", "-eps_two_sided"])
+    db = PETSc.Options()
+    assert db.getString("target") == "1000" and db.hasName("nopopup") and db.getInt("eps_ncv") == 40
+    assert db.getReal("eps_tol") == 1e-9 and db.getScalar("eps_target") == -1500 + 2j       # "-1.5e3+2i" is a value, not a name
+    E = EPS().create()
+    E.setDimensions(2, -1)
+    E.setTolerances(1e-15)
+    E.setFromOptions()
+    assert (E._nev, E._ncv, E._tol, E._max_it) == (6, 40, 1e-9, 7)
+    assert E._target == -1500 + 2j and E._two_sided and E.st_type == "lu" and E._ksp_opts["rtol"] == 1e-12
+    assert _hx.get_option("cocg_single_reduction") == "2"
+    _hx.set_option("cocg_single_reduction", None)
+    Q = PEP().create()
+    Q.setDimensions(4, -1)
+    Q.setFromOptions()
+    assert Q._nev == 3 and Q._ncv is None and Q._tol == 1e-15 and Q.st_type == "lu"
+    # the code-level argument of the drop-in functions is the default, the database overrides it -- and names that are not
+    # on this path fail loudly instead of being ignored
+    db["st_pc_type"] = "gamg"
+    Q.setFromOptions()
+    assert Q.st_type == "amg"
+    db["pep_type"] = "qarnoldi"
+    with pytest.raises(NotImplementedError):
+        Q.setFromOptions()
+    db.delValue("pep_type")
+    db["st_type"] = "cayley"
+    with pytest.raises(NotImplementedError):
+        Q.setFromOptions()
+    Options(prefix="st_").clear()
+    assert not db.hasName("st_type") and db.hasName("eps_nev")

@@ -243,8 +243,16 @@ def spmv_roofline(K, reps=50, in_situ=None, pmc=None):
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     gbs_fmt = fmt_bytes / (ms * 1e-3) / 1e9
     traffic = measured_traffic(n, nnz, pmc)
+    prof = profile_record(n, nnz, pmc)
+    prof_us = prof.get("rocprof_avg_launch_us") if prof else None
     return dict(bound="hbm", kernel="k_sell<c128, 0> (hx_sell_spmv_z)", achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
-                unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic, n_rows=n, nnz=nnz,
+                unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                # the same byte count over the average duration of the COMMITTED rocprofv3 kernel statistics (another box, another
+                # day: the two boxes' numbers side by side)
+                frac_profile=None if not prof_us else round(alg_bytes / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                profile_avg_launch_ms=None if not prof_us else round(prof_us * 1e-3, 5),
+                profile_source=None if not prof else prof.get("rocprof_source"),
+                traffic=traffic, n_rows=n, nnz=nnz,
                 bytes_per_launch=alg_bytes, bytes_model="CSR-algorithmic: nnz*20 + n*36 (SURVEY 8d)",
                 format_bytes_per_launch=fmt_bytes,
                 format="SELL-64: %d slices (%d index-free stencil slices), %d padded entries, %d-bit indices elsewhere"
@@ -291,18 +299,24 @@ def smoother_roofline(inner, n, in_situ, numbering="native"):
                 traffic_ratio=None if not traffic else round(traffic / nbytes, 3))
 
 
-def measured_traffic(n, nnz, pmc=None, kernel="k_sell"):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/spmv_traffic.json): 2 x FETCH_SIZE
-    (gfx950 correction of MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, for the matrix of exactly this size; else None."""
+def profile_record(n, nnz, pmc=None, kernel="k_sell"):
+    """The committed profile record (profiles/spmv_traffic.json) of ``kernel`` for the matrix of exactly this size; else None."""
     try:
         with open(os.path.join(ROOT, "profiles", "spmv_traffic.json")) as fh:
             for rec in json.load(fh)["records"]:
                 if rec["n_rows"] == n and (nnz is None or rec["nnz"] == nnz) and rec["kernel"].startswith(kernel) \
                         and (pmc is None or rec.get("numbering", "native") == pmc):
-                    return rec["hbm_bytes_per_launch"]
+                    return rec
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def measured_traffic(n, nnz, pmc=None, kernel="k_sell"):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes: 2 x FETCH_SIZE (gfx950 correction of
+    MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, for the matrix of exactly this size; else None."""
+    rec = profile_record(n, nnz, pmc, kernel)
+    return rec["hbm_bytes_per_launch"] if rec else None
 
 
 def cpu_baseline(sample="micca-real", gpu_same_sample=True):
@@ -597,6 +611,9 @@ def run_sharded(args, case, shape, rank, world, backend, n_dev, barrier):
            "config": {"workload": args.workload, "grid_nr_ntheta_nz": list(shape), "numbering": args.numbering,
                       "jitter": args.jitter, "parallelism": "row-sharded x%d" % world, "backend": backend,
                       "devices_visible": n_dev,
+                      "host_setup": "every rank builds the GLOBAL host mesh (build_case) before it cuts its part: N x the host work and "
+                                    "memory of one mesh on the node (5 M DOF: 29 M tets, ~1 GB per rank); a distributing reader is not "
+                                    "part of the hot path",
                       "rehearsal": None if n_dev >= world else
                       "%d ranks share %d GPU(s): gloo stages every exchange through the host" % (world, n_dev)}}
 

@@ -28,6 +28,10 @@ int hx_csr_spmv_creal(int32_t, int64_t, const int32_t*, const int32_t*, const fl
 int hx_csr_spmv_zreal(int32_t, int64_t, const int32_t*, const int32_t*, const double*, const hx_c128*, hx_c128*, double, double, hx_stream);
 int hx_csr_spmv_c(int role, int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, float*, float,
                   float, hx_stream);
+int hx_csr_restrict_diag_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, float*, const float*, float*, float,
+                           hx_stream);
+int hx_csr_restrict_diag_z(int32_t, int64_t, const int32_t*, const int32_t*, const double*, const hx_c128*, hx_c128*, const hx_c128*,
+                           hx_c128*, double, hx_stream);
 int hx_csr_jacobi_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
                     const float*, float*, float, hx_stream);
 int hx_cdiag_scale(int64_t, float, const float*, const float*, float*, hx_stream);
@@ -151,6 +155,13 @@ static int op_smooth(const LevelT<float>& L, const float* b, const float* xin, f
   if (L.sell) return hx_sell_smooth_c64_part(L.sell, part, (const hx_c64*)L.dinv, (const hx_c64*)b, (const hx_c64*)xin, (hx_c64*)xout,
                                              (float)w, (const hx_c64*)xprev, (float)mom, s);
   return hx_csr_smooth_c(L.n, L.K.nnz, L.K.rp, L.K.ci, L.K.va, L.dinv, b, xin, xout, (float)w, xprev, (float)mom, s);
+}
+// bc = R r and, in the same launch, the coarse level's first smoothing step x1 = a0 Dc^-1 bc (real-valued transfers only)
+static int op_restrict_diag(const CsrT<double>& R, const double* r, double* bc, const double* dc, double* x1, double a0, hx_stream s) {
+  return hx_csr_restrict_diag_z(R.rows, R.nnz, R.rp, R.ci, R.va, (const hx_c128*)r, (hx_c128*)bc, (const hx_c128*)dc, (hx_c128*)x1, a0, s);
+}
+static int op_restrict_diag(const CsrT<float>& R, const float* r, float* bc, const float* dc, float* x1, double a0, hx_stream s) {
+  return hx_csr_restrict_diag_c(R.rows, R.nnz, R.rp, R.ci, R.va, r, bc, dc, x1, (float)a0, s);
 }
 static int op_diag(const LevelT<double>& L, double w, const double* b, double* x, hx_stream s) {
   return hx_zdiag_scale(L.n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
@@ -371,8 +382,9 @@ static Cheb cheb_coeffs(double rho) {
 
 // xout = V-cycle(b) on level l with zero initial guess (xout must not be one of the level's x buffers or b).
 // Smoother: `pre` / `post` steps of damped Jacobi (rho == 0) or of a Chebyshev polynomial in D^-1 K (rho > 0).
+// x1_ready: the level's first pre-smoothing step (x1 = a0 D^-1 b, in L.x) was written by the restriction that produced b.
 template <typename T>
-static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream s) {
+static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream s, bool x1_ready = false) {
   LevelT<T>& L = H.L[l];
   int rc;
   if (l == (int)H.L.size() - 1) return op_spmv(H.coarse_inv, b, xout, (T)1, (T)0, true, s);
@@ -391,8 +403,17 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
   // restriction of the residual in `res`: a sharded coarse level computes its OWNED entries from the exchanged fine
   // residual (R: owned coarse rows over [owned | ghost] fine columns); the first replicated level sums the ranks'
   // partial right-hand sides
+  // The restriction also leaves the coarse level's first smoothing step (one launch fewer per level and cycle) when that level
+  // smooths at all, its right-hand side is final here (no all-reduce of partial sums follows) and the transfers are real-valued.
+  const bool coarse_is_last = l + 1 == (int)H.L.size() - 1;
+  const int n_pre_c = h->pre + extra;
+  const bool fold = HX_OPT_INT("amg_fold_diag", 1) != 0 && !coarse_is_last && n_pre_c > 0 && L.R.real_vals && !(sh && !shc) && Lc.dinv;
   auto restrict_from = [&](T* res) -> int {
     if (shc && (rc = halo_level(h, l, res, EB, s))) return rc;
+    if (fold) {
+      const double a0c = Lc.rho > 0.0 ? cheb_coeffs(Lc.rho).a[0] : h->omega;
+      return op_restrict_diag(L.R, res, Lc.b, Lc.dinv, Lc.x, a0c, s);
+    }
     if ((rc = op_spmv(L.R, res, Lc.b, (T)1, (T)0, true, s))) return rc;
     if (sh && !shc && h->allreduce(h->ctx, Lc.b, 2 * (int64_t)Lc.n, sizeof(T) == 8 ? 1 : 0, 0, s) != 0)
       return hx_fail(HX_ERR_COMM, "vcycle", "all-reduce callback failed");
@@ -405,8 +426,8 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
       if ((rc = restrict_from(L.r))) return rc;
     } else if ((rc = restrict_from(const_cast<T*>(b)))) return rc;
   } else {
-    // pre-smoothing from x = 0: the first step is a diagonal scaling
-    if ((rc = op_diag(L, cheb ? C.a[0] : h->omega, b, cur, s))) return rc;
+    // pre-smoothing from x = 0: the first step is a diagonal scaling (already in L.x when the restriction above this level wrote it)
+    if (!x1_ready && (rc = op_diag(L, cheb ? C.a[0] : h->omega, b, cur, s))) return rc;
     for (int k = 1; k < n_pre; ++k) {
       T* nxt = other(cur, prev);
       // (for k = 1 the previous iterate of the Chebyshev recurrence is the zero start vector: prev == nullptr)
@@ -420,7 +441,7 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
     if ((rc = restrict_from(L.r))) return rc;
   }
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
-  if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s))) return rc;
+  if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s, fold))) return rc;
   if (shc && (rc = halo_level(h, l + 1, ec, EB, s))) return rc;        // P: owned rows over [owned | ghost] coarse columns
   if ((rc = op_spmv(L.P, ec, cur, (T)1, n_pre == 0 ? (T)0 : (T)1, true, s))) return rc;    // x (+)= P e_c
   // post-smoothing: a fresh polynomial started from the corrected x; the last step writes xout

@@ -29,7 +29,8 @@ __device__ __forceinline__ V row_dot(const int32_t* __restrict__ col, const MV* 
 template <int LPR, int ROLE, typename V, typename MV = V>
 __global__ void __launch_bounds__(256)
 k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const MV* __restrict__ val,
-       const V* __restrict__ x, V* y, const V* yin, V alpha, V beta, int beta_is_zero) {
+       const V* __restrict__ x, V* y, const V* yin, V alpha, V beta, int beta_is_zero,
+       const V* __restrict__ ep_d = nullptr, V* __restrict__ ep_x = nullptr, typename real_of<V>::type ep_a = 0) {
   constexpr int RPB = 256 / LPR;                       // rows per block per sweep
   const int sub = threadIdx.x % LPR;
   const int64_t stride = (int64_t)gridDim.x * RPB;
@@ -44,17 +45,22 @@ k_spmv(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict_
       V r = zmul(alpha, acc);
       if (!beta_is_zero) zfma(r, beta, yin[row]);
       y[row] = r;
+      // epilogue of a RESTRICTION (transfer role only): the first smoothing step of the coarse level from a zero start,
+      // x1 = a0 D^-1 b, leaves with its right-hand side -- the arithmetic of k_diag_scale on the value just stored
+      if constexpr (ROLE == 1) { if (ep_x) ep_x[row] = zscale(ep_a, zmul(ep_d[row], r)); }
     }
   }
 }
 
 // yin: the vector scaled by beta (y itself when NULL): y = alpha*A*x + beta*yin
+template <typename V> struct SpmvEpilogue { const V* d = nullptr; V* x = nullptr; typename real_of<V>::type a = 0; };
 template <int LPR, int ROLE, typename V, typename MV = V>
 static int launch(int32_t n, const int32_t* rowptr, const int32_t* col, const MV* val, const V* x, V* y,
-                  V alpha, V beta, hipStream_t s, const V* yin = nullptr) {
+                  V alpha, V beta, hipStream_t s, const V* yin = nullptr, SpmvEpilogue<V> ep = SpmvEpilogue<V>()) {
   int64_t rows_per_block = 256 / LPR;
   int grid = hx_grid((int64_t)n, (int)rows_per_block, 256 * 16);
-  k_spmv<LPR, ROLE, V, MV><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, yin ? yin : y, alpha, beta, (beta.x == 0 && beta.y == 0));
+  k_spmv<LPR, ROLE, V, MV><<<grid, 256, 0, s>>>(n, rowptr, col, val, x, y, yin ? yin : y, alpha, beta, (beta.x == 0 && beta.y == 0),
+                                                ep.d, ep.x, ep.a);
   HX_LAUNCH_CHECK("k_spmv");
   return HX_OK;
 }
@@ -66,18 +72,19 @@ static inline int pick_lpr(int64_t nnz, int32_t n_rows) {
 
 template <int ROLE, typename V, typename MV = V>
 static int spmv_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const MV* val,
-                         const V* x, V* y, V a, V b, int lanes_per_row, hx_stream s, const V* yin = nullptr) {
+                         const V* x, V* y, V a, V b, int lanes_per_row, hx_stream s, const V* yin = nullptr,
+                         SpmvEpilogue<V> ep = SpmvEpilogue<V>()) {
   HX_REQUIRE(n_rows >= 0 && nnz >= 0 && rowptr && x && y && (nnz == 0 || (col && val)), "bad argument");
   if (n_rows == 0) return HX_OK;
   const int lpr = lanes_per_row ? lanes_per_row : pick_lpr(nnz, n_rows);
   switch (lpr) {
-    case 1: return launch<1, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 2: return launch<2, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 4: return launch<4, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 8: return launch<8, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 16: return launch<16, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 32: return launch<32, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
-    case 64: return launch<64, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin);
+    case 1: return launch<1, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin, ep);
+    case 2: return launch<2, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin, ep);
+    case 4: return launch<4, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin, ep);
+    case 8: return launch<8, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin, ep);
+    case 16: return launch<16, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin, ep);
+    case 32: return launch<32, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin, ep);
+    case 64: return launch<64, ROLE, V, MV>(n_rows, rowptr, col, val, x, y, a, b, hx_s(s), yin, ep);
     default: return hx_fail(HX_ERR_ARG, __func__, "lanes_per_row must be 0,1,2,4,8,16,32,64");
   }
 }
@@ -114,6 +121,21 @@ int hx_csr_spmv_zreal(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const 
                       const hx_c128* x, hx_c128* y, double alpha, double beta, hx_stream s) {
   return spmv_dispatch<1, zc, double>(n_rows, nnz, rowptr, col, val, (const zc*)x, (zc*)y, make_double2(alpha, 0.0),
                                       make_double2(beta, 0.0), 0, s);
+}
+// restriction with the coarse level's first smoothing step as epilogue: y = R x, x1 = a0 .* d .* y  (one launch instead of two)
+int hx_csr_restrict_diag_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val, const float* x,
+                           float* y, const float* d, float* x1, float a0, hx_stream s) {
+  HX_REQUIRE(d && x1, "bad argument");
+  SpmvEpilogue<cc> ep; ep.d = (const cc*)d; ep.x = (cc*)x1; ep.a = a0;
+  return spmv_dispatch<1, cc, float>(n_rows, nnz, rowptr, col, val, (const cc*)x, (cc*)y, make_float2(1.f, 0.f), make_float2(0.f, 0.f), 0, s,
+                                     nullptr, ep);
+}
+int hx_csr_restrict_diag_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const double* val, const hx_c128* x,
+                           hx_c128* y, const hx_c128* d, hx_c128* x1, double a0, hx_stream s) {
+  HX_REQUIRE(d && x1, "bad argument");
+  SpmvEpilogue<zc> ep; ep.d = (const zc*)d; ep.x = (zc*)x1; ep.a = a0;
+  return spmv_dispatch<1, zc, double>(n_rows, nnz, rowptr, col, val, (const zc*)x, (zc*)y, make_double2(1.0, 0.0), make_double2(0.0, 0.0), 0,
+                                      s, nullptr, ep);
 }
 // r = b - A x in one pass (internal; the V-cycle's residual on the CSR levels)
 int hx_csr_residual_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val, const float* x,

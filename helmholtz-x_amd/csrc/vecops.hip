@@ -268,7 +268,7 @@ int hx_zpanel_bdot_c64(int64_t n, int k, const hx_c64* Vf, int64_t ldv, const hx
 }
 
 // ---------------------------------------------------------------- w -= V h
-#define PS_MAXK 128
+#define PS_MAXK 192
 template <typename PT>
 __global__ void __launch_bounds__(256)
 k_panel_sub(int64_t n, int k, const PT* __restrict__ V, int64_t ldv, const zc* __restrict__ h, zc* __restrict__ w) {

@@ -668,20 +668,30 @@ class AMGSolver:
         self.solve_s = 0.0
         self.setup_s = 0.0
         self.last = (0, 0.0)
+        self.max_iters_in_a_solve = 0
         self.ladder = []                              # [{rung, after_solve, reason}]: the steps taken so far
         self.rung = int(os.environ.get("HX_AMG_RUNG", "0"))      # (experiment hook: start on a later rung)
         self._apply_rung()
         self._build()
 
     # ---- escalation ladder: what changes from rung to rung (everything else stays as PARAMS has it)
-    #   default          V(2,2) on the hierarchy of K itself, deflated COCG / FGMRES(50), at most 200 iterations per solve
-    #   long             the same hierarchy, three times the iteration budget (a solve that was converging slowly: nothing is rebuilt)
-    #   shifted          hierarchy of K + i 0.5 sigma^2 C with transfers from the Laplacian part, FGMRES / COCG on K itself
-    #   shifted-strong   the same with beta = 1 and one more smoothing step on each side
+    #   default          V(2,2) on the hierarchy of K, FGMRES(50) for the first solve, deflated COCG with the <= 8 harmonic Ritz vectors
+    #                    harvested from it, at most 200 iterations per solve
+    #   wide             the same hierarchy; FGMRES(100), up to 32 recycled vectors (the harvest keeps those with |theta| < 0.45: the
+    #                    number of near-kernel modes of the shifted operator grows like target^3), three times the iteration budget.
+    #                    Entered when a solve stalls -- or straight after a first solve that needed more than one GMRES cycle, before
+    #                    anything fails: measured at 1 M DOF (profiles/r05_envelope_*): 17 500 rad/s 105 -> 61 iterations per solve,
+    #                    20 000 rad/s 448 -> 69, 22 000 rad/s no convergence -> 79, 25 000 rad/s no convergence -> 216
+    #   shifted          wide + hierarchy of K + i 0.5 sigma^2 C with transfers from the Laplacian part, Krylov method on K itself:
+    #                    the last resort.  Measured (EXPERIMENTS.md, round 5): where "wide" converges the shifted hierarchy is SLOWER
+    #                    (1 M DOF, 22 000 rad/s: 393 against 144 iterations per solve; beta = 1 with three smoothing steps: 697) and
+    #                    at 25 000 rad/s neither converges at 1 M DOF -- what limits the iterative route is the NUMBER of near-kernel
+    #                    modes (the deflation panel holds 32), not an unstable smoother or coarse grid; it rescued one case (refined
+    #                    real mesh, 25 000 rad/s, 566 iterations per solve) and costs nothing unless it is reached.
     LADDER = (dict(name="default"),
-              dict(name="long", max_it_factor=3),
-              dict(name="shifted", max_it_factor=3, beta=0.5, graph=True),
-              dict(name="shifted-strong", max_it_factor=4, beta=1.0, graph=True, sweeps=3))
+              dict(name="wide", max_it_factor=3, restart=100, recycle=32),
+              dict(name="shifted", max_it_factor=4, restart=100, recycle=32, beta=0.5, graph=True))
+    REBUILD_KEYS = ("beta", "graph", "sweeps", "restart", "recycle")
 
     def _apply_rung(self):
         import os
@@ -690,6 +700,11 @@ class AMGSolver:
         self.use_graph = bool(int(os.environ.get("HX_AMG_GRAPH_FROM_A", int(bool(r.get("graph"))))))
         self._max_it = int(self.params["max_it"] * r.get("max_it_factor", 1))
         self._sweeps = r.get("sweeps")
+        if not hasattr(self, "_base"):
+            self._base = dict(restart=self.params["restart"], recycle=self.params["recycle"])
+        for key in ("restart", "recycle"):
+            if not os.environ.get("HX_AMG_" + key.upper()):
+                self.params[key] = max(int(r.get(key, 0)), int(self._base[key])) if self._base[key] > 0 else 0
         if self.beta and self._shifted is None:
             raise ArithmeticError("rung %r needs the complex-shifted operator, which this caller did not supply" % r["name"])
 
@@ -699,7 +714,7 @@ class AMGSolver:
         nxt = self.rung + 1
         if nxt >= len(self.LADDER) or (self.LADDER[nxt].get("beta") and self._shifted is None):
             return False
-        rebuild = any(self.LADDER[nxt].get(k) != self.LADDER[self.rung].get(k) for k in ("beta", "graph", "sweeps"))
+        rebuild = any(self.LADDER[nxt].get(k) != self.LADDER[self.rung].get(k) for k in self.REBUILD_KEYS)
         self.rung = nxt
         self.ladder.append(dict(rung=self.LADDER[nxt]["name"], after_solve=self.n_solves, reason=reason))
         info("! inner solver: %s -- moving to rung %r of the escalation ladder" % (reason, self.LADDER[nxt]["name"]))
@@ -918,8 +933,10 @@ class AMGSolver:
         self.setup_s += time.perf_counter() - t_setup
         self.agg_times = list(AGG_TIMES) if hierarchy is None else []
         del AGG_TIMES[:]
+        self.operator_complexity = round(sum(lv["K"].nnz for lv in levels) / levels[0]["K"].nnz, 3)
+        self.level_nnz = [int(lv["K"].nnz) for lv in levels]
         info("- AMG hierarchy: " + " -> ".join("%d" % lv["n"] for lv in levels)
-             + "  (operator complexity %.2f)" % (sum(lv["K"].nnz for lv in levels) / levels[0]["K"].nnz))
+             + "  (operator complexity %.2f)" % self.operator_complexity)
 
     supports_x0 = True
 
@@ -975,11 +992,23 @@ class AMGSolver:
             self.backward_stable = 0.0 <= be.value <= 10 * 2.220446049250313e-16
             self.attainable_stops += int(self.backward_stable)
         if self.recycle_k > 0 and not self.recycled:
+            if (self.rung == 0 and not done and it.value > self.params["restart"] and rr.value <= 100 * rtol
+                    and os.environ.get("HX_AMG_EARLY_WIDE", "1") != "0"):
+                # the harvest solve needed more than one GMRES cycle: the operator has more slow modes than the default Krylov
+                # space and deflation panel hold.  Move to the "wide" rung NOW (the solution just computed stands; the next solve
+                # harvests from a 100-dimensional space) instead of paying 100+ iterations per solve until something stalls.
+                self.solve_s += time.perf_counter() - t0
+                self.total_iters += it.value
+                self.n_solves += 1
+                self.last = (it.value, rr.value)
+                self._escalate("first solve needed %d iterations (more than one FGMRES(%d) cycle)" % (it.value, self.params["restart"]))
+                return it.value, rr.value
             self._harvest()
         self.solve_s += time.perf_counter() - t0        # hx_gmres synchronises internally
         self.total_iters += it.value
         self.n_solves += 1
         self.last = (it.value, rr.value)
+        self.max_iters_in_a_solve = max(self.max_iters_in_a_solve, it.value)
         if os.environ.get("HX_AMG_LOG_ITS"):
             print("[amg] solve %d: %d its, relres %.2e" % (self.n_solves, it.value, rr.value), file=__import__("sys").stderr)
         return it.value, rr.value
@@ -1036,6 +1065,9 @@ class AMGSolver:
     def _solve_gmres(self, b, x, rtol, it, rr):
         K = self.K
         if self.shard is not None:
+            if self.shard.comm is not None:          # the library's communicator takes over: nothing of torch's may be in flight
+                from .distributed import assert_no_outstanding_work
+                assert_no_outstanding_work("hx_gmres_sharded")
             rc = _hx.lib.hx_gmres_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
                                           self.sell, _hx.ptr(b), _hx.ptr(x), rtol, self._max_it,
                                           self.params["restart"], _hx.ptr(self.ws), _hx.ptr(self._xe),
@@ -1055,6 +1087,8 @@ class AMGSolver:
         if self.shard is not None:
             native = self.shard.comm is not None
             if native:                      # exchanges issued inside this solve (library-issued path: counted by the communicator)
+                from .distributed import assert_no_outstanding_work
+                assert_no_outstanding_work("hx_cocg_sharded")
                 ne0, na0 = C.c_int64(0), C.c_int64(0)
                 _hx.check(_hx.lib.hx_comm_counters(self.shard.comm, C.byref(ne0), C.byref(na0), 0))
             rc = _hx.lib.hx_cocg_sharded(self.handle, self.n, K.nnz, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(K.val),
@@ -1127,6 +1161,7 @@ class AMGSolver:
                     transfers_from="A" if (self.use_graph and self._graph is not None) else "K",
                     recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)),
                     levels=[lv.get("n_global", lv["n"]) for lv in self.levels],
+                    operator_complexity=getattr(self, "operator_complexity", None), level_nnz=getattr(self, "level_nnz", None),
                     sharded_levels=[[lv["n"], lv["n_ext"] - lv["n"]] for lv in self.levels if lv.get("sharded")],
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
                     if self.sell else "csr",
@@ -1139,6 +1174,7 @@ class AMGSolver:
                     attainable_stops=self.attainable_stops,
                     gmres_iters=self.total_iters, solve_s=round(self.solve_s, 3),
                     iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1),
+                    max_iters_in_a_solve=self.max_iters_in_a_solve,
                     harmonic_ritz=[round(float(t), 3) for t in getattr(self, "harmonic_ritz", [])],
                     warm_starts=getattr(self, "warm_starts", 0),
                     cocg_halos=getattr(self, "cocg_halos", 0), cocg_allreduces=getattr(self, "cocg_allreduces", 0),

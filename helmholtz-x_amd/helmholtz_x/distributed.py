@@ -201,6 +201,40 @@ def distribute_mesh(mesh, ranges, rank, cell_tags=None, facet_tags=None, fields=
     return local, cut_tags(cell_tags, keep), cut_tags(facet_tags, fkeep), out_fields
 
 
+# ---- torch.distributed work handles of this module
+# Under the nccl backend a rank holds TWO NCCL communicators: torch's process group (the point-to-point messages and object
+# collectives of the SET-UP below) and the library's own hx_comm (every exchange of the solves, csrc/comm.hip).  NCCL does not
+# order operations of different communicators: a torch request still in flight when an hx_comm operation is enqueued may meet its
+# peers in a different order on another rank -- a deadlock no single-GPU stand-in can show.  The rule: every request issued here is
+# waited for before control can reach the library's communicator.  ``issue`` / ``wait_all`` keep the requests in a registry and
+# ``assert_no_outstanding_work`` (called at every Python entry into hx_comm: ShardContext.halo / all_reduce_ / the sharded solves)
+# raises when one was left behind.
+_OUTSTANDING = []
+
+
+def issue(ops):
+    """dist.batch_isend_irecv with the returned work handles registered as outstanding."""
+    reqs = dist.batch_isend_irecv(ops)
+    _OUTSTANDING.extend(reqs)
+    return reqs
+
+
+def wait_all(reqs):
+    for req in reqs:
+        req.wait()
+        for k, r in enumerate(_OUTSTANDING):
+            if r is req:
+                del _OUTSTANDING[k]
+                break
+
+
+def assert_no_outstanding_work(where):
+    if _OUTSTANDING:
+        raise RuntimeError("%d torch.distributed request(s) issued by the set-up are still outstanding at %s: a request must be "
+                           "waited for before the library's own communicator (hx_comm) is used -- NCCL does not order two "
+                           "communicators" % (len(_OUTSTANDING), where))
+
+
 class HaloPlan:
     """Ghost columns of a rank, grouped by owner, and the matching send lists (built with one all_gather of the
     ghost id lists -- integer set-up work)."""
@@ -272,8 +306,7 @@ class HaloPlan:
             else:
                 buf = dst
             ops.append(dist.P2POp(dist.irecv, buf, p, group=self.group))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        wait_all(issue(ops))
         for dst, buf in staged:
             dst.copy_(buf)
         self.n_exchanges += 1
@@ -326,8 +359,7 @@ class HaloPlan:
             recv_len[p] = b
             ops.append(dist.P2POp(dist.irecv, b, p, group=self.group))
         if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            wait_all(issue(ops))
         # 2) columns and values
         ops, recv_col, recv_val = [], {}, {}
         for p, _, c, v in sends:
@@ -346,8 +378,7 @@ class HaloPlan:
             ops.append(dist.P2POp(dist.irecv, bc, p, group=self.group))
             ops.append(dist.P2POp(dist.irecv, bv, p, group=self.group))
         if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            wait_all(issue(ops))
         order = sorted(self.recv_from, key=lambda p: int(self.recv_from[p][0]))      # ghost order = ascending position
         lens = torch.cat([recv_len[p].to(dev) for p in order]) if order else torch.zeros(0, dtype=torch.int32, device=dev)
         rp = torch.zeros(lens.numel() + 1, dtype=torch.int32, device=dev)

@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hx
-from .distributed import HaloPlan, partition_rows
+from .distributed import HaloPlan, assert_no_outstanding_work, issue, partition_rows, wait_all
 from .petsc import CSR
 
 
@@ -127,6 +127,7 @@ class ShardContext:
         v = torch.view_as_real(t) if t.is_complex() else t
         if self.comm is not None and v.is_cuda:
             assert v.is_contiguous() and v.dtype in (torch.float32, torch.float64)
+            assert_no_outstanding_work("ShardContext.all_reduce_ (hx_comm_allreduce)")
             _hx.check(_hx.lib.hx_comm_allreduce(self.comm, _hx.ptr(v), v.numel(), int(v.dtype == torch.float64),
                                                 int(op == "max"), _hx.stream()))
             return t
@@ -142,6 +143,7 @@ class ShardContext:
     def halo(self, x_ext, level=0):
         """Fill the ghost block of a level's extended vector (any 4-, 8- or 16-byte element type)."""
         if self.comm is not None and x_ext.is_cuda:
+            assert_no_outstanding_work("ShardContext.halo (hx_comm_halo)")
             _hx.check(_hx.lib.hx_comm_halo(self.comm, level, _hx.ptr(x_ext), x_ext.element_size(), _hx.stream()))
             return
         self.plans[level].exchange(x_ext, self.level_n[level][0])
@@ -293,8 +295,7 @@ class ShardContext:
         p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer, group=self.group)
                for peer, kind, buf, _u in sorted(ops, key=lambda o: (o[0], o[3]))]
         if p2p:
-            for req in dist.batch_isend_irecv(p2p):
-                req.wait()
+            wait_all(issue(p2p))
         for view, buf in staged:
             view.copy_(buf)
         return dst

@@ -843,11 +843,15 @@ def test_micca_newton_solver_distributed_over_two_ranks(ref_logs, golden_dir):
         assert abs(r["omega"] - final) / abs(final) < 1e-9, (r["omega"], final)
 
 
-def _bloch_sharded_worker(rank, world, port, out):
+def _bloch_sharded_worker(rank, world, port, out, shape=(12, 12, 48), transport="gloo"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
     os.environ["HX_QUIET"] = "1"
+    if transport == "fake_rccl":    # exchanges issued BY THE LIBRARY (hx_comm) through the asynchronous librccl stand-in
+        os.environ["HX_NATIVE_COMM"] = "1"
+        os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
+        os.environ["HX_AMG_REPLICATE_MAX_ROWS"] = "20000"     # levels 0 AND 1 stay row-sharded (422 k -> 52 k -> replicated tail)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
@@ -870,7 +874,7 @@ def _bloch_sharded_worker(rank, world, port, out):
         class Geometry:
             pass
 
-        mesh0, sub0, ft0 = annulus(12, 12, 48, n_flames=1, sector=(-half, half))
+        mesh0, sub0, ft0 = annulus(*shape, n_flames=1, sector=(-half, half))
         perm, planes = sector_slab_numbering(mesh0, "z")             # numbering that runs z-plane by z-plane
         G = Geometry()
         G.mesh = mesh0.renumbered(perm)
@@ -920,7 +924,8 @@ def _bloch_sharded_worker(rank, world, port, out):
             res["sharded"] = dict(eig=E_l.getEigenvalue(0), hist=list(hist_l), adj=E_a.getEigenvalue(0), stats=inner.stats(),
                                   p_own=p2.x.array[:n_own].copy(), own_ids=np.asarray(l2g[:n_own]), pairs=int(bloch_l.dofs_master.size),
                                   n_red=(bloch_l.shard.n_own, bloch_l.shard.n_ext, bloch_l.shard.n_global),
-                                  f_b=bloch_l.f_b, pm=p2.x.array[bloch_l.dofs_master].copy(), ps=p2.x.array[bloch_l.dofs_slave].copy())
+                                  f_b=bloch_l.f_b, pm=p2.x.array[bloch_l.dofs_master].copy(), ps=p2.x.array[bloch_l.dofs_slave].copy(),
+                                  counters=bloch_l.shard.counters())
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -957,6 +962,129 @@ def test_bloch_sector_row_sharded_over_two_ranks_matches_single_gpu():
         assert err < 1e-6, err
     assert n_pairs == 13 * 49                       # every pair of the (12 + 1) x (48 + 1) periodic face is owned by exactly one rank
     assert out[0]["sharded"]["eig"] == out[1]["sharded"]["eig"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bloch_sector_row_sharded_two_ranks_200k_rows_each_library_issued_exchanges():
+    """Config 5's row-sharded split ABOVE toy size inside the driver-run suite: sector grid (40, 40, 250) ->
+    422,091 DOF, two ranks with ~211 k rows each (3,300 SELL-64 slices per slab, two row-sharded hierarchy levels), the exchanges
+    issued by the library through the asynchronous librccl stand-in -- the first time hx_gmres_sharded (the reduced operator is
+    not complex symmetric) runs on the library's own communicator at a multi-slice size.  Eigenvalue and trajectory of the
+    single-GPU Bloch run to 1e-8, adjoint = conjugate to 1e-8, p(master) = f_b p(slave), one stream per communicator."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "fake_rccl")])
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_bloch_sharded_worker, args=(world, port, out, (40, 40, 250), "fake_rccl"), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        s, d = out[rank]["single"], out[rank]["sharded"]
+        assert len(s["hist"]) == len(d["hist"])
+        for a, b in zip(s["hist"], d["hist"]):
+            assert abs(a - b) / abs(a) < 1e-8, (a, b)
+        assert abs(s["eig"] - d["eig"]) / abs(s["eig"]) < 1e-8
+        # (no Robin wall in the sector: the linear branch, whose eigenvalue is omega^2 -- the parity bar is on omega)
+        w, wa = np.sqrt(d["eig"]), np.sqrt(d["adj"])
+        assert abs(wa - np.conj(w)) / abs(w) < 1e-8, (wa, w)
+        assert d["stats"]["krylov"] == "fgmres" and len(d["stats"]["sharded_levels"]) >= 2, d["stats"]
+        assert min(lv[0] for lv in d["stats"]["sharded_levels"][:1]) >= 200_000, d["stats"]["sharded_levels"]
+        assert "libhx" in d["counters"]["issued_by"] and d["counters"]["communicator_stream_switches"] == 0, d["counters"]
+        assert np.max(np.abs(d["pm"] - d["f_b"] * d["ps"])) < 1e-12 * np.max(np.abs(d["ps"]))
+    print("bloch 422k sharded:", out[0]["sharded"]["stats"]["sharded_levels"], out[0]["sharded"]["counters"])
+
+
+def _rcb_bench_worker(rank, world, port, out, workload, transport, partition="rcb"):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
+    os.environ["HX_QUIET"] = "1"
+    if transport == "fake_rccl":
+        os.environ["HX_NATIVE_COMM"] = "1"
+        os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import contextlib
+        import io
+        import bench
+        case = bench.build_case(bench.WORKLOADS[workload], resident=(rank == 0))
+        if partition == "morton":
+            # contiguous ranges of a space-filling-curve numbering: compact blobs, every rank a neighbour of every other one at
+            # world 4 (recursive coordinate bisection cuts this ring-shaped geometry into a RING of parts: two neighbours each)
+            from helmholtz_x.fem import MeshTags, locality_permutation
+            os.environ["HX_PARTITION"] = "rows"
+            m0 = case["mesh"]
+            m1 = m0.renumbered(locality_permutation(m0.geometry.x))
+            case["facet_tags"] = MeshTags(m1, case["facet_tags"].dim, case["facet_tags"].indices, case["facet_tags"].values)
+            case["subdomains"] = MeshTags(m1, case["subdomains"].dim, case["subdomains"].indices, case["subdomains"].values)
+            from helmholtz_x.fem import Function, FunctionSpace
+            c1 = Function(FunctionSpace(m1, "DG", 0), "soundspeed")
+            c1.x.array[:] = case["c"].x.array                      # cell-wise field: the cells keep their order
+            case["mesh"], case["c"], case["numbering"] = m1, c1, "morton"
+            if rank == 0:
+                c1.resident()
+        res = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            if rank == 0:                                   # the single-GPU answer, once
+                h1 = []
+                E1, _ = bench.hot_path(case, None, nev=4, tol=1e-3, history=h1)
+                res["single"] = dict(eigs=[E1.getEigenvalue(i) for i in range(2)], hist=list(h1))
+                E1.destroy()
+                del E1
+                case["c"].release()
+                case["mesh"]._assembler = None
+                torch.cuda.empty_cache()
+            dist.barrier()
+            hist = []
+            E, _ = bench.hot_path(case, st_type="amg", nev=4, tol=1e-3, history=hist, sharded=True)
+        inner = [v for v in E.inner_cache.values() if hasattr(v, "stats")][0]
+        sh = case["shard"]
+        res["sharded"] = dict(eigs=[E.getEigenvalue(i) for i in range(2)], hist=list(hist), stats=inner.stats(),
+                              partition=case["partition"], counters=sh.counters(),
+                              peers=(sorted(sh.plan.send_to), sorted(sh.plan.recv_from)))
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("partition", ["rcb", "morton"])
+def test_partitions_of_the_refined_real_mesh_four_ranks_library_issued_exchanges(partition):
+    """Sharded parity on an UNSTRUCTURED partition inside the driver-run suite: the reference's real MICCA
+    mesh refined once (249,497 DOF) cut into four parts by recursive coordinate bisection with reverse Cuthill-McKee inside
+    every part (what the N > 1 bench uses for every non-native numbering), ~62 k rows = ~1000 SELL-64 slices per rank, gathered
+    (non-contiguous) send lists, ranks with three neighbours -- the exchanges issued by the library through the asynchronous
+    librccl stand-in.  Trajectory and eigenvalues of the single-GPU run on the same mesh to 1e-8; one stream per communicator.
+    "rcb": the partitioner of the N > 1 bench (this ring-shaped geometry becomes a ring of parts: two neighbours per rank up to
+    six ranks); "morton": contiguous ranges of a space-filling-curve numbering -- every rank a neighbour of the three others."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "fake_rccl")])
+    world, port = 4, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_rcb_bench_worker, args=(world, port, out, "micca-real-r1", "fake_rccl", partition), nprocs=world, join=True)
+    assert len(out) == world
+    single = out[0]["single"]
+    rows = 0
+    for rank in range(world):
+        d = out[rank]["sharded"]
+        assert len(d["hist"]) == len(single["hist"])
+        for a, b in zip(single["hist"], d["hist"]):
+            assert abs(a - b) / abs(a) < 1e-8, (a, b)
+        for a, b in zip(single["eigs"], d["eigs"]):
+            assert abs(a - b) / abs(a) < 1e-8, (a, b)
+        assert "libhx" in d["counters"]["issued_by"] and d["counters"]["communicator_stream_switches"] == 0, d["counters"]
+        assert d["partition"]["kind"].startswith("recursive coordinate bisection" if partition == "rcb" else "contiguous row ranges")
+        rows += d["partition"]["per_rank"][rank]["rows"]
+    per_rank = out[0]["sharded"]["partition"]["per_rank"]
+    assert rows == 249497 and min(q["rows"] for q in per_rank) >= 60_000
+    assert max(q["neighbours"] for q in per_rank) >= (3 if partition == "morton" else 2), per_rank
+    print("rcb x4 micca-real-r1:", per_rank, out[0]["sharded"]["counters"], out[0]["sharded"]["stats"]["iters_per_solve"])
 
 
 def _rcb_worker(rank, world, port, out, golden_dir):
@@ -1023,3 +1151,92 @@ def test_rcb_partition_of_the_real_micca_mesh_over_eight_ranks(golden_dir):
     for rank in range(world):
         assert out[rank][2] == q_rcb[rank]["neighbours"]
     assert max(d["rows"] for d in q_rcb) - min(d["rows"] for d in q_rcb) <= 1
+
+
+def _outstanding_work_worker(rank, world, port, out, gpu):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd")]
+    if gpu:
+        os.environ["HX_NATIVE_COMM"] = "1"
+        os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
+        os.environ["HX_FAKE_RCCL_TIMEOUT_S"] = "4"
+        torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from helmholtz_x import distributed as dd
+        peer = 1 - rank
+        send, recv = torch.full((4,), float(rank)), torch.empty(4)
+        reqs = dd.issue([dist.P2POp(dist.isend, send, peer), dist.P2POp(dist.irecv, recv, peer)])
+        res = {}
+        if gpu:
+            from helmholtz_x.sharded import ShardContext
+            ctx = ShardContext(1000)
+            assert ctx.comm is not None
+            t = torch.ones(2, dtype=torch.float64, device="cuda")
+            for name, call in (("all_reduce", lambda: ctx.all_reduce_(t)),):
+                try:
+                    call()
+                    res[name] = "no error"
+                except RuntimeError as e:
+                    res[name] = str(e)
+        else:
+            try:
+                dd.assert_no_outstanding_work("test")
+                res["assert"] = "no error"
+            except RuntimeError as e:
+                res["assert"] = str(e)
+        dd.wait_all(reqs)
+        dd.assert_no_outstanding_work("after wait_all")          # the registry is empty again
+        res["recv"] = recv.tolist()
+        if gpu:
+            ctx.all_reduce_(t)                                    # and the library's communicator may be used
+            torch.cuda.synchronize()
+            res["sum"] = t.tolist()
+            # the stand-in's barrier has a deadline: rank 1 skips the next all-reduce; rank 0's operation must FAIL (not hang)
+            if rank == 0:
+                import time
+                t0 = time.perf_counter()
+                try:
+                    ctx.all_reduce_(t)
+                    torch.cuda.synchronize()
+                    ctx.all_reduce_(t)                            # every later operation of the failed communicator reports it
+                    res["timeout"] = "no error"
+                except Exception as e:
+                    res["timeout"] = "%s after %.1f s" % (type(e).__name__, time.perf_counter() - t0)
+            dist.barrier()
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_outstanding_torch_request_is_caught_before_the_library_communicator_is_used():
+    """Two NCCL communicators live in a rank under the nccl backend (torch's process group for the set-up, the library's hx_comm
+    for the solves); NCCL does not order them.  Every point-to-point request of the set-up goes through distributed.issue /
+    wait_all, and a request left un-waited makes the next entry into hx_comm raise.  CPU half: the registry itself (gloo)."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_outstanding_work_worker, args=(world, port, out, False), nprocs=world, join=True)
+    for rank in range(world):
+        assert "still outstanding" in out[rank]["assert"], out[rank]
+        assert out[rank]["recv"] == [float(1 - rank)] * 4
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_outstanding_request_guard_and_stand_in_deadline_two_ranks_one_gpu():
+    """GPU half (two ranks on the one GPU, exchanges issued by the library through tests/fake_rccl): hx_comm_allreduce refuses to
+    start while a batch_isend_irecv request of the set-up is un-waited and works once it was waited for; and the stand-in's
+    cross-process barrier gives up after its deadline when a peer never enqueues the matching operation (it used to
+    spin for ever inside a host function, blocking the stream, hipDeviceSynchronize and the pool behind it)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "fake_rccl")])
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_outstanding_work_worker, args=(world, port, out, True), nprocs=world, join=True)
+    for rank in range(world):
+        assert "still outstanding" in out[rank]["all_reduce"], out[rank]
+        assert out[rank]["sum"] == [2.0, 2.0]
+    assert out[0]["timeout"] != "no error" and "after" in out[0]["timeout"], out[0]

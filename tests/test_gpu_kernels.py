@@ -961,10 +961,11 @@ def test_pool_notes_every_caller_stream_where_it_is_used():
             _hx.check(_hx.lib.hx_sell_spmv_z(h, _hx.ptr(x), _hx.ptr(ya), one, zero, _hx.stream()))
     with torch.cuda.stream(sb):                            # the LAST stream the library sees before the release is B
         K.spmv(x, yb)
+    _hx.check(_hx.lib.hx_pool_ordering_stats(C.byref(ev0), None, None))     # (the set-up's own scratch releases are behind us)
     _hx.lib.hx_sell_destroy(h)                             # released while stream A may still be reading the block
     ev1 = C.c_int64(0)
     _hx.check(_hx.lib.hx_pool_ordering_stats(C.byref(ev1), None, None))
-    # one event per noted caller stream and pooled block: with A forgotten there would be half as many
+    # one event per noted caller stream (A and B) and pooled block: with A forgotten there would be half as many
     h2 = C.c_void_p()
     _hx.check(_hx.lib.hx_sell_create(C.byref(h2), n, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr((2.0 * K.val).contiguous()), 1, 0, _hx.stream()))
     torch.cuda.synchronize()

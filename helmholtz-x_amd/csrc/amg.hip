@@ -30,6 +30,10 @@ int hx_csr_spmv_c(int role, int32_t, int64_t, const int32_t*, const int32_t*, co
                   float, hx_stream);
 int hx_csr_restrict_diag_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, float*, const float*, float*, float,
                            hx_stream);
+int hx_csr_restrict_residual_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, int64_t, const int32_t*,
+                               const int32_t*, const float*, const float*, float*, const float*, float*, float, hx_stream);
+int hx_csr_restrict_residual_z(int32_t, int64_t, const int32_t*, const int32_t*, const double*, const hx_c128*, int64_t, const int32_t*,
+                               const int32_t*, const hx_c128*, const hx_c128*, hx_c128*, const hx_c128*, hx_c128*, double, hx_stream);
 int hx_csr_restrict_diag_z(int32_t, int64_t, const int32_t*, const int32_t*, const double*, const hx_c128*, hx_c128*, const hx_c128*,
                            hx_c128*, double, hx_stream);
 int hx_csr_jacobi_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
@@ -163,6 +167,17 @@ static int op_restrict_diag(const CsrT<double>& R, const double* r, double* bc, 
 static int op_restrict_diag(const CsrT<float>& R, const float* r, float* bc, const float* dc, float* x1, double a0, hx_stream s) {
   return hx_csr_restrict_diag_c(R.rows, R.nnz, R.rp, R.ci, R.va, r, bc, dc, x1, (float)a0, s);
 }
+// bc = R b - (R K) x  [+ x1 = a0 Dc^-1 bc when x1 != NULL]: residual and restriction of a CSR level in one launch
+static int op_restrict_residual(const LevelT<double>& L, const double* b, const double* x, double* bc, const double* dc, double* x1,
+                                double a0, hx_stream s) {
+  return hx_csr_restrict_residual_z(L.R.rows, L.R.nnz, L.R.rp, L.R.ci, L.R.va, (const hx_c128*)b, L.RK.nnz, L.RK.rp, L.RK.ci,
+                                    (const hx_c128*)L.RK.va, (const hx_c128*)x, (hx_c128*)bc, (const hx_c128*)dc, (hx_c128*)x1, a0, s);
+}
+static int op_restrict_residual(const LevelT<float>& L, const float* b, const float* x, float* bc, const float* dc, float* x1, double a0,
+                                hx_stream s) {
+  return hx_csr_restrict_residual_c(L.R.rows, L.R.nnz, L.R.rp, L.R.ci, L.R.va, b, L.RK.nnz, L.RK.rp, L.RK.ci, L.RK.va, x, bc, dc, x1,
+                                    (float)a0, s);
+}
 static int op_diag(const LevelT<double>& L, double w, const double* b, double* x, hx_stream s) {
   return hx_zdiag_scale(L.n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
 }
@@ -208,6 +223,7 @@ static int set_level(bool real_transfers, HierT<T>& H, int l, int32_t n, int64_t
   LevelT<T>& L = H.L[l];
   L.n = n;
   L.p_ghost_rows = false;      // a level that is set again starts without ghost rows in P (hx_amg_set_prolongator_ghost_rows re-arms it)
+  L.RK = CsrT<T>();            // ... and without the fused residual-restriction product (hx_amg_set_level_rk re-arms it)
   L.K.rows = n; L.K.nnz = nnzK; L.K.rp = rpK; L.K.ci = ciK; L.K.va = vaK;
   L.dinv = dinv;
   if (l != (int)H.L.size() - 1) {
@@ -259,6 +275,19 @@ extern "C" int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell) {
   drop_graph(h);
   h->D.L[l].sell = sell;       // the handle must carry the value copy of the precision the V-cycle runs in
   h->S.L[l].sell = sell;
+  return HX_OK;
+}
+
+// R K of level l (n_coarse x n, sorted CSR; values complex64 when the handle carries the complex64 hierarchy, complex128
+// otherwise): with it the cycle computes the restricted residual of this level as R b - (R K) x in ONE launch instead of a
+// residual pass and a restriction.  For launch-bound CSR levels; ignored on levels with a SELL-64 companion and on sharded ones.
+extern "C" int hx_amg_set_level_rk(hx_amg* h, int l, int64_t nnz, const int32_t* rp, const int32_t* ci, const void* va) {
+  HX_REQUIRE(h && l >= 0 && l + 1 < (int)h->D.L.size() && nnz >= 0 && rp && ci && va, "bad argument");
+  drop_graph(h);
+  if (h->single) { auto& L = h->S.L[l]; HX_REQUIRE(L.R.rows > 0, "set the level first");
+                   L.RK.rows = L.R.rows; L.RK.nnz = nnz; L.RK.rp = rp; L.RK.ci = ci; L.RK.va = (const float*)va; }
+  else { auto& L = h->D.L[l]; HX_REQUIRE(L.R.rows > 0, "set the level first");
+         L.RK.rows = L.R.rows; L.RK.nnz = nnz; L.RK.rp = rp; L.RK.ci = ci; L.RK.va = (const double*)va; }
   return HX_OK;
 }
 
@@ -436,9 +465,14 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
                         : op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, st, part); }))) return rc;
       prev = cur; cur = nxt;
     }
-    // residual r = b - K x, restrict
-    if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part, hx_stream st) { return op_residual(L, cur, b, L.r, st, part); }))) return rc;
-    if ((rc = restrict_from(L.r))) return rc;
+    // residual r = b - K x, restrict -- or, on a launch-bound CSR level that carries R K, both in one launch: bc = R b - (R K) x
+    if (L.RK.rp && !L.sell && !sh && HX_OPT_INT("amg_fold_residual", 1) != 0) {
+      const double a0c = Lc.rho > 0.0 ? cheb_coeffs(Lc.rho).a[0] : h->omega;
+      if ((rc = op_restrict_residual(L, b, cur, Lc.b, fold ? Lc.dinv : nullptr, fold ? Lc.x : nullptr, a0c, s))) return rc;
+    } else {
+      if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part, hx_stream st) { return op_residual(L, cur, b, L.r, st, part); }))) return rc;
+      if ((rc = restrict_from(L.r))) return rc;
+    }
   }
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
   if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s, fold))) return rc;

@@ -13,6 +13,7 @@ template <typename T> struct CsrT { int32_t rows = 0; int64_t nnz = 0; const int
 template <typename T> struct LevelT {
   int32_t n = 0;
   CsrT<T> K, P, R;             // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
+  CsrT<T> RK;                  // optional R K (n_coarse x n, complex values): residual + restriction of a CSR level in one launch
   const T* dinv = nullptr;
   double rho = 0.0;            // estimate of rho(D^-1 K) for the Chebyshev smoother (0: damped Jacobi with h->omega)
   const hx_sell* sell = nullptr;   // optional SELL-64 companion of K (fine level): used for the K products

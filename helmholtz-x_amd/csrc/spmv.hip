@@ -137,6 +137,62 @@ int hx_csr_restrict_diag_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, c
   return spmv_dispatch<1, zc, double>(n_rows, nnz, rowptr, col, val, (const zc*)x, (zc*)y, make_double2(1.0, 0.0), make_double2(0.0, 0.0), 0,
                                       s, nullptr, ep);
 }
+// Residual AND restriction of a CSR level in one launch: bc = R (b - K x) = R b - (R K) x with the product RK formed once at set-up
+// (the Galerkin chain has R and K anyway).  One sub-wave per coarse row walks its R row over b and its RK row over x; the optional
+// epilogue leaves the coarse level's first smoothing step (see k_spmv).  Launch-bound levels only (a few thousand rows): RK has
+// more entries than R but fewer than K, and the residual vector is never written.
+template <int LPR, typename V, typename MR>
+__global__ void __launch_bounds__(256)
+k_restrict_residual(int32_t n, const int32_t* __restrict__ rrp, const int32_t* __restrict__ rci, const MR* __restrict__ rva,
+                    const V* __restrict__ b, const int32_t* __restrict__ krp, const int32_t* __restrict__ kci,
+                    const V* __restrict__ kva, const V* __restrict__ x, V* __restrict__ y,
+                    const V* __restrict__ ep_d, V* __restrict__ ep_x, typename real_of<V>::type ep_a) {
+  constexpr int RPB = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  const int64_t stride = (int64_t)gridDim.x * RPB;
+  const int64_t sweeps = ((int64_t)n + stride - 1) / stride;
+  int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  for (int64_t it = 0; it < sweeps; ++it, row += stride) {
+    V acc = czero<V>();
+    if (row < n) {
+      acc = row_dot<LPR, V, MR>(rci, rva, b, rrp[row], rrp[row + 1], sub);
+      const V k = row_dot<LPR, V, V>(kci, kva, x, krp[row], krp[row + 1], sub);
+      acc.x -= k.x; acc.y -= k.y;
+    }
+    if (LPR > 1) acc = zreduce_sub<LPR>(acc);
+    if (row < n && sub == 0) {
+      y[row] = acc;
+      if (ep_x) ep_x[row] = zscale(ep_a, zmul(ep_d[row], acc));
+    }
+  }
+}
+template <typename V, typename MR>
+static int restrict_residual(int32_t n, int64_t nnzR, const int32_t* rrp, const int32_t* rci, const MR* rva, const V* b, int64_t nnzK,
+                             const int32_t* krp, const int32_t* kci, const V* kva, const V* x, V* y, const V* d, V* x1,
+                             typename real_of<V>::type a0, hx_stream s) {
+  HX_REQUIRE(n >= 0 && rrp && krp && b && x && y && (!x1 || d), "bad argument");
+  if (n == 0) return HX_OK;
+  const int lpr = pick_lpr(nnzR + nnzK, n);
+#define HX_RR(L) { int grid = hx_grid((int64_t)n, 256 / L, 256 * 16); \
+    k_restrict_residual<L, V, MR><<<grid, 256, 0, hx_s(s)>>>(n, rrp, rci, rva, b, krp, kci, kva, x, y, d, x1, a0); } break
+  switch (lpr) { case 1: HX_RR(1); case 2: HX_RR(2); case 4: HX_RR(4); case 8: HX_RR(8); case 16: HX_RR(16); case 32: HX_RR(32);
+                 default: HX_RR(64); }
+#undef HX_RR
+  HX_LAUNCH_CHECK("k_restrict_residual");
+  return HX_OK;
+}
+int hx_csr_restrict_residual_c(int32_t n, int64_t nnzR, const int32_t* rrp, const int32_t* rci, const float* rva, const float* b,
+                               int64_t nnzK, const int32_t* krp, const int32_t* kci, const float* kva, const float* x, float* y,
+                               const float* d, float* x1, float a0, hx_stream s) {
+  return restrict_residual<cc, float>(n, nnzR, rrp, rci, rva, (const cc*)b, nnzK, krp, kci, (const cc*)kva, (const cc*)x, (cc*)y,
+                                      (const cc*)d, (cc*)x1, a0, s);
+}
+int hx_csr_restrict_residual_z(int32_t n, int64_t nnzR, const int32_t* rrp, const int32_t* rci, const double* rva, const hx_c128* b,
+                               int64_t nnzK, const int32_t* krp, const int32_t* kci, const hx_c128* kva, const hx_c128* x, hx_c128* y,
+                               const hx_c128* d, hx_c128* x1, double a0, hx_stream s) {
+  return restrict_residual<zc, double>(n, nnzR, rrp, rci, rva, (const zc*)b, nnzK, krp, kci, (const zc*)kva, (const zc*)x, (zc*)y,
+                                       (const zc*)d, (zc*)x1, a0, s);
+}
 // r = b - A x in one pass (internal; the V-cycle's residual on the CSR levels)
 int hx_csr_residual_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val, const float* x,
                       const float* b, float* r, hx_stream s) {

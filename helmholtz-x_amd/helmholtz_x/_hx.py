@@ -85,6 +85,7 @@ SIGNATURES = {
     "hx_amg_create": (C.c_int, [C.POINTER(_vp), _int, _int, _int, C.c_double]),
     "hx_amg_set_level": (C.c_int, [_vp, _int, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
                                    _vp, _vp]),
+    "hx_amg_set_level_rk": (C.c_int, [_vp, _int, _i64, _vp, _vp, _vp]),
     "hx_amg_set_smoother": (C.c_int, [_vp, _int, C.c_double]),
     "hx_amg_set_real_transfers": (C.c_int, [_vp, _int]),
     "hx_amg_set_coarse": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),

@@ -841,6 +841,7 @@ class AMGSolver:
         # coarse SELL levels take the same storage (5 M DOF: iterations unchanged, 8.38 -> 8.27 s)
         half_coarse = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
         for l, lv in enumerate(levels):
+            n_sells_before = len(self.coarse_sells)
             if l == 0:
                 k0 = Kp.val.to(cdt) if mixed else Kp.val
                 self._keep.append(k0)
@@ -869,6 +870,16 @@ class AMGSolver:
                                     _hx.ptr(rrp), _hx.ptr(rci), _hx.ptr(rva)))
                 if self.params["smoother"] == "chebyshev":
                     _hx.check(_hx.lib.hx_amg_set_smoother(h, l, float(lv["rho"])))
+                # launch-bound CSR levels: R K, so that residual + restriction are one launch (hx_amg_set_level_rk).  Not for
+                # levels with a SELL-64 companion (their residual pass is bandwidth-bound and R K would add bytes), not sharded.
+                has_sell = (self.sell is not None) if l == 0 else (len(self.coarse_sells) > n_sells_before)
+                if (not has_sell and not lv.get("sharded") and isinstance(Rl, DevCSR) and self.params["pre"] > 0
+                        and os.environ.get("HX_AMG_FOLD_RESIDUAL", "1") != "0"):
+                    Kl_c128 = DevCSR((nl, nl), krp, kci, Kp.val if l == 0 else values_c128(lv["K"]))
+                    RK = _dev_spgemm(Rl, Kl_c128)
+                    rkv = RK.val.to(cdt).contiguous()
+                    self._keep.append((RK.rowptr, RK.col, rkv))
+                    _hx.check(_hx.lib.hx_amg_set_level_rk(h, l, RK.nnz, _hx.ptr(RK.rowptr), _hx.ptr(RK.col), _hx.ptr(rkv)))
             else:
                 _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), None, 0, 0, None,
                                     None, None, 0, None, None, None))

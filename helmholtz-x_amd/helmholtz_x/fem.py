@@ -635,8 +635,9 @@ class P2Assembler:
         csr = mat.csr_part()
         flags = np.zeros(self.n, dtype=np.uint8)
         flags[np.asarray(dofs, dtype=np.int64)] = 1
+        flags_d = to_device(flags)          # (bound to a name: the launch below is asynchronous)
         _hx.check(_hx.lib.hx_csr_apply_dirichlet(self.n, _hx.ptr(csr.rowptr), _hx.ptr(csr.col), _hx.ptr(csr.val),
-                                                 _hx.ptr(to_device(flags)), float(diag), _hx.stream()))
+                                                 _hx.ptr(flags_d), float(diag), _hx.stream()))
 
     def facet_dofs(self, facets):
         """(nf, 6) global P2 dofs of boundary triangles: 3 vertices + the edges in TRI_EDGES order."""

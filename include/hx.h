@@ -343,6 +343,12 @@ int hx_amg_set_real_transfers(hx_amg* h, int flag);
 /* Optional SELL-64 companion of K_l (must hold the value copy of the precision the V-cycle runs in): the smoother
  * steps and the residual product of that level then use the SELL kernels. */
 int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell);
+/* R K of level l (n_coarse x n, sorted CSR on the device; values complex64 when the handle carries the complex64 hierarchy, else
+ * complex128): the cycle then forms the restricted residual of that level as R b - (R K) x in one launch (k_restrict_residual)
+ * instead of a residual pass followed by a restriction.  Meant for the launch-bound CSR levels; ignored where the level has a SELL-64
+ * companion or is row-sharded.  Option amg_fold_residual = 0 switches the fused pass off.
+ * replaces: nothing in the reference (part of the PCLU alternative, eigensolvers.py:49-50,102-103). */
+int hx_amg_set_level_rk(hx_amg* h, int l, int64_t nnz, const int32_t* rp, const int32_t* ci, const void* va);
 /* Smoother of level l: rho = 0 -> `pre`/`post` damped-Jacobi sweeps with the weight given to hx_amg_create;
  * rho > 0 (estimate of the spectral radius of D^-1 K_l) -> Chebyshev polynomial of degree pre/post on D^-1 K_l
  * targeting [0.11 rho, 1.1 rho], evaluated by the same fused kernel as a three-term recurrence. */

@@ -1240,3 +1240,61 @@ def test_outstanding_request_guard_and_stand_in_deadline_two_ranks_one_gpu():
         assert "still outstanding" in out[rank]["all_reduce"], out[rank]
         assert out[rank]["sum"] == [2.0, 2.0]
     assert out[0]["timeout"] != "no error" and "after" in out[0]["timeout"], out[0]
+
+
+def _sharded_ladder_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
+    os.environ["HX_QUIET"] = "1"
+    os.environ["HX_NATIVE_COMM"] = "1"
+    os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import contextlib
+        import io
+        import bench
+        from helmholtz_x.petsc import Options
+        Options._db = {}
+        case = bench.build_case((10, 192, 11))
+        res = {}
+        for mode, max_it in (("free", None), ("limited", "auto")):
+            if max_it == "auto":                          # half of what the hardest solve of the unrestricted run needed
+                Options()["st_ksp_max_it"] = max(3, res["free"]["stats"]["max_iters_in_a_solve"] // 2)
+            hist = []
+            with contextlib.redirect_stdout(io.StringIO()):
+                E, _ = bench.hot_path(case, st_type="amg", nev=4, tol=1e-3, history=hist, sharded=True)
+            inner = [v for v in E.inner_cache.values() if hasattr(v, "stats")][0]
+            res[mode] = dict(eigs=[E.getEigenvalue(i) for i in range(2)], hist=list(hist), stats=inner.stats())
+            E.destroy()
+        res["counters"] = case["shard"].counters()
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_escalation_ladder_on_the_row_sharded_path_two_ranks():
+    """The ladder's decisions rest on all-reduced residual norms, so every rank takes the same step at the same solve: two ranks
+    (library-issued exchanges through the stand-in), iteration limit of the first rung cut to half of what the hardest solve needs
+    (-st_ksp_max_it) -> both ranks move to the wide rung after the same solve, rebuild their slab of the hierarchy, the recycling
+    workspace and the level plans, and return the eigenvalues of the unrestricted run."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "fake_rccl")])
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_sharded_ladder_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        free, lim = out[rank]["free"], out[rank]["limited"]
+        assert free["stats"]["rung"] == "default" and free["stats"]["ladder"] == []
+        assert lim["stats"]["rung"] == "wide" and "stalled" in lim["stats"]["ladder"][0]["reason"], lim["stats"]
+        assert len(lim["stats"]["sharded_levels"]) >= 1
+        for a, b in zip(free["eigs"], lim["eigs"]):
+            assert abs(a - b) / abs(a) < 1e-8, (a, b)
+        assert out[rank]["counters"]["communicator_stream_switches"] == 0
+    assert out[0]["limited"]["stats"]["ladder"] == out[1]["limited"]["stats"]["ladder"]       # same step, same solve, same reason

@@ -605,8 +605,9 @@ def test_device_amg_setup_passes_match_host(hx):
                                             C.byref(pnnz), hx.stream()))
     pci = torch.empty(pnnz.value, dtype=torch.int32, device=Kd.val.device)
     pv = torch.empty(pnnz.value, dtype=torch.float64, device=Kd.val.device)
+    isc_d = _dev(isc)
     hx.check(hx.lib.hx_sa_prolongator_fill(n, hx.ptr(Lf_d.rowptr), hx.ptr(Lf_d.col), hx.ptr(Lf_d.val), hx.ptr(agg_d),
-                                           hx.ptr(_dev(isc)), 0.6, hx.ptr(prp), hx.ptr(pci), hx.ptr(pv), hx.stream()))
+                                           hx.ptr(isc_d), 0.6, hx.ptr(prp), hx.ptr(pci), hx.ptr(pv), hx.stream()))
     P_d = amg.DevCSR((n, na), prp, pci, pv)
     P_h = amg._prolongator(Lf_h, agg, na, 0.6)
     _same_csr(P_d, P_h, 1e-14)
@@ -967,7 +968,8 @@ def test_pool_notes_every_caller_stream_where_it_is_used():
     _hx.check(_hx.lib.hx_pool_ordering_stats(C.byref(ev1), None, None))
     # one event per noted caller stream (A and B) and pooled block: with A forgotten there would be half as many
     h2 = C.c_void_p()
-    _hx.check(_hx.lib.hx_sell_create(C.byref(h2), n, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr((2.0 * K.val).contiguous()), 1, 0, _hx.stream()))
+    val2 = (2.0 * K.val).contiguous()
+    _hx.check(_hx.lib.hx_sell_create(C.byref(h2), n, _hx.ptr(K.rowptr), _hx.ptr(K.col), _hx.ptr(val2), 1, 0, _hx.stream()))
     torch.cuda.synchronize()
     assert _rel(ya.cpu().numpy(), A @ np.ones(n)) < 1e-14          # A's products never saw the re-used block's new values
     y2 = torch.empty_like(x)
@@ -1003,9 +1005,14 @@ def test_factored_flame_term_scatter_with_device_coefficients(hx):
         for f in range(r):
             ref[sup[f]] += coef * t[f] * vals[f]
         y = _dev(y0)
-        hx.check(hx.lib.hx_zsparse_axpys(r, hx.ptr(_dev(ptr)), hx.ptr(_dev(idx)), hx.ptr(_dev(np.concatenate(vals))), hx.ptr(_dev(t)),
+        # (device operands are bound to names: a temporary would be released -- and its block handed to the next allocation --
+        # before the asynchronous launch has read it)
+        d_ptr, d_idx, d_val, d_t = _dev(ptr), _dev(idx), _dev(np.concatenate(vals)), _dev(t)
+        hx.check(hx.lib.hx_zsparse_axpys(r, hx.ptr(d_ptr), hx.ptr(d_idx), hx.ptr(d_val), hx.ptr(d_t),
                                          hx.z2(coef), hx.ptr(y), int(not overlapping), hx.stream()))
+        torch.cuda.synchronize()
         assert _rel(y.cpu().numpy(), ref) < 1e-14
+        del d_ptr, d_idx, d_val, d_t
         # the petsc4py-shaped product: (S + coef * sum_f u_f v_f^T) x
         S = sp.random(n, n, density=0.001, random_state=rng, format="csr") + sp.eye(n)
         S = sp.csr_matrix(S.astype(np.complex128))

@@ -28,12 +28,12 @@ int hx_csr_spmv_creal(int32_t, int64_t, const int32_t*, const int32_t*, const fl
 int hx_csr_spmv_zreal(int32_t, int64_t, const int32_t*, const int32_t*, const double*, const hx_c128*, hx_c128*, double, double, hx_stream);
 int hx_csr_spmv_c(int role, int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, float*, float,
                   float, hx_stream);
+int hx_csr_smooth_rows_c(int32_t, int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*,
+                         float*, float, const float*, float, hx_stream);
+int hx_csr_smooth_rows_z(int32_t, int32_t, int64_t, const int32_t*, const int32_t*, const hx_c128*, const hx_c128*, const hx_c128*,
+                         const hx_c128*, hx_c128*, double, const hx_c128*, double, hx_stream);
 int hx_csr_restrict_diag_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, float*, const float*, float*, float,
                            hx_stream);
-int hx_csr_restrict_residual_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, int64_t, const int32_t*,
-                               const int32_t*, const float*, const float*, float*, const float*, float*, float, hx_stream);
-int hx_csr_restrict_residual_z(int32_t, int64_t, const int32_t*, const int32_t*, const double*, const hx_c128*, int64_t, const int32_t*,
-                               const int32_t*, const hx_c128*, const hx_c128*, hx_c128*, const hx_c128*, hx_c128*, double, hx_stream);
 int hx_csr_restrict_diag_z(int32_t, int64_t, const int32_t*, const int32_t*, const double*, const hx_c128*, hx_c128*, const hx_c128*,
                            hx_c128*, double, hx_stream);
 int hx_csr_jacobi_c(int32_t, int64_t, const int32_t*, const int32_t*, const float*, const float*, const float*,
@@ -167,16 +167,30 @@ static int op_restrict_diag(const CsrT<double>& R, const double* r, double* bc, 
 static int op_restrict_diag(const CsrT<float>& R, const float* r, float* bc, const float* dc, float* x1, double a0, hx_stream s) {
   return hx_csr_restrict_diag_c(R.rows, R.nnz, R.rp, R.ci, R.va, r, bc, dc, x1, (float)a0, s);
 }
-// bc = R b - (R K) x  [+ x1 = a0 Dc^-1 bc when x1 != NULL]: residual and restriction of a CSR level in one launch
-static int op_restrict_residual(const LevelT<double>& L, const double* b, const double* x, double* bc, const double* dc, double* x1,
-                                double a0, hx_stream s) {
-  return hx_csr_restrict_residual_z(L.R.rows, L.R.nnz, L.R.rp, L.R.ci, L.R.va, (const hx_c128*)b, L.RK.nnz, L.RK.rp, L.RK.ci,
-                                    (const hx_c128*)L.RK.va, (const hx_c128*)x, (hx_c128*)bc, (const hx_c128*)dc, (hx_c128*)x1, a0, s);
+// ---- deep-halo mode: the same steps on the rows of the FIRST GHOST LAYER (stored apart in L.K1; vector rows n .. n + n_g1 - 1)
+static int op_smooth_g1(const LevelT<double>& L, const double* b, const double* xin, double* xout, double w, const double* xprev,
+                        double mom, hx_stream s) {
+  return hx_csr_smooth_rows_z(L.n_g1, L.n, L.K1.nnz, L.K1.rp, L.K1.ci, (const hx_c128*)L.K1.va, (const hx_c128*)L.dinv, (const hx_c128*)b,
+                              (const hx_c128*)xin, (hx_c128*)xout, w, (const hx_c128*)xprev, mom, s);
 }
-static int op_restrict_residual(const LevelT<float>& L, const float* b, const float* x, float* bc, const float* dc, float* x1, double a0,
-                                hx_stream s) {
-  return hx_csr_restrict_residual_c(L.R.rows, L.R.nnz, L.R.rp, L.R.ci, L.R.va, b, L.RK.nnz, L.RK.rp, L.RK.ci, L.RK.va, x, bc, dc, x1,
-                                    (float)a0, s);
+static int op_smooth_g1(const LevelT<float>& L, const float* b, const float* xin, float* xout, double w, const float* xprev, double mom,
+                        hx_stream s) {
+  return hx_csr_smooth_rows_c(L.n_g1, L.n, L.K1.nnz, L.K1.rp, L.K1.ci, L.K1.va, L.dinv, b, xin, xout, (float)w, xprev, (float)mom, s);
+}
+static int op_residual_g1(const LevelT<double>& L, const double* x, const double* b, double* r, hx_stream s) {
+  const size_t o = 2 * (size_t)L.n;
+  return hx_csr_residual_z(L.n_g1, L.K1.nnz, L.K1.rp, L.K1.ci, (const hx_c128*)L.K1.va, (const hx_c128*)x, (const hx_c128*)(b + o),
+                           (hx_c128*)(r + o), s);
+}
+static int op_residual_g1(const LevelT<float>& L, const float* x, const float* b, float* r, hx_stream s) {
+  const size_t o = 2 * (size_t)L.n;
+  return hx_csr_residual_c(L.n_g1, L.K1.nnz, L.K1.rp, L.K1.ci, L.K1.va, x, b + o, r + o, s);
+}
+static int op_diag_n(const LevelT<double>& L, int64_t n, double w, const double* b, double* x, hx_stream s) {
+  return hx_zdiag_scale(n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
+}
+static int op_diag_n(const LevelT<float>& L, int64_t n, double w, const float* b, float* x, hx_stream s) {
+  return hx_cdiag_scale(n, (float)w, L.dinv, b, x, s);
 }
 static int op_diag(const LevelT<double>& L, double w, const double* b, double* x, hx_stream s) {
   return hx_zdiag_scale(L.n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
@@ -223,7 +237,7 @@ static int set_level(bool real_transfers, HierT<T>& H, int l, int32_t n, int64_t
   LevelT<T>& L = H.L[l];
   L.n = n;
   L.p_ghost_rows = false;      // a level that is set again starts without ghost rows in P (hx_amg_set_prolongator_ghost_rows re-arms it)
-  L.RK = CsrT<T>();            // ... and without the fused residual-restriction product (hx_amg_set_level_rk re-arms it)
+  L.deep = false; L.K1 = CsrT<T>(); L.n_g1 = 0;      // ... and out of deep-halo mode (hx_amg_set_level_deep re-arms it)
   L.K.rows = n; L.K.nnz = nnzK; L.K.rp = rpK; L.K.ci = ciK; L.K.va = vaK;
   L.dinv = dinv;
   if (l != (int)H.L.size() - 1) {
@@ -275,19 +289,6 @@ extern "C" int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell) {
   drop_graph(h);
   h->D.L[l].sell = sell;       // the handle must carry the value copy of the precision the V-cycle runs in
   h->S.L[l].sell = sell;
-  return HX_OK;
-}
-
-// R K of level l (n_coarse x n, sorted CSR; values complex64 when the handle carries the complex64 hierarchy, complex128
-// otherwise): with it the cycle computes the restricted residual of this level as R b - (R K) x in ONE launch instead of a
-// residual pass and a restriction.  For launch-bound CSR levels; ignored on levels with a SELL-64 companion and on sharded ones.
-extern "C" int hx_amg_set_level_rk(hx_amg* h, int l, int64_t nnz, const int32_t* rp, const int32_t* ci, const void* va) {
-  HX_REQUIRE(h && l >= 0 && l + 1 < (int)h->D.L.size() && nnz >= 0 && rp && ci && va, "bad argument");
-  drop_graph(h);
-  if (h->single) { auto& L = h->S.L[l]; HX_REQUIRE(L.R.rows > 0, "set the level first");
-                   L.RK.rows = L.R.rows; L.RK.nnz = nnz; L.RK.rp = rp; L.RK.ci = ci; L.RK.va = (const float*)va; }
-  else { auto& L = h->D.L[l]; HX_REQUIRE(L.R.rows > 0, "set the level first");
-         L.RK.rows = L.R.rows; L.RK.nnz = nnz; L.RK.rp = rp; L.RK.ci = ci; L.RK.va = (const double*)va; }
   return HX_OK;
 }
 
@@ -358,6 +359,31 @@ extern "C" int hx_amg_set_prolongator_ghost_rows(hx_amg* h, int n_levels) {
   return HX_OK;
 }
 
+// Deep-halo mode of row-sharded level l (call after hx_amg_set_sharded, whose n_ext[l] then counts BOTH ghost layers, and after the
+// level was set with an inverse diagonal of n_ext[l] entries): K1 = the operator rows of the level's first ghost layer (n_g1 rows;
+// columns in the extended numbering [owned | layer 1 | layer 2]; values in the precision of the handle's cycle), fetched from
+// their owners at set-up.  The cycle then exchanges the level's RIGHT-HAND SIDE two layers deep (plan 32 + l of the exchange
+// callback), smooths layer 1 redundantly and exchanges the pre-smoothed iterate once more: 3 exchanges per cycle on a level whose
+// coarse level is sharded too (5 in the classic schedule), 2 where the coarse level is replicated (3) -- same arithmetic.
+// Needs pre = post = 2 smoothing steps; option amg_deep_halo = 0 falls back to the classic schedule.
+extern "C" int hx_amg_set_level_deep(hx_amg* h, int l, int32_t n_g1, int64_t nnz1, const int32_t* rp1, const int32_t* ci1, const void* va1) {
+  HX_REQUIRE(h && h->sharded && l >= 0 && l < h->n_sharded && n_g1 >= 0 && nnz1 >= 0 && rp1 && (nnz1 == 0 || (ci1 && va1)), "bad argument");
+  drop_graph(h);
+  auto arm = [&](auto& L, auto tag) -> int {
+    typedef decltype(tag) T;
+    HX_REQUIRE(L.n > 0 && L.n_ext >= L.n + n_g1, "n_ext of a deep level counts owned rows + both ghost layers");
+    L.K1.rows = n_g1; L.K1.nnz = nnz1; L.K1.rp = rp1; L.K1.ci = ci1; L.K1.va = (const T*)va1;
+    L.n_g1 = n_g1; L.deep = true;
+    (void)hx_free(L.b); L.b = nullptr;                     // the right-hand side now lives in an extended buffer
+    const size_t bytes = 2 * sizeof(T) * (size_t)L.n_ext;
+    HX_HIP(hx_malloc((void**)&L.b, bytes));
+    HX_HIP(hipMemsetAsync(L.b, 0, bytes, nullptr));
+    HX_HIP(hipStreamSynchronize(nullptr));
+    return HX_OK;
+  };
+  return h->single ? arm(h->S.L[l], float()) : arm(h->D.L[l], double());
+}
+
 extern "C" int hx_amg_set_halo_overlap(hx_amg* h, hx_halo_begin_fn begin, hx_halo_end_fn end) {
   HX_REQUIRE(h && ((begin && end) || (!begin && !end)), "both callbacks or none");
   h->halo_begin = begin; h->halo_end = end;
@@ -411,12 +437,72 @@ static Cheb cheb_coeffs(double rho) {
 
 // xout = V-cycle(b) on level l with zero initial guess (xout must not be one of the level's x buffers or b).
 // Smoother: `pre` / `post` steps of damped Jacobi (rho == 0) or of a Chebyshev polynomial in D^-1 K (rho > 0).
+template <typename T> static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream s, bool x1_ready = false);
+
+// The cycle of a row-sharded level in DEEP-HALO mode (hx_amg_set_level_deep): V(2,2) with the arithmetic of the classic schedule,
+// three exchanges instead of five.  Vectors are [owned | g1 | g2]; "valid on" says where an iterate equals the global one.
+//   exchange b two layers deep                      -> b valid everywhere
+//   x1 = a0 D^-1 b on all entries                   -> x1 valid everywhere (local)
+//   x2 = step(x1) on owned rows and on g1 rows (K1) -> x2 valid on owned + g1
+//   exchange x2 two layers deep                     -> x2 valid everywhere
+//   r = b - K x2 on owned rows and on g1 rows       -> r valid on owned + g1: the restriction (owned coarse rows over
+//                                                      [owned | g1] fine columns) needs no exchange of its own
+//   coarse solve; [exchange of the coarse correction when the coarse level is sharded: its ordinary plan]
+//   x~ = x2 + P e on owned + g1 + g2 (P carries the owners' rows of both layers)
+//   x3 = step(x~) on owned rows and on g1 rows      -> valid on owned + g1
+//   x4 = step(x3, x~) on owned rows                 -> the result
+template <typename T>
+static int vcycle_deep(hx_amg* h, HierT<T>& H, int l, const T* b_in, T* xout, hx_stream s) {
+  const int DEEP = 32;                                      // plan number of a level's two-layer exchange: 32 + level
+  LevelT<T>& L = H.L[l];
+  LevelT<T>& Lc = H.L[l + 1];
+  int rc;
+  const int EB = (int)(2 * sizeof(T));
+  const bool cheb = L.rho > 0.0;
+  const Cheb C = cheb ? cheb_coeffs(L.rho) : Cheb();
+  const bool shc = l + 1 < h->n_sharded;
+  auto deep_halo = [&](T* v) -> int {
+    return h->halo(h->ctx, DEEP + l, v, EB, s) == 0 ? HX_OK : hx_fail(HX_ERR_COMM, "vcycle_deep", "two-layer halo exchange failed");
+  };
+  auto step = [&](const T* xin, T* out, int k, const T* xprev, bool with_g1) -> int {
+    const double w = cheb ? C.a[k] : h->omega, mom = (cheb && k) ? C.c[k] : 0.0;
+    int r1 = cheb ? op_smooth(L, L.b, xin, out, w, k ? xprev : nullptr, mom, s) : op_smooth(L, L.b, xin, out, h->omega, nullptr, 0.0, s);
+    if (r1 || !with_g1 || L.n_g1 == 0) return r1;
+    return cheb ? op_smooth_g1(L, L.b, xin, out, w, k ? xprev : nullptr, mom, s) : op_smooth_g1(L, L.b, xin, out, h->omega, nullptr, 0.0, s);
+  };
+  if (b_in != L.b) HX_HIP(hipMemcpyAsync(L.b, b_in, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
+  if ((rc = deep_halo(L.b))) return rc;
+  T* x1 = L.x; T* x2 = L.x2; T* x3 = L.x3;
+  if ((rc = op_diag_n(L, L.n_ext, cheb ? C.a[0] : h->omega, L.b, x1, s))) return rc;
+  // (pre-smoothing step 1 of the Chebyshev recurrence: the iterate before x1 is the zero start vector -> xprev NULL with momentum)
+  {
+    const double w = cheb ? C.a[1] : h->omega, mom = cheb ? C.c[1] : 0.0;
+    if ((rc = op_smooth(L, L.b, x1, x2, w, nullptr, mom, s))) return rc;
+    if (L.n_g1 > 0 && (rc = op_smooth_g1(L, L.b, x1, x2, w, nullptr, mom, s))) return rc;
+  }
+  if ((rc = deep_halo(x2))) return rc;
+  if ((rc = op_residual(L, x2, L.b, L.r, s))) return rc;
+  if (L.n_g1 > 0 && (rc = op_residual_g1(L, x2, L.b, L.r, s))) return rc;
+  if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
+  if (!shc && h->allreduce(h->ctx, Lc.b, 2 * (int64_t)Lc.n, sizeof(T) == 8 ? 1 : 0, 0, s) != 0)
+    return hx_fail(HX_ERR_COMM, "vcycle_deep", "all-reduce callback failed");
+  T* ec = Lc.r;
+  if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s, false))) return rc;
+  if (shc && (rc = halo_level(h, l + 1, ec, EB, s))) return rc;
+  if ((rc = op_spmv(L.P, ec, x2, (T)1, (T)1, true, s))) return rc;        // x~ on owned + g1 + g2 (P.rows = n_ext)
+  if ((rc = step(x2, x3, 0, nullptr, true))) return rc;                   // x3 on owned + g1
+  return step(x3, xout, 1, x2, false);                                    // x4 on owned rows (xout is none of x1, x2, x3)
+}
+
 // x1_ready: the level's first pre-smoothing step (x1 = a0 D^-1 b, in L.x) was written by the restriction that produced b.
 template <typename T>
-static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream s, bool x1_ready = false) {
+static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream s, bool x1_ready) {
   LevelT<T>& L = H.L[l];
   int rc;
   if (l == (int)H.L.size() - 1) return op_spmv(H.coarse_inv, b, xout, (T)1, (T)0, true, s);
+  if (h->sharded && l < h->n_sharded && L.deep && L.p_ghost_rows && h->pre == 2 && h->post == 2 && xout != L.x2 && xout != L.x3 &&
+      HX_OPT_INT("amg_deep_halo", 1) != 0 && HX_OPT_INT("amg_coarse_extra", 0) == 0)
+    return vcycle_deep<T>(h, H, l, b, xout, s);
   const bool cheb = L.rho > 0.0;
   const Cheb C = cheb ? cheb_coeffs(L.rho) : Cheb();
   const int extra = (int)HX_OPT_INT("amg_coarse_extra", 0);   // experiment hook
@@ -465,14 +551,9 @@ static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream 
                         : op_smooth(L, b, cur, nxt, h->omega, nullptr, 0.0, st, part); }))) return rc;
       prev = cur; cur = nxt;
     }
-    // residual r = b - K x, restrict -- or, on a launch-bound CSR level that carries R K, both in one launch: bc = R b - (R K) x
-    if (L.RK.rp && !L.sell && !sh && HX_OPT_INT("amg_fold_residual", 1) != 0) {
-      const double a0c = Lc.rho > 0.0 ? cheb_coeffs(Lc.rho).a[0] : h->omega;
-      if ((rc = op_restrict_residual(L, b, cur, Lc.b, fold ? Lc.dinv : nullptr, fold ? Lc.x : nullptr, a0c, s))) return rc;
-    } else {
-      if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part, hx_stream st) { return op_residual(L, cur, b, L.r, st, part); }))) return rc;
-      if ((rc = restrict_from(L.r))) return rc;
-    }
+    // residual r = b - K x, restrict
+    if ((rc = with_halo(h, L, l, cur, EB, s, [&](int part, hx_stream st) { return op_residual(L, cur, b, L.r, st, part); }))) return rc;
+    if ((rc = restrict_from(L.r))) return rc;
   }
   T* ec = Lc.r;      // coarse correction lands in the coarse level's r buffer (free at this point)
   if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s, fold))) return rc;
@@ -515,9 +596,27 @@ int hx_amg_vcycle_buffers(hx_amg* h, hx_c64** b, hx_c64** z) {
   *z = (hx_c64*)h->S.L[0].r;
   return HX_OK;
 }
+// Where the producer of the cycle's complex64 input may ALSO leave level 0's first smoothing step x1 = a0 D^-1 b (the diagonal
+// launch of the cycle then goes away): inverse diagonal, destination and coefficient -- or dinv == NULL when the cycle cannot take
+// it (complex128 cycle, sharded, captured graph, no pre-smoothing, single level, fold switched off).  The producer announces a
+// written x1 with hx_amg_x1_ready; the announcement lasts for one cycle.
+int hx_amg_level0_diag(hx_amg* h, const hx_c64** dinv, hx_c64** x1, float* a0) {
+  HX_REQUIRE(h && dinv && x1 && a0, "bad argument");
+  *dinv = nullptr; *x1 = nullptr; *a0 = 0.f;
+  if (!h->single || h->sharded || h->graph_state >= 0 || h->pre < 1 || h->S.L.size() < 2 || HX_OPT_INT("amg_fold_diag", 1) == 0) return HX_OK;
+  LevelT<float>& L0 = h->S.L[0];
+  if (!L0.dinv || !L0.x) return HX_OK;
+  *dinv = (const hx_c64*)L0.dinv; *x1 = (hx_c64*)L0.x;
+  *a0 = (float)(L0.rho > 0.0 ? cheb_coeffs(L0.rho).a[0] : h->omega);
+  return HX_OK;
+}
+void hx_amg_x1_ready(hx_amg* h, bool ready) { if (h) h->x1_ready0 = ready; }
+
 int hx_amg_vcycle_c64(hx_amg* h, hx_stream s) {
   HX_REQUIRE(h && h->single && h->S.coarse_inv.rp && h->S.L[0].n > 0, "complex64 hierarchy not set");
   LevelT<float>& L0 = h->S.L[0];
+  const bool x1_ready = h->x1_ready0 && !h->sharded && h->graph_state < 0;
+  h->x1_ready0 = false;
   // on level 0 the residual buffer L0.r is consumed by the restriction before the last post-sweep writes it
   if (h->graph_state == 0 && !h->sharded) {                      // capture the cycle once (its buffers never change)
     bool ok = true;
@@ -549,7 +648,7 @@ int hx_amg_vcycle_c64(hx_amg* h, hx_stream s) {
     }
     return HX_OK;
   }
-  return vcycle<float>(h, h->S, 0, L0.b, L0.r, s);
+  return vcycle<float>(h, h->S, 0, L0.b, L0.r, s, x1_ready);
 }
 
 // ---- the complex64 V-cycle on a BLOCK of hx_block_width() interleaved right-hand sides (single GPU): the same cycle as
@@ -635,6 +734,7 @@ extern "C" int hx_amg_vcycle(hx_amg* h, const hx_c128* b, hx_c128* x, hx_stream 
     HX_REQUIRE(h->S.coarse_inv.rp && h->S.L[0].n > 0, "complex64 hierarchy not set");
     LevelT<float>& L0 = h->S.L[0];
     int rc;
+    h->x1_ready0 = false;                                         // (this entry casts its own input: nobody wrote x1)
     if ((rc = hx_cast_z2c(L0.n, b, L0.b, s))) return rc;          // narrow the right-hand side
     if ((rc = hx_amg_vcycle_c64(h, s))) return rc;
     return hx_cast_c2z(L0.n, L0.r, x, s);                         // widen the result

@@ -13,13 +13,17 @@ template <typename T> struct CsrT { int32_t rows = 0; int64_t nnz = 0; const int
 template <typename T> struct LevelT {
   int32_t n = 0;
   CsrT<T> K, P, R;             // P: n x n_coarse, R = P^T: n_coarse x n   (absent on the coarsest level)
-  CsrT<T> RK;                  // optional R K (n_coarse x n, complex values): residual + restriction of a CSR level in one launch
   const T* dinv = nullptr;
   double rho = 0.0;            // estimate of rho(D^-1 K) for the Chebyshev smoother (0: damped Jacobi with h->omega)
   const hx_sell* sell = nullptr;   // optional SELL-64 companion of K (fine level): used for the K products
   T *x = nullptr, *x2 = nullptr, *x3 = nullptr, *b = nullptr, *r = nullptr;   // owned work vectors
   int32_t n_ext = 0;           // row-sharded level: owned + ghost length of x, x2, x3, r (0: not sharded)
   bool p_ghost_rows = false;   // row-sharded level: P carries n_ext rows (the owners' rows of the ghost vertices behind the owned ones)
+  // deep-halo mode of a row-sharded level (hx_amg_set_level_deep): the vectors carry TWO ghost layers [owned | g1 | g2] (n_ext counts
+  // both), K1 holds the operator rows of the first layer (n_g1 rows over the whole extended numbering), dinv covers n_ext entries
+  CsrT<T> K1;
+  int32_t n_g1 = 0;
+  bool deep = false;
 };
 template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };
 
@@ -63,6 +67,7 @@ struct hx_amg {
   const void* normK_val = nullptr;
   double last_backward = -1.0;
   bool x0_next = false;        // the next hx_cocg call takes the contents of x as its initial guess (hx_amg_next_solve_uses_x)
+  bool x1_ready0 = false;      // the producer of the next cycle's input (k_cocg_update) also wrote level 0's first smoothing step
   // hipGraph of the complex64 V-cycle (all buffers of the cycle are owned by the handle, so the ~45 launches of one cycle
   // are captured once and replayed): for small and mid-size problems, where the cycle is launch-bound
   int graph_state = -1;        // -1 off, 0 requested (capture at the next cycle), 1 ready

@@ -38,9 +38,13 @@ int hx_zpanel_bdot_w32_partials(int64_t, int, const hx_c128*, int64_t, const hx_
 int hx_cast_z2c(int64_t, const hx_c128*, float*, hx_stream);
 int hx_amg_vcycle_buffers(hx_amg*, hx_c64**, hx_c64**);
 int hx_amg_vcycle_c64(hx_amg*, hx_stream);
+int hx_amg_level0_diag(hx_amg*, const hx_c64**, hx_c64**, float*);
+void hx_amg_x1_ready(hx_amg*, bool);
 int hx_panel_dot_blocks(int64_t n, int64_t* rows_per_block);
 int hx_panel_dot_finish(int nblocks, int k, const hx_c128* partials, hx_c128* out, hx_stream s);
 int hx_sell_spmv_z_dot(const hx_sell* h, const hx_c128* x, hx_c128* y, hx_c128* dot, hx_stream s);
+int hx_csr_spmv_z_dot(int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val, const hx_c128* x,
+                      hx_c128* y, hx_c128* partials, int max_blocks, int* n_blocks, hx_stream s);
 
 static const double ONE[2] = {1.0, 0.0}, ZERO[2] = {0.0, 0.0};
 
@@ -60,7 +64,9 @@ __global__ void __launch_bounds__(256)
 k_cocg_update(int64_t n, const zc* __restrict__ p, const zc* __restrict__ q, zc* __restrict__ x, zc* __restrict__ r,
               cc* __restrict__ r32 /* may be NULL: complex64 copy of the new residual = the V-cycle's input */,
               const zc* __restrict__ sc, zc* __restrict__ partials, int64_t rows_per_block,
-              const zc* __restrict__ pq_partials /* may be NULL */, int pq_blocks) {
+              const zc* __restrict__ pq_partials /* may be NULL */, int pq_blocks,
+              const cc* __restrict__ dinv0 = nullptr /* with x1_0: also the cycle's first smoothing step x1 = a0 D^-1 r */,
+              cc* __restrict__ x1_0 = nullptr, float a0 = 0.f) {
   __shared__ double red[256 / HX_WAVE];
   __shared__ zc s_pq;
   // p^T q: reduced already (sc[CG_OUT]), or -- single-GPU path -- the stage-1 partials of its panel dot, summed here by every
@@ -88,7 +94,11 @@ k_cocg_update(int64_t n, const zc* __restrict__ p, const zc* __restrict__ q, zc*
     rv.x = fma(-alpha.x, qv.x, rv.x); rv.x = fma(alpha.y, qv.y, rv.x);
     rv.y = fma(-alpha.x, qv.y, rv.y); rv.y = fma(-alpha.y, qv.x, rv.y);
     x[i] = xv; r[i] = rv;
-    if (r32) r32[i] = make_float2((float)rv.x, (float)rv.y);
+    if (r32) {
+      const cc rs = make_float2((float)rv.x, (float)rv.y);
+      r32[i] = rs;
+      if (x1_0) x1_0[i] = zscale(a0, zmul(dinv0[i], rs));        // (the arithmetic of k_diag_scale<c64> on the value just stored)
+    }
     acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
   }
 #pragma unroll
@@ -365,6 +375,10 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
   // result is consumed as complex64: no cast passes, half the bytes for z in the two passes that read it
   hx_c64 *r32 = nullptr, *z32 = nullptr;
   if ((rc0 = hx_amg_vcycle_buffers(M, &r32, &z32))) return rc0;
+  // level 0's first smoothing step written by the update kernel (one launch fewer per inner iteration; single GPU, complex64 cycle)
+  const hx_c64* d0 = nullptr; hx_c64* x10 = nullptr; float a00 = 0.f;
+  if (r32 && !sharded && (rc0 = hx_amg_level0_diag(M, &d0, &x10, &a00))) return rc0;
+  hx_amg_x1_ready(M, false);
   hx_c128* part = tmp + n;
   hx_c128* sc = sharded ? hbuf : part + hx_panel_dot_ws(CG_MAXK + 1);
   int64_t rpb;
@@ -579,6 +593,7 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       if (!std::isfinite(relres)) return hx_fail(HX_ERR_BREAKDOWN, "hx_cocg", "non-finite residual");
     }
     if (r32) { if ((rc = hx_cast_z2c(n, r, (float*)r32, s))) return rc; }     // later residuals: written by k_cocg_update
+    hx_amg_x1_ready(M, false);                  // (the cycle's input was just rewritten by a cast: an x1 left by an earlier update is stale)
     bool first = true;
     double best = relres, prev = relres;
     int since_best = 0;
@@ -754,8 +769,14 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       // replaces ran out of the Infinity Cache anyway: no gain (1.4445 vs 1.4474 ms per iteration), so larger operators keep
       // the panel dot.  HX_COCG_PQ_IN_PRODUCT=0 / 2: never / at every size.
       const bool pq_in_product = !sharded && Ksell && (pq_env == 2 || (pq_env == 1 && n <= 2000000));
+      // operators on the CSR kernels (small problems, every launch counts): the product leaves the per-block partials of p^T q,
+      // the update sums them like those of the panel dot it replaces (one launch fewer per inner iteration)
+      const bool pq_in_csr_product = !sharded && !Ksell && fuse && pq_env != 0;
+      int pq_blocks = nblocks;
       if (pq_in_product) {
         if ((rc = hx_sell_spmv_z_dot(Ksell, p, q, sc + CG_OUT, s))) return rc;
+      } else if (pq_in_csr_product) {
+        if ((rc = hx_csr_spmv_z_dot(n, nnz, rowptr, col, val, p, q, part, PD_NB, &pq_blocks, s))) return rc;
       } else {
         if ((rc = Kx(p, q, ONE, ZERO))) return rc;
         if ((rc = fuse ? hx_zpanel_bdot_partials(n, 0, nullptr, n, q, p, part, s)
@@ -764,8 +785,10 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       }
       hx_c128* part_r = part + PD_NB;             // |r|^2 partials of the update: behind the p^T q partials it reads
       k_cocg_update<<<nblocks, 256, 0, hx_s(s)>>>(n, (const zc*)p, (const zc*)q, (zc*)x, (zc*)r, (cc*)r32, (const zc*)sc,
-                                                  (zc*)part_r, rpb, fuse && !pq_in_product ? (const zc*)part : nullptr, nblocks);
+                                                  (zc*)part_r, rpb, fuse && !pq_in_product ? (const zc*)part : nullptr, pq_blocks,
+                                                  (const cc*)d0, (cc*)x10, a00);
       HX_LAUNCH_CHECK("k_cocg_update");
+      if (d0) hx_amg_x1_ready(M, true);           // the next cycle skips its diagonal launch (a cycle that never comes: no harm)
       x_zero = false;
       double r2;
       const int slot = queued & 1;

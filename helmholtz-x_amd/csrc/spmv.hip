@@ -97,6 +97,48 @@ extern "C" int hx_csr_spmv_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr,
                               lanes_per_row, s);
 }
 
+// y = A x together with the per-block partial sums of the BILINEAR form x^T y (square A): hx_cocg's q = K p and p^T q in one
+// launch for operators that run on the CSR kernels (small, launch-bound problems; the SELL-64 product has its own fused form).
+// partials[b], b < gridDim.x <= max_blocks; the consumer (k_cocg_update) adds them in a fixed order.
+template <int LPR>
+__global__ void __launch_bounds__(256)
+k_spmv_dot(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const zc* __restrict__ val,
+           const zc* __restrict__ x, zc* __restrict__ y, zc* __restrict__ partials) {
+  constexpr int RPB = 256 / LPR;
+  __shared__ zc red[256 / HX_WAVE];
+  const int sub = threadIdx.x % LPR;
+  const int64_t stride = (int64_t)gridDim.x * RPB;
+  const int64_t sweeps = ((int64_t)n + stride - 1) / stride;
+  int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  zc dot = make_double2(0.0, 0.0);
+  for (int64_t it = 0; it < sweeps; ++it, row += stride) {
+    zc acc = make_double2(0.0, 0.0);
+    if (row < n) acc = row_dot<LPR, zc, zc>(col, val, x, rowptr[row], rowptr[row + 1], sub);
+    if (LPR > 1) acc = zreduce_sub<LPR>(acc);
+    if (row < n && sub == 0) { y[row] = acc; zfma(dot, x[row], acc); }
+  }
+  dot = zreduce_sub<HX_WAVE>(dot);
+  if ((threadIdx.x & (HX_WAVE - 1)) == 0) red[threadIdx.x / HX_WAVE] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    zc v = red[0];
+    for (int w = 1; w < 256 / HX_WAVE; ++w) v = zadd(v, red[w]);
+    partials[blockIdx.x] = v;
+  }
+}
+int hx_csr_spmv_z_dot(int32_t n, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val, const hx_c128* x,
+                      hx_c128* y, hx_c128* partials, int max_blocks, int* n_blocks, hx_stream s) {
+  HX_REQUIRE(n > 0 && rowptr && col && val && x && y && partials && max_blocks >= 1 && n_blocks, "bad argument");
+  const int lpr = pick_lpr(nnz, n);
+#define HX_SD(L) { int grid = hx_grid((int64_t)n, 256 / L, max_blocks); *n_blocks = grid; \
+    k_spmv_dot<L><<<grid, 256, 0, hx_s(s)>>>(n, rowptr, col, (const zc*)val, (const zc*)x, (zc*)y, (zc*)partials); } break
+  switch (lpr) { case 1: HX_SD(1); case 2: HX_SD(2); case 4: HX_SD(4); case 8: HX_SD(8); case 16: HX_SD(16); case 32: HX_SD(32);
+                 default: HX_SD(64); }
+#undef HX_SD
+  HX_LAUNCH_CHECK("k_spmv_dot");
+  return HX_OK;
+}
+
 // internal entry points for amg.hip: ROLE 1 = transfer / coarse products; complex64 variants for the
 // single-precision V-cycle (role 2 = its operator products, so profiles keep the roofline kernel separate)
 int hx_csr_spmv_transfer(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
@@ -137,62 +179,6 @@ int hx_csr_restrict_diag_z(int32_t n_rows, int64_t nnz, const int32_t* rowptr, c
   return spmv_dispatch<1, zc, double>(n_rows, nnz, rowptr, col, val, (const zc*)x, (zc*)y, make_double2(1.0, 0.0), make_double2(0.0, 0.0), 0,
                                       s, nullptr, ep);
 }
-// Residual AND restriction of a CSR level in one launch: bc = R (b - K x) = R b - (R K) x with the product RK formed once at set-up
-// (the Galerkin chain has R and K anyway).  One sub-wave per coarse row walks its R row over b and its RK row over x; the optional
-// epilogue leaves the coarse level's first smoothing step (see k_spmv).  Launch-bound levels only (a few thousand rows): RK has
-// more entries than R but fewer than K, and the residual vector is never written.
-template <int LPR, typename V, typename MR>
-__global__ void __launch_bounds__(256)
-k_restrict_residual(int32_t n, const int32_t* __restrict__ rrp, const int32_t* __restrict__ rci, const MR* __restrict__ rva,
-                    const V* __restrict__ b, const int32_t* __restrict__ krp, const int32_t* __restrict__ kci,
-                    const V* __restrict__ kva, const V* __restrict__ x, V* __restrict__ y,
-                    const V* __restrict__ ep_d, V* __restrict__ ep_x, typename real_of<V>::type ep_a) {
-  constexpr int RPB = 256 / LPR;
-  const int sub = threadIdx.x % LPR;
-  const int64_t stride = (int64_t)gridDim.x * RPB;
-  const int64_t sweeps = ((int64_t)n + stride - 1) / stride;
-  int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
-  for (int64_t it = 0; it < sweeps; ++it, row += stride) {
-    V acc = czero<V>();
-    if (row < n) {
-      acc = row_dot<LPR, V, MR>(rci, rva, b, rrp[row], rrp[row + 1], sub);
-      const V k = row_dot<LPR, V, V>(kci, kva, x, krp[row], krp[row + 1], sub);
-      acc.x -= k.x; acc.y -= k.y;
-    }
-    if (LPR > 1) acc = zreduce_sub<LPR>(acc);
-    if (row < n && sub == 0) {
-      y[row] = acc;
-      if (ep_x) ep_x[row] = zscale(ep_a, zmul(ep_d[row], acc));
-    }
-  }
-}
-template <typename V, typename MR>
-static int restrict_residual(int32_t n, int64_t nnzR, const int32_t* rrp, const int32_t* rci, const MR* rva, const V* b, int64_t nnzK,
-                             const int32_t* krp, const int32_t* kci, const V* kva, const V* x, V* y, const V* d, V* x1,
-                             typename real_of<V>::type a0, hx_stream s) {
-  HX_REQUIRE(n >= 0 && rrp && krp && b && x && y && (!x1 || d), "bad argument");
-  if (n == 0) return HX_OK;
-  const int lpr = pick_lpr(nnzR + nnzK, n);
-#define HX_RR(L) { int grid = hx_grid((int64_t)n, 256 / L, 256 * 16); \
-    k_restrict_residual<L, V, MR><<<grid, 256, 0, hx_s(s)>>>(n, rrp, rci, rva, b, krp, kci, kva, x, y, d, x1, a0); } break
-  switch (lpr) { case 1: HX_RR(1); case 2: HX_RR(2); case 4: HX_RR(4); case 8: HX_RR(8); case 16: HX_RR(16); case 32: HX_RR(32);
-                 default: HX_RR(64); }
-#undef HX_RR
-  HX_LAUNCH_CHECK("k_restrict_residual");
-  return HX_OK;
-}
-int hx_csr_restrict_residual_c(int32_t n, int64_t nnzR, const int32_t* rrp, const int32_t* rci, const float* rva, const float* b,
-                               int64_t nnzK, const int32_t* krp, const int32_t* kci, const float* kva, const float* x, float* y,
-                               const float* d, float* x1, float a0, hx_stream s) {
-  return restrict_residual<cc, float>(n, nnzR, rrp, rci, rva, (const cc*)b, nnzK, krp, kci, (const cc*)kva, (const cc*)x, (cc*)y,
-                                      (const cc*)d, (cc*)x1, a0, s);
-}
-int hx_csr_restrict_residual_z(int32_t n, int64_t nnzR, const int32_t* rrp, const int32_t* rci, const double* rva, const hx_c128* b,
-                               int64_t nnzK, const int32_t* krp, const int32_t* kci, const hx_c128* kva, const hx_c128* x, hx_c128* y,
-                               const hx_c128* d, hx_c128* x1, double a0, hx_stream s) {
-  return restrict_residual<zc, double>(n, nnzR, rrp, rci, rva, (const zc*)b, nnzK, krp, kci, (const zc*)kva, (const zc*)x, (zc*)y,
-                                       (const zc*)d, (zc*)x1, a0, s);
-}
 // r = b - A x in one pass (internal; the V-cycle's residual on the CSR levels)
 int hx_csr_residual_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val, const float* x,
                       const float* b, float* r, hx_stream s) {
@@ -214,7 +200,9 @@ template <int LPR, typename V>
 __global__ void __launch_bounds__(256)
 k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const V* __restrict__ val,
          const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xin, V* __restrict__ xout,
-         typename real_of<V>::type omega, const V* __restrict__ xprev, typename real_of<V>::type mom) {
+         typename real_of<V>::type omega, const V* __restrict__ xprev, typename real_of<V>::type mom, int32_t row0 = 0) {
+  // row0: the n rows of this CSR are rows row0 .. row0 + n - 1 of the vectors (the ghost-layer rows a rank smooths redundantly
+  // in the deep-halo cycle: their matrix is stored on its own, their columns index the whole extended vector)
   constexpr int RPB = 256 / LPR;
   const int sub = threadIdx.x % LPR;
   const int64_t stride = (int64_t)gridDim.x * RPB;
@@ -225,12 +213,13 @@ k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restric
     if (row < n) acc = row_dot<LPR, V, V>(col, val, xin, rowptr[row], rowptr[row + 1], sub);
     if (LPR > 1) acc = zreduce_sub<LPR>(acc);
     if (row < n && sub == 0) {
-      const V r = zsub(b[row], acc);
-      const V x0 = xin[row];
+      const int64_t g = row0 + row;
+      const V r = zsub(b[g], acc);
+      const V x0 = xin[g];
       V x = x0;
-      zfma(x, zscale(omega, dinv[row]), r);
-      if (mom != 0) x = zadd(x, zscale(mom, xprev ? zsub(x0, xprev[row]) : x0));   // xprev == NULL: previous iterate is 0
-      xout[row] = x;
+      zfma(x, zscale(omega, dinv[g]), r);
+      if (mom != 0) x = zadd(x, zscale(mom, xprev ? zsub(x0, xprev[g]) : x0));   // xprev == NULL: previous iterate is 0
+      xout[g] = x;
     }
   }
 }
@@ -238,14 +227,14 @@ k_jacobi(int32_t n, const int32_t* __restrict__ rowptr, const int32_t* __restric
 template <typename V>
 static int jacobi_dispatch(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const V* val,
                            const V* dinv, const V* b, const V* xin, V* xout, typename real_of<V>::type omega,
-                           const V* xprev, typename real_of<V>::type mom, hx_stream s) {
+                           const V* xprev, typename real_of<V>::type mom, hx_stream s, int32_t row0 = 0) {
   HX_REQUIRE(n_rows >= 0 && rowptr && col && val && dinv && b && xin && xout && xin != xout, "bad argument");
   if (n_rows == 0) return HX_OK;
   int lpr = pick_lpr(nnz, n_rows);
   if (lpr < 2) lpr = 2;
   if (lpr > 32) lpr = 32;
 #define HX_GO(L) k_jacobi<L, V><<<hx_grid((int64_t)n_rows, 256 / L, 256 * 16), 256, 0, hx_s(s)>>>(                \
-      n_rows, rowptr, col, val, dinv, b, xin, xout, omega, xprev, mom)
+      n_rows, rowptr, col, val, dinv, b, xin, xout, omega, xprev, mom, row0)
   switch (lpr) {
     case 2: HX_GO(2); break;
     case 4: HX_GO(4); break;
@@ -281,6 +270,20 @@ int hx_csr_smooth_c(int32_t n_rows, int64_t nnz, const int32_t* rowptr, const in
                     float mom, hx_stream s) {
   return jacobi_dispatch<cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)dinv, (const cc*)b, (const cc*)xin,
                              (cc*)xout, omega, (const cc*)xprev, mom, s);
+}
+
+// the same step on a block of rows that starts at row0 of the vectors (deep-halo cycle: first ghost layer)
+int hx_csr_smooth_rows_c(int32_t n_rows, int32_t row0, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val,
+                         const float* dinv, const float* b, const float* xin, float* xout, float omega, const float* xprev, float mom,
+                         hx_stream s) {
+  return jacobi_dispatch<cc>(n_rows, nnz, rowptr, col, (const cc*)val, (const cc*)dinv, (const cc*)b, (const cc*)xin, (cc*)xout, omega,
+                             (const cc*)xprev, mom, s, row0);
+}
+int hx_csr_smooth_rows_z(int32_t n_rows, int32_t row0, int64_t nnz, const int32_t* rowptr, const int32_t* col, const hx_c128* val,
+                         const hx_c128* dinv, const hx_c128* b, const hx_c128* xin, hx_c128* xout, double omega, const hx_c128* xprev,
+                         double mom, hx_stream s) {
+  return jacobi_dispatch<zc>(n_rows, nnz, rowptr, col, (const zc*)val, (const zc*)dinv, (const zc*)b, (const zc*)xin, (zc*)xout, omega,
+                             (const zc*)xprev, mom, s, row0);
 }
 
 // x = scale .* d .* b  (first Jacobi sweep from a zero initial guess; also a diagonal preconditioner)

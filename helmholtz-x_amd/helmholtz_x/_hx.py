@@ -85,7 +85,6 @@ SIGNATURES = {
     "hx_amg_create": (C.c_int, [C.POINTER(_vp), _int, _int, _int, C.c_double]),
     "hx_amg_set_level": (C.c_int, [_vp, _int, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _vp,
                                    _vp, _vp]),
-    "hx_amg_set_level_rk": (C.c_int, [_vp, _int, _i64, _vp, _vp, _vp]),
     "hx_amg_set_smoother": (C.c_int, [_vp, _int, C.c_double]),
     "hx_amg_set_real_transfers": (C.c_int, [_vp, _int]),
     "hx_amg_set_coarse": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
@@ -112,6 +111,7 @@ SIGNATURES = {
     "hx_gmres_hessenberg": (C.c_int, [_vp, C.POINTER(_int), _vp]),
     "hx_amg_set_recycle": (C.c_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
+    "hx_amg_set_level_deep": (C.c_int, [_vp, _int, _i32, _i64, _vp, _vp, _vp]),
     "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_BEGIN_FN, HALO_END_FN]),
     "hx_amg_set_prolongator_ghost_rows": (C.c_int, [_vp, C.c_int]),
     "hx_block_width": (C.c_int, []),

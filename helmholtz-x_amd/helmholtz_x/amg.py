@@ -451,6 +451,7 @@ def _localize_columns(A, c0, c1, ghost_sorted, n_own):
 
 # row-sharded levels: prolongators with the ghost vertices' rows (one halo fewer per level and cycle); HX_AMG_GHOST_P=0: owned rows only
 PARAMS_GHOST_P = os.environ.get("HX_AMG_GHOST_P", "1") != "0"
+PARAMS_DEEP_HALO = "0"      # default of HX_AMG_DEEP_HALO (two ghost layers per sharded level; see build_hierarchy_sharded)
 
 
 def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"],
@@ -482,6 +483,10 @@ def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["
     l = 0
     ranges = list(shard.level_ranges[0])
     n_glob = ranges[-1][1]
+    # deep-halo mode (round 5): operator rows of the first ghost layer + a second layer of ghost entries per sharded level, so that
+    # a cycle needs 3 exchanges on a level instead of 5 (vcycle_deep, csrc/amg.hip).  Needs the ghost-row prolongators.
+    deep = PARAMS_GHOST_P and os.environ.get("HX_AMG_DEEP_HALO", PARAMS_DEEP_HALO) != "0"
+    ghost_l = shard.ghost.long() if shard.ghost is not None else torch.zeros(0, dtype=torch.int64, device=dev)
     while True:
         n_own, n_ext = Kl.shape
         assert (n_own, n_ext) == shard.level_n[l], "operator does not match the level's exchange plan"
@@ -582,8 +587,36 @@ def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["
         # The level's prolongator keeps the owners' rows of my ghost vertices behind my own (hx_amg_set_prolongator_ghost_rows):
         # the prolongation then corrects the ghost block of the iterate too and the first post-smoothing step needs no exchange
         P_lvl = P_ext if PARAMS_GHOST_P else P_glob
+        dinv_l = 1.0 / diag
+        if deep:
+            # ---- two ghost layers.  Layer 1 = the level's ghost set; its OPERATOR ROWS come from their owners (sparse-row halo,
+            # columns as global ids); layer 2 = their columns that are neither owned nor in layer 1.  Vectors: [owned | g1 | g2].
+            r0_l = ranges[shard.rank][0]
+            n1 = n_ext - n_own
+            loc2glob_f = torch.cat([torch.arange(r0_l, r0_l + n_own, device=dev, dtype=torch.int64), ghost_l])
+            K1 = DevCSR((n1, n_glob), *plan.exchange_rows(Kl.rowptr, loc2glob_f[Kl.col.long()].to(torch.int32).contiguous(), Kl.val))
+            kcol = K1.col.long()
+            own1 = (kcol >= r0_l) & (kcol < r0_l + n_own)
+            if ghost_l.numel():
+                pos1 = torch.searchsorted(ghost_l, kcol).clamp(max=int(ghost_l.numel()) - 1)
+                in1 = ghost_l[pos1] == kcol
+            else:
+                pos1, in1 = torch.zeros_like(kcol), torch.zeros_like(own1)
+            g2 = torch.unique(kcol[~(own1 | in1)])                              # ascending global ids of layer 2
+            dplan = shard.set_level_deep_plan(l, g2.cpu().numpy())
+            n2 = int(g2.numel())
+            pos2 = torch.searchsorted(g2, kcol).clamp(max=max(n2 - 1, 0)) if n2 else torch.zeros_like(kcol)
+            lcol = torch.where(own1, kcol - r0_l, torch.where(in1, n_own + pos1, n_own + n1 + pos2)).to(torch.int32).contiguous()
+            level["K1"] = DevCSR((n1, n_own + n1 + n2), K1.rowptr, lcol, K1.val)
+            level["n_g1"], level["n_ext2"] = n1, n_own + n1 + n2
+            dinv_ext = torch.zeros(n_own + n1 + n2, dtype=torch.complex128, device=dev)
+            dinv_ext[:n_own] = dinv_l
+            shard.halo(dinv_ext, shard.DEEP + l)
+            dinv_l = dinv_ext
+            # prolongator rows of layer 2 (behind those of layer 1): the correction then reaches x on owned + g1 + g2
+            P_lvl = _rows_concat(P_ext, DevCSR((n2, na_glob), *dplan.p2.exchange_rows(prp, P_glob.col, pv)))
         del KP, KP_ext, P_ext, Lf, sd, v, w
-        level.update(dinv=1.0 / diag, omega=4.0 / (3.0 * 1.05 * rho), rho=1.05 * rho, n_coarse=na, n_coarse_global=na_glob,
+        level.update(dinv=dinv_l, omega=4.0 / (3.0 * 1.05 * rho), rho=1.05 * rho, n_coarse=na, n_coarse_global=na_glob,
                      R=R_loc)
         levels.append(level)
         th *= 0.5
@@ -600,7 +633,7 @@ def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["
             (n_bad,) = _host_sum(shard, bad_p + bad_k)                     # (collective: every rank raises or none)
             if n_bad:
                 raise ValueError("row-sharded AMG: %d column(s) of level %d lie outside the ghost set of their rank" % (n_bad, l + 1))
-            ranges, n_glob, l = c_ranges, na_glob, l + 1
+            ranges, n_glob, l, ghost_l = c_ranges, na_glob, l + 1, ghost_c
             continue
         # level l + 1 is replicated: P keeps global columns, the restriction is the transpose of MY prolongator rows (the
         # ranks' partial right-hand sides are summed by one all-reduce), the coarse operator is all-gathered
@@ -841,7 +874,6 @@ class AMGSolver:
         # coarse SELL levels take the same storage (5 M DOF: iterations unchanged, 8.38 -> 8.27 s)
         half_coarse = mixed and os.environ.get("HX_AMG_VALUES", self.params["vcycle_values"]) == "fp16"
         for l, lv in enumerate(levels):
-            n_sells_before = len(self.coarse_sells)
             if l == 0:
                 k0 = Kp.val.to(cdt) if mixed else Kp.val
                 self._keep.append(k0)
@@ -870,16 +902,6 @@ class AMGSolver:
                                     _hx.ptr(rrp), _hx.ptr(rci), _hx.ptr(rva)))
                 if self.params["smoother"] == "chebyshev":
                     _hx.check(_hx.lib.hx_amg_set_smoother(h, l, float(lv["rho"])))
-                # launch-bound CSR levels: R K, so that residual + restriction are one launch (hx_amg_set_level_rk).  Not for
-                # levels with a SELL-64 companion (their residual pass is bandwidth-bound and R K would add bytes), not sharded.
-                has_sell = (self.sell is not None) if l == 0 else (len(self.coarse_sells) > n_sells_before)
-                if (not has_sell and not lv.get("sharded") and isinstance(Rl, DevCSR) and self.params["pre"] > 0
-                        and os.environ.get("HX_AMG_FOLD_RESIDUAL", "1") != "0"):
-                    Kl_c128 = DevCSR((nl, nl), krp, kci, Kp.val if l == 0 else values_c128(lv["K"]))
-                    RK = _dev_spgemm(Rl, Kl_c128)
-                    rkv = RK.val.to(cdt).contiguous()
-                    self._keep.append((RK.rowptr, RK.col, rkv))
-                    _hx.check(_hx.lib.hx_amg_set_level_rk(h, l, RK.nnz, _hx.ptr(RK.rowptr), _hx.ptr(RK.col), _hx.ptr(rkv)))
             else:
                 _hx.check(set_level(h, l, lv["n"], knnz, _hx.ptr(krp), _hx.ptr(kci), _hx.ptr(kva), None, 0, 0, None,
                                     None, None, 0, None, None, None))
@@ -905,13 +927,22 @@ class AMGSolver:
                 _hx.check(set_coarse(h, lv["n"], cnnz, _hx.ptr(crp), _hx.ptr(cci), _hx.ptr(cva)))
         if shard is not None:
             self._cb = shard.callbacks()             # (halo_fn, allreduce_fn, ctx): the library's own RCCL calls, or gloo trampolines
-            n_ext = np.ascontiguousarray([lv["n_ext"] for lv in levels[:self.n_sharded]], dtype=np.int32)
+            # (deep-halo levels: vectors carry two ghost layers, n_ext2 = owned + layer 1 + layer 2)
+            n_ext = np.ascontiguousarray([lv.get("n_ext2", lv["n_ext"]) for lv in levels[:self.n_sharded]], dtype=np.int32)
             _hx.check(_hx.lib.hx_amg_set_sharded(h, self.n_sharded, _hx.nptr(n_ext), self._cb[0], self._cb[1], self._cb[2]))
             n_pg = 0
             while n_pg < self.n_sharded and levels[n_pg].get("p_ghost_rows"):
                 n_pg += 1
             if n_pg:
                 _hx.check(_hx.lib.hx_amg_set_prolongator_ghost_rows(h, n_pg))
+            self.deep_levels = 0
+            for l, lv in enumerate(levels[:n_pg]):
+                if "K1" in lv:                      # operator rows of the first ghost layer: the level runs the deep-halo cycle
+                    K1 = lv["K1"]
+                    v1 = K1.val.to(cdt).contiguous()
+                    self._keep.append((K1.rowptr, K1.col, v1))
+                    _hx.check(_hx.lib.hx_amg_set_level_deep(h, l, lv["n_g1"], K1.nnz, _hx.ptr(K1.rowptr), _hx.ptr(K1.col), _hx.ptr(v1)))
+                    self.deep_levels += 1
             if shard.comm is not None and os.environ.get("HX_HALO_OVERLAP", "1") != "0":
                 # library-issued exchanges: split every halo around the interior slices of its product (exchange on the
                 # compute stream like every other operation of the communicator, interior slices on its side stream)
@@ -1174,6 +1205,7 @@ class AMGSolver:
                     levels=[lv.get("n_global", lv["n"]) for lv in self.levels],
                     operator_complexity=getattr(self, "operator_complexity", None), level_nnz=getattr(self, "level_nnz", None),
                     sharded_levels=[[lv["n"], lv["n_ext"] - lv["n"]] for lv in self.levels if lv.get("sharded")],
+                    deep_halo_levels=[[lv["n_g1"], lv["n_ext2"] - lv["n_ext"]] for lv in self.levels if lv.get("sharded") and "n_ext2" in lv],
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
                     if self.sell else "csr",
                     stencil_slices=_hx.lib.hx_sell_stencil_slices(self.sell) if self.sell else 0, vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",

@@ -272,6 +272,15 @@ class HaloPlan:
         the ghost block: received in place, no scatter."""
         if self.world == 1 or (not self.send_to and not self.recv_from):
             return
+        ops, staged, keep = self.p2p_ops(x_ext, n_own, n_own)
+        wait_all(issue(ops))
+        for dst, buf in staged:
+            dst.copy_(buf)
+        self.n_exchanges += 1
+
+    def p2p_ops(self, x_ext, n_own, ghost_base):
+        """The point-to-point operations of one exchange (sends of listed owned entries, receives into the ghost block that starts
+        at ``ghost_base``): (ops, [(device destination, host buffer)] to copy back under gloo, buffers to keep alive)."""
         backend = dist.get_backend(self.group)
         stage = backend == "gloo" and x_ext.is_cuda       # gloo moves host buffers only
         ops, staged, keep = [], [], []
@@ -298,7 +307,7 @@ class HaloPlan:
         for p, pos in sorted(self.recv_from.items()):
             a, b = int(pos[0]), int(pos[-1]) + 1
             assert b - a == len(pos), "ghost entries of one owner must be contiguous"
-            dst = x_ext[n_own + a:n_own + b]
+            dst = x_ext[ghost_base + a:ghost_base + b]
             dst = torch.view_as_real(dst) if dst.is_complex() else dst
             if stage:
                 buf = torch.empty(dst.shape, dtype=dst.dtype, device="cpu")
@@ -306,10 +315,7 @@ class HaloPlan:
             else:
                 buf = dst
             ops.append(dist.P2POp(dist.irecv, buf, p, group=self.group))
-        wait_all(issue(ops))
-        for dst, buf in staged:
-            dst.copy_(buf)
-        self.n_exchanges += 1
+        return ops, staged, keep
 
     def native_arrays(self):
         """The plan as the HOST arrays hx_comm_set_plan takes: send lists (owned indices) per peer, receive ranges of the
@@ -404,6 +410,49 @@ class ShardedOperator:
         """y_own = A [x_own; x_ghost]; x_ext must have room for the ghost block (length n_own + n_ghost)."""
         self.plan.exchange(x_ext, self.n_own)
         self.A.spmv(x_ext, y_own)
+
+
+class DeepHaloPlan:
+    """TWO ghost layers of a level in ONE exchange (the deep-halo cycle of a row-sharded level, amg.hip: vcycle_deep): layer 1 =
+    the level's ordinary ghost set (plan ``p1``: the off-rank columns of the rank's operator rows, positions [n_own, n_own + n1) of
+    an extended vector), layer 2 = the off-rank columns of the OPERATOR ROWS OF LAYER 1 that are not in layer 1 (positions behind
+    it).  Both layers travel in one batch of point-to-point messages -- per peer a layer-1 message followed by a layer-2 message,
+    issued in that order on both sides -- i.e. one exchange in the counters where the classic schedule needs two."""
+
+    def __init__(self, p1, ranges, rank, ghost2_global, group=None):
+        self.p1 = p1
+        self.p2 = HaloPlan(ranges, rank, ghost2_global, group)          # (collective: one all_gather of the id lists)
+        self.n1, self.n2 = p1.n_ghost, self.p2.n_ghost
+        self.n_ghost = self.n1 + self.n2
+        self.n_exchanges = 0
+        self.world, self.group = p1.world, group
+        self.send_to = {**{("1", p): v for p, v in p1.send_to.items()}, **{("2", p): v for p, v in self.p2.send_to.items()}}
+        self.recv_from = {**{("1", p): v for p, v in p1.recv_from.items()}, **{("2", p): v for p, v in self.p2.recv_from.items()}}
+
+    def exchange(self, x_ext, n_own):
+        if self.world == 1 or (not self.send_to and not self.recv_from):
+            return
+        o1, s1, k1 = self.p1.p2p_ops(x_ext, n_own, n_own)
+        o2, s2, k2 = self.p2.p2p_ops(x_ext, n_own, n_own + self.n1)
+        if o1 or o2:
+            wait_all(issue(o1 + o2))
+        for dst, buf in s1 + s2:
+            dst.copy_(buf)
+        self.n_exchanges += 1
+
+    def native_arrays(self):
+        """Both layers as ONE plan of hx_comm_set_plan: the peers of layer 1, then those of layer 2 (a peer may appear twice: its
+        two messages are matched in issue order on both sides, as NCCL does for one pair of ranks)."""
+        a = self.p1.native_arrays()
+        b = self.p2.native_arrays()
+        send_peer = np.concatenate([a[0], b[0]])
+        send_ptr = np.concatenate([a[1], a[1][-1] + b[1][1:]])
+        send_idx = np.concatenate([a[2], b[2]])
+        recv_peer = np.concatenate([a[3], b[3]])
+        recv_off = np.concatenate([a[4], b[4] + self.n1])
+        recv_cnt = np.concatenate([a[5], b[5]])
+        return send_peer, send_ptr, send_idx, recv_peer, recv_off, recv_cnt
+
 
 
 def sharded_panel_dot(V, k, w, group=None):

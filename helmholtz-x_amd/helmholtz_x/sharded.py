@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hx
-from .distributed import HaloPlan, assert_no_outstanding_work, issue, partition_rows, wait_all
+from .distributed import DeepHaloPlan, HaloPlan, assert_no_outstanding_work, issue, partition_rows, wait_all
 from .petsc import CSR
 
 
@@ -180,6 +180,24 @@ class ShardContext:
         if self.comm is not None:
             sp, sptr, sidx, rp_, roff, rcnt = plan.native_arrays()
             _hx.check(_hx.lib.hx_comm_set_plan(self.comm, level, len(sp), _hx.nptr(sp), _hx.nptr(sptr), _hx.nptr(sidx),
+                                               len(rp_), _hx.nptr(rp_), _hx.nptr(roff), _hx.nptr(rcnt)))
+        return plan
+
+    DEEP = 32         # exchange plan of a level's TWO ghost layers: number DEEP + level (csrc/amg.hip: vcycle_deep)
+
+    def set_level_deep_plan(self, level, ghost2_global):
+        """Two-layer exchange of a sharded level: its ordinary ghost set (layer 1) + ``ghost2_global`` (ascending global ids of the
+        off-rank columns of the layer-1 operator rows that are not in layer 1), as ONE plan numbered DEEP + level.  Extended
+        vectors of the level are then [owned | layer 1 | layer 2].  Collective."""
+        p1 = self.plans[level]
+        plan = DeepHaloPlan(p1, self.level_ranges[level], self.rank, np.asarray(ghost2_global, dtype=np.int64), self.group)
+        key = self.DEEP + level
+        self.plans[key] = plan
+        n_own = self.level_n[level][0]
+        self.level_n[key] = (n_own, n_own + plan.n_ghost)
+        if self.comm is not None:
+            sp, sptr, sidx, rp_, roff, rcnt = plan.native_arrays()
+            _hx.check(_hx.lib.hx_comm_set_plan(self.comm, key, len(sp), _hx.nptr(sp), _hx.nptr(sptr), _hx.nptr(sidx.astype(np.int32)),
                                                len(rp_), _hx.nptr(rp_), _hx.nptr(roff), _hx.nptr(rcnt)))
         return plan
 

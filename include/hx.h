@@ -343,12 +343,6 @@ int hx_amg_set_real_transfers(hx_amg* h, int flag);
 /* Optional SELL-64 companion of K_l (must hold the value copy of the precision the V-cycle runs in): the smoother
  * steps and the residual product of that level then use the SELL kernels. */
 int hx_amg_set_level_sell(hx_amg* h, int l, const hx_sell* sell);
-/* R K of level l (n_coarse x n, sorted CSR on the device; values complex64 when the handle carries the complex64 hierarchy, else
- * complex128): the cycle then forms the restricted residual of that level as R b - (R K) x in one launch (k_restrict_residual)
- * instead of a residual pass followed by a restriction.  Meant for the launch-bound CSR levels; ignored where the level has a SELL-64
- * companion or is row-sharded.  Option amg_fold_residual = 0 switches the fused pass off.
- * replaces: nothing in the reference (part of the PCLU alternative, eigensolvers.py:49-50,102-103). */
-int hx_amg_set_level_rk(hx_amg* h, int l, int64_t nnz, const int32_t* rp, const int32_t* ci, const void* va);
 /* Smoother of level l: rho = 0 -> `pre`/`post` damped-Jacobi sweeps with the weight given to hx_amg_create;
  * rho > 0 (estimate of the spectral radius of D^-1 K_l) -> Chebyshev polynomial of degree pre/post on D^-1 K_l
  * targeting [0.11 rho, 1.1 rho], evaluated by the same fused kernel as a three-term recurrence. */
@@ -459,6 +453,17 @@ typedef int (*hx_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype, i
  * handle re-allocates its level-l work vectors with that length. */
 int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext, hx_halo_fn halo, hx_allreduce_fn allreduce,
                        void* ctx);
+/* Deep-halo mode of row-sharded level l (after hx_amg_set_sharded -- whose n_ext[l] then counts owned rows + BOTH ghost layers -- after
+ * hx_amg_set_prolongator_ghost_rows, with the level set with an inverse diagonal of n_ext[l] entries and a prolongator of n_ext[l]
+ * rows): K1 = operator rows of the level's FIRST ghost layer (n_g1 rows, sorted CSR on the device, columns in the extended numbering
+ * [owned | layer 1 | layer 2], values in the precision of the handle's cycle), fetched from their owners at set-up.  The cycle
+ * then exchanges the level's right-hand side and its pre-smoothed iterate two layers deep (the exchange callback is called with
+ * level number 32 + l: a plan that fills both layers in one exchange), smooths and forms the residual of layer 1 redundantly, and
+ * needs no exchange for the restriction and the post-smoothing: 3 exchanges per cycle and level instead of 5 (2 instead of 3 where
+ * the next level is replicated), same arithmetic.  pre = post = 2 only; option amg_deep_halo = 0 falls back to the classic schedule.
+ * replaces: the ghost updates inside PCApply of the reference's distributed preconditioner (eigensolvers.py:49-50,102-103 under
+ * mpirun, fullAnnulus/runAll.sh:10-11). */
+int hx_amg_set_level_deep(hx_amg* h, int l, int32_t n_g1, int64_t nnz1, const int32_t* rp1, const int32_t* ci1, const void* va1);
 /* Optional split form of the halo exchange.  begin(ctx, level, x_ext, elem_bytes, s, &interior) enqueues the exchange ON s,
  * ordered after the work enqueued there, and hands out a side stream `interior` that waits for the same point of s;
  * end(ctx, level, s) makes s wait for the side stream.  With both set, every product with a SELL-64 operator of a sharded level

@@ -188,9 +188,11 @@ def _gpu_fpi_worker(rank, world, port, out, krylov, transport="gloo"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
     os.environ["HX_QUIET"] = "1"
-    if transport == "fake_rccl":    # exchanges issued BY THE LIBRARY (hx_comm) through the host-staged librccl stand-in
+    if transport.startswith("fake_rccl"):    # exchanges issued BY THE LIBRARY (hx_comm) through the host-staged librccl stand-in
         os.environ["HX_NATIVE_COMM"] = "1"
         os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
+    if transport.endswith("_deep"):          # two ghost layers per sharded level: 3 (2) exchanges per level and cycle instead of 5 (3)
+        os.environ["HX_AMG_DEEP_HALO"] = "1"
     if krylov == "fgmres":          # the flexible GMRES path (hx_gmres_sharded): "auto" picks COCG for this symmetric operator
         os.environ["HX_AMG_KRYLOV"] = "fgmres"
     if krylov == "cocg":            # the deflated COCG path (hx_cocg_sharded) with recycling, SELL-64 and two sharded levels
@@ -238,7 +240,8 @@ def _gpu_fpi_worker(rank, world, port, out, krylov, transport="gloo"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("krylov,transport", [("fgmres", "gloo"), ("cocg", "gloo"), ("cocg", "fake_rccl")])
+@pytest.mark.parametrize("krylov,transport", [("fgmres", "gloo"), ("cocg", "gloo"), ("cocg", "fake_rccl"), ("cocg", "gloo_deep"),
+                                              ("cocg", "fake_rccl_deep"), ("fgmres", "fake_rccl_deep")])
 def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport):
     """The whole hot path partitioned over two ranks (sharing the one GPU; gloo stages the exchanges through the host): every
     rank assembles ITS rows on its part of the mesh (owner computes), builds its slab of the hierarchy (uncoupled aggregation,
@@ -250,7 +253,8 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
     transport "fake_rccl": the exchanges are issued by the library itself (hx_comm: the production path under RCCL) through
     tests/fake_rccl, a host-staged stand-in for librccl (RCCL refuses two ranks on one GPU): zero Python frames per
     exchange, same plans and call sequence as on two GPUs."""
-    if transport == "fake_rccl":          # the stand-in is built by __graft_entry__.build(); build it here if it did not travel
+    deep = transport.endswith("_deep")
+    if transport.startswith("fake_rccl"):          # the stand-in is built by __graft_entry__.build(); build it here if it did not travel
         import subprocess
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         if not os.path.exists(os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")):
@@ -280,9 +284,13 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
                 assert sharded["stats"]["fine_format"].startswith("sell64") and sharded["stats"]["stencil_slices"] > 0
         counters, n_own, n_ext = r["exchanges"]
         assert counters["halo_exchanges"] > 0 and counters["all_reduces"] > 0 and n_ext > n_own
-        assert ("libhx" in counters["issued_by"]) == (transport == "fake_rccl"), counters
-        if transport == "fake_rccl":      # most halos run split: interior slices of the product while the exchange is in flight
-            assert counters["halos_overlapped_with_interior_slices"] > 0.5 * counters["halo_exchanges"], counters
+        assert ("libhx" in counters["issued_by"]) == transport.startswith("fake_rccl"), counters
+        assert len(r["distributed"]["stats"]["deep_halo_levels"]) == (len(r["distributed"]["stats"]["sharded_levels"]) if deep else 0)
+        if transport.startswith("fake_rccl"):      # most halos run split: interior slices of the product while the exchange is in flight
+            # (deep-halo mode: the cycle's exchanges are two layers deep and blocking; the operator product's stays split)
+            # (the fgmres case keeps its small levels on the CSR kernels: no slice lists, nothing to split)
+            if krylov == "cocg":
+                assert counters["halos_overlapped_with_interior_slices"] > (0.1 if deep else 0.5) * counters["halo_exchanges"], counters
             # every operation of the communicator -- blocking and split halos, all-reduces -- was issued on ONE stream (RCCL
             # orders the operations of a communicator only within a stream; the asynchronous stand-in fails a run that mixes)
             assert counters["communicator_stream_switches"] == 0, counters
@@ -292,6 +300,11 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
             st = r["distributed"]["stats"]
             assert st["cocg_allreduces"] <= 2 * st["cocg_iters"] + 2 * st["cocg_solves"] + 3 * st["cocg_solves"], st
             assert st["cocg_allreduces"] / st["cocg_iters"] < 2.7, st
+            if krylov == "cocg":
+                # halos per inner iteration with two sharded levels: classic 9 (fine level 5, second level 3, operator product 1),
+                # deep-halo schedule 6 (3 + 2 + 1); a few more per solve (start, closing residual)
+                per_it = st["cocg_halos"] / st["cocg_iters"]
+                assert (per_it < 6.9) if deep else (8.5 < per_it < 10.5), (per_it, st)
         nv_loc, nc_loc, nv, nc = r["local_mesh"]
         assert nv_loc < 0.6 * nv and nc_loc < 0.6 * nc            # a rank holds its half of the mesh + one ghost layer
     # both ranks hold identical (all-reduced) results
@@ -1298,3 +1311,61 @@ def test_escalation_ladder_on_the_row_sharded_path_two_ranks():
             assert abs(a - b) / abs(a) < 1e-8, (a, b)
         assert out[rank]["counters"]["communicator_stream_switches"] == 0
     assert out[0]["limited"]["stats"]["ladder"] == out[1]["limited"]["stats"]["ladder"]       # same step, same solve, same reason
+
+
+def _deep_plan_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd")]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from helmholtz_x.distributed import DeepHaloPlan, HaloPlan, partition_rows
+        n = 40
+        ranges = partition_rows(n, world, 1)
+        r0, r1 = ranges[rank]
+        # a periodic band graph of half-width 2: layer 1 = ids within 2 of my range, layer 2 = the next 2 on each side
+        near = lambda lo, hi: np.unique(np.concatenate([np.arange(r0 - hi, r0 - lo + 1), np.arange(r1 - 1 + lo, r1 + hi)]) % n)
+        mine = np.arange(r0, r1)
+        g1 = np.setdiff1d(near(1, 2), mine)
+        g2 = np.setdiff1d(np.setdiff1d(near(3, 4), mine), g1)
+        p1 = HaloPlan(ranges, rank, g1)
+        deep = DeepHaloPlan(p1, ranges, rank, g2)
+        n_own = r1 - r0
+        x = torch.full((n_own + len(g1) + len(g2),), -1.0, dtype=torch.float64)
+        x[:n_own] = torch.arange(r0, r1, dtype=torch.float64)
+        deep.exchange(x, n_own)
+        want = np.concatenate([mine, g1, g2]).astype(np.float64)
+        z = torch.full((n_own + len(g1) + len(g2),), -1.0, dtype=torch.complex128)
+        z[:n_own] = torch.arange(r0, r1, dtype=torch.float64) * (1 + 2j)
+        deep.exchange(z, n_own)
+        sp, sptr, sidx, rp_, roff, rcnt = deep.native_arrays()
+        out[rank] = dict(ok=bool(np.array_equal(x.numpy(), want)), okz=bool(np.allclose(z.numpy(), want * (1 + 2j))),
+                         sends=[(int(p), int(sptr[q + 1] - sptr[q])) for q, p in enumerate(sp)],
+                         recvs=[(int(p), int(c), int(o)) for p, c, o in zip(rp_, rcnt, roff)], n=(n_own, len(g1), len(g2)),
+                         exchanges=deep.n_exchanges)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_deep_halo_plan_two_layers_in_one_exchange(world):
+    """DeepHaloPlan (the two-layer exchange of the deep-halo V-cycle): both ghost layers of every rank filled by ONE batch of
+    point-to-point messages, real and complex entries; the host arrays for hx_comm_set_plan list per peer a layer-1 message followed
+    by a layer-2 message, and what one rank sends to a peer is what that peer expects from it, message by message."""
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_deep_plan_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        r = out[rank]
+        assert r["ok"] and r["okz"] and r["exchanges"] == 2, r
+        n_own, n1, n2 = r["n"]
+        assert n1 > 0 and n2 > 0
+        # receive ranges tile the two ghost blocks
+        assert sorted(o for _, _, o in r["recvs"])[0] == n_own and sum(c for _, c, _ in r["recvs"]) == n1 + n2
+        for peer in range(world):
+            if peer == rank:
+                continue
+            mine = [c for p, c in r["sends"] if p == peer]                      # my messages to the peer, in issue order
+            theirs = [c for p, c, _ in out[peer]["recvs"] if p == rank]          # what the peer expects from me, in issue order
+            assert mine == theirs, (rank, peer, mine, theirs)

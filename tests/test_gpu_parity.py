@@ -610,24 +610,6 @@ def test_cocg_fused_reductions_and_lagged_norm_reads_leave_the_solve_bitwise_unc
     assert all(its > 3 for its, _, _ in runs[0][1:])          # (solve 0 is the harvested GMRES run; the others are COCG)
 
 
-def test_fused_residual_restriction_of_csr_levels_leaves_the_solves_unchanged():
-    """Round 5: a launch-bound CSR level computes its restricted residual as R b - (R K) x in ONE launch (k_restrict_residual, R K
-    from the set-up) instead of a residual pass and a restriction.  Mathematically the same cycle; the complex64 sums are taken in
-    another order, so the comparison is not bitwise: same iteration counts within one, same solutions to the solver's tolerance --
-    with every level on the CSR kernels (sell_min_rows beyond the problem), fused pass on (default) and off (amg_fold_residual = 0)."""
-    import torch
-    kw = dict(sell_min_rows=10 ** 9)
-    fused, xf = _cocg_ab_runs({}, **kw)
-    plain, xp = _cocg_ab_runs({"amg_fold_residual": 0}, **kw)
-    for k in range(4):
-        assert abs(fused[k][0] - plain[k][0]) <= 1, (fused, plain)
-        xa, ra = xf[k]
-        xb, rb = xp[k]
-        tol = 1e-11 * (1.0 if k < 3 else 1e3)
-        assert ra < 20 * tol and rb < 20 * tol, (k, ra, rb)
-        assert float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xa)) < 1e-7 * (1.0 if k < 3 else 1e3)
-
-
 def test_cocg_single_reduction_form_solves_to_the_same_tolerance_in_the_same_iterations():
     """The single-reduction (Chronopoulos-Gear) form of the deflated COCG recurrence -- what the row-sharded solve runs so that an
     inner iteration needs ONE all-reduce of k + 3 scalars instead of three reductions -- forced on one GPU

@@ -451,7 +451,9 @@ def _localize_columns(A, c0, c1, ghost_sorted, n_own):
 
 # row-sharded levels: prolongators with the ghost vertices' rows (one halo fewer per level and cycle); HX_AMG_GHOST_P=0: owned rows only
 PARAMS_GHOST_P = os.environ.get("HX_AMG_GHOST_P", "1") != "0"
-PARAMS_DEEP_HALO = "0"      # default of HX_AMG_DEEP_HALO (two ghost layers per sharded level; see build_hierarchy_sharded)
+# default of HX_AMG_DEEP_HALO: two ghost layers per sharded level, 6 instead of 9 halos per inner iteration at two sharded levels
+# (measured on the one-GPU rehearsals: same iteration counts and eigenvalues, profiles/r05_deep_halo_rehearsals.txt); "0": classic
+PARAMS_DEEP_HALO = "1"
 
 
 def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["max_levels"],

@@ -191,8 +191,8 @@ def _gpu_fpi_worker(rank, world, port, out, krylov, transport="gloo"):
     if transport.startswith("fake_rccl"):    # exchanges issued BY THE LIBRARY (hx_comm) through the host-staged librccl stand-in
         os.environ["HX_NATIVE_COMM"] = "1"
         os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
-    if transport.endswith("_deep"):          # two ghost layers per sharded level: 3 (2) exchanges per level and cycle instead of 5 (3)
-        os.environ["HX_AMG_DEEP_HALO"] = "1"
+    # two ghost layers per sharded level (the default): 3 (2) exchanges per level and cycle; "classic": one layer, 5 (3) exchanges
+    os.environ["HX_AMG_DEEP_HALO"] = "1" if transport.endswith("_deep") else "0"
     if krylov == "fgmres":          # the flexible GMRES path (hx_gmres_sharded): "auto" picks COCG for this symmetric operator
         os.environ["HX_AMG_KRYLOV"] = "fgmres"
     if krylov == "cocg":            # the deflated COCG path (hx_cocg_sharded) with recycling, SELL-64 and two sharded levels
@@ -298,9 +298,9 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
             # restriction onto the first replicated level) and three per solve (|b|, the Galerkin start, the closing true
             # residual); round 3 needed 3.9 per inner iteration
             st = r["distributed"]["stats"]
-            assert st["cocg_allreduces"] <= 2 * st["cocg_iters"] + 2 * st["cocg_solves"] + 3 * st["cocg_solves"], st
-            assert st["cocg_allreduces"] / st["cocg_iters"] < 2.7, st
             if krylov == "cocg":
+                assert st["cocg_allreduces"] <= 2 * st["cocg_iters"] + 2 * st["cocg_solves"] + 3 * st["cocg_solves"], st
+                assert st["cocg_allreduces"] / st["cocg_iters"] < 2.7, st
                 # halos per inner iteration with two sharded levels: classic 9 (fine level 5, second level 3, operator product 1),
                 # deep-halo schedule 6 (3 + 2 + 1); a few more per solve (start, closing residual)
                 per_it = st["cocg_halos"] / st["cocg_iters"]

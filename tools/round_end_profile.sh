@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-end measurement on the GPU box (usage: round_end_profile.sh [round tag, default r04]): default bench line (5M, with CPU baseline; warm-up pass), 1M line, rocprofv3 kernel-trace
+# Round-end measurement on the GPU box (usage: round_end_profile.sh [round tag, default r05]): default bench line (5M, with CPU baseline; warm-up pass), 1M line, rocprofv3 kernel-trace
 # statistics of the same bench command, PMC traffic of the SELL-64 kernels.  Only small summaries are kept.
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
-TAG="${1:-r04}"
+TAG="${1:-r05}"
 mkdir -p gpurun_out/final
 python bench.py --warmup 1 --steps 3 > gpurun_out/final/bench_5M.json 2> gpurun_out/final/bench_5M.err || exit 1
 python bench.py --workload annulus-1M --no-cpu-baseline --warmup 1 --steps 3 > gpurun_out/final/bench_1M.json 2> /dev/null || exit 1

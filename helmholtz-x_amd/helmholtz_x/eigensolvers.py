@@ -124,7 +124,9 @@ def _iterate(solve_passive, solve_active, nev, i, tol, maxiter, s, history, stat
     alpha = np.zeros(maxiter, dtype=complex)
     lean = min(nev, i + 1)
     if state is not None:
-        state["warm_pairs"] = nev - lean        # lean solves also hand over their best unconverged Ritz directions
+        # lean solves also hand over their best unconverged Ritz directions (HX_WARM_EXTRA more than the missing pairs: the partner of
+        # a doublet the nev boundary cuts)
+        state["warm_pairs"] = nev - lean + int(__import__("os").environ.get("HX_WARM_EXTRA", "0"))
         state["lean_nev"] = lean
         state["nev_max"] = nev
     if state is not None:

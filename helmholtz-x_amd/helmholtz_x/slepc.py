@@ -40,6 +40,13 @@ W_WARM = __import__("os").environ.get("HX_WOODBURY_WARM", "1") != "0"      # tra
 # applications of ~45 ms each at 5 M DOF, eight spare columns cost 1.3 GB of HBM.
 NCV_EXTRA = int(__import__("os").environ.get("HX_NCV_EXTRA", "8"))
 ROTATE_SLABS = 8                 # DeviceBasis.rotate: the panel is rotated in this many slabs of positions (scratch = panel / 8)
+# Start vector of the final multi-pair solve of a fixed-point call: the latest leading eigenvector + the unconverged Ritz directions of
+# the RICHEST earlier solve ("richest": the passive solve, whose random start vector carries every symmetry class of the annulus),
+# or the Ritz vectors of the last lean solve ("last", until round 5: a 3-column space grown from the leading eigenvector alone, in
+# which the azimuthal doublets exist at rounding level only -- the final solve needed 25 columns to "discover" them).  Measured:
+# final solve 40 -> 35 applications at 5 M DOF (2.37 -> 2.25 s per call), 40 -> 34 at 1 M (0.60 -> 0.56 s), 25 -> 24 on the refined
+# real mesh; same eigenvalues (fourth pair to 2e-10).  profiles/r05_final_solve_start_vector.txt
+WIDE_START = "richest"
 RELAX_CAP = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP", "1e4"))     # 1 switches the relaxation off
 RELAX_CAP_MULTI = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP_MULTI", "30"))  # cap for nev > 1 (see set_inner_accuracy)
 
@@ -808,6 +815,12 @@ class _EigenSolverBase:
             self._remember(basis, kc)
             k = min(len(res.theta), kc + n_extra)
             self.state["start_wide"] = _row_sum(basis.V, k) if k > kc else None    # a following solve that wants more pairs
+            # ... and, kept apart, the sum of the UNCONVERGED Ritz vectors of the richest solve so far (the one with the largest
+            # Krylov space: in a fixed-point call the passive solve, 12 columns against 3-7 of the later lean solves): the directions
+            # of the other wanted pairs a final multi-pair solve starts from (see _start)
+            if k > kc and basis.n_ops >= self.state.get("_extras_ops", 0):
+                self.state["_extras"] = _row_sum(basis.V[kc:], k - kc)
+                self.state["_extras_ops"] = basis.n_ops
             self.state["krylov_ops"] = self.state.get("krylov_ops", 0) + basis.n_ops
             self.state["restarts"] = self.state.get("restarts", 0) + res.its
             self.state["eig_solves"] = self.state.get("eig_solves", 0) + 1
@@ -860,6 +873,17 @@ class _EigenSolverBase:
         if __import__("os").environ.get("HX_NO_WIDE_START"):          # experiment hook
             wide = None
         if wide is not None and self._nev > self.state.get("lean_nev", self._nev):
+            mode = __import__("os").environ.get("HX_WIDE_START", WIDE_START)
+            extras = self.state.get("_extras")
+            if mode == "richest" and extras is not None:
+                # leading pair: the latest (extrapolated) vector; the other wanted pairs: the unconverged Ritz directions of the
+                # solve that had the largest Krylov space -- the last lean solve's own extras come from 3-4 columns
+                lead = self._extrapolated()
+                lead = lead if lead is not None else self.state.get("start")
+                if lead is not None and lead.numel() == extras.numel():
+                    out = lead.clone()
+                    _hx.check(_hx.lib.hx_zaxpy(out.numel(), _hx.z2(1.0), _hx.ptr(extras), _hx.ptr(out), _hx.stream()))
+                    return out
             return wide
         ext = self._extrapolated()
         return ext if ext is not None else self.state.get("start")

@@ -168,23 +168,23 @@ static int op_restrict_diag(const CsrT<float>& R, const float* r, float* bc, con
   return hx_csr_restrict_diag_c(R.rows, R.nnz, R.rp, R.ci, R.va, r, bc, dc, x1, (float)a0, s);
 }
 // ---- deep-halo mode: the same steps on the rows of the FIRST GHOST LAYER (stored apart in L.K1; vector rows n .. n + n_g1 - 1)
-static int op_smooth_g1(const LevelT<double>& L, const double* b, const double* xin, double* xout, double w, const double* xprev,
-                        double mom, hx_stream s) {
-  return hx_csr_smooth_rows_z(L.n_g1, L.n, L.K1.nnz, L.K1.rp, L.K1.ci, (const hx_c128*)L.K1.va, (const hx_c128*)L.dinv, (const hx_c128*)b,
+static int op_smooth_g(const LevelT<double>& L, int32_t rows, int64_t nnz, const double* b, const double* xin, double* xout, double w,
+                       const double* xprev, double mom, hx_stream s) {
+  return hx_csr_smooth_rows_z(rows, L.n, nnz, L.K1.rp, L.K1.ci, (const hx_c128*)L.K1.va, (const hx_c128*)L.dinv, (const hx_c128*)b,
                               (const hx_c128*)xin, (hx_c128*)xout, w, (const hx_c128*)xprev, mom, s);
 }
-static int op_smooth_g1(const LevelT<float>& L, const float* b, const float* xin, float* xout, double w, const float* xprev, double mom,
-                        hx_stream s) {
-  return hx_csr_smooth_rows_c(L.n_g1, L.n, L.K1.nnz, L.K1.rp, L.K1.ci, L.K1.va, L.dinv, b, xin, xout, (float)w, xprev, (float)mom, s);
+static int op_smooth_g(const LevelT<float>& L, int32_t rows, int64_t nnz, const float* b, const float* xin, float* xout, double w,
+                       const float* xprev, double mom, hx_stream s) {
+  return hx_csr_smooth_rows_c(rows, L.n, nnz, L.K1.rp, L.K1.ci, L.K1.va, L.dinv, b, xin, xout, (float)w, xprev, (float)mom, s);
 }
 static int op_residual_g1(const LevelT<double>& L, const double* x, const double* b, double* r, hx_stream s) {
   const size_t o = 2 * (size_t)L.n;
-  return hx_csr_residual_z(L.n_g1, L.K1.nnz, L.K1.rp, L.K1.ci, (const hx_c128*)L.K1.va, (const hx_c128*)x, (const hx_c128*)(b + o),
+  return hx_csr_residual_z(L.n_g1, L.nnz_g1, L.K1.rp, L.K1.ci, (const hx_c128*)L.K1.va, (const hx_c128*)x, (const hx_c128*)(b + o),
                            (hx_c128*)(r + o), s);
 }
 static int op_residual_g1(const LevelT<float>& L, const float* x, const float* b, float* r, hx_stream s) {
   const size_t o = 2 * (size_t)L.n;
-  return hx_csr_residual_c(L.n_g1, L.K1.nnz, L.K1.rp, L.K1.ci, L.K1.va, x, b + o, r + o, s);
+  return hx_csr_residual_c(L.n_g1, L.nnz_g1, L.K1.rp, L.K1.ci, L.K1.va, x, b + o, r + o, s);
 }
 static int op_diag_n(const LevelT<double>& L, int64_t n, double w, const double* b, double* x, hx_stream s) {
   return hx_zdiag_scale(n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
@@ -237,7 +237,7 @@ static int set_level(bool real_transfers, HierT<T>& H, int l, int32_t n, int64_t
   LevelT<T>& L = H.L[l];
   L.n = n;
   L.p_ghost_rows = false;      // a level that is set again starts without ghost rows in P (hx_amg_set_prolongator_ghost_rows re-arms it)
-  L.deep = false; L.K1 = CsrT<T>(); L.n_g1 = 0;      // ... and out of deep-halo mode (hx_amg_set_level_deep re-arms it)
+  L.deep = false; L.K1 = CsrT<T>(); L.n_g1 = 0; L.nnz_g1 = 0; L.deep_layers = 0;      // ... and out of deep-halo mode (hx_amg_set_level_deep re-arms it)
   L.K.rows = n; L.K.nnz = nnzK; L.K.rp = rpK; L.K.ci = ciK; L.K.va = vaK;
   L.dinv = dinv;
   if (l != (int)H.L.size() - 1) {
@@ -359,21 +359,25 @@ extern "C" int hx_amg_set_prolongator_ghost_rows(hx_amg* h, int n_levels) {
   return HX_OK;
 }
 
-// Deep-halo mode of row-sharded level l (call after hx_amg_set_sharded, whose n_ext[l] then counts BOTH ghost layers, and after the
-// level was set with an inverse diagonal of n_ext[l] entries): K1 = the operator rows of the level's first ghost layer (n_g1 rows;
-// columns in the extended numbering [owned | layer 1 | layer 2]; values in the precision of the handle's cycle), fetched from
-// their owners at set-up.  The cycle then exchanges the level's RIGHT-HAND SIDE two layers deep (plan 32 + l of the exchange
-// callback), smooths layer 1 redundantly and exchanges the pre-smoothed iterate once more: 3 exchanges per cycle on a level whose
-// coarse level is sharded too (5 in the classic schedule), 2 where the coarse level is replicated (3) -- same arithmetic.
-// Needs pre = post = 2 smoothing steps; option amg_deep_halo = 0 falls back to the classic schedule.
-extern "C" int hx_amg_set_level_deep(hx_amg* h, int l, int32_t n_g1, int64_t nnz1, const int32_t* rp1, const int32_t* ci1, const void* va1) {
-  HX_REQUIRE(h && h->sharded && l >= 0 && l < h->n_sharded && n_g1 >= 0 && nnz1 >= 0 && rp1 && (nnz1 == 0 || (ci1 && va1)), "bad argument");
+// Deep-halo mode of row-sharded level l (call after hx_amg_set_sharded, whose n_ext[l] then counts ALL ghost layers, and after the
+// level was set with an inverse diagonal of n_ext[l] entries and a prolongator of n_ext[l] rows).  layers = 2: vectors
+// [owned | g1 | g2], K1 = the operator rows of layer 1 (n_g1 = n_gs rows) -- the cycle exchanges its right-hand side and its
+// pre-smoothed iterate two layers deep: 3 exchanges per cycle on a level whose coarse level is sharded too (5 in the classic
+// schedule), 2 where it is replicated (3).  layers = 3: vectors [owned | g1 | g2 | g3], K1 = the rows of layer 1 followed by those
+// of layer 2 (n_gs rows in all) -- the right-hand side travels three layers deep, both layers are pre-smoothed redundantly and the
+// second exchange goes away: 2 and 1.  Columns of K1 in the extended numbering, values in the precision of the handle's cycle, all
+// fetched from their owners at set-up; the exchange callback is called with level number 32 + l.  Same arithmetic as the classic
+// schedule.  Needs pre = post = 2 smoothing steps; option amg_deep_halo = 0 falls back to the classic schedule.
+extern "C" int hx_amg_set_level_deep(hx_amg* h, int l, int layers, int32_t n_g1, int64_t nnz_g1, int32_t n_gs, int64_t nnz_gs,
+                                     const int32_t* rp1, const int32_t* ci1, const void* va1) {
+  HX_REQUIRE(h && h->sharded && l >= 0 && l < h->n_sharded && (layers == 2 || layers == 3) && n_g1 >= 0 && n_gs >= n_g1 &&
+             nnz_g1 >= 0 && nnz_gs >= nnz_g1 && rp1 && (nnz_gs == 0 || (ci1 && va1)) && (layers == 3 || n_gs == n_g1), "bad argument");
   drop_graph(h);
   auto arm = [&](auto& L, auto tag) -> int {
     typedef decltype(tag) T;
-    HX_REQUIRE(L.n > 0 && L.n_ext >= L.n + n_g1, "n_ext of a deep level counts owned rows + both ghost layers");
-    L.K1.rows = n_g1; L.K1.nnz = nnz1; L.K1.rp = rp1; L.K1.ci = ci1; L.K1.va = (const T*)va1;
-    L.n_g1 = n_g1; L.deep = true;
+    HX_REQUIRE(L.n > 0 && L.n_ext >= L.n + n_gs, "n_ext of a deep level counts owned rows + all ghost layers");
+    L.K1.rows = n_gs; L.K1.nnz = nnz_gs; L.K1.rp = rp1; L.K1.ci = ci1; L.K1.va = (const T*)va1;
+    L.n_g1 = n_g1; L.nnz_g1 = nnz_g1; L.deep_layers = layers; L.deep = true;
     (void)hx_free(L.b); L.b = nullptr;                     // the right-hand side now lives in an extended buffer
     const size_t bytes = 2 * sizeof(T) * (size_t)L.n_ext;
     HX_HIP(hx_malloc((void**)&L.b, bytes));
@@ -440,11 +444,12 @@ static Cheb cheb_coeffs(double rho) {
 template <typename T> static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* b, T* xout, hx_stream s, bool x1_ready = false);
 
 // The cycle of a row-sharded level in DEEP-HALO mode (hx_amg_set_level_deep): V(2,2) with the arithmetic of the classic schedule,
-// three exchanges instead of five.  Vectors are [owned | g1 | g2]; "valid on" says where an iterate equals the global one.
-//   exchange b two layers deep                      -> b valid everywhere
+// three (layers = 2) or two (layers = 3) exchanges instead of five.  Vectors are [owned | g1 | g2 (| g3)]; "valid on" says where an
+// iterate equals the global one.
+//   exchange b over all layers                      -> b valid everywhere
 //   x1 = a0 D^-1 b on all entries                   -> x1 valid everywhere (local)
-//   x2 = step(x1) on owned rows and on g1 rows (K1) -> x2 valid on owned + g1
-//   exchange x2 two layers deep                     -> x2 valid everywhere
+//   x2 = step(x1) on owned rows and on the rows of K1 (g1; with three layers also g2)
+//   [two layers: exchange x2 two layers deep]       -> x2 valid on owned + g1 + g2 either way
 //   r = b - K x2 on owned rows and on g1 rows       -> r valid on owned + g1: the restriction (owned coarse rows over
 //                                                      [owned | g1] fine columns) needs no exchange of its own
 //   coarse solve; [exchange of the coarse correction when the coarse level is sharded: its ordinary plan]
@@ -453,7 +458,7 @@ template <typename T> static int vcycle(hx_amg* h, HierT<T>& H, int l, const T* 
 //   x4 = step(x3, x~) on owned rows                 -> the result
 template <typename T>
 static int vcycle_deep(hx_amg* h, HierT<T>& H, int l, const T* b_in, T* xout, hx_stream s) {
-  const int DEEP = 32;                                      // plan number of a level's two-layer exchange: 32 + level
+  const int DEEP = 32;                                      // plan number of a level's multi-layer exchange: 32 + level
   LevelT<T>& L = H.L[l];
   LevelT<T>& Lc = H.L[l + 1];
   int rc;
@@ -462,25 +467,23 @@ static int vcycle_deep(hx_amg* h, HierT<T>& H, int l, const T* b_in, T* xout, hx
   const Cheb C = cheb ? cheb_coeffs(L.rho) : Cheb();
   const bool shc = l + 1 < h->n_sharded;
   auto deep_halo = [&](T* v) -> int {
-    return h->halo(h->ctx, DEEP + l, v, EB, s) == 0 ? HX_OK : hx_fail(HX_ERR_COMM, "vcycle_deep", "two-layer halo exchange failed");
+    return h->halo(h->ctx, DEEP + l, v, EB, s) == 0 ? HX_OK : hx_fail(HX_ERR_COMM, "vcycle_deep", "multi-layer halo exchange failed");
   };
-  auto step = [&](const T* xin, T* out, int k, const T* xprev, bool with_g1) -> int {
+  // one smoothing step on the owned rows and on the first `g_rows` ghost-layer rows (entries g_nnz of K1)
+  auto step = [&](const T* xin, T* out, int k, const T* xprev, bool zero_prev, int32_t g_rows, int64_t g_nnz) -> int {
     const double w = cheb ? C.a[k] : h->omega, mom = (cheb && k) ? C.c[k] : 0.0;
-    int r1 = cheb ? op_smooth(L, L.b, xin, out, w, k ? xprev : nullptr, mom, s) : op_smooth(L, L.b, xin, out, h->omega, nullptr, 0.0, s);
-    if (r1 || !with_g1 || L.n_g1 == 0) return r1;
-    return cheb ? op_smooth_g1(L, L.b, xin, out, w, k ? xprev : nullptr, mom, s) : op_smooth_g1(L, L.b, xin, out, h->omega, nullptr, 0.0, s);
+    const T* pv = zero_prev ? nullptr : xprev;
+    int r1 = op_smooth(L, L.b, xin, out, w, pv, mom, s);
+    if (r1 || g_rows == 0) return r1;
+    return op_smooth_g(L, g_rows, g_nnz, L.b, xin, out, w, pv, mom, s);
   };
   if (b_in != L.b) HX_HIP(hipMemcpyAsync(L.b, b_in, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
   if ((rc = deep_halo(L.b))) return rc;
   T* x1 = L.x; T* x2 = L.x2; T* x3 = L.x3;
   if ((rc = op_diag_n(L, L.n_ext, cheb ? C.a[0] : h->omega, L.b, x1, s))) return rc;
-  // (pre-smoothing step 1 of the Chebyshev recurrence: the iterate before x1 is the zero start vector -> xprev NULL with momentum)
-  {
-    const double w = cheb ? C.a[1] : h->omega, mom = cheb ? C.c[1] : 0.0;
-    if ((rc = op_smooth(L, L.b, x1, x2, w, nullptr, mom, s))) return rc;
-    if (L.n_g1 > 0 && (rc = op_smooth_g1(L, L.b, x1, x2, w, nullptr, mom, s))) return rc;
-  }
-  if ((rc = deep_halo(x2))) return rc;
+  // pre-smoothing step 1: the iterate before x1 is the zero start vector (xprev NULL with momentum); redundantly on every row K1 holds
+  if ((rc = step(x1, x2, 1, nullptr, true, L.K1.rows, L.K1.nnz))) return rc;
+  if (L.deep_layers == 2 && (rc = deep_halo(x2))) return rc;
   if ((rc = op_residual(L, x2, L.b, L.r, s))) return rc;
   if (L.n_g1 > 0 && (rc = op_residual_g1(L, x2, L.b, L.r, s))) return rc;
   if ((rc = op_spmv(L.R, L.r, Lc.b, (T)1, (T)0, true, s))) return rc;
@@ -489,9 +492,9 @@ static int vcycle_deep(hx_amg* h, HierT<T>& H, int l, const T* b_in, T* xout, hx
   T* ec = Lc.r;
   if ((rc = vcycle<T>(h, H, l + 1, Lc.b, ec, s, false))) return rc;
   if (shc && (rc = halo_level(h, l + 1, ec, EB, s))) return rc;
-  if ((rc = op_spmv(L.P, ec, x2, (T)1, (T)1, true, s))) return rc;        // x~ on owned + g1 + g2 (P.rows = n_ext)
-  if ((rc = step(x2, x3, 0, nullptr, true))) return rc;                   // x3 on owned + g1
-  return step(x3, xout, 1, x2, false);                                    // x4 on owned rows (xout is none of x1, x2, x3)
+  if ((rc = op_spmv(L.P, ec, x2, (T)1, (T)1, true, s))) return rc;        // x~ on owned + g1 + g2 (P.rows = n_ext; empty rows on g3)
+  if ((rc = step(x2, x3, 0, nullptr, true, L.n_g1, L.nnz_g1))) return rc;  // x3 on owned + g1
+  return step(x3, xout, 1, x2, false, 0, 0);                              // x4 on owned rows (xout is none of x1, x2, x3)
 }
 
 // x1_ready: the level's first pre-smoothing step (x1 = a0 D^-1 b, in L.x) was written by the restriction that produced b.

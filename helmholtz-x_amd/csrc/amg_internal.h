@@ -21,8 +21,10 @@ template <typename T> struct LevelT {
   bool p_ghost_rows = false;   // row-sharded level: P carries n_ext rows (the owners' rows of the ghost vertices behind the owned ones)
   // deep-halo mode of a row-sharded level (hx_amg_set_level_deep): the vectors carry TWO ghost layers [owned | g1 | g2] (n_ext counts
   // both), K1 holds the operator rows of the first layer (n_g1 rows over the whole extended numbering), dinv covers n_ext entries
-  CsrT<T> K1;
+  CsrT<T> K1;                  // rows of layer 1 first (n_g1 rows, nnz_g1 entries), then -- three layers -- those of layer 2
   int32_t n_g1 = 0;
+  int64_t nnz_g1 = 0;
+  int deep_layers = 0;         // 2: vectors [owned | g1 | g2], K1 = rows of g1;  3: [owned | g1 | g2 | g3], K1 = rows of g1 and g2
   bool deep = false;
 };
 template <typename T> struct HierT { std::vector<LevelT<T>> L; CsrT<T> coarse_inv; };

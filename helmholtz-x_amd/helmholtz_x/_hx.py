@@ -111,7 +111,7 @@ SIGNATURES = {
     "hx_gmres_hessenberg": (C.c_int, [_vp, C.POINTER(_int), _vp]),
     "hx_amg_set_recycle": (C.c_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "hx_amg_set_sharded": (C.c_int, [_vp, _int, _vp, HALO_FN, ALLREDUCE_FN, _vp]),
-    "hx_amg_set_level_deep": (C.c_int, [_vp, _int, _i32, _i64, _vp, _vp, _vp]),
+    "hx_amg_set_level_deep": (C.c_int, [_vp, _int, _int, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "hx_amg_set_halo_overlap": (C.c_int, [_vp, HALO_BEGIN_FN, HALO_END_FN]),
     "hx_amg_set_prolongator_ghost_rows": (C.c_int, [_vp, C.c_int]),
     "hx_block_width": (C.c_int, []),

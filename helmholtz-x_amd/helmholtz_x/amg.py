@@ -591,32 +591,72 @@ def build_hierarchy_sharded(K, shard, theta=PARAMS["theta"], max_levels=PARAMS["
         P_lvl = P_ext if PARAMS_GHOST_P else P_glob
         dinv_l = 1.0 / diag
         if deep:
-            # ---- two ghost layers.  Layer 1 = the level's ghost set; its OPERATOR ROWS come from their owners (sparse-row halo,
-            # columns as global ids); layer 2 = their columns that are neither owned nor in layer 1.  Vectors: [owned | g1 | g2].
+            # ---- ghost layers beyond the first.  Layer 1 = the level's ghost set; its OPERATOR ROWS come from their owners
+            # (sparse-row halo, columns as global ids); layer 2 = their columns that are neither owned nor in layer 1; with three
+            # layers (default) the rows of layer 2 are fetched as well and layer 3 = their new columns.  Vectors: [owned | g1 | g2 | g3].
+            n_layers = int(os.environ.get("HX_AMG_DEEP_LAYERS", "3"))
             r0_l = ranges[shard.rank][0]
             n1 = n_ext - n_own
             loc2glob_f = torch.cat([torch.arange(r0_l, r0_l + n_own, device=dev, dtype=torch.int64), ghost_l])
-            K1 = DevCSR((n1, n_glob), *plan.exchange_rows(Kl.rowptr, loc2glob_f[Kl.col.long()].to(torch.int32).contiguous(), Kl.val))
-            kcol = K1.col.long()
-            own1 = (kcol >= r0_l) & (kcol < r0_l + n_own)
-            if ghost_l.numel():
-                pos1 = torch.searchsorted(ghost_l, kcol).clamp(max=int(ghost_l.numel()) - 1)
-                in1 = ghost_l[pos1] == kcol
-            else:
-                pos1, in1 = torch.zeros_like(kcol), torch.zeros_like(own1)
-            g2 = torch.unique(kcol[~(own1 | in1)])                              # ascending global ids of layer 2
-            dplan = shard.set_level_deep_plan(l, g2.cpu().numpy())
-            n2 = int(g2.numel())
-            pos2 = torch.searchsorted(g2, kcol).clamp(max=max(n2 - 1, 0)) if n2 else torch.zeros_like(kcol)
-            lcol = torch.where(own1, kcol - r0_l, torch.where(in1, n_own + pos1, n_own + n1 + pos2)).to(torch.int32).contiguous()
-            level["K1"] = DevCSR((n1, n_own + n1 + n2), K1.rowptr, lcol, K1.val)
-            level["n_g1"], level["n_ext2"] = n1, n_own + n1 + n2
-            dinv_ext = torch.zeros(n_own + n1 + n2, dtype=torch.complex128, device=dev)
+            Kcol_g = loc2glob_f[Kl.col.long()].to(torch.int32).contiguous()
+            known = [ghost_l]                                                  # ascending id lists of the layers so far
+            rows = [DevCSR((n1, n_glob), *plan.exchange_rows(Kl.rowptr, Kcol_g, Kl.val))]
+            extra_plans = []
+
+            def new_columns(M):
+                kcol = M.col.long()
+                seen = (kcol >= r0_l) & (kcol < r0_l + n_own)
+                for ids in known:
+                    if ids.numel():
+                        pos = torch.searchsorted(ids, kcol).clamp(max=int(ids.numel()) - 1)
+                        seen = seen | (ids[pos] == kcol)
+                return torch.unique(kcol[~seen])
+
+            for layer in range(2, n_layers + 1):
+                g = new_columns(rows[-1])                                       # ascending global ids of this layer
+                pl = shard.layer_plan(l, g.cpu().numpy())
+                extra_plans.append(pl)
+                known.append(g)
+                if layer < n_layers:                                            # its operator rows feed the next layer
+                    rows.append(DevCSR((int(g.numel()), n_glob), *pl.exchange_rows(Kl.rowptr, Kcol_g, Kl.val)))
+            dplan = shard.set_level_deep_plan(l, extra_plans)
+            sizes = [int(ids.numel()) for ids in known]
+            n_ext2 = n_own + sum(sizes)
+
+            def localized(M):
+                kcol = M.col.long()
+                lcol = torch.where((kcol >= r0_l) & (kcol < r0_l + n_own), kcol - r0_l, torch.full_like(kcol, -1))
+                base = n_own
+                for ids in known:
+                    if ids.numel():
+                        pos = torch.searchsorted(ids, kcol).clamp(max=int(ids.numel()) - 1)
+                        lcol = torch.where((lcol < 0) & (ids[pos] == kcol), base + pos, lcol)
+                    base += int(ids.numel())
+                return lcol
+
+            Kg = rows[0]
+            for M in rows[1:]:
+                Kg = _rows_concat(Kg, M)
+            lcol = localized(Kg)
+            (n_bad_deep,) = _host_sum(shard, int((lcol < 0).sum()))
+            if n_bad_deep:
+                raise ValueError("row-sharded AMG: %d column(s) of the ghost-layer rows of level %d are in no layer" % (n_bad_deep, l))
+            level["K1"] = DevCSR((Kg.shape[0], n_ext2), Kg.rowptr, lcol.to(torch.int32).contiguous(), Kg.val)
+            level["n_g1"], level["n_gs"], level["n_ext2"], level["deep_layers"] = n1, int(Kg.shape[0]), n_ext2, n_layers
+            level["nnz_g1"] = int(Kg.rowptr[n1].item())
+            dinv_ext = torch.zeros(n_ext2, dtype=torch.complex128, device=dev)
             dinv_ext[:n_own] = dinv_l
             shard.halo(dinv_ext, shard.DEEP + l)
             dinv_l = dinv_ext
-            # prolongator rows of layer 2 (behind those of layer 1): the correction then reaches x on owned + g1 + g2
-            P_lvl = _rows_concat(P_ext, DevCSR((n2, na_glob), *dplan.p2.exchange_rows(prp, P_glob.col, pv)))
+            # prolongator rows of layer 2 (behind those of layer 1): the correction then reaches x on owned + g1 + g2 (layer 3, if
+            # present, only ever holds right-hand-side entries and the first smoothing step: empty prolongator rows)
+            n2 = sizes[1]
+            P_lvl = _rows_concat(P_ext, DevCSR((n2, na_glob), *extra_plans[0].exchange_rows(prp, P_glob.col, pv)))
+            if n_ext2 > n_own + n1 + n2:
+                n3 = n_ext2 - (n_own + n1 + n2)
+                P_lvl = _rows_concat(P_lvl, DevCSR((n3, na_glob), torch.zeros(n3 + 1, dtype=torch.int32, device=dev),
+                                                   torch.zeros(0, dtype=torch.int32, device=dev),
+                                                   torch.zeros(0, dtype=P_ext.val.dtype, device=dev)))
         del KP, KP_ext, P_ext, Lf, sd, v, w
         level.update(dinv=dinv_l, omega=4.0 / (3.0 * 1.05 * rho), rho=1.05 * rho, n_coarse=na, n_coarse_global=na_glob,
                      R=R_loc)
@@ -939,11 +979,12 @@ class AMGSolver:
                 _hx.check(_hx.lib.hx_amg_set_prolongator_ghost_rows(h, n_pg))
             self.deep_levels = 0
             for l, lv in enumerate(levels[:n_pg]):
-                if "K1" in lv:                      # operator rows of the first ghost layer: the level runs the deep-halo cycle
+                if "K1" in lv:                      # operator rows of the ghost layers: the level runs the deep-halo cycle
                     K1 = lv["K1"]
                     v1 = K1.val.to(cdt).contiguous()
                     self._keep.append((K1.rowptr, K1.col, v1))
-                    _hx.check(_hx.lib.hx_amg_set_level_deep(h, l, lv["n_g1"], K1.nnz, _hx.ptr(K1.rowptr), _hx.ptr(K1.col), _hx.ptr(v1)))
+                    _hx.check(_hx.lib.hx_amg_set_level_deep(h, l, lv["deep_layers"], lv["n_g1"], lv["nnz_g1"], lv["n_gs"], K1.nnz,
+                                                            _hx.ptr(K1.rowptr), _hx.ptr(K1.col), _hx.ptr(v1)))
                     self.deep_levels += 1
             if shard.comm is not None and os.environ.get("HX_HALO_OVERLAP", "1") != "0":
                 # library-issued exchanges: split every halo around the interior slices of its product (exchange on the
@@ -1208,6 +1249,7 @@ class AMGSolver:
                     operator_complexity=getattr(self, "operator_complexity", None), level_nnz=getattr(self, "level_nnz", None),
                     sharded_levels=[[lv["n"], lv["n_ext"] - lv["n"]] for lv in self.levels if lv.get("sharded")],
                     deep_halo_levels=[[lv["n_g1"], lv["n_ext2"] - lv["n_ext"]] for lv in self.levels if lv.get("sharded") and "n_ext2" in lv],
+                    deep_halo_layers=max([lv.get("deep_layers", 0) for lv in self.levels if lv.get("sharded")] or [0]),
                     fine_format=("sell64/%s/i%d" % (self.fine_values, _hx.lib.hx_sell_index_bits(self.sell)))
                     if self.sell else "csr",
                     stencil_slices=_hx.lib.hx_sell_stencil_slices(self.sell) if self.sell else 0, vcycle_precision="c64" if self.params["precision"] == "mixed" else "c128",

@@ -413,46 +413,55 @@ class ShardedOperator:
 
 
 class DeepHaloPlan:
-    """TWO ghost layers of a level in ONE exchange (the deep-halo cycle of a row-sharded level, amg.hip: vcycle_deep): layer 1 =
-    the level's ordinary ghost set (plan ``p1``: the off-rank columns of the rank's operator rows, positions [n_own, n_own + n1) of
-    an extended vector), layer 2 = the off-rank columns of the OPERATOR ROWS OF LAYER 1 that are not in layer 1 (positions behind
-    it).  Both layers travel in one batch of point-to-point messages -- per peer a layer-1 message followed by a layer-2 message,
-    issued in that order on both sides -- i.e. one exchange in the counters where the classic schedule needs two."""
+    """SEVERAL ghost layers of a level in ONE exchange (the deep-halo cycle of a row-sharded level, amg.hip: vcycle_deep): layer 1 =
+    the level's ordinary ghost set (the off-rank columns of the rank's operator rows, positions [n_own, n_own + n1) of an extended
+    vector), layer k + 1 = the off-rank columns of the OPERATOR ROWS OF LAYER k that are in no earlier layer (positions behind
+    it).  ``layers``: one HaloPlan per layer (each built on the ascending global ids of its layer).  All layers travel in one batch
+    of point-to-point messages -- per peer one message per layer, issued in layer order on both sides -- i.e. ONE exchange in the
+    counters where the classic schedule needs one per smoothing step."""
 
-    def __init__(self, p1, ranges, rank, ghost2_global, group=None):
-        self.p1 = p1
-        self.p2 = HaloPlan(ranges, rank, ghost2_global, group)          # (collective: one all_gather of the id lists)
-        self.n1, self.n2 = p1.n_ghost, self.p2.n_ghost
-        self.n_ghost = self.n1 + self.n2
+    def __init__(self, layers, group=None):
+        self.layers = list(layers)
+        self.p1 = self.layers[0]
+        self.sizes = [p.n_ghost for p in self.layers]
+        self.n_ghost = int(sum(self.sizes))
         self.n_exchanges = 0
-        self.world, self.group = p1.world, group
-        self.send_to = {**{("1", p): v for p, v in p1.send_to.items()}, **{("2", p): v for p, v in self.p2.send_to.items()}}
-        self.recv_from = {**{("1", p): v for p, v in p1.recv_from.items()}, **{("2", p): v for p, v in self.p2.recv_from.items()}}
+        self.world, self.group = self.p1.world, group
+        self.send_to = {(k, p): v for k, pl in enumerate(self.layers) for p, v in pl.send_to.items()}
+        self.recv_from = {(k, p): v for k, pl in enumerate(self.layers) for p, v in pl.recv_from.items()}
 
     def exchange(self, x_ext, n_own):
         if self.world == 1 or (not self.send_to and not self.recv_from):
             return
-        o1, s1, k1 = self.p1.p2p_ops(x_ext, n_own, n_own)
-        o2, s2, k2 = self.p2.p2p_ops(x_ext, n_own, n_own + self.n1)
-        if o1 or o2:
-            wait_all(issue(o1 + o2))
-        for dst, buf in s1 + s2:
+        ops, staged, keep, base = [], [], [], n_own
+        for pl, nk in zip(self.layers, self.sizes):
+            o, st, kp = pl.p2p_ops(x_ext, n_own, base)
+            ops += o
+            staged += st
+            keep += kp
+            base += nk
+        if ops:
+            wait_all(issue(ops))
+        for dst, buf in staged:
             dst.copy_(buf)
         self.n_exchanges += 1
 
     def native_arrays(self):
-        """Both layers as ONE plan of hx_comm_set_plan: the peers of layer 1, then those of layer 2 (a peer may appear twice: its
-        two messages are matched in issue order on both sides, as NCCL does for one pair of ranks)."""
-        a = self.p1.native_arrays()
-        b = self.p2.native_arrays()
-        send_peer = np.concatenate([a[0], b[0]])
-        send_ptr = np.concatenate([a[1], a[1][-1] + b[1][1:]])
-        send_idx = np.concatenate([a[2], b[2]])
-        recv_peer = np.concatenate([a[3], b[3]])
-        recv_off = np.concatenate([a[4], b[4] + self.n1])
-        recv_cnt = np.concatenate([a[5], b[5]])
+        """All layers as ONE plan of hx_comm_set_plan: the peers of layer 1, then those of layer 2, ... (a peer may appear several
+        times: its messages are matched in issue order on both sides, as NCCL does for one pair of ranks)."""
+        parts = [pl.native_arrays() for pl in self.layers]
+        send_peer = np.concatenate([a[0] for a in parts])
+        send_ptr, off = [np.zeros(1, np.int64)], 0
+        for a in parts:
+            send_ptr.append(off + a[1][1:])
+            off += int(a[1][-1])
+        send_ptr = np.concatenate(send_ptr)
+        send_idx = np.concatenate([a[2] for a in parts])
+        recv_peer = np.concatenate([a[3] for a in parts])
+        shift = np.concatenate([[0], np.cumsum(self.sizes)[:-1]])
+        recv_off = np.concatenate([a[4] + int(sh) for a, sh in zip(parts, shift)])
+        recv_cnt = np.concatenate([a[5] for a in parts])
         return send_peer, send_ptr, send_idx, recv_peer, recv_off, recv_cnt
-
 
 
 def sharded_panel_dot(V, k, w, group=None):

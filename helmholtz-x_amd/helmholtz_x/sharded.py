@@ -185,20 +185,25 @@ class ShardContext:
 
     DEEP = 32         # exchange plan of a level's TWO ghost layers: number DEEP + level (csrc/amg.hip: vcycle_deep)
 
-    def set_level_deep_plan(self, level, ghost2_global):
-        """Two-layer exchange of a sharded level: its ordinary ghost set (layer 1) + ``ghost2_global`` (ascending global ids of the
-        off-rank columns of the layer-1 operator rows that are not in layer 1), as ONE plan numbered DEEP + level.  Extended
-        vectors of the level are then [owned | layer 1 | layer 2].  Collective."""
-        p1 = self.plans[level]
-        plan = DeepHaloPlan(p1, self.level_ranges[level], self.rank, np.asarray(ghost2_global, dtype=np.int64), self.group)
+    def layer_plan(self, level, ghost_global):
+        """HaloPlan of one further ghost layer of a sharded level (ascending global ids, disjoint from the earlier layers): used by
+        the set-up to fetch the operator rows of that layer before the deep plan is registered.  Collective."""
+        return HaloPlan(self.level_ranges[level], self.rank, np.asarray(ghost_global, dtype=np.int64), self.group)
+
+    def set_level_deep_plan(self, level, extra_layers):
+        """Multi-layer exchange of a sharded level: its ordinary ghost set (layer 1) + ``extra_layers`` (HaloPlans from
+        ``layer_plan``, in layer order), as ONE plan numbered DEEP + level.  Extended vectors of the level are then
+        [owned | layer 1 | layer 2 | ...]."""
+        plan = DeepHaloPlan([self.plans[level]] + list(extra_layers), self.group)
         key = self.DEEP + level
         self.plans[key] = plan
         n_own = self.level_n[level][0]
         self.level_n[key] = (n_own, n_own + plan.n_ghost)
         if self.comm is not None:
             sp, sptr, sidx, rp_, roff, rcnt = plan.native_arrays()
-            _hx.check(_hx.lib.hx_comm_set_plan(self.comm, key, len(sp), _hx.nptr(sp), _hx.nptr(sptr), _hx.nptr(sidx.astype(np.int32)),
-                                               len(rp_), _hx.nptr(rp_), _hx.nptr(roff), _hx.nptr(rcnt)))
+            _hx.check(_hx.lib.hx_comm_set_plan(self.comm, key, len(sp), _hx.nptr(sp.astype(np.int32)), _hx.nptr(sptr.astype(np.int64)),
+                                               _hx.nptr(sidx.astype(np.int32)), len(rp_), _hx.nptr(rp_.astype(np.int32)),
+                                               _hx.nptr(roff.astype(np.int64)), _hx.nptr(rcnt.astype(np.int64))))
         return plan
 
     def set_pattern(self, K):

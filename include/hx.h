@@ -453,17 +453,20 @@ typedef int (*hx_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype, i
  * handle re-allocates its level-l work vectors with that length. */
 int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext, hx_halo_fn halo, hx_allreduce_fn allreduce,
                        void* ctx);
-/* Deep-halo mode of row-sharded level l (after hx_amg_set_sharded -- whose n_ext[l] then counts owned rows + BOTH ghost layers -- after
+/* Deep-halo mode of row-sharded level l (after hx_amg_set_sharded -- whose n_ext[l] then counts owned rows + ALL ghost layers -- after
  * hx_amg_set_prolongator_ghost_rows, with the level set with an inverse diagonal of n_ext[l] entries and a prolongator of n_ext[l]
- * rows): K1 = operator rows of the level's FIRST ghost layer (n_g1 rows, sorted CSR on the device, columns in the extended numbering
- * [owned | layer 1 | layer 2], values in the precision of the handle's cycle), fetched from their owners at set-up.  The cycle
- * then exchanges the level's right-hand side and its pre-smoothed iterate two layers deep (the exchange callback is called with
- * level number 32 + l: a plan that fills both layers in one exchange), smooths and forms the residual of layer 1 redundantly, and
- * needs no exchange for the restriction and the post-smoothing: 3 exchanges per cycle and level instead of 5 (2 instead of 3 where
- * the next level is replicated), same arithmetic.  pre = post = 2 only; option amg_deep_halo = 0 falls back to the classic schedule.
+ * rows).  K1 = operator rows of the level's ghost layers (sorted CSR on the device, columns in the extended numbering
+ * [owned | layer 1 | layer 2 (| layer 3)], values in the precision of the handle's cycle), fetched from their owners at set-up:
+ * layers = 2: rows of layer 1 only (n_gs = n_g1); layers = 3: rows of layer 1 (the first n_g1 rows / nnz_g1 entries) followed by
+ * those of layer 2 (n_gs rows / nnz_gs entries in all).  The cycle exchanges the level's right-hand side over all layers in ONE
+ * exchange (the callback is called with level number 32 + l), smooths the layer rows redundantly and forms the residual of layer 1
+ * itself, so restriction and post-smoothing need no exchange; with two layers the pre-smoothed iterate is exchanged once more.
+ * Exchanges per cycle and level: 5 classic, 3 / 2 (coarse level sharded / replicated) with two layers, 2 / 1 with three.  Same
+ * arithmetic.  pre = post = 2 only; option amg_deep_halo = 0 falls back to the classic schedule.
  * replaces: the ghost updates inside PCApply of the reference's distributed preconditioner (eigensolvers.py:49-50,102-103 under
  * mpirun, fullAnnulus/runAll.sh:10-11). */
-int hx_amg_set_level_deep(hx_amg* h, int l, int32_t n_g1, int64_t nnz1, const int32_t* rp1, const int32_t* ci1, const void* va1);
+int hx_amg_set_level_deep(hx_amg* h, int l, int layers, int32_t n_g1, int64_t nnz_g1, int32_t n_gs, int64_t nnz_gs, const int32_t* rp1,
+                          const int32_t* ci1, const void* va1);
 /* Optional split form of the halo exchange.  begin(ctx, level, x_ext, elem_bytes, s, &interior) enqueues the exchange ON s,
  * ordered after the work enqueued there, and hands out a side stream `interior` that waits for the same point of s;
  * end(ctx, level, s) makes s wait for the side stream.  With both set, every product with a SELL-64 operator of a sharded level

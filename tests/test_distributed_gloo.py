@@ -191,8 +191,10 @@ def _gpu_fpi_worker(rank, world, port, out, krylov, transport="gloo"):
     if transport.startswith("fake_rccl"):    # exchanges issued BY THE LIBRARY (hx_comm) through the host-staged librccl stand-in
         os.environ["HX_NATIVE_COMM"] = "1"
         os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
-    # two ghost layers per sharded level (the default): 3 (2) exchanges per level and cycle; "classic": one layer, 5 (3) exchanges
-    os.environ["HX_AMG_DEEP_HALO"] = "1" if transport.endswith("_deep") else "0"
+    # ghost layers per sharded level: "_deep" three (the default: 2 (1) exchanges per level and cycle), "_deep2" two (3 (2)); otherwise
+    # the classic schedule, one layer, 5 (3) exchanges
+    os.environ["HX_AMG_DEEP_HALO"] = "1" if "_deep" in transport else "0"
+    os.environ["HX_AMG_DEEP_LAYERS"] = "2" if transport.endswith("_deep2") else "3"
     if krylov == "fgmres":          # the flexible GMRES path (hx_gmres_sharded): "auto" picks COCG for this symmetric operator
         os.environ["HX_AMG_KRYLOV"] = "fgmres"
     if krylov == "cocg":            # the deflated COCG path (hx_cocg_sharded) with recycling, SELL-64 and two sharded levels
@@ -241,7 +243,7 @@ def _gpu_fpi_worker(rank, world, port, out, krylov, transport="gloo"):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("krylov,transport", [("fgmres", "gloo"), ("cocg", "gloo"), ("cocg", "fake_rccl"), ("cocg", "gloo_deep"),
-                                              ("cocg", "fake_rccl_deep"), ("fgmres", "fake_rccl_deep")])
+                                              ("cocg", "fake_rccl_deep"), ("cocg", "fake_rccl_deep2"), ("fgmres", "fake_rccl_deep")])
 def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport):
     """The whole hot path partitioned over two ranks (sharing the one GPU; gloo stages the exchanges through the host): every
     rank assembles ITS rows on its part of the mesh (owner computes), builds its slab of the hierarchy (uncoupled aggregation,
@@ -253,7 +255,8 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
     transport "fake_rccl": the exchanges are issued by the library itself (hx_comm: the production path under RCCL) through
     tests/fake_rccl, a host-staged stand-in for librccl (RCCL refuses two ranks on one GPU): zero Python frames per
     exchange, same plans and call sequence as on two GPUs."""
-    deep = transport.endswith("_deep")
+    deep = "_deep" in transport
+    layers = 0 if not deep else (2 if transport.endswith("_deep2") else 3)
     if transport.startswith("fake_rccl"):          # the stand-in is built by __graft_entry__.build(); build it here if it did not travel
         import subprocess
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -302,9 +305,11 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
                 assert st["cocg_allreduces"] <= 2 * st["cocg_iters"] + 2 * st["cocg_solves"] + 3 * st["cocg_solves"], st
                 assert st["cocg_allreduces"] / st["cocg_iters"] < 2.7, st
                 # halos per inner iteration with two sharded levels: classic 9 (fine level 5, second level 3, operator product 1),
-                # deep-halo schedule 6 (3 + 2 + 1); a few more per solve (start, closing residual)
+                # deep-halo schedule with two layers 6 (3 + 2 + 1), with three layers 4 (2 + 1 + 1); a few more per solve (start,
+                # closing residual)
                 per_it = st["cocg_halos"] / st["cocg_iters"]
-                assert (per_it < 6.9) if deep else (8.5 < per_it < 10.5), (per_it, st)
+                assert {0: 8.5 < per_it < 10.5, 2: 5.5 < per_it < 6.9, 3: per_it < 4.9}[layers], (per_it, st)
+                assert st["deep_halo_layers"] == layers
         nv_loc, nc_loc, nv, nc = r["local_mesh"]
         assert nv_loc < 0.6 * nv and nc_loc < 0.6 * nc            # a rank holds its half of the mesh + one ghost layer
     # both ranks hold identical (all-reduced) results
@@ -1328,9 +1333,10 @@ def _deep_plan_worker(rank, world, port, out):
         mine = np.arange(r0, r1)
         g1 = np.setdiff1d(near(1, 2), mine)
         g2 = np.setdiff1d(np.setdiff1d(near(3, 4), mine), g1)
-        p1 = HaloPlan(ranges, rank, g1)
-        deep = DeepHaloPlan(p1, ranges, rank, g2)
+        g3 = np.setdiff1d(np.setdiff1d(np.setdiff1d(near(5, 6), mine), g1), g2)
+        deep = DeepHaloPlan([HaloPlan(ranges, rank, g1), HaloPlan(ranges, rank, g2), HaloPlan(ranges, rank, g3)])
         n_own = r1 - r0
+        g2 = np.concatenate([g2, g3])                      # (layers 2 and 3 are checked together below)
         x = torch.full((n_own + len(g1) + len(g2),), -1.0, dtype=torch.float64)
         x[:n_own] = torch.arange(r0, r1, dtype=torch.float64)
         deep.exchange(x, n_own)
@@ -1349,9 +1355,9 @@ def _deep_plan_worker(rank, world, port, out):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_deep_halo_plan_two_layers_in_one_exchange(world):
-    """DeepHaloPlan (the two-layer exchange of the deep-halo V-cycle): both ghost layers of every rank filled by ONE batch of
-    point-to-point messages, real and complex entries; the host arrays for hx_comm_set_plan list per peer a layer-1 message followed
-    by a layer-2 message, and what one rank sends to a peer is what that peer expects from it, message by message."""
+    """DeepHaloPlan (the multi-layer exchange of the deep-halo V-cycle): three ghost layers of every rank filled by ONE batch of
+    point-to-point messages, real and complex entries; the host arrays for hx_comm_set_plan list per peer one message per layer, in
+    layer order, and what one rank sends to a peer is what that peer expects from it, message by message."""
     port = _free_port()
     out = mp.Manager().dict()
     mp.spawn(_deep_plan_worker, args=(world, port, out), nprocs=world, join=True)

@@ -1228,6 +1228,28 @@ def test_six_reference_targets_certified_1M():
         print("annulus-1M target %g: %d fixed-point iterations, %.1f inner iterations per solve (rung %s), clusters %s" % line)
 
 
+def test_wide_rung_is_entered_before_anything_fails_at_15000_rad_s_5M():
+    """At the headline size the harvest solve of a 15 000 rad/s target (1.36 x the reference's highest) needs more than one
+    FGMRES(50) cycle: the solver moves to the wide rung straight after it -- logged with that reason, no stall -- and the passive
+    eigen-solve converges with 45-60 inner iterations per solve (round 4: 65, and an error from 17 500 rad/s on)."""
+    import bench
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import pep_solver
+    case = bench.build_case(bench.WORKLOADS["annulus-5M"])
+    P = case["P"]
+    M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    caches = ({}, {}, {})
+    E = pep_solver(M.A, M.B, M.C, 15000.0, nev=2, _caches=caches)
+    assert E.getConverged() >= 2
+    st = next(v for v in caches[0].values() if hasattr(v, "stats")).stats()
+    assert st["rung"] == "wide" and len(st["ladder"]) == 1 and "first solve needed" in st["ladder"][0]["reason"], st
+    assert st["recycled_pairs"] > 8 and st["iters_per_solve"] < 70, st
+    w = E.getEigenvalue(0)
+    assert abs(w - 15000.0) < 400.0, w
+    E._owns_caches = True
+    E.destroy()
+
+
 def test_escalation_ladder_of_the_iterative_inner_solve(monkeypatch):
     """A stalled inner solve no longer ends the call (the reference's PCLU answers for any target,
     eigensolvers.py:49-50,102-103): the solver climbs its ladder -- default -> wide (FGMRES(100), up to 32 recycled vectors, 3x the

@@ -151,7 +151,7 @@ def bandwidth_permutation(mesh, degree_window=None):
     """perm[old] = new vertex id in the reverse Cuthill-McKee order of the vertex graph (vertices sharing a cell are adjacent).
     A mesh file numbers vertices entity by entity (gmsh: points, curves, surfaces, volumes), which scatters the neighbours
     of a row over the whole index range: a randomly numbered 5 M-DOF annulus runs the hot path five times slower than the
-    same mesh in this order, because the SpMV gathers lose their locality and the column
+    same mesh in this order (EXPERIMENTS.md, round 3), because the SpMV gathers lose their locality and the column
     deltas of the SELL-64 format no longer fit 16 bits.  The graph is the P1 sparsity pattern: taken from the assembler
     when it has been built on the device, else formed on the host from the cells.  One-off integer work at ingestion
     (scipy.sparse.csgraph, O(nnz))."""

@@ -48,7 +48,10 @@ enum hx_status {
  *   HX_SELL_STENCIL=0 / HX_SELL_INDEX=i32 / HX_SELL_LDS=0|2   SELL-64 format and kernel variants (hx_sell_create, k_sell)
  *   HX_POOL=0, HX_POOL_MAX_GIB, HX_POOL_MIN_BYTES                 device-buffer pool off / cap of the cached bytes / smallest pooled block
  *   HX_SELL_XCD=0|3, HX_SELL_ABLATE                            XCD-contiguous slice schedule never / always (default: by footprint); timing-only ablations
- *   HX_COCG_PQ_IN_PRODUCT=0|2                                 hx_cocg: p^T K p from the SELL-64 product itself never / at every size (default: up to 2 M rows)
+ *   HX_COCG_PQ_IN_PRODUCT=0|2                                 hx_cocg: p^T K p from the product itself (SELL-64: default up to 2 M rows; CSR operators: always) never / at every size
+ *   HX_AMG_FOLD_DIAG=0                                        the first smoothing step of a level (x1 = a0 D^-1 b) as a launch of its own again (default: written by the
+ *                                                             restriction that produced b, on the fine level by hx_cocg's update kernel)
+ *   HX_AMG_DEEP_HALO=0                                        row-sharded levels in deep-halo mode run the classic schedule (one exchange per smoothing step) anyway
  *   HX_COCG_LAG=0                                             hx_cocg: wait for every residual norm (default: read one iteration late while far from the tolerance)
  *   HX_COCG_FUSE_REDUCTIONS=0                                  hx_cocg: two-stage reductions on one GPU too
  *   HX_COCG_SINGLE_REDUCTION=0|2                               single-reduction (Chronopoulos-Gear) recurrence never / also on one GPU (default: row-sharded solves)

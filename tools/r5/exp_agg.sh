@@ -1,7 +1,6 @@
+# size-capped aggregation on the refined real mesh (needs tools/experiments/size_capped_aggregation.patch applied: HX_AMG_AGG_CAP / _SEED_MIN)
 set -x
 mkdir -p gpurun_out/r5
-python -m pytest tests/test_gpu_parity.py -x -q -k "six_reference_targets or certified_1M" > gpurun_out/r5/test_six.log 2>&1; tail -3 gpurun_out/r5/test_six.log
-python -m pytest tests/test_gpu_kernels.py -x -q -k "pool or factored_flame or small_dense or block_products" > gpurun_out/r5/test_kern.log 2>&1; tail -3 gpurun_out/r5/test_kern.log
 for cap in 0 6 8 10 12; do
   HX_AMG_AGG_CAP=$cap timeout -k 10 300 python bench.py --workload micca-real-r2 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r5/agg_r2_cap$cap.json 2> gpurun_out/r5/agg_r2_cap$cap.log
 done

@@ -186,11 +186,12 @@ static int op_residual_g1(const LevelT<float>& L, const float* x, const float* b
   const size_t o = 2 * (size_t)L.n;
   return hx_csr_residual_c(L.n_g1, L.nnz_g1, L.K1.rp, L.K1.ci, L.K1.va, x, b + o, r + o, s);
 }
-static int op_diag_n(const LevelT<double>& L, int64_t n, double w, const double* b, double* x, hx_stream s) {
-  return hx_zdiag_scale(n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
+// x[off .. off + n) = w D^-1 b on a range of the extended vectors
+static int op_diag_n(const LevelT<double>& L, int64_t off, int64_t n, double w, const double* b, double* x, hx_stream s) {
+  return hx_zdiag_scale(n, w, (const hx_c128*)(L.dinv + 2 * off), (const hx_c128*)(b + 2 * off), (hx_c128*)(x + 2 * off), s);
 }
-static int op_diag_n(const LevelT<float>& L, int64_t n, double w, const float* b, float* x, hx_stream s) {
-  return hx_cdiag_scale(n, (float)w, L.dinv, b, x, s);
+static int op_diag_n(const LevelT<float>& L, int64_t off, int64_t n, double w, const float* b, float* x, hx_stream s) {
+  return hx_cdiag_scale(n, (float)w, L.dinv + 2 * off, b + 2 * off, x + 2 * off, s);
 }
 static int op_diag(const LevelT<double>& L, double w, const double* b, double* x, hx_stream s) {
   return hx_zdiag_scale(L.n, w, (const hx_c128*)L.dinv, (const hx_c128*)b, (hx_c128*)x, s);
@@ -478,11 +479,28 @@ static int vcycle_deep(hx_amg* h, HierT<T>& H, int l, const T* b_in, T* xout, hx
     return op_smooth_g(L, g_rows, g_nnz, L.b, xin, out, w, pv, mom, s);
   };
   if (b_in != L.b) HX_HIP(hipMemcpyAsync(L.b, b_in, 2 * sizeof(T) * (size_t)L.n, hipMemcpyDeviceToDevice, hx_s(s)));
-  if ((rc = deep_halo(L.b))) return rc;
   T* x1 = L.x; T* x2 = L.x2; T* x3 = L.x3;
-  if ((rc = op_diag_n(L, L.n_ext, cheb ? C.a[0] : h->omega, L.b, x1, s))) return rc;
-  // pre-smoothing step 1: the iterate before x1 is the zero start vector (xprev NULL with momentum); redundantly on every row K1 holds
-  if ((rc = step(x1, x2, 1, nullptr, true, L.K1.rows, L.K1.nnz))) return rc;
+  const double a0 = cheb ? C.a[0] : h->omega;
+  // The exchange of b overlaps what needs OWNED entries only: x1 on the owned block and the interior slices of the first smoothing
+  // step (split form of the exchange, as for the operator product: the exchange stays on the caller's stream, that work runs on the
+  // communicator's side stream); then x1 on the ghost layers, the boundary slices and the redundantly smoothed layer rows.
+  if (h->halo_begin && h->halo_end && L.sell && hx_sell_has_parts(L.sell) && HX_OPT_INT("amg_deep_overlap", 1) != 0) {
+    hx_stream side = nullptr;
+    if (h->halo_begin(h->ctx, DEEP + l, L.b, EB, s, &side) != 0) return hx_fail(HX_ERR_COMM, "vcycle_deep", "multi-layer halo exchange (begin) failed");
+    int r1 = op_diag_n(L, 0, L.n, a0, L.b, x1, side);
+    if (!r1) r1 = op_smooth(L, L.b, x1, x2, cheb ? C.a[1] : h->omega, nullptr, cheb ? C.c[1] : 0.0, side, 1);
+    if (h->halo_end(h->ctx, DEEP + l, s) != 0) return hx_fail(HX_ERR_COMM, "vcycle_deep", "multi-layer halo exchange (end) failed");
+    if (r1) return r1;
+    if ((rc = op_diag_n(L, L.n, (int64_t)L.n_ext - L.n, a0, L.b, x1, s))) return rc;
+    if ((rc = op_smooth(L, L.b, x1, x2, cheb ? C.a[1] : h->omega, nullptr, cheb ? C.c[1] : 0.0, s, 2))) return rc;
+    if (L.K1.rows > 0 && (rc = op_smooth_g(L, L.K1.rows, L.K1.nnz, L.b, x1, x2, cheb ? C.a[1] : h->omega, nullptr, cheb ? C.c[1] : 0.0, s)))
+      return rc;
+  } else {
+    if ((rc = deep_halo(L.b))) return rc;
+    if ((rc = op_diag_n(L, 0, L.n_ext, a0, L.b, x1, s))) return rc;
+    // pre-smoothing step 1: the iterate before x1 is the zero start vector (xprev NULL with momentum); redundantly on every row K1 holds
+    if ((rc = step(x1, x2, 1, nullptr, true, L.K1.rows, L.K1.nnz))) return rc;
+  }
   if (L.deep_layers == 2 && (rc = deep_halo(x2))) return rc;
   if ((rc = op_residual(L, x2, L.b, L.r, s))) return rc;
   if (L.n_g1 > 0 && (rc = op_residual_g1(L, x2, L.b, L.r, s))) return rc;

@@ -52,6 +52,8 @@ enum hx_status {
  *   HX_AMG_FOLD_DIAG=0                                        the first smoothing step of a level (x1 = a0 D^-1 b) as a launch of its own again (default: written by the
  *                                                             restriction that produced b, on the fine level by hx_cocg's update kernel)
  *   HX_AMG_DEEP_HALO=0                                        row-sharded levels in deep-halo mode run the classic schedule (one exchange per smoothing step) anyway
+ *   HX_AMG_DEEP_OVERLAP=0                                     the deep-halo cycle's multi-layer exchange of b blocks (default: split -- x1 on the owned block and the
+ *                                                             interior slices of the first smoothing step run on the side stream while it travels; SELL-64 levels)
  *   HX_COCG_LAG=0                                             hx_cocg: wait for every residual norm (default: read one iteration late while far from the tolerance)
  *   HX_COCG_FUSE_REDUCTIONS=0                                  hx_cocg: two-stage reductions on one GPU too
  *   HX_COCG_SINGLE_REDUCTION=0|2                               single-reduction (Chronopoulos-Gear) recurrence never / also on one GPU (default: row-sharded solves)
@@ -465,7 +467,10 @@ int hx_amg_set_sharded(hx_amg* h, int n_sharded, const int32_t* n_ext, hx_halo_f
  * exchange (the callback is called with level number 32 + l), smooths the layer rows redundantly and forms the residual of layer 1
  * itself, so restriction and post-smoothing need no exchange; with two layers the pre-smoothed iterate is exchanged once more.
  * Exchanges per cycle and level: 5 classic, 3 / 2 (coarse level sharded / replicated) with two layers, 2 / 1 with three.  Same
- * arithmetic.  pre = post = 2 only; option amg_deep_halo = 0 falls back to the classic schedule.
+ * arithmetic.  pre = post = 2 only; option amg_deep_halo = 0 falls back to the classic schedule.  With the split callbacks set
+ * (hx_amg_set_halo_overlap) and slice lists on the level's SELL-64 operator, the exchange of the right-hand side is split like the
+ * operator product's: the owned part of x1 and the interior slices of the first smoothing step run while it travels (option
+ * amg_deep_overlap = 0: blocking).
  * replaces: the ghost updates inside PCApply of the reference's distributed preconditioner (eigensolvers.py:49-50,102-103 under
  * mpirun, fullAnnulus/runAll.sh:10-11). */
 int hx_amg_set_level_deep(hx_amg* h, int l, int layers, int32_t n_g1, int64_t nnz_g1, int32_t n_gs, int64_t nnz_gs, const int32_t* rp1,

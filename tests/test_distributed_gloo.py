@@ -290,10 +290,11 @@ def test_row_sharded_fixed_point_matches_single_gpu_two_ranks(krylov, transport)
         assert ("libhx" in counters["issued_by"]) == transport.startswith("fake_rccl"), counters
         assert len(r["distributed"]["stats"]["deep_halo_levels"]) == (len(r["distributed"]["stats"]["sharded_levels"]) if deep else 0)
         if transport.startswith("fake_rccl"):      # most halos run split: interior slices of the product while the exchange is in flight
-            # (deep-halo mode: the cycle's exchanges are two layers deep and blocking; the operator product's stays split)
+            # (deep-halo mode: the fine level's multi-layer exchange of b is split as well -- x1 on the owned block and the interior
+            # slices of the first smoothing step run while it travels; the second level has no slice lists and its exchange blocks)
             # (the fgmres case keeps its small levels on the CSR kernels: no slice lists, nothing to split)
             if krylov == "cocg":
-                assert counters["halos_overlapped_with_interior_slices"] > (0.1 if deep else 0.5) * counters["halo_exchanges"], counters
+                assert counters["halos_overlapped_with_interior_slices"] > (0.25 if deep else 0.5) * counters["halo_exchanges"], counters
             # every operation of the communicator -- blocking and split halos, all-reduces -- was issued on ONE stream (RCCL
             # orders the operations of a communicator only within a stream; the asynchronous stand-in fails a run that mixes)
             assert counters["communicator_stream_switches"] == 0, counters

@@ -235,6 +235,79 @@ def p2_dofmap(n_vertices, cells):
     return np.ascontiguousarray(cell_dofs, dtype=np.int32), np.ascontiguousarray(edges, dtype=np.int32)
 
 
+def p2_dofmap_distributed(mesh):
+    """P2 dofs of a DISTRIBUTED local mesh (``mesh.part``, distributed.distribute_mesh) -- what DOLFINx's dofmap builder does for
+    the reference under mpirun (acoustic_matrices.py:25 with degree = 2).  An edge belongs to the rank that owns its lower GLOBAL
+    vertex: every cell containing the edge touches that vertex, so the owner holds all of them and the assembled row of the
+    edge dof is complete there (owner computes, no assembly communication -- as for the vertices).  Global numbering: rank after
+    rank, a rank's owned vertices (ascending global vertex id) followed by its owned edges (ascending (low, high) pair); local
+    numbering [owned vertices | owned edges | ghost dofs ascending global id] -- the [owned | ghost] layout of the row-sharded
+    solve.  The global ids of ghost edges come from their owners: two small object collectives (the keys asked for, the positions
+    answered).  Collective over ``mesh.comm``.
+
+    Returns dict(cell_dofs (nc, 10) int32 local, edges (ne, 2) local vertex pairs, edge_keys (ne,) ascending low * n_global + high
+    of GLOBAL vertex ids, vertex_dof (nv,), edge_dof (ne,), n_own, dof_l2g, dof_ranges, n_global_dofs)."""
+    import torch.distributed as dist
+    part = mesh.part
+    N, r0, r1, n_vo, rank = int(part["n_global"]), int(part["r0"]), int(part["r1"]), int(part["n_own"]), int(part["rank"])
+    l2g = np.asarray(part["local_to_global"], dtype=np.int64)
+    cells = np.asarray(mesh.topology.cells, dtype=np.int64)
+    pl = cells[:, TET_EDGES].reshape(-1, 2)
+    pg = l2g[pl]
+    swap = pg[:, 0] > pg[:, 1]
+    pl[swap] = pl[swap][:, ::-1]
+    pg[swap] = pg[swap][:, ::-1]
+    uniq, first, inv = np.unique(pg[:, 0] * N + pg[:, 1], return_index=True, return_inverse=True)
+    edges = pl[first]
+    own_e = (uniq // N >= r0) & (uniq // N < r1)
+    own_keys = uniq[own_e]
+    n_eo, n_own = int(own_keys.size), n_vo + int(own_keys.size)
+    group, world = mesh.comm.group, mesh.comm.size
+    v_ranges = np.asarray(part["ranges"], dtype=np.int64).reshape(world, 2)
+    if world > 1:
+        counts = [None] * world
+        dist.all_gather_object(counts, n_own, group=group)
+    else:
+        counts = [n_own]
+    starts = np.concatenate([[0], np.cumsum(np.asarray(counts, dtype=np.int64))])
+    gv = l2g[n_vo:]
+    owner_v = np.searchsorted(v_ranges[:, 1], gv, side="right")
+    gv_dof = starts[owner_v] + (gv - v_ranges[owner_v, 0])
+    ghost_keys = uniq[~own_e]
+    owner_e = np.searchsorted(v_ranges[:, 1], ghost_keys // N, side="right")
+    ge_dof = np.empty(ghost_keys.size, dtype=np.int64)
+    if world > 1:
+        asked = [None] * world
+        dist.all_gather_object(asked, {int(q): ghost_keys[owner_e == q] for q in np.unique(owner_e)}, group=group)
+        mine = {}
+        for r, req in enumerate(asked):
+            if rank in req:
+                pos = np.searchsorted(own_keys, req[rank])
+                if not np.array_equal(own_keys[np.minimum(pos, max(n_eo - 1, 0))], req[rank]):
+                    raise ValueError("rank %d asked rank %d for an edge it does not hold" % (r, rank))
+                mine[r] = pos
+        answered = [None] * world
+        dist.all_gather_object(answered, mine, group=group)
+        for q in np.unique(owner_e):
+            q = int(q)
+            ge_dof[owner_e == q] = starts[q] + (v_ranges[q, 1] - v_ranges[q, 0]) + answered[q][rank]
+    elif ghost_keys.size:
+        raise ValueError("ghost edges on a one-rank mesh")
+    ghost_global = np.concatenate([gv_dof, ge_dof])
+    order = np.argsort(ghost_global, kind="stable")
+    ghost_local = np.empty(ghost_global.size, dtype=np.int64)
+    ghost_local[order] = n_own + np.arange(ghost_global.size)
+    vertex_dof = np.concatenate([np.arange(n_vo, dtype=np.int64), ghost_local[:gv.size]])
+    edge_dof = np.empty(uniq.size, dtype=np.int64)
+    edge_dof[own_e] = n_vo + np.arange(n_eo)
+    edge_dof[~own_e] = ghost_local[gv.size:]
+    cell_dofs = np.concatenate([vertex_dof[cells], edge_dof[inv].reshape(-1, 6)], axis=1)
+    return dict(cell_dofs=np.ascontiguousarray(cell_dofs, dtype=np.int32), edges=np.ascontiguousarray(edges, dtype=np.int32),
+                edge_keys=uniq, vertex_dof=vertex_dof, edge_dof=edge_dof, n_own=n_own,
+                dof_l2g=np.concatenate([starts[rank] + np.arange(n_own), ghost_global[order]]),
+                dof_ranges=[(int(starts[p]), int(starts[p + 1])) for p in range(world)], n_global_dofs=int(starts[-1]))
+
+
 def collapsed_gauss(dim, n=4):
     """Barycentric quadrature table (nq, dim + 2): points + weight (sum 1) on the reference simplex -- tensor
     Gauss-Legendre in collapsed coordinates, exact to total degree 2n - 1 - (dim - 1) (n = 4: 5 on tetrahedra, 6 on
@@ -269,11 +342,27 @@ class FunctionSpace:
             if mesh.topology.dim != 3:
                 raise NotImplementedError("quadratic elements are provided on tetrahedra (the reference's degree-2 case)")
             self.kind = "P2"
-            self.cell_dofs, self.edges = p2_dofmap(mesh.num_vertices, mesh.topology.cells)
-            self.size = mesh.num_vertices + self.edges.shape[0]
+            nv = mesh.num_vertices
+            if getattr(mesh, "part", None) is not None:
+                # distributed local mesh: one numbering (and one exchange plan) per mesh, shared by every quadratic space on it
+                d = mesh.__dict__.get("_p2_dist")
+                if d is None:
+                    d = mesh.__dict__["_p2_dist"] = p2_dofmap_distributed(mesh)
+                self._dist = d
+                self.cell_dofs, self.edges, self.edge_keys = d["cell_dofs"], d["edges"], d["edge_keys"]
+                self.vertex_dof, self.edge_dof, self.n_own = d["vertex_dof"], d["edge_dof"], d["n_own"]
+                self.size = nv + self.edges.shape[0]
+            else:
+                self.cell_dofs, self.edges = p2_dofmap(nv, mesh.topology.cells)
+                self.edge_keys = self.edges[:, 0].astype(np.int64) * nv + self.edges[:, 1]
+                self.vertex_dof, self.edge_dof = np.arange(nv, dtype=np.int64), nv + np.arange(self.edges.shape[0], dtype=np.int64)
+                self.size = self.n_own = nv + self.edges.shape[0]
         else:
             raise NotImplementedError("P1, P2 (tetrahedra) and DG0 spaces are on the hot path (got %s %d)" % (family, degree))
         self.mesh = mesh
+        if self.kind != "P2":
+            part = getattr(mesh, "part", None)
+            self.n_own = part["n_own"] if (part is not None and self.kind == "P1") else self.size
         if self.kind == "P1":
             self.dofmap = mesh.topology.cells
         elif self.kind == "P2":
@@ -290,12 +379,29 @@ class FunctionSpace:
             return cache
         return self.mesh.assembler()
 
+    @property
+    def shard(self):
+        """Row-sharding context of this space on a distributed local mesh (``fixed_point_iteration(..., shard=V.shard)``): the
+        mesh's own for P1 (ShardContext.distribute), one over the quadratic dofs for P2 (built on first use; collective)."""
+        d = getattr(self, "_dist", None)
+        if d is None:
+            return getattr(self.mesh, "shard", None)
+        if "shard" not in d:
+            from .sharded import ShardContext
+            ctx = ShardContext(d["n_global_dofs"], group=self.mesh.comm.group, ranges=d["dof_ranges"])
+            ctx.set_ghosts(d["dof_l2g"][d["n_own"]:])
+            d["shard"] = ctx
+        return d["shard"]
+
     def tabulate_dof_coordinates(self):
         if self.kind == "P1":
             return self.mesh.geometry.x
         if self.kind == "P2":
             x = self.mesh.geometry.x
-            return np.concatenate([x, 0.5 * (x[self.edges[:, 0]] + x[self.edges[:, 1]])], axis=0)
+            out = np.empty((self.size, x.shape[1]), dtype=x.dtype)
+            out[self.vertex_dof] = x
+            out[self.edge_dof] = 0.5 * (x[self.edges[:, 0]] + x[self.edges[:, 1]])
+            return out
         return self.mesh.geometry.x[self.mesh.topology.cells].mean(axis=1)
 
 
@@ -318,7 +424,7 @@ class _X:
         from .petsc import Vec
         v = Vec(self.array)
         # on a distributed local mesh the vector is row-sharded: dots are sums over the ranks' owned entries
-        v.shard = getattr(getattr(self._space, "mesh", None), "shard", None)
+        v.shard = getattr(self._space, "shard", None)
         return v
 
 
@@ -610,6 +716,19 @@ class P2Assembler:
     def _csr(self, val):
         out = CSR((self.n, self.n), self.rowptr, self.col, val, pattern_id=self.pattern_id)
         out.symmetric = True
+        return self._own_rows(out)
+
+    def _own_rows(self, csr):
+        """Distributed local mesh: the rows of the OWNED dofs (vertices and edges, complete: ``p2_dofmap_distributed``) over
+        [owned | ghost] columns, as P1Assembler._own_rows."""
+        if getattr(self.mesh, "part", None) is None:
+            return csr
+        n_own = self.V.n_own
+        nnz = int(csr.rowptr[n_own].item())
+        out = CSR((n_own, csr.shape[1]), csr.rowptr[:n_own + 1].contiguous(), csr.col[:nnz],
+                  None if csr.val is None else csr.val[:nnz], pattern_id=("own", csr.pattern_id))
+        out.symmetric = getattr(csr, "symmetric", False)
+        out.local = True
         return out
 
     @staticmethod
@@ -633,26 +752,47 @@ class P2Assembler:
         """DOLFINx ``assemble_matrix(bcs=...)`` for the quadratic space: rows and columns of the listed dofs (vertices and edge
         midpoints of the boundary facets: ``facet_dofs``) zeroed, ``diag`` on their diagonal."""
         csr = mat.csr_part()
+        n_rows = csr.shape[0]
         flags = np.zeros(self.n, dtype=np.uint8)
         flags[np.asarray(dofs, dtype=np.int64)] = 1
-        flags_d = to_device(flags)          # (bound to a name: the launch below is asynchronous)
-        _hx.check(_hx.lib.hx_csr_apply_dirichlet(self.n, _hx.ptr(csr.rowptr), _hx.ptr(csr.col), _hx.ptr(csr.val),
+        if getattr(self.mesh, "part", None) is not None:
+            # distributed: an owned boundary dof is always known here (a tagged facet holding an owned vertex -- or an owned edge,
+            # whose lower vertex is owned -- is local); the flags of the ghost dofs come from their owners by one exchange
+            f = torch.zeros(self.n, dtype=torch.int32, device=csr.val.device)
+            f[:n_rows] = to_device(flags[:n_rows].astype(np.int32))
+            self.V.shard.halo(f)
+            flags_d = f.to(torch.uint8)
+        else:
+            flags_d = to_device(flags)          # (bound to a name: the launch below is asynchronous)
+        _hx.check(_hx.lib.hx_csr_apply_dirichlet(n_rows, _hx.ptr(csr.rowptr), _hx.ptr(csr.col), _hx.ptr(csr.val),
                                                  _hx.ptr(flags_d), float(diag), _hx.stream()))
 
     def facet_dofs(self, facets):
-        """(nf, 6) global P2 dofs of boundary triangles: 3 vertices + the edges in TRI_EDGES order."""
-        nv = self.mesh.num_vertices
+        """(nf, 6) P2 dofs of boundary triangles: 3 vertices + the edges in TRI_EDGES order."""
+        V = self.V
         facets = np.asarray(facets, dtype=np.int64)
-        ekey = self.V.edges[:, 0].astype(np.int64) * nv + self.V.edges[:, 1]
-        pairs = np.sort(facets[:, TRI_EDGES], axis=2)
-        key = pairs[..., 0] * nv + pairs[..., 1]
-        pos = np.searchsorted(ekey, key)
-        if not np.array_equal(ekey[np.minimum(pos, len(ekey) - 1)], key):
+        part = getattr(self.mesh, "part", None)
+        if part is None:
+            g, N = facets, self.mesh.num_vertices
+        else:                                  # edge keys are pairs of GLOBAL vertex ids there
+            g, N = np.asarray(part["local_to_global"], dtype=np.int64)[facets], int(part["n_global"])
+        pairs = np.sort(g[:, TRI_EDGES], axis=2)
+        key = pairs[..., 0] * N + pairs[..., 1]
+        pos = np.searchsorted(V.edge_keys, key)
+        if not np.array_equal(V.edge_keys[np.minimum(pos, len(V.edge_keys) - 1)], key):
             raise ValueError("a boundary facet edge is not a mesh edge")
-        return np.ascontiguousarray(np.concatenate([facets, nv + pos], axis=1), dtype=np.int32)
+        return np.ascontiguousarray(np.concatenate([V.vertex_dof[facets], V.edge_dof[pos]], axis=1), dtype=np.int32)
 
     def robin(self, facet_ids, coef_per_facet, c):
         facet_ids = np.asarray(facet_ids, dtype=np.int64)
+        part = getattr(self.mesh, "part", None)
+        if facet_ids.size == 0:               # (a part that does not touch the boundary: an operator without entries, as for P1)
+            rows = self.V.n_own if part is not None else self.n
+            dev = self.x.device
+            out = CSR((rows, self.n), torch.zeros(rows + 1, dtype=torch.int32, device=dev),
+                      torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.complex128, device=dev))
+            out.symmetric, out.local = True, part is not None
+            return Mat.from_csr(out)
         fv = self.mesh.facets[facet_ids]
         facets = to_device(np.ascontiguousarray(fv, dtype=np.int32))
         fdofs = to_device(self.facet_dofs(fv))
@@ -665,7 +805,9 @@ class P2Assembler:
         _hx.check(_hx.lib.hx_assemble_p2_robin(self.n, _hx.ptr(self.x), _hx.ptr(facets), _hx.ptr(fdofs), _hx.ptr(ptr),
                                                _hx.ptr(idx), _hx.ptr(rowptr), _hx.ptr(col), _hx.ptr(cf), _hx.ptr(coef),
                                                self.quad2.shape[0], _hx.ptr(self.quad2), _hx.ptr(val), _hx.stream()))
-        return Mat.from_csr(CSR((self.n, self.n), rowptr, col, val))
+        out = CSR((self.n, self.n), rowptr, col, val)
+        out.symmetric = True            # boundary mass matrix
+        return Mat.from_csr(self._own_rows(out))
 
     def load_cells(self, h_cell, cell_tag, tag, scale=1.0):
         """scale * sum over the cells tagged ``tag`` of h_cell int phi_j dx (h: DG0 array; cell_tag: device int32 per cell)."""

@@ -91,7 +91,7 @@ class FlameMatrix:
         part = getattr(self.mesh, "part", None)
         local = part is not None        # distributed local mesh: the factors hold this rank's OWNED entries (local indices)
         if local:
-            n = part["n_own"]
+            n = self.V.n_own            # (owned vertices; with degree 2 the owned vertices and edges)
         if problem_type == 'direct':
             self._D_ij = Mat((n, n), lr_terms=[(1.0, LowRank(n, pairs, local))])
         elif problem_type == 'adjoint':            # plain transpose, no conjugate (flame_matrices.py:84-89)
@@ -136,8 +136,8 @@ class PointwiseFlameMatrix(FlameMatrix):
         super().__init__(mesh, h, q_0, u_b, FTF, degree, bloch_object, tol)
         if degree not in (1, 2):
             raise NotImplementedError("pointwise flames: degree 1 or 2")
-        if degree == 2 and (mesh.topology.dim != 3 or getattr(mesh, "part", None) is not None):
-            raise NotImplementedError("degree-2 pointwise flames are provided on undistributed tetrahedral meshes")
+        if degree == 2 and mesh.topology.dim != 3:
+            raise NotImplementedError("degree-2 pointwise flames are provided on tetrahedral meshes")
         self.subdomains = subdomains
         self.x_r = x_r
         self.rho_u = rho_u
@@ -216,9 +216,15 @@ class PointwiseFlameMatrix(FlameMatrix):
         h_dev = p1._field(self.h)[0]
         left = self.indices_and_values(asm.load_cells(h_dev, p1.cell_tag_array(self.subdomains), flame,
                                                       scale=(self.gamma - 1) * self.q_0 / self.u_b))
+        part = getattr(self.mesh, "part", None)
+        n_own = self.V.n_own
+        if part is not None:             # distributed mesh: this rank's OWNED entries (every cell touching an owned dof is local)
+            left = (left[0][left[0] < n_own], left[1][left[0] < n_own])
         if getattr(self, "_x_r_cells", None) is None:
-            self._x_r_cells = p1.locate_points(self.x_r)
+            self._x_r_cells = self._locate_distributed() if part is not None else p1.locate_points(self.x_r)
         c = int(self._x_r_cells[flame])
+        if c < 0:                        # the cell that holds the point lives on other ranks only
+            return left, (np.zeros(0, np.int32), np.zeros(0, np.complex128))
         G = _cell_gradients(self.mesh, c)                        # rows: grad lambda_m
         X = self.mesh.geometry.x[self.mesh.topology.cells[c]]
         l123 = np.linalg.solve((X[1:] - X[0]).T, np.asarray(self.x_r[flame], dtype=float).reshape(-1)[:3] - X[0])
@@ -230,6 +236,9 @@ class PointwiseFlameMatrix(FlameMatrix):
         for e, (a, b) in enumerate(TET_EDGES):
             grad[4 + e] = 4 * (lam[a] * G[b] + lam[b] * G[a])
         right = (self.V.cell_dofs[c].astype(np.int32), (grad @ self.n_r) / self.rho_u + 0j)
+        if part is not None:
+            mine = right[0] < n_own
+            right = (right[0][mine], right[1][mine])
         return left, right
 
     def assemble_submatrices(self, problem_type='direct'):
@@ -283,7 +292,7 @@ class DistributedFlameMatrix(FlameMatrix):
         right = self.indices_and_values(asm.load(2, self.rho.x.array, self.w.x.array))
         part = getattr(self.mesh, "part", None)
         if part is not None:            # distributed mesh: the entries of the owned vertices are complete (every cell touching
-            n_own = part["n_own"]       # them is local); the ghost entries belong to their owners (flame_matrices.py:64-65
+            n_own = self.V.n_own        # them is local); the ghost entries belong to their owners (flame_matrices.py:64-65
             left = (left[0][left[0] < n_own], left[1][left[0] < n_own])        # does a ghost add + insert instead)
             right = (right[0][right[0] < n_own], right[1][right[0] < n_own])
         return left, right

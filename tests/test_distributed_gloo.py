@@ -885,7 +885,6 @@ def _rijke_distributed_worker(rank, world, port, out, golden_dir):
                         # ghost entries of the normalised mode equal their owners' values: checked below
                         local.part["local_to_global"][n_own:].copy(), p.x.array[n_own:].copy(), ctx.r0)
         out[rank] = res
-        out[rank] = res
     finally:
         dist.destroy_process_group()
 

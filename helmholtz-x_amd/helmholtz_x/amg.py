@@ -993,7 +993,7 @@ class AMGSolver:
                 _hx.check(_hx.lib.hx_amg_set_halo_overlap(h, self._ov[0], self._ov[1]))
             self._xe = shard.ext_vector(torch.complex128)
             self._hbuf = torch.zeros(max(self.params["restart"] + 2 + 32, 80), dtype=torch.complex128, device=dev)
-        # hipGraph replay of the V-cycle where it is launch-bound (measured: see EXPERIMENTS.md, rounds 1-4)
+        # hipGraph replay of the V-cycle: off by default (graph_max_rows = 0; slower than the folded eager cycle at every size, EXPERIMENTS.md round 5)
         gmax = int(os.environ.get("HX_AMG_GRAPH_MAX_ROWS", self.params["graph_max_rows"]))
         if mixed and shard is None and len(levels) > 1 and self.n <= gmax:
             _hx.check(_hx.lib.hx_amg_enable_graph(h, 1))

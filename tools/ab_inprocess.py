@@ -4,6 +4,7 @@ once, the configurations are visited round-robin several times, the best and the
 configuration -- no process-to-process or box-to-box spread in the comparison.
 
   python tools/ab_inprocess.py annulus-1M "amg_fold_diag=1" "amg_fold_diag=0" "amg_fold_diag=1,cocg_pq_in_product=0" [--rounds 4]
+(names starting with HX_ are environment switches of the Python layer, set for the calls of their configuration only)
 """
 import gc
 import os
@@ -49,7 +50,13 @@ def apply(cfg, on):
     for kv in cfg.split(","):
         if kv:
             k, v = kv.split("=")
-            _hx.set_option(k, v if on else None)
+            if k.startswith("HX_"):                  # a switch of the Python layer: read from the environment when the solver is built
+                if on:
+                    os.environ[k] = v
+                else:
+                    os.environ.pop(k, None)
+            else:
+                _hx.set_option(k, v if on else None)
 
 
 for _ in range(2):

@@ -348,6 +348,11 @@ class FunctionSpace:
                 d = mesh.__dict__.get("_p2_dist")
                 if d is None:
                     d = mesh.__dict__["_p2_dist"] = p2_dofmap_distributed(mesh)
+                    # the row-sharding context of the quadratic dofs is made HERE, where every rank is (the numbering above is
+                    # collective too) -- not on first use, which need not happen on all ranks at the same point
+                    from .sharded import ShardContext
+                    d["shard"] = ShardContext(d["n_global_dofs"], group=mesh.comm.group, ranges=d["dof_ranges"])
+                    d["shard"].set_ghosts(d["dof_l2g"][d["n_own"]:])
                 self._dist = d
                 self.cell_dofs, self.edges, self.edge_keys = d["cell_dofs"], d["edges"], d["edge_keys"]
                 self.vertex_dof, self.edge_dof, self.n_own = d["vertex_dof"], d["edge_dof"], d["n_own"]
@@ -382,16 +387,10 @@ class FunctionSpace:
     @property
     def shard(self):
         """Row-sharding context of this space on a distributed local mesh (``fixed_point_iteration(..., shard=V.shard)``): the
-        mesh's own for P1 (ShardContext.distribute), one over the quadratic dofs for P2 (built on first use; collective)."""
+        mesh's own for P1 (ShardContext.distribute), one over the quadratic dofs for P2 (made with the mesh's first quadratic
+        space)."""
         d = getattr(self, "_dist", None)
-        if d is None:
-            return getattr(self.mesh, "shard", None)
-        if "shard" not in d:
-            from .sharded import ShardContext
-            ctx = ShardContext(d["n_global_dofs"], group=self.mesh.comm.group, ranges=d["dof_ranges"])
-            ctx.set_ghosts(d["dof_l2g"][d["n_own"]:])
-            d["shard"] = ctx
-        return d["shard"]
+        return getattr(self.mesh, "shard", None) if d is None else d["shard"]
 
     def tabulate_dof_coordinates(self):
         if self.kind == "P1":

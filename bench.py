@@ -388,8 +388,8 @@ def emit(out):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=3)      # (no flags: one warm-up call + three timed ones, a few minutes with the CPU sample)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("HX_BENCH_WORKLOAD", "annulus-5M"))
     ap.add_argument("--st-type", default=None, help="inner solver for the shifted operator: lu | amg | auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1,0 +1,890 @@
+// Sparse direct solver on the device: supernodal multifrontal LU of a complex128 matrix (hx_splu_*).
+//
+// replaces: KSP(preonly) + PC(LU) inside ST sinvert -- MatLUFactorNumeric / MatSolve / MatSolveTranspose of PETSc's LU or MUMPS
+// (eigensolvers.py:49-50,102-103 -> :62,:113 of the reference).  Host analysis: splu_analyse.hip; layout: splu_internal.h.
+//
+// Numeric factorisation, level by level up the assembly tree (fronts of one level are independent and share every launch):
+//   zero the contribution blocks -> extend-add the children (round r adds the r-th child of every front: race-free, fixed order)
+//   -> per pivot block of 64 columns: k_diag (LU of the 64 x 64 diagonal block in LDS, partial pivoting INSIDE the block, explicit
+//   inverses W_L = L^-1 P and W_U = U^-1), k_gemm<PANEL> (L21 <- F21 W_U, U12^T <- F12^T W_L^T), k_gemm<INNER> (right-looking
+//   update of the rest of the current 256-column outer block) -- before an outer block starts k_gemm<LEFT> applies all earlier
+//   outer blocks at once (left-looking: K = hundreds, the rank-64 updates stay inside 256 columns) -> k_gemm<SUPD> F22 -= L21 U12.
+// Everything GEMM-shaped is ONE kernel: C (-)= A B^T on column-major complex128 operands, 64 x 64 tiles, 4 waves, each wave a
+// 32 x 32 block as 2 x 2 x (re, im) accumulators of v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex product block; operands
+// staged through LDS as interleaved complex so one ds_read_b128 feeds the re and im fragments).
+// No pivoting across blocks: K = A + sigma B + sigma^2 C of a Helmholtz problem is complex symmetric with a complex shift
+// (every leading block is a shifted sub-problem); tiny pivots are replaced (static pivoting) and counted, the caller checks the
+// residual and refines.
+//
+// Solves: forward up the levels, backward down, supernodal (dense panels): small fronts run whole in one workgroup per front and
+// level, large fronts step through their pivot blocks with row-tiled launches.  Child updates travel through per-front workspace
+// slices (no atomics: bitwise reproducible).  Transposed solves use the same factors (U^T L^T).
+#include <algorithm>
+#include <string.h>
+#include <vector>
+
+#include "hx_common.h"
+#include "splu_internal.h"
+
+#define NB SPLU_NB
+#define NBO 256                 // outer block of the panel factorisation (left-looking granularity)
+#define GT 64                   // GEMM tile
+#define GK 16                   // GEMM k chunk
+#define GLD (GT + 1)            // LDS stride (complex elements) of a staged operand chunk
+#define DLD (NB + 1)            // LDS stride of the diagonal block
+#define BIG_FRONT_ELEMS (96 * 1024)   // a front whose panel has more entries than this steps through launches in the solves
+#define SOLVE_ROWS 512          // rows per workgroup of the large-front solve kernels
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+enum { K_ZERO = 0, K_EXTEND, K_DIAG, K_PANEL, K_INNER, K_LEFT, K_SUPD,
+       S_FWD_SMALL, S_FWD_GATHER, S_FWD_DIAG, S_FWD_UPD, S_BWD_SMALL, S_BWD_GATHER, S_BWD_DOT, S_BWD_DIAG };
+
+struct SpluDev {
+  const int32_t* sfirst; const int64_t* sptr; const int32_t* srow; const int32_t* rel; const int32_t* sparent;
+  const int64_t* loff; const int64_t* uoff; const int64_t* ioff; const int64_t* soff; const int64_t* woff; const int64_t* poff;
+  const int32_t* child_ptr; const int32_t* child_list;
+  zc* F; zc* W; zc* T; zc* wk; zc* part; int32_t* status;
+};
+
+struct Launch { int kind; int64_t list; int32_t nf; int32_t grid; int32_t p0; };
+
+struct hx_splu {
+  SpluSymbolic sym;
+  int64_t nnz_in = 0;
+  bool factored = false;
+  std::vector<Launch> fplan, fwd_plan, bwd_plan;
+  std::vector<int64_t> poff;
+  int64_t part_elems = 0;
+  // device
+  int32_t *d_i32 = nullptr; int64_t* d_i64 = nullptr; int32_t* d_lists = nullptr; int64_t* d_amap = nullptr;
+  int32_t *d_perm = nullptr, *d_status = nullptr;
+  zc *F = nullptr, *W = nullptr, *T = nullptr, *wk = nullptr, *part = nullptr, *pb = nullptr, *xp = nullptr;
+  SpluDev dev{};
+  int32_t tiny_pivots = 0;
+  double factor_seconds = 0.0;
+};
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int trap_tiles(int tm, int tn) {      // tiles (ti, tj) with ti >= tj
+  int c = 0;
+  for (int tj = 0; tj < tn; ++tj) c += tm > tj ? tm - tj : 0;
+  return c;
+}
+__host__ __device__ static inline int splu_tiles(int kind, int ns, int nr, int p0) {
+  const int m = ns + nr;
+  switch (kind) {
+    case K_PANEL: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return 2 * cdiv(m - c1, GT); }
+    case K_INNER: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB), cj1 = min(ns, (c0 / NBO + 1) * NBO);
+                    return 2 * trap_tiles(cdiv(m - c1, GT), cdiv(cj1 - c1, GT)); }
+    case K_LEFT: { const int cj0 = p0 * NBO, cj1 = min(ns, cj0 + NBO); return 2 * trap_tiles(cdiv(m - cj0, GT), cdiv(cj1 - cj0, GT)); }
+    case K_SUPD: return cdiv(nr, GT) * cdiv(nr, GT);
+    case K_ZERO: return cdiv(nr * nr, 256 * 16);     // nr <= 46 k: no overflow
+    case K_EXTEND: return cdiv(nr, GT) * cdiv(nr, GT);
+    case S_FWD_UPD: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, SOLVE_ROWS); }
+    case S_BWD_DOT: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, SOLVE_ROWS); }
+    default: return 1;
+  }
+}
+
+// which front does workgroup b of a launch serve: prefix[f] <= b < prefix[f + 1]
+__device__ __forceinline__ int find_front(const int32_t* __restrict__ prefix, int nf, int b) {
+  int lo = 0, hi = nf;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= b) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------------- assembly of the fronts
+__global__ void __launch_bounds__(256) k_splu_scatter(int64_t nnz, const int64_t* __restrict__ amap, const zc* __restrict__ val,
+                                                      zc* __restrict__ F) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+    const zc v = val[k];
+    zc* d = F + amap[k];
+    d->x += v.x; d->y += v.y;        // duplicates of a (row, col) pair do not occur in a CSR matrix: plain add
+  }
+}
+
+__global__ void __launch_bounds__(256) k_splu_zero(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf) {
+  const int f = find_front(prefix, nf, blockIdx.x);
+  const int s = fronts[f];
+  const int64_t nr = d.sptr[s + 1] - d.sptr[s];
+  zc* S = d.T + d.soff[s];
+  const int64_t base = (int64_t)(blockIdx.x - prefix[f]) * 256 * 16;
+  for (int q = 0; q < 16; ++q) {
+    const int64_t e = base + q * 256 + threadIdx.x;
+    if (e < nr * nr) S[e] = make_double2(0.0, 0.0);
+  }
+}
+
+// fronts[] holds CHILDREN here: tile (ti, tj) of the child's contribution block is added into its parent's storage
+__global__ void __launch_bounds__(256) k_splu_extend(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf) {
+  const int f = find_front(prefix, nf, blockIdx.x);
+  const int c = fronts[f];
+  const int t = blockIdx.x - prefix[f];
+  const int nrc = (int)(d.sptr[c + 1] - d.sptr[c]);
+  const int tm = cdiv(nrc, GT);
+  const int ti = t % tm, tj = t / tm;
+  const int p = d.sparent[c];
+  const int nsp = d.sfirst[p + 1] - d.sfirst[p];
+  const int64_t nrp = d.sptr[p + 1] - d.sptr[p], mp = nsp + nrp;
+  const int32_t* rel = d.rel + d.sptr[c];
+  const zc* Sc = d.T + d.soff[c];
+  zc* Lp = d.F + d.loff[p];
+  zc* Up = d.F + d.uoff[p];
+  zc* Sp = d.T + (nrp > 0 ? d.soff[p] : 0);
+  __shared__ int32_t rj[GT];
+  if (threadIdx.x < GT) rj[threadIdx.x] = (tj * GT + (int)threadIdx.x < nrc) ? rel[tj * GT + threadIdx.x] : -1;
+  __syncthreads();
+  const int i = ti * GT + (threadIdx.x & 63);
+  if (i >= nrc) return;
+  const int64_t a = rel[i];
+  for (int jj = threadIdx.x >> 6; jj < GT; jj += 4) {
+    const int64_t b = rj[jj];
+    if (b < 0) break;
+    const zc v = Sc[i + (int64_t)(tj * GT + jj) * nrc];
+    zc* dst;
+    if (b < nsp && a >= b) dst = Lp + a + b * mp;
+    else if (a < nsp && b > a) dst = Up + b + a * mp;
+    else dst = Sp + (a - nsp) + (b - nsp) * nrp;
+    dst->x += v.x; dst->y += v.y;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- diagonal block
+// One workgroup per front: D = F[c0:c1, c0:c1] (lower + diagonal from Lp, strict upper from Utp) -> P D = L U in LDS ->
+// W_L = L^-1 P (stored column-major), W_U = U^-1 (stored ROW-major: both are then the "B^T" operand of k_gemm<PANEL>).
+__global__ void __launch_bounds__(256) k_splu_diag(SpluDev d, const int32_t* __restrict__ fronts, int kb) {
+  extern __shared__ zc lds[];
+  zc* D = lds;                     // NB x DLD, element (a, b) at a + b * DLD
+  zc* X = lds + NB * DLD;
+  __shared__ int piv_row;
+  __shared__ double scale_ref;
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  const int c0 = kb * NB, w = min(ns, c0 + NB) - c0;
+  const zc* Lp = d.F + d.loff[s];
+  const zc* Up = d.F + d.uoff[s];
+  const int tid = threadIdx.x;
+  double amax = 0.0;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int a = e & (NB - 1), b = e >> 6;
+    zc v = make_double2(a == b ? 1.0 : 0.0, 0.0);
+    if (a < w && b < w) v = (a >= b) ? Lp[(c0 + a) + (int64_t)(c0 + b) * m] : Up[(c0 + b) + (int64_t)(c0 + a) * m];
+    D[a + b * DLD] = v;
+    X[a + b * DLD] = make_double2(a == b ? 1.0 : 0.0, 0.0);
+    amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
+  }
+  // block-wide max |entry| (reference magnitude of the static pivoting)
+  for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
+  __shared__ double wmax[4];
+  if ((tid & 63) == 0) wmax[tid >> 6] = amax;
+  __syncthreads();
+  if (tid == 0) scale_ref = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+  __syncthreads();
+  for (int k = 0; k < w; ++k) {
+    if (tid < 64) {                              // pivot search in column k, rows k .. w-1
+      double best = -1.0; int row = k;
+      if (tid >= k && tid < w) { const zc v = D[tid + k * DLD]; best = v.x * v.x + v.y * v.y; row = tid; }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o); const int orow = __shfl_xor(row, o);
+        if (ob > best || (ob == best && orow < row)) { best = ob; row = orow; }
+      }
+      if (tid == 0) piv_row = row;
+    }
+    __syncthreads();
+    const int p = piv_row;
+    if (p != k && tid < 2 * NB) {                // swap rows k and p of D (all columns) and of X
+      zc* M = tid < NB ? D : X;
+      const int b = tid & (NB - 1);
+      const zc t = M[k + b * DLD]; M[k + b * DLD] = M[p + b * DLD]; M[p + b * DLD] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      zc pv = D[k + k * DLD];
+      const double tiny = 1e-13 * scale_ref;
+      if (!(pv.x * pv.x + pv.y * pv.y > tiny * tiny)) {       // also catches NaN
+        atomicAdd(d.status, 1);
+        const double nrm = sqrt(pv.x * pv.x + pv.y * pv.y);
+        pv = nrm > 0.0 ? make_double2(pv.x / nrm * 1e-8 * scale_ref, pv.y / nrm * 1e-8 * scale_ref) : make_double2(1e-8 * scale_ref, 0.0);
+        if (!(scale_ref > 0.0)) pv = make_double2(1.0, 0.0);
+        D[k + k * DLD] = pv;
+      }
+    }
+    __syncthreads();
+    const zc inv = zdiv(make_double2(1.0, 0.0), D[k + k * DLD]);
+    __syncthreads();
+    if (tid > k && tid < w) D[tid + k * DLD] = zmul(D[tid + k * DLD], inv);
+    __syncthreads();
+    // trailing update D[a, b] -= l[a] u[b], a, b > k
+    const int rem = w - k - 1;
+    for (int e = tid; e < rem * rem; e += 256) {
+      const int a = k + 1 + e % rem, b = k + 1 + e / rem;
+      zc v = D[a + b * DLD];
+      const zc l = D[a + k * DLD], u = D[k + b * DLD];
+      v.x -= l.x * u.x - l.y * u.y; v.y -= l.x * u.y + l.y * u.x;
+      D[a + b * DLD] = v;
+    }
+    __syncthreads();
+  }
+  // X = P so far.  W_L = L^-1 P: forward substitution on all columns at once
+  for (int k = 0; k < w; ++k) {
+    const int rem = w - k - 1;
+    for (int e = tid; e < rem * w; e += 256) {
+      const int a = k + 1 + e % rem, b = e / rem;
+      const zc l = D[a + k * DLD], x = X[k + b * DLD];
+      zc v = X[a + b * DLD];
+      v.x -= l.x * x.x - l.y * x.y; v.y -= l.x * x.y + l.y * x.x;
+      X[a + b * DLD] = v;
+    }
+    __syncthreads();
+  }
+  zc* WL = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB;
+  zc* WU = WL + NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int a = e & (NB - 1), b = e >> 6;
+    WL[a + b * NB] = (a < w && b < w) ? X[a + b * DLD] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  // W_U = U^-1: backward substitution on the identity
+  for (int e = tid; e < NB * NB; e += 256) { const int a = e & (NB - 1), b = e >> 6; X[a + b * DLD] = make_double2(a == b ? 1.0 : 0.0, 0.0); }
+  __syncthreads();
+  for (int k = w - 1; k >= 0; --k) {
+    const zc inv = zdiv(make_double2(1.0, 0.0), D[k + k * DLD]);
+    if (tid < w) X[k + tid * DLD] = zmul(X[k + tid * DLD], inv);
+    __syncthreads();
+    for (int e = tid; e < k * w; e += 256) {
+      const int a = e % k, b = e / k;
+      const zc u = D[a + k * DLD], x = X[k + b * DLD];
+      zc v = X[a + b * DLD];
+      v.x -= u.x * x.x - u.y * x.y; v.y -= u.x * x.y + u.y * x.x;
+      X[a + b * DLD] = v;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int b = e & (NB - 1), a = e >> 6;          // row-major: W_U[a, b] at a * NB + b
+    WU[a * NB + b] = (a < w && b < w) ? X[a + b * DLD] : make_double2(0.0, 0.0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- GEMM  C (-)= A B^T
+// A: M x K, B: N x K, C: M x N, all column-major complex128.  ASSIGN: C = A B^T (C may be A itself when N = K <= 64: every
+// operand chunk is in LDS / registers before the first store).  One 64 x 64 tile per workgroup.
+// MFMA mapping: D[row][col] of v_mfma_f64_16x16x4_f64 has col = lane & 15, so the tile's ROW index i (contiguous in memory)
+// rides on lane & 15: the "a" operand is the B-matrix fragment (index j), the "b" operand the A-matrix fragment (index i).
+struct GemmProb { const zc* A; const zc* B; zc* C; int64_t lda, ldb, ldc; int M, N, K; };
+
+template <bool ASSIGN>
+__device__ __forceinline__ void gemm_tile(const GemmProb& p, int ti, int tj, zc* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wi = wv & 1, wj = wv >> 1;
+  const int row0 = ti * GT, col0 = tj * GT;
+  const int lr = tid & 63, lk = tid >> 6;           // staging: row lr, k offset lk + 4q
+  const bool a_ok = row0 + lr < p.M, b_ok = col0 + lr < p.N;
+  const zc* Ag = p.A + row0 + lr;
+  const zc* Bg = p.B + col0 + lr;
+  zc ra[4], rb[4];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + lk + 4 * q;
+      ra[q] = (a_ok && k < p.K) ? Ag[(int64_t)k * p.lda] : make_double2(0.0, 0.0);
+      rb[q] = (b_ok && k < p.K) ? Bg[(int64_t)k * p.ldb] : make_double2(0.0, 0.0);
+    }
+  };
+  v4d cr[2][2], ci[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) { cr[x][y] = (v4d){0, 0, 0, 0}; ci[x][y] = (v4d){0, 0, 0, 0}; }
+  load(0);
+  int buf = 0;
+  const int fi = lane & 15, fk = lane >> 4;
+  for (int k0 = 0; k0 < p.K; k0 += GK) {
+    zc* sA = lds + buf * 2 * GK * GLD;
+    zc* sB = sA + GK * GLD;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sA[(lk + 4 * q) * GLD + lr] = ra[q]; sB[(lk + 4 * q) * GLD + lr] = rb[q]; }
+    __syncthreads();
+    if (k0 + GK < p.K) load(k0 + GK);
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 4) {
+      zc av[2], bv[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        av[x] = sA[(kk + fk) * GLD + 32 * wi + 16 * x + fi];
+        bv[x] = sB[(kk + fk) * GLD + 32 * wj + 16 * x + fi];
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          cr[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[y].x, av[x].x, cr[x][y], 0, 0, 0);
+          cr[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[y].y, -av[x].y, cr[x][y], 0, 0, 0);
+          ci[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[y].y, av[x].x, ci[x][y], 0, 0, 0);
+          ci[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[y].x, av[x].y, ci[x][y], 0, 0, 0);
+        }
+    }
+    buf ^= 1;
+  }
+  // D[row = j][col = i]: lane & 15 -> i, (lane >> 4) + 4 r -> j
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = row0 + 32 * wi + 16 * x + fi;
+        const int j = col0 + 32 * wj + 16 * y + fk + 4 * r;
+        if (i < p.M && j < p.N) {
+          zc* c = p.C + i + (int64_t)j * p.ldc;
+          if (ASSIGN) *c = make_double2(cr[x][y][r], ci[x][y][r]);
+          else { zc v = *c; v.x -= cr[x][y][r]; v.y -= ci[x][y][r]; *c = v; }
+        }
+      }
+}
+
+// trapezoid decode: t-th tile (ti >= tj) of a tm x tn tile grid, column by column
+__device__ __forceinline__ void trap_decode(int t, int tm, int tn, int& ti, int& tj) {
+  tj = 0;
+  for (; tj < tn; ++tj) {
+    const int c = tm > tj ? tm - tj : 0;
+    if (t < c) break;
+    t -= c;
+  }
+  ti = tj + t;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf, int p0) {
+  extern __shared__ zc lds[];
+  const int f = find_front(prefix, nf, blockIdx.x);
+  const int s = fronts[f];
+  int t = blockIdx.x - prefix[f];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int nr = (int)(d.sptr[s + 1] - d.sptr[s]);
+  const int64_t m = ns + nr;
+  zc* Lp = d.F + d.loff[s];
+  zc* Up = d.F + d.uoff[s];
+  GemmProb p;
+  int ti, tj;
+  if (KIND == K_PANEL) {
+    const int c0 = p0 * NB, c1 = min(ns, c0 + NB);
+    const int tm = cdiv((int)m - c1, GT);
+    const int side = t / tm; ti = t % tm; tj = 0;
+    zc* P = side == 0 ? Lp : Up;
+    const zc* Wb = d.W + d.ioff[s] + (int64_t)p0 * 2 * NB * NB + (side == 0 ? NB * NB : 0);   // side 0: W_U (row-major), side 1: W_L
+    p.A = P + c1 + (int64_t)c0 * m; p.lda = m; p.C = (zc*)p.A; p.ldc = m; p.B = Wb; p.ldb = NB;
+    p.M = (int)m - c1; p.N = p.K = c1 - c0;
+    gemm_tile<true>(p, ti, tj, lds);
+  } else if (KIND == K_INNER || KIND == K_LEFT) {
+    int r0, k0, k1, cj1;           // C = P[r0:m, r0:cj1] -= P[r0:m, k0:k1] Q[r0:cj1, k0:k1]^T
+    if (KIND == K_INNER) { k0 = p0 * NB; k1 = min(ns, k0 + NB); r0 = k1; cj1 = min(ns, (k0 / NBO + 1) * NBO); }
+    else { k0 = 0; k1 = p0 * NBO; r0 = k1; cj1 = min(ns, r0 + NBO); }
+    const int tm = cdiv((int)m - r0, GT), tn = cdiv(cj1 - r0, GT);
+    const int per = trap_tiles(tm, tn);
+    const int side = t / per; t -= side * per;
+    trap_decode(t, tm, tn, ti, tj);
+    zc* P = side == 0 ? Lp : Up;
+    zc* Q = side == 0 ? Up : Lp;
+    p.A = P + r0 + (int64_t)k0 * m; p.lda = m; p.B = Q + r0 + (int64_t)k0 * m; p.ldb = m;
+    p.C = P + r0 + (int64_t)r0 * m; p.ldc = m; p.M = (int)m - r0; p.N = cj1 - r0; p.K = k1 - k0;
+    gemm_tile<false>(p, ti, tj, lds);
+  } else {   // K_SUPD
+    const int tm = cdiv(nr, GT);
+    ti = t % tm; tj = t / tm;
+    p.A = Lp + ns; p.lda = m; p.B = Up + ns; p.ldb = m; p.C = d.T + d.soff[s]; p.ldc = nr; p.M = p.N = nr; p.K = ns;
+    gemm_tile<false>(p, ti, tj, lds);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- solves
+// y (length w) = W v for a 64 x 64 stored block; COLMAJOR: element (a, k) at a + k NB, else at a NB + k.  All 256 threads.
+template <bool COLMAJOR>
+__device__ __forceinline__ void block_apply(const zc* __restrict__ Wb, int w, const zc* sv, zc* sy, zc* sred) {
+  const int a = threadIdx.x & 63, q = threadIdx.x >> 6;
+  zc acc = make_double2(0.0, 0.0);
+  if (a < w)
+    for (int k = q * 16; k < min(w, q * 16 + 16); ++k) zfma(acc, COLMAJOR ? Wb[a + k * NB] : Wb[a * NB + k], sv[k]);
+  sred[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    zc r = zadd(zadd(sred[a], sred[a + 64]), zadd(sred[a + 128], sred[a + 192]));
+    sy[a] = r;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void fwd_gather(const SpluDev& d, int s, int ns, int64_t m, const zc* __restrict__ pb, zc* w) {
+  const int first = d.sfirst[s];
+  for (int64_t i = threadIdx.x; i < m; i += blockDim.x) w[i] = i < ns ? pb[first + i] : make_double2(0.0, 0.0);
+  __syncthreads();
+  for (int q = d.child_ptr[s]; q < d.child_ptr[s + 1]; ++q) {
+    const int c = d.child_list[q];
+    const int nsc = d.sfirst[c + 1] - d.sfirst[c];
+    const int64_t nrc = d.sptr[c + 1] - d.sptr[c];
+    const zc* wc = d.wk + d.woff[c] + nsc;
+    const int32_t* rel = d.rel + d.sptr[c];
+    for (int64_t i = threadIdx.x; i < nrc; i += blockDim.x) { zc* t = w + rel[i]; const zc v = wc[i]; t->x += v.x; t->y += v.y; }
+    __syncthreads();
+  }
+}
+
+// forward: w[0:ns] <- block-forward-substituted right-hand side (= y of this supernode), w[ns:m] <- update for the ancestors
+__global__ void __launch_bounds__(256) k_splu_fwd_small(SpluDev d, const int32_t* __restrict__ fronts, int trans,
+                                                        const zc* __restrict__ pb, zc* __restrict__ y) {
+  __shared__ zc sv[NB], sy[NB], sred[256];
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  zc* w = d.wk + d.woff[s];
+  const zc* P = d.F + (trans ? d.uoff[s] : d.loff[s]);
+  fwd_gather(d, s, ns, m, pb, w);
+  for (int kb = 0; kb * NB < ns; ++kb) {
+    const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
+    const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB + (trans ? NB * NB : 0);
+    if (threadIdx.x < wd) sv[threadIdx.x] = w[c0 + threadIdx.x];
+    __syncthreads();
+    block_apply<true>(Wb, wd, sv, sy, sred);
+    if (threadIdx.x < wd) w[c0 + threadIdx.x] = sy[threadIdx.x];
+    for (int64_t r = c1 + threadIdx.x; r < m; r += 256) {
+      zc acc = make_double2(0.0, 0.0);
+      const zc* pr = P + r + (int64_t)c0 * m;
+      for (int k = 0; k < wd; ++k) zfma(acc, pr[(int64_t)k * m], sy[k]);
+      w[r].x -= acc.x; w[r].y -= acc.y;
+    }
+    __syncthreads();
+  }
+  const int first = d.sfirst[s];
+  for (int i = threadIdx.x; i < ns; i += 256) y[first + i] = w[i];
+}
+
+__global__ void __launch_bounds__(256) k_splu_fwd_gather(SpluDev d, const int32_t* __restrict__ fronts, const zc* __restrict__ pb) {
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  fwd_gather(d, s, ns, m, pb, d.wk + d.woff[s]);
+}
+
+// large fronts, pivot block kb: w[c0:c1] <- W w[c0:c1]  (also written to y)
+__global__ void __launch_bounds__(256) k_splu_fwd_diag(SpluDev d, const int32_t* __restrict__ fronts, int kb, int trans, zc* __restrict__ y) {
+  __shared__ zc sv[NB], sy[NB], sred[256];
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int c0 = kb * NB, wd = min(ns, c0 + NB) - c0;
+  zc* w = d.wk + d.woff[s];
+  const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB + (trans ? NB * NB : 0);
+  if (threadIdx.x < wd) sv[threadIdx.x] = w[c0 + threadIdx.x];
+  __syncthreads();
+  block_apply<true>(Wb, wd, sv, sy, sred);
+  if (threadIdx.x < wd) { w[c0 + threadIdx.x] = sy[threadIdx.x]; y[d.sfirst[s] + c0 + threadIdx.x] = sy[threadIdx.x]; }
+}
+
+// large fronts, pivot block kb: w[c1:m] -= P[c1:m, c0:c1] w[c0:c1]; SOLVE_ROWS rows per workgroup
+__global__ void __launch_bounds__(256) k_splu_fwd_upd(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf,
+                                                      int kb, int trans) {
+  __shared__ zc sy[NB];
+  const int f = find_front(prefix, nf, blockIdx.x);
+  const int s = fronts[f];
+  const int t = blockIdx.x - prefix[f];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
+  zc* w = d.wk + d.woff[s];
+  const zc* P = d.F + (trans ? d.uoff[s] : d.loff[s]);
+  if (threadIdx.x < wd) sy[threadIdx.x] = w[c0 + threadIdx.x];
+  __syncthreads();
+  const int64_t rend = min(m, (int64_t)c1 + (int64_t)(t + 1) * SOLVE_ROWS);
+  for (int64_t r = c1 + (int64_t)t * SOLVE_ROWS + threadIdx.x; r < rend; r += 256) {
+    zc acc = make_double2(0.0, 0.0);
+    const zc* pr = P + r + (int64_t)c0 * m;
+    for (int k = 0; k < wd; ++k) zfma(acc, pr[(int64_t)k * m], sy[k]);
+    w[r].x -= acc.x; w[r].y -= acc.y;
+  }
+}
+
+__device__ __forceinline__ void bwd_gather(const SpluDev& d, int s, int ns, int64_t m, const zc* __restrict__ y, const zc* __restrict__ x, zc* w) {
+  const int first = d.sfirst[s];
+  const int32_t* rows = d.srow + d.sptr[s];
+  for (int64_t i = threadIdx.x; i < m; i += blockDim.x) w[i] = i < ns ? y[first + i] : x[rows[i - ns]];
+  __syncthreads();
+}
+
+// column dots of one pivot block against w[r0:r1]: out[k] = sum_a P[a, c0 + k] w[a]; wave wv takes k = wv, wv + 4, ...
+__device__ __forceinline__ void block_dots(const zc* __restrict__ P, int64_t m, int c0, int wd, int64_t r0, int64_t r1, const zc* __restrict__ w, zc* out) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = wv; k < wd; k += 4) {
+    zc acc = make_double2(0.0, 0.0);
+    const zc* pc = P + (int64_t)(c0 + k) * m;
+    for (int64_t a = r0 + lane; a < r1; a += 64) zfma(acc, pc[a], w[a]);
+    acc = zreduce_sub<64>(acc);
+    if (lane == 0) out[k] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_splu_bwd_small(SpluDev d, const int32_t* __restrict__ fronts, int trans,
+                                                        const zc* __restrict__ y, zc* __restrict__ x) {
+  __shared__ zc sv[NB], sy[NB], sred[256];
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  zc* w = d.wk + d.woff[s];
+  const zc* P = d.F + (trans ? d.loff[s] : d.uoff[s]);
+  bwd_gather(d, s, ns, m, y, x, w);
+  for (int kb = (ns - 1) / NB; kb >= 0; --kb) {
+    const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
+    const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB + (trans ? 0 : NB * NB);
+    block_dots(P, m, c0, wd, c1, m, w, sy);
+    __syncthreads();
+    if (threadIdx.x < wd) sv[threadIdx.x] = zsub(w[c0 + threadIdx.x], sy[threadIdx.x]);
+    __syncthreads();
+    block_apply<false>(Wb, wd, sv, sy, sred);
+    if (threadIdx.x < wd) w[c0 + threadIdx.x] = sy[threadIdx.x];
+    __syncthreads();
+  }
+  const int first = d.sfirst[s];
+  for (int i = threadIdx.x; i < ns; i += 256) x[first + i] = w[i];
+}
+
+__global__ void __launch_bounds__(256) k_splu_bwd_gather(SpluDev d, const int32_t* __restrict__ fronts, const zc* __restrict__ y, const zc* __restrict__ x) {
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  bwd_gather(d, s, ns, m, y, x, d.wk + d.woff[s]);
+}
+
+__global__ void __launch_bounds__(256) k_splu_bwd_dot(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf,
+                                                      int kb, int trans) {
+  const int f = find_front(prefix, nf, blockIdx.x);
+  const int s = fronts[f];
+  const int t = blockIdx.x - prefix[f];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
+  const zc* P = d.F + (trans ? d.loff[s] : d.uoff[s]);
+  const int64_t r0 = c1 + (int64_t)t * SOLVE_ROWS, r1 = min(m, r0 + SOLVE_ROWS);
+  block_dots(P, m, c0, wd, r0, r1, d.wk + d.woff[s], d.part + d.poff[s] + (int64_t)t * NB);
+}
+
+__global__ void __launch_bounds__(256) k_splu_bwd_diag(SpluDev d, const int32_t* __restrict__ fronts, int kb, int trans, zc* __restrict__ x) {
+  __shared__ zc sv[NB], sy[NB], sred[256];
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
+  zc* w = d.wk + d.woff[s];
+  const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB + (trans ? 0 : NB * NB);
+  const int ntile = cdiv((int)(m - c1), SOLVE_ROWS);
+  if (threadIdx.x < wd) {
+    zc acc = make_double2(0.0, 0.0);
+    const zc* pp = d.part + d.poff[s] + threadIdx.x;
+    for (int t = 0; t < ntile; ++t) acc = zadd(acc, pp[(int64_t)t * NB]);
+    sv[threadIdx.x] = zsub(w[c0 + threadIdx.x], acc);
+  }
+  __syncthreads();
+  block_apply<false>(Wb, wd, sv, sy, sred);
+  if (threadIdx.x < wd) { w[c0 + threadIdx.x] = sy[threadIdx.x]; x[d.sfirst[s] + c0 + threadIdx.x] = sy[threadIdx.x]; }
+}
+
+__global__ void __launch_bounds__(256) k_splu_permute(int32_t n, const int32_t* __restrict__ perm, const zc* __restrict__ in, zc* __restrict__ out, int scatter) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (scatter) out[perm[i]] = in[i]; else out[i] = in[perm[i]];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+static void add_launch(std::vector<Launch>& plan, std::vector<int32_t>& lists, int kind, const std::vector<int32_t>& fronts,
+                       const SpluSymbolic& S, int p0, bool tiled) {
+  if (fronts.empty()) return;
+  Launch L; L.kind = kind; L.list = (int64_t)lists.size(); L.nf = (int32_t)fronts.size(); L.p0 = p0;
+  lists.insert(lists.end(), fronts.begin(), fronts.end());
+  if (tiled) {
+    int32_t acc = 0;
+    lists.push_back(0);
+    for (int32_t s : fronts) {
+      const int ns = S.sfirst[s + 1] - S.sfirst[s], nr = (int)(S.sptr[s + 1] - S.sptr[s]);
+      acc += splu_tiles(kind, ns, nr, p0);
+      lists.push_back(acc);
+    }
+    L.grid = acc;
+  } else {
+    L.grid = L.nf;
+  }
+  if (L.grid > 0) plan.push_back(L);
+}
+
+static void build_plans(hx_splu* h, std::vector<int32_t>& lists) {
+  const SpluSymbolic& S = h->sym;
+  auto ns_of = [&](int s) { return S.sfirst[s + 1] - S.sfirst[s]; };
+  auto nr_of = [&](int s) { return (int)(S.sptr[s + 1] - S.sptr[s]); };
+  h->poff.assign(S.nsuper, 0);
+  int64_t pcur = 0;
+  std::vector<char> big(S.nsuper, 0);
+  for (int s = 0; s < S.nsuper; ++s) {
+    const int64_t ns = ns_of(s), m = ns + nr_of(s);
+    if (m * ns > BIG_FRONT_ELEMS) { big[s] = 1; h->poff[s] = pcur; pcur += (int64_t)cdiv((int)m, SOLVE_ROWS) * NB; }
+  }
+  h->part_elems = pcur;
+  std::vector<std::vector<int32_t>> fwd_by_level(S.nlevels);
+  for (int l = 0; l < S.nlevels; ++l) {
+    std::vector<int32_t> fr(S.level_list.begin() + S.level_ptr[l], S.level_list.begin() + S.level_ptr[l + 1]);
+    // ---- factorisation
+    std::vector<int32_t> sel;
+    for (int s : fr) if (nr_of(s) > 0) sel.push_back(s);
+    add_launch(h->fplan, lists, K_ZERO, sel, S, 0, true);
+    for (int r = 0;; ++r) {
+      sel.clear();
+      for (int s : fr) if (S.child_ptr[s + 1] - S.child_ptr[s] > r) sel.push_back(S.child_list[S.child_ptr[s] + r]);
+      if (sel.empty()) break;
+      add_launch(h->fplan, lists, K_EXTEND, sel, S, 0, true);
+    }
+    int max_ns = 0;
+    for (int s : fr) max_ns = std::max(max_ns, ns_of(s));
+    for (int kb = 0; kb * NB < max_ns; ++kb) {
+      const int c0 = kb * NB;
+      if (c0 % NBO == 0 && c0 > 0) {
+        sel.clear();
+        for (int s : fr) if (ns_of(s) > c0) sel.push_back(s);
+        add_launch(h->fplan, lists, K_LEFT, sel, S, c0 / NBO, true);
+      }
+      sel.clear();
+      for (int s : fr) if (ns_of(s) > c0) sel.push_back(s);
+      add_launch(h->fplan, lists, K_DIAG, sel, S, kb, false);
+      std::vector<int32_t> sp, si;
+      for (int s : sel) {
+        const int ns = ns_of(s), m = ns + nr_of(s), c1 = std::min(ns, c0 + NB), cj1 = std::min(ns, (c0 / NBO + 1) * NBO);
+        if (m > c1) sp.push_back(s);
+        if (cj1 > c1) si.push_back(s);
+      }
+      add_launch(h->fplan, lists, K_PANEL, sp, S, kb, true);
+      add_launch(h->fplan, lists, K_INNER, si, S, kb, true);
+    }
+    sel.clear();
+    for (int s : fr) if (nr_of(s) > 0) sel.push_back(s);
+    add_launch(h->fplan, lists, K_SUPD, sel, S, 0, true);
+    // ---- solves
+    std::vector<int32_t> small, large;
+    for (int s : fr) (big[s] ? large : small).push_back(s);
+    add_launch(h->fwd_plan, lists, S_FWD_SMALL, small, S, 0, false);
+    add_launch(h->fwd_plan, lists, S_FWD_GATHER, large, S, 0, false);
+    int max_big = 0;
+    for (int s : large) max_big = std::max(max_big, ns_of(s));
+    for (int kb = 0; kb * NB < max_big; ++kb) {
+      sel.clear();
+      std::vector<int32_t> su;
+      for (int s : large) if (ns_of(s) > kb * NB) { sel.push_back(s); if (ns_of(s) + nr_of(s) > std::min(ns_of(s), kb * NB + NB)) su.push_back(s); }
+      add_launch(h->fwd_plan, lists, S_FWD_DIAG, sel, S, kb, false);
+      add_launch(h->fwd_plan, lists, S_FWD_UPD, su, S, kb, true);
+    }
+  }
+  for (int l = S.nlevels - 1; l >= 0; --l) {
+    std::vector<int32_t> small, large, sel;
+    for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) { const int s = S.level_list[k]; (big[s] ? large : small).push_back(s); }
+    add_launch(h->bwd_plan, lists, S_BWD_SMALL, small, S, 0, false);
+    add_launch(h->bwd_plan, lists, S_BWD_GATHER, large, S, 0, false);
+    int max_big = 0;
+    for (int s : large) max_big = std::max(max_big, ns_of(s));
+    for (int kb = (max_big - 1) / NB; kb >= 0 && max_big > 0; --kb) {
+      sel.clear();
+      std::vector<int32_t> sd;
+      for (int s : large) if (ns_of(s) > kb * NB) { sel.push_back(s); if (ns_of(s) + nr_of(s) > std::min(ns_of(s), kb * NB + NB)) sd.push_back(s); }
+      add_launch(h->bwd_plan, lists, S_BWD_DOT, sd, S, kb, true);
+      add_launch(h->bwd_plan, lists, S_BWD_DIAG, sel, S, kb, false);
+    }
+  }
+}
+
+template <typename T>
+static hipError_t upload(T** dst, const std::vector<T>& v) {
+  hipError_t e = hx_malloc(dst, std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (!v.empty()) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+
+static void splu_release(hx_splu* h) {
+  hx_free(h->d_i32); hx_free(h->d_i64); hx_free(h->d_lists); hx_free(h->d_amap); hx_free(h->d_perm); hx_free(h->d_status);
+  hx_free(h->F); hx_free(h->W); hx_free(h->T); hx_free(h->wk); hx_free(h->part); hx_free(h->pb); hx_free(h->xp);
+  h->d_i32 = h->d_lists = h->d_perm = h->d_status = nullptr; h->d_i64 = h->d_amap = nullptr;
+  h->F = h->W = h->T = h->wk = h->part = h->pb = h->xp = nullptr;
+}
+
+extern "C" int hx_splu_analyse(hx_splu** out, int32_t n, const int32_t* h_rowptr, const int32_t* h_col,
+                               const double* h_coords, int dim, int leaf_size) {
+  HX_REQUIRE(out && h_rowptr && h_col, "null argument");
+  hx_splu* h = new hx_splu();
+  const int rc = splu_analyse_host(h->sym, n, h_rowptr, h_col, h_coords, dim, leaf_size > 0 ? leaf_size : SPLU_NB);
+  if (rc != HX_OK) { delete h; return rc; }
+  h->nnz_in = h_rowptr[n];
+  *out = h;
+  return HX_OK;
+}
+
+// uploads the plan; called by the first hx_splu_factor (the analysis itself needs no device)
+static int splu_prepare_device(hx_splu* h) {
+  if (h->d_i32) return HX_OK;
+  const SpluSymbolic& S = h->sym;
+  std::vector<int32_t> lists;
+  build_plans(h, lists);
+  // one int32 and one int64 slab
+  std::vector<int32_t> i32;
+  std::vector<int64_t> i64;
+  auto put32 = [&](const std::vector<int32_t>& v) { const size_t o = i32.size(); i32.insert(i32.end(), v.begin(), v.end()); return o; };
+  auto put64 = [&](const std::vector<int64_t>& v) { const size_t o = i64.size(); i64.insert(i64.end(), v.begin(), v.end()); return o; };
+  const size_t o_sfirst = put32(S.sfirst), o_srow = put32(S.srow), o_rel = put32(S.rel), o_par = put32(S.sparent),
+               o_cp = put32(S.child_ptr), o_cl = put32(S.child_list);
+  const size_t o_sptr = put64(S.sptr), o_loff = put64(S.loff), o_uoff = put64(S.uoff), o_ioff = put64(S.ioff), o_soff = put64(S.soff),
+               o_woff = put64(S.woff), o_poff = put64(h->poff);
+  HX_HIP(upload(&h->d_i32, i32));
+  HX_HIP(upload(&h->d_i64, i64));
+  HX_HIP(upload(&h->d_lists, lists));
+  HX_HIP(upload(&h->d_amap, S.amap));
+  HX_HIP(upload(&h->d_perm, S.perm));
+  HX_HIP(hx_malloc(&h->d_status, 4 * sizeof(int32_t)));
+  HX_HIP(hx_malloc(&h->F, std::max<int64_t>(S.factor_elems, 1) * sizeof(zc)));
+  HX_HIP(hx_malloc(&h->W, std::max<int64_t>(S.inverse_elems, 1) * sizeof(zc)));
+  HX_HIP(hx_malloc(&h->wk, std::max<int64_t>(S.work_elems, 1) * sizeof(zc)));
+  HX_HIP(hx_malloc(&h->part, std::max<int64_t>(h->part_elems, 1) * sizeof(zc)));
+  HX_HIP(hx_malloc(&h->pb, (size_t)S.n * sizeof(zc)));
+  HX_HIP(hx_malloc(&h->xp, (size_t)S.n * sizeof(zc)));
+  SpluDev& d = h->dev;
+  d.sfirst = h->d_i32 + o_sfirst; d.srow = h->d_i32 + o_srow; d.rel = h->d_i32 + o_rel; d.sparent = h->d_i32 + o_par;
+  d.child_ptr = h->d_i32 + o_cp; d.child_list = h->d_i32 + o_cl;
+  d.sptr = h->d_i64 + o_sptr; d.loff = h->d_i64 + o_loff; d.uoff = h->d_i64 + o_uoff; d.ioff = h->d_i64 + o_ioff;
+  d.soff = h->d_i64 + o_soff; d.woff = h->d_i64 + o_woff; d.poff = h->d_i64 + o_poff;
+  d.F = h->F; d.W = h->W; d.T = nullptr; d.wk = h->wk; d.part = h->part; d.status = h->d_status;
+  return HX_OK;
+}
+
+extern "C" int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream stream) {
+  HX_REQUIRE(h && val, "null argument");
+  int rc = splu_prepare_device(h);
+  if (rc != HX_OK) return rc;
+  hipStream_t st = hx_s(stream);
+  const SpluSymbolic& S = h->sym;
+  hipEvent_t e0, e1;
+  HX_HIP(hipEventCreate(&e0)); HX_HIP(hipEventCreate(&e1));
+  HX_HIP(hipEventRecord(e0, st));
+  HX_HIP(hx_malloc(&h->T, std::max<int64_t>(S.temp_elems, 1) * sizeof(zc)));
+  h->dev.T = h->T;
+  HX_HIP(hipMemsetAsync(h->F, 0, S.factor_elems * sizeof(zc), st));
+  HX_HIP(hipMemsetAsync(h->d_status, 0, 4 * sizeof(int32_t), st));
+  k_splu_scatter<<<hx_grid(h->nnz_in, 256), 256, 0, st>>>(h->nnz_in, h->d_amap, (const zc*)val, h->F);
+  HX_LAUNCH_CHECK("k_splu_scatter");
+  const size_t gemm_lds = 2 * 2 * GK * GLD * sizeof(zc), diag_lds = 2 * NB * DLD * sizeof(zc);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HX_HIP(hipFuncSetAttribute((const void*)k_splu_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+    HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_PANEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_INNER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_LEFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_SUPD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    attr_done = true;
+  }
+  for (const Launch& L : h->fplan) {
+    const int32_t* fr = h->d_lists + L.list;
+    const int32_t* px = fr + L.nf;
+    switch (L.kind) {
+      case K_ZERO: k_splu_zero<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf); break;
+      case K_EXTEND: k_splu_extend<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf); break;
+      case K_DIAG: k_splu_diag<<<L.grid, 256, diag_lds, st>>>(h->dev, fr, L.p0); break;
+      case K_PANEL: k_splu_gemm<K_PANEL><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      case K_INNER: k_splu_gemm<K_INNER><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      case K_LEFT: k_splu_gemm<K_LEFT><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      case K_SUPD: k_splu_gemm<K_SUPD><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      default: break;
+    }
+    HX_LAUNCH_CHECK("hx_splu_factor");
+  }
+  HX_HIP(hipEventRecord(e1, st));
+  int32_t status[4] = {0, 0, 0, 0};
+  HX_HIP(hipMemcpyAsync(status, h->d_status, sizeof(status), hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  float ms = 0.f;
+  HX_HIP(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  h->factor_seconds = ms * 1e-3;
+  h->tiny_pivots = status[0];
+  hx_free(h->T); h->T = nullptr; h->dev.T = nullptr;      // the contribution blocks are dead: back to the pool
+  h->factored = true;
+  return HX_OK;
+}
+
+extern "C" int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int transposed, hx_stream stream) {
+  HX_REQUIRE(h && b && x, "null argument");
+  HX_REQUIRE(h->factored, "hx_splu_factor has not run");
+  hipStream_t st = hx_s(stream);
+  const SpluSymbolic& S = h->sym;
+  const int tr = transposed ? 1 : 0;
+  k_splu_permute<<<hx_grid(S.n, 256), 256, 0, st>>>(S.n, h->d_perm, (const zc*)b, h->pb, 0);
+  // forward writes y into xp, backward overwrites it with x supernode by supernode (a front reads y of its own columns only)
+  zc* y = h->xp;
+  for (const Launch& L : h->fwd_plan) {
+    const int32_t* fr = h->d_lists + L.list;
+    const int32_t* px = fr + L.nf;
+    switch (L.kind) {
+      case S_FWD_SMALL: k_splu_fwd_small<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, h->pb, y); break;
+      case S_FWD_GATHER: k_splu_fwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, h->pb); break;
+      case S_FWD_DIAG: k_splu_fwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0, tr, y); break;
+      case S_FWD_UPD: k_splu_fwd_upd<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
+      default: break;
+    }
+  }
+  for (const Launch& L : h->bwd_plan) {
+    const int32_t* fr = h->d_lists + L.list;
+    const int32_t* px = fr + L.nf;
+    switch (L.kind) {
+      case S_BWD_SMALL: k_splu_bwd_small<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, y, y); break;
+      case S_BWD_GATHER: k_splu_bwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, y, y); break;
+      case S_BWD_DOT: k_splu_bwd_dot<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
+      case S_BWD_DIAG: k_splu_bwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0, tr, y); break;
+      default: break;
+    }
+  }
+  k_splu_permute<<<hx_grid(S.n, 256), 256, 0, st>>>(S.n, h->d_perm, y, (zc*)x, 1);
+  HX_LAUNCH_CHECK("hx_splu_solve");
+  return HX_OK;
+}
+
+extern "C" int hx_splu_info(const hx_splu* h, int64_t* iout, double* dout) {
+  HX_REQUIRE(h && iout && dout, "null argument");
+  const SpluSymbolic& S = h->sym;
+  iout[0] = S.n; iout[1] = S.nsuper; iout[2] = S.nlevels; iout[3] = S.nnz_L; iout[4] = S.factor_elems;
+  iout[5] = S.inverse_elems; iout[6] = S.temp_elems; iout[7] = S.work_elems; iout[8] = S.max_front; iout[9] = S.max_ns;
+  iout[10] = (int64_t)S.srow.size(); iout[11] = h->nnz_in; iout[12] = h->tiny_pivots;
+  iout[13] = (int64_t)h->fplan.size(); iout[14] = (int64_t)h->fwd_plan.size(); iout[15] = (int64_t)h->bwd_plan.size();
+  dout[0] = S.flops; dout[1] = S.analyse_seconds; dout[2] = h->factor_seconds;
+  return HX_OK;
+}
+
+template <typename T>
+static int copy_out(const std::vector<T>& v, void* h_out, int64_t capacity_bytes, int64_t* count) {
+  if (count) *count = (int64_t)v.size();
+  if (!h_out) return HX_OK;
+  if ((int64_t)(v.size() * sizeof(T)) > capacity_bytes) return hx_fail(HX_ERR_ARG, "hx_splu_symbolic", "buffer too small");
+  memcpy(h_out, v.data(), v.size() * sizeof(T));
+  return HX_OK;
+}
+
+extern "C" int hx_splu_symbolic(const hx_splu* h, const char* name, void* h_out, int64_t capacity_bytes, int64_t* count) {
+  HX_REQUIRE(h && name, "null argument");
+  const SpluSymbolic& S = h->sym;
+#define HX_SPLU_FIELD(f) if (!strcmp(name, #f)) return copy_out(S.f, h_out, capacity_bytes, count)
+  HX_SPLU_FIELD(perm); HX_SPLU_FIELD(iperm); HX_SPLU_FIELD(sfirst); HX_SPLU_FIELD(sparent); HX_SPLU_FIELD(sptr);
+  HX_SPLU_FIELD(srow); HX_SPLU_FIELD(rel); HX_SPLU_FIELD(slevel); HX_SPLU_FIELD(level_ptr); HX_SPLU_FIELD(level_list);
+  HX_SPLU_FIELD(child_ptr); HX_SPLU_FIELD(child_list); HX_SPLU_FIELD(loff); HX_SPLU_FIELD(uoff); HX_SPLU_FIELD(ioff);
+  HX_SPLU_FIELD(soff); HX_SPLU_FIELD(woff); HX_SPLU_FIELD(amap);
+#undef HX_SPLU_FIELD
+  return hx_fail(HX_ERR_ARG, "hx_splu_symbolic", "unknown field");
+}
+
+extern "C" int hx_splu_destroy(hx_splu* h) {
+  if (!h) return HX_OK;
+  splu_release(h);
+  delete h;
+  return HX_OK;
+}

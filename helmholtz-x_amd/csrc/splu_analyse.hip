@@ -1,0 +1,411 @@
+// Host analysis of the sparse direct solver (hx_splu_analyse): fill-reducing ordering, supernodes, fronts, storage plan.
+//
+// replaces: the symbolic phase of PCLU / MUMPS behind ST sinvert (eigensolvers.py:49-50,102-103 of the reference; METIS / SCOTCH
+// orderings inside MUMPS).  No device code in this file.
+//
+//  1. graph of the pattern of A + A^T (no diagonal);
+//  2. nested dissection.  With vertex coordinates: recursive INERTIAL bisection (cut perpendicular to the principal axis of the
+//     point cloud at its median), without: level-set bisection from a pseudo-peripheral vertex (George's automatic nested
+//     dissection).  The vertex separator is the smaller one-sided boundary of the edge cut.  Parts of at most `leaf_size` vertices
+//     are not cut further;
+//  3. every leaf and every separator is ONE supernode (treated as dense; separators of a mesh are connected sets that fill in
+//     anyway).  Border rows by the supernodal symbolic factorisation over the true supernodal elimination tree (parent = owner of
+//     the first border row), children merged in ascending order;
+//  4. the plan the device factorisation follows without further decisions: levels (height above the leaves), panel / inverse
+//     offsets, a first-fit simulated arena for the contribution blocks (allocated when a level starts, released when the parent's
+//     level has been assembled), the destination of every stored entry of the input CSR, extend-add positions.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <map>
+#include <numeric>
+
+#include "hx_common.h"
+#include "splu_internal.h"
+
+namespace {
+
+struct Graph {
+  int32_t n;
+  std::vector<int64_t> xadj;
+  std::vector<int32_t> adj;
+};
+
+void build_graph(Graph& g, int32_t n, const int32_t* rowptr, const int32_t* col) {
+  g.n = n;
+  g.xadj.assign((size_t)n + 1, 0);
+  for (int32_t i = 0; i < n; ++i)
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const int32_t j = col[k];
+      if (j != i) { g.xadj[i + 1]++; g.xadj[j + 1]++; }
+    }
+  for (int32_t i = 0; i < n; ++i) g.xadj[i + 1] += g.xadj[i];
+  std::vector<int32_t> raw((size_t)g.xadj[n]);
+  std::vector<int64_t> pos(g.xadj.begin(), g.xadj.end() - 1);
+  for (int32_t i = 0; i < n; ++i)
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const int32_t j = col[k];
+      if (j != i) { raw[pos[i]++] = j; raw[pos[j]++] = i; }
+    }
+  // sort + unique every list, compact
+  std::vector<int64_t> nx((size_t)n + 1, 0);
+  int64_t w = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    int32_t* b = raw.data() + g.xadj[i];
+    int32_t* e = raw.data() + g.xadj[i + 1];
+    std::sort(b, e);
+    e = std::unique(b, e);
+    nx[i] = w;
+    for (int32_t* p = b; p < e; ++p) raw[w++] = *p;      // w never passes the read position
+  }
+  nx[n] = w;
+  raw.resize((size_t)w);
+  g.xadj.swap(nx);
+  g.adj.swap(raw);
+}
+
+struct Dissector {
+  const Graph& g;
+  const double* xy;          // n x dim or null
+  int dim;
+  int leaf;
+  std::vector<int32_t> verts;        // permuted in place: every call owns a contiguous slice
+  std::vector<int32_t> mark;         // which call / side a vertex currently belongs to
+  std::vector<int32_t> order;        // emitted vertices (new -> old)
+  std::vector<int32_t> sfirst;       // supernode boundaries in `order`
+  std::vector<double> proj;
+  std::vector<int32_t> queue, lvl, scratch;
+  int32_t stamp = 0;
+
+  Dissector(const Graph& g_, const double* xy_, int dim_, int leaf_) : g(g_), xy(xy_), dim(dim_), leaf(leaf_) {
+    verts.resize(g.n);
+    std::iota(verts.begin(), verts.end(), 0);
+    mark.assign(g.n, -1);
+    proj.resize(g.n);
+    queue.resize(g.n);
+    lvl.resize(g.n);
+    scratch.resize(g.n);
+    order.reserve(g.n);
+    sfirst.push_back(0);
+  }
+
+  void emit(int32_t lo, int32_t hi) {
+    if (hi <= lo) return;
+    for (int32_t i = lo; i < hi; ++i) order.push_back(verts[i]);
+    sfirst.push_back((int32_t)order.size());
+  }
+
+  // splits verts[lo, hi) into [lo, mid) and [mid, hi) by the median plane perpendicular to the principal axis; false: degenerate
+  bool split_inertial(int32_t lo, int32_t hi, int32_t& mid) {
+    const int32_t cnt = hi - lo;
+    double c[3] = {0, 0, 0}, M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int32_t i = lo; i < hi; ++i)
+      for (int d = 0; d < dim; ++d) c[d] += xy[(size_t)verts[i] * dim + d];
+    for (int d = 0; d < dim; ++d) c[d] /= cnt;
+    for (int32_t i = lo; i < hi; ++i) {
+      double r[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) r[d] = xy[(size_t)verts[i] * dim + d] - c[d];
+      for (int a = 0; a < dim; ++a)
+        for (int b = 0; b < dim; ++b) M[a][b] += r[a] * r[b];
+    }
+    double v[3] = {1.0, 0.913, 0.791};           // deterministic, not aligned with any mesh axis
+    for (int it = 0; it < 40; ++it) {
+      double w[3] = {0, 0, 0}, nrm = 0;
+      for (int a = 0; a < dim; ++a)
+        for (int b = 0; b < dim; ++b) w[a] += M[a][b] * v[b];
+      for (int a = 0; a < dim; ++a) nrm += w[a] * w[a];
+      if (nrm <= 0) return false;
+      nrm = std::sqrt(nrm);
+      for (int a = 0; a < dim; ++a) v[a] = w[a] / nrm;
+    }
+    // snap to a coordinate axis when the principal axis is within ~8 degrees of it: planar cuts on structured grids
+    for (int a = 0; a < dim; ++a)
+      if (std::fabs(v[a]) > 0.99) { for (int b = 0; b < dim; ++b) v[b] = (b == a) ? 1.0 : 0.0; break; }
+    for (int32_t i = lo; i < hi; ++i) {
+      double p = 0;
+      for (int d = 0; d < dim; ++d) p += v[d] * (xy[(size_t)verts[i] * dim + d] - c[d]);
+      proj[verts[i]] = p;
+    }
+    for (int32_t i = 0; i < cnt; ++i) scratch[i] = verts[lo + i];
+    std::nth_element(scratch.begin(), scratch.begin() + cnt / 2, scratch.begin() + cnt,
+                     [&](int32_t a, int32_t b) { return proj[a] < proj[b]; });
+    const double t = proj[scratch[cnt / 2]];
+    double span = 0;
+    for (int32_t i = 0; i < cnt; ++i) span = std::max(span, std::fabs(proj[scratch[i]]));
+    const double eps = 1e-9 * (span > 0 ? span : 1.0);
+    auto below = [&](int32_t u) { return proj[u] < t - eps; };
+    int32_t* b = verts.data() + lo;
+    int32_t* m = std::partition(b, b + cnt, below);
+    if (m == b) {                                   // everything at or above the median value: cut above it instead
+      m = std::partition(b, b + cnt, [&](int32_t u) { return proj[u] <= t + eps; });
+      if (m == b + cnt) return false;
+    }
+    mid = lo + (int32_t)(m - b);
+    return mid > lo && mid < hi;
+  }
+
+  // BFS over the slice (vertices with mark == id) from `root`; appends to queue[qlo..), returns new end; lvl[] by position
+  int32_t bfs(int32_t root, int32_t id, int32_t visited_id, int32_t qlo, int32_t start_level) {
+    int32_t head = qlo, tail = qlo;
+    queue[tail] = root; lvl[tail] = start_level; ++tail;
+    mark[root] = visited_id;
+    while (head < tail) {
+      const int32_t v = queue[head];
+      const int32_t l = lvl[head];
+      ++head;
+      for (int64_t k = g.xadj[v]; k < g.xadj[v + 1]; ++k) {
+        const int32_t u = g.adj[k];
+        if (mark[u] == id) { mark[u] = visited_id; queue[tail] = u; lvl[tail] = l + 1; ++tail; }
+      }
+    }
+    return tail;
+  }
+
+  bool split_levelset(int32_t lo, int32_t hi, int32_t& mid) {
+    const int32_t cnt = hi - lo;
+    int32_t id = ++stamp;
+    for (int32_t i = lo; i < hi; ++i) mark[verts[i]] = id;
+    // two sweeps towards a pseudo-peripheral vertex of the first component
+    int32_t root = verts[lo];
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      const int32_t vis = ++stamp;
+      const int32_t end = bfs(root, id, vis, 0, 0);
+      root = queue[end - 1];
+      for (int32_t i = 0; i < end; ++i) mark[queue[i]] = id;
+    }
+    const int32_t vis = ++stamp;
+    int32_t end = bfs(root, id, vis, 0, 0);
+    for (int32_t i = lo; i < hi && end < cnt; ++i)          // further components, each starting a new level
+      if (mark[verts[i]] == id) end = bfs(verts[i], id, vis, end, lvl[end - 1] + 1);
+    // cut at the level boundary closest to the middle
+    int32_t best = -1;
+    for (int32_t i = 1; i < cnt; ++i)
+      if (lvl[i] != lvl[i - 1] && (best < 0 || std::abs(i - cnt / 2) < std::abs(best - cnt / 2))) best = i;
+    if (best < 0) best = cnt / 2;
+    for (int32_t i = 0; i < cnt; ++i) scratch[i] = queue[i];
+    for (int32_t i = 0; i < cnt; ++i) verts[lo + i] = scratch[i];
+    mid = lo + best;
+    return mid > lo && mid < hi;
+  }
+
+  void dissect(int32_t lo, int32_t hi) {
+    const int32_t cnt = hi - lo;
+    if (cnt <= leaf) { emit(lo, hi); return; }
+    int32_t mid = lo;
+    bool ok = (xy != nullptr) && split_inertial(lo, hi, mid);
+    if (!ok) ok = split_levelset(lo, hi, mid);
+    if (!ok) { emit(lo, hi); return; }
+    const int32_t idA = ++stamp, idB = ++stamp;
+    for (int32_t i = lo; i < mid; ++i) mark[verts[i]] = idA;
+    for (int32_t i = mid; i < hi; ++i) mark[verts[i]] = idB;
+    auto touches = [&](int32_t v, int32_t other) {
+      for (int64_t k = g.xadj[v]; k < g.xadj[v + 1]; ++k)
+        if (mark[g.adj[k]] == other) return true;
+      return false;
+    };
+    int32_t nbA = 0, nbB = 0;
+    for (int32_t i = lo; i < mid; ++i) nbA += touches(verts[i], idB) ? 1 : 0;
+    for (int32_t i = mid; i < hi; ++i) nbB += touches(verts[i], idA) ? 1 : 0;
+    int32_t a_end, b_end;                        // [lo, a_end) = A', [a_end, b_end) = B', [b_end, hi) = separator
+    if (nbA <= nbB) {                            // separator taken out of A
+      int32_t* m = std::stable_partition(verts.data() + lo, verts.data() + mid, [&](int32_t v) { return !touches(v, idB); });
+      const int32_t a1 = (int32_t)(m - verts.data());           // [a1, mid) = separator, then B follows: rotate it to the end
+      std::rotate(verts.begin() + a1, verts.begin() + mid, verts.begin() + hi);
+      a_end = a1; b_end = a1 + (hi - mid);
+    } else {
+      int32_t* m = std::stable_partition(verts.data() + mid, verts.data() + hi, [&](int32_t v) { return !touches(v, idA); });
+      a_end = mid; b_end = (int32_t)(m - verts.data());
+    }
+    if (a_end - lo == 0 && b_end - a_end == 0) { emit(lo, hi); return; }
+    dissect(lo, a_end);
+    dissect(a_end, b_end);
+    emit(b_end, hi);
+  }
+};
+
+}  // namespace
+
+int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const int32_t* col, const double* coords, int dim,
+                      int leaf_size) {
+  const auto t0 = std::chrono::steady_clock::now();
+  if (n <= 0) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "n <= 0");
+  if (coords && (dim < 1 || dim > 3)) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "dim must be 1, 2 or 3");
+  for (int32_t i = 0; i < n; ++i)
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if (col[k] < 0 || col[k] >= n) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "column index out of range");
+  Graph g;
+  build_graph(g, n, rowptr, col);
+  Dissector D(g, coords, dim, leaf_size < 8 ? 8 : leaf_size);
+  D.dissect(0, n);
+  if ((int32_t)D.order.size() != n) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: ordering lost vertices");
+  S.n = n;
+  S.perm.swap(D.order);
+  S.iperm.assign(n, 0);
+  for (int32_t i = 0; i < n; ++i) S.iperm[S.perm[i]] = i;
+  S.sfirst.swap(D.sfirst);
+  const int32_t ns_ = S.nsuper = (int32_t)S.sfirst.size() - 1;
+  std::vector<int32_t> super_of(n);
+  for (int32_t s = 0; s < ns_; ++s)
+    for (int32_t j = S.sfirst[s]; j < S.sfirst[s + 1]; ++j) super_of[j] = s;
+
+  // ---- supernodal symbolic factorisation over the true elimination tree
+  S.sparent.assign(ns_, -1);
+  S.sptr.assign((size_t)ns_ + 1, 0);
+  S.srow.clear();
+  std::vector<int32_t> head(ns_, -1), tail(ns_, -1), next(ns_, -1), flag(n, -1), rows;
+  for (int32_t s = 0; s < ns_; ++s) {
+    const int32_t first = S.sfirst[s], last = S.sfirst[s + 1];
+    rows.clear();
+    for (int32_t j = first; j < last; ++j) {
+      const int32_t v = S.perm[j];
+      for (int64_t k = g.xadj[v]; k < g.xadj[v + 1]; ++k) {
+        const int32_t r = S.iperm[g.adj[k]];
+        if (r >= last && flag[r] != s) { flag[r] = s; rows.push_back(r); }
+      }
+    }
+    for (int32_t c = head[s]; c >= 0; c = next[c])
+      for (int64_t k = S.sptr[c]; k < S.sptr[c + 1]; ++k) {
+        const int32_t r = S.srow[k];
+        if (r >= last && flag[r] != s) { flag[r] = s; rows.push_back(r); }
+      }
+    std::sort(rows.begin(), rows.end());
+    S.srow.insert(S.srow.end(), rows.begin(), rows.end());
+    S.sptr[s + 1] = (int64_t)S.srow.size();
+    if (!rows.empty()) {
+      const int32_t p = super_of[rows[0]];
+      S.sparent[s] = p;
+      if (head[p] < 0) head[p] = s; else next[tail[p]] = s;
+      tail[p] = s;
+    }
+  }
+  S.child_ptr.assign((size_t)ns_ + 1, 0);
+  S.child_list.clear();
+  for (int32_t s = 0; s < ns_; ++s) {
+    for (int32_t c = head[s]; c >= 0; c = next[c]) S.child_list.push_back(c);
+    S.child_ptr[s + 1] = (int32_t)S.child_list.size();
+  }
+  // ---- extend-add positions
+  S.rel.assign(S.srow.size(), 0);
+  for (int32_t c = 0; c < ns_; ++c) {
+    const int32_t p = S.sparent[c];
+    if (p < 0) continue;
+    const int32_t pf = S.sfirst[p], pl = S.sfirst[p + 1], pns = pl - pf;
+    int64_t q = S.sptr[p];
+    for (int64_t k = S.sptr[c]; k < S.sptr[c + 1]; ++k) {
+      const int32_t r = S.srow[k];
+      if (r < pl) { S.rel[k] = r - pf; continue; }
+      while (q < S.sptr[p + 1] && S.srow[q] < r) ++q;
+      if (q >= S.sptr[p + 1] || S.srow[q] != r) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: border row missing in parent");
+      S.rel[k] = pns + (int32_t)(q - S.sptr[p]);
+    }
+  }
+  // ---- levels
+  S.slevel.assign(ns_, 0);
+  for (int32_t s = 0; s < ns_; ++s) {
+    const int32_t p = S.sparent[s];
+    if (p >= 0) S.slevel[p] = std::max(S.slevel[p], S.slevel[s] + 1);
+  }
+  S.nlevels = 0;
+  for (int32_t s = 0; s < ns_; ++s) S.nlevels = std::max(S.nlevels, S.slevel[s] + 1);
+  S.level_ptr.assign((size_t)S.nlevels + 1, 0);
+  for (int32_t s = 0; s < ns_; ++s) S.level_ptr[S.slevel[s] + 1]++;
+  for (int32_t l = 0; l < S.nlevels; ++l) S.level_ptr[l + 1] += S.level_ptr[l];
+  S.level_list.assign(ns_, 0);
+  {
+    std::vector<int32_t> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
+    for (int32_t s = 0; s < ns_; ++s) S.level_list[pos[S.slevel[s]]++] = s;
+  }
+  // ---- storage plan
+  S.loff.assign(ns_, 0); S.uoff.assign(ns_, 0); S.ioff.assign(ns_, 0); S.soff.assign(ns_, -1); S.woff.assign(ns_, 0);
+  int64_t fcur = 0, icur = 0, wcur = 0;
+  S.nnz_L = 0; S.flops = 0; S.max_front = 0; S.max_ns = 0;
+  for (int32_t s = 0; s < ns_; ++s) {
+    const int64_t ns = S.sfirst[s + 1] - S.sfirst[s], nr = S.sptr[s + 1] - S.sptr[s], m = ns + nr;
+    S.loff[s] = fcur; fcur += m * ns;
+    S.uoff[s] = fcur; fcur += m * ns;
+    S.ioff[s] = icur; icur += 2 * (int64_t)SPLU_NB * SPLU_NB * ((ns + SPLU_NB - 1) / SPLU_NB);
+    S.woff[s] = wcur; wcur += m;
+    S.nnz_L += ns * (ns + 1) / 2 + nr * ns;
+    S.flops += 8.0 * ((double)ns * ns * ns / 3.0 + (double)nr * ns * ns + (double)nr * nr * ns);
+    S.max_front = std::max<int32_t>(S.max_front, (int32_t)m);
+    S.max_ns = std::max<int32_t>(S.max_ns, (int32_t)ns);
+  }
+  S.factor_elems = fcur; S.inverse_elems = icur; S.work_elems = wcur;
+  {
+    // first-fit arena simulation: contribution blocks of a level are allocated when the level starts and released when the
+    // parents' level has absorbed them
+    std::map<int64_t, int64_t> freeb;           // offset -> size
+    int64_t top = 0;
+    auto alloc = [&](int64_t sz) -> int64_t {
+      for (auto it = freeb.begin(); it != freeb.end(); ++it)
+        if (it->second >= sz) {
+          const int64_t off = it->first, rest = it->second - sz;
+          freeb.erase(it);
+          if (rest > 0) freeb[off + sz] = rest;
+          return off;
+        }
+      // grow: extend a free block that ends at the top, if any
+      if (!freeb.empty()) {
+        auto lastb = std::prev(freeb.end());
+        if (lastb->first + lastb->second == top) {
+          const int64_t off = lastb->first;
+          freeb.erase(lastb);
+          top = off + sz;
+          return off;
+        }
+      }
+      const int64_t off = top;
+      top += sz;
+      return off;
+    };
+    auto release = [&](int64_t off, int64_t sz) {
+      auto it = freeb.emplace(off, sz).first;
+      auto nx = std::next(it);
+      if (nx != freeb.end() && it->first + it->second == nx->first) { it->second += nx->second; freeb.erase(nx); }
+      if (it != freeb.begin()) {
+        auto pv = std::prev(it);
+        if (pv->first + pv->second == it->first) { pv->second += it->second; freeb.erase(it); }
+      }
+    };
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+      for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+        const int32_t s = S.level_list[k];
+        const int64_t nr = S.sptr[s + 1] - S.sptr[s];
+        if (nr > 0) S.soff[s] = alloc(nr * nr);
+      }
+      for (int32_t k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+        const int32_t s = S.level_list[k];
+        for (int32_t q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+          const int32_t c = S.child_list[q];
+          const int64_t nr = S.sptr[c + 1] - S.sptr[c];
+          if (nr > 0) release(S.soff[c], nr * nr);
+        }
+      }
+    }
+    S.temp_elems = top;
+  }
+  // ---- destination of every stored entry of the input
+  S.amap.assign((size_t)rowptr[n], -1);
+  for (int32_t i = 0; i < n; ++i) {
+    const int32_t pi = S.iperm[i];
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const int32_t pj = S.iperm[col[k]];
+      const bool lower = pi >= pj;
+      const int32_t piv = lower ? pj : pi, oth = lower ? pi : pj;
+      const int32_t s = super_of[piv];
+      const int64_t ns = S.sfirst[s + 1] - S.sfirst[s], nr = S.sptr[s + 1] - S.sptr[s], m = ns + nr;
+      int64_t a;
+      if (oth < S.sfirst[s + 1]) a = oth - S.sfirst[s];
+      else {
+        const int32_t* b = S.srow.data() + S.sptr[s];
+        const int32_t* e = S.srow.data() + S.sptr[s + 1];
+        const int32_t* p = std::lower_bound(b, e, oth);
+        if (p == e || *p != oth) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: entry outside its front");
+        a = ns + (p - b);
+      }
+      S.amap[k] = (lower ? S.loff[s] : S.uoff[s]) + a + (int64_t)(piv - S.sfirst[s]) * m;
+    }
+  }
+  S.analyse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return HX_OK;
+}

@@ -1,0 +1,42 @@
+// Sparse direct solver of libhx (hx_splu_*): what the host analysis hands to the device factorisation.
+//
+// Supernodal multifrontal LU of a structurally symmetric(ised) complex128 matrix, nested-dissection ordered:
+//   * a supernode s owns the pivot columns [first, first + ns) of the permuted matrix and a sorted list of nr border rows;
+//     its front is the (ns + nr)^2 matrix [F11 F12; F21 F22] over (own columns ++ border);
+//   * the factor keeps two column-major panels of m = ns + nr rows and ns columns per supernode:
+//       Lp [a, b] = L(front row a, pivot b)   for a >= b   (the strict upper triangle of its top block is unused space),
+//       Utp[a, b] = U(pivot b, front column a) for a >  b   (U stored transposed: both panels are "tall"),
+//     the inverses of the SB x SB diagonal blocks (block-local partial pivoting folded in) live in a separate array;
+//   * F22 (the contribution block) is temporary: it lives in an arena until the parent front has absorbed it.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+#define SPLU_NB 64          // pivot block: one LDS-resident diagonal block, one step of the panel recurrences
+
+struct SpluSymbolic {
+  int32_t n = 0, nsuper = 0, nlevels = 0;
+  std::vector<int32_t> perm, iperm;          // perm[new] = old, iperm[old] = new
+  std::vector<int32_t> sfirst;               // nsuper + 1: first pivot column of a supernode
+  std::vector<int32_t> sparent;              // -1: a root
+  std::vector<int64_t> sptr;                 // nsuper + 1: border rows of a supernode in srow / rel
+  std::vector<int32_t> srow;                 // border rows (permuted numbering, ascending)
+  std::vector<int32_t> rel;                  // parallel to srow: position of that row in the PARENT's front (0 .. m_parent)
+  std::vector<int32_t> slevel;               // height above the leaves
+  std::vector<int32_t> level_ptr, level_list;  // supernodes grouped by level
+  std::vector<int32_t> child_ptr, child_list;  // children in ascending order (the order of the extend-add)
+  std::vector<int64_t> loff, uoff;           // element offsets of Lp / Utp in the factor arena
+  std::vector<int64_t> ioff;                 // element offset of the diagonal-block inverses (2 * NB*NB per pivot block)
+  std::vector<int64_t> soff;                 // element offset of the contribution block in the temporary arena
+  std::vector<int64_t> woff;                 // offset of the front's slice of the solve workspace (m entries)
+  int64_t factor_elems = 0, inverse_elems = 0, temp_elems = 0, work_elems = 0;
+  int64_t nnz_L = 0;                         // entries of L incl. diagonal (= entries of U)
+  double flops = 0.0;                        // real flops of the numeric factorisation (complex multiply-add = 8)
+  int32_t max_front = 0, max_ns = 0;
+  double analyse_seconds = 0.0;
+  std::vector<int64_t> amap;                 // per stored entry of the input CSR: destination in the factor arena
+};
+
+// splu_analyse.hip (host only)
+int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const int32_t* col, const double* coords, int dim,
+                      int leaf_size);

@@ -317,6 +317,33 @@ int hx_sptrsv_info(const hx_sptrsv* t, int32_t* n_levels, int32_t* n_launches, i
 int hx_sptrsv_solve(hx_sptrsv* t, const hx_c128* b, hx_c128* x, hx_stream s);
 int hx_sptrsv_destroy(hx_sptrsv* t);
 
+/* ------------------------------------------------------------------ sparse direct solver (device multifrontal LU)
+ * replaces: KSP(preonly) + PC(LU): MatLUFactorSymbolic / MatLUFactorNumeric / MatSolve / MatSolveTranspose behind ST sinvert
+ * (eigensolvers.py:49-50,102-103 -> :62,:113), i.e. PETSc's LU or MUMPS under -st_pc_factor_mat_solver_type.
+ * Supernodal multifrontal LU of a complex128 CSR matrix (pattern symmetrised for the analysis), nested-dissection ordering,
+ * fronts factorised on the device with f64 MFMA (csrc/splu.hip); partial pivoting inside 64 x 64 diagonal blocks, static
+ * pivoting otherwise (replaced pivots are counted in hx_splu_info: check the residual, refine).  Solves are supernodal
+ * (dense panels), bitwise reproducible; the transposed solve uses the same factors. */
+typedef struct hx_splu hx_splu;
+/* HOST analysis (no device needed): h_rowptr / h_col = CSR pattern, h_coords = n x dim vertex coordinates of the unknowns
+ * (inertial nested dissection) or NULL (level-set nested dissection on the graph); leaf_size <= 0: default 64.  SYNC. */
+int hx_splu_analyse(hx_splu** out, int32_t n, const int32_t* h_rowptr, const int32_t* h_col, const double* h_coords,
+                    int dim, int leaf_size);
+/* iout[16]: n, supernodes, levels, nnz(L) (= nnz(U), diagonal included), factor / inverse / temporary / workspace elements,
+ * largest front, widest supernode, border rows, nnz of the input, replaced pivots of the last factorisation, launches of
+ * the factorisation / forward / backward sweeps;  dout[8]: real flops of the factorisation, seconds of the analysis (host),
+ * seconds of the last numeric factorisation (HIP events). */
+int hx_splu_info(const hx_splu* h, int64_t* iout, double* dout);
+/* the symbolic structure by field name (tests, diagnostics): perm, iperm, sfirst, sparent, sptr, srow, rel, slevel, level_ptr,
+ * level_list, child_ptr, child_list, loff, uoff, ioff, soff, woff, amap.  h_out NULL: only *count.  HOST buffers. */
+int hx_splu_symbolic(const hx_splu* h, const char* name, void* h_out, int64_t capacity_bytes, int64_t* count);
+/* numeric factorisation of the values `val` (device, in the CSR order of the analysed pattern).  May be repeated with new
+ * values.  SYNC (reads back the pivot counter). */
+int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream s);
+/* x = A^-1 b (transposed != 0: A^-T b); b, x device vectors of length n, may alias. */
+int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int transposed, hx_stream s);
+int hx_splu_destroy(hx_splu* h);
+
 /* ------------------------------------------------------------------ AMG-preconditioned GMRES (iterative MatSolve)
  * replaces: the same KSP/PC solve as above for 3-D problems where a sparse direct factorisation does not fit
  * (the reference switches PCLU to MUMPS/SuperLU_DIST there).  Hierarchy arrays are device pointers owned by

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _hx
-from .petsc import CSR, Mat, new_pattern_id, to_device
+from .petsc import CSR, Mat, new_pattern_id, register_coords, to_device
 
 
 # ----------------------------------------------------------------------------- host-side objects
@@ -478,6 +478,8 @@ class P1Assembler:
         self.v2c_ptr, self.v2c_idx = self._adjacency(self.cells, self.nc, self.dim + 1)
         self.rowptr, self.col = self._pattern(self.cells, self.nc, self.dim + 1, self.v2c_ptr, self.v2c_idx)
         self.pattern_id = new_pattern_id()
+        if getattr(mesh, "part", None) is None:
+            register_coords(self.pattern_id, mesh.geometry.x)
         self._h_pattern = None
         self.device = dev
 
@@ -708,6 +710,8 @@ class P2Assembler:
         self.d2c_ptr, self.d2c_idx = self._adjacency(self.cdofs, self.nc, 10)
         self.rowptr, self.col = self._pattern(self.cdofs, self.nc, 10, self.d2c_ptr, self.d2c_idx)
         self.pattern_id = new_pattern_id()
+        if getattr(self.mesh, "part", None) is None and hasattr(V, "tabulate_dof_coordinates"):
+            register_coords(self.pattern_id, V.tabulate_dof_coordinates())
 
     _adjacency = P1Assembler._adjacency
     _pattern = P1Assembler._pattern

@@ -221,6 +221,21 @@ def new_pattern_id():
     return next(_PATTERN_IDS)
 
 
+_PATTERN_COORDS = __import__("collections").OrderedDict()     # pattern id -> host (n, dim) coordinates of the unknowns
+
+
+def register_coords(pattern_id, coords):
+    """Where the unknowns of a sparsity pattern sit in space (a reference to the caller's host array, not a copy): the direct
+    solver's nested dissection cuts along these (slepc.LUSolver); patterns without coordinates are dissected on their graph."""
+    _PATTERN_COORDS[pattern_id] = coords
+    while len(_PATTERN_COORDS) > 16:
+        _PATTERN_COORDS.popitem(last=False)
+
+
+def coords_of(pattern_id):
+    return _PATTERN_COORDS.get(pattern_id)
+
+
 def panel_dot(V, k, w):
     """[V_j^H w for j<k] + [w^H w] as a host numpy array (one D2H sync).  V: (m, n) tensor, rows = vectors."""
     n = w.numel()

@@ -53,9 +53,129 @@ RELAX_CAP_MULTI = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP_MULTI"
 
 # ----------------------------------------------------------------------------- inner solvers for sparse K
 class LUSolver:
-    """Pr K Pc = L U on the host (SuperLU, sequential) + device triangular solves."""
+    """K = L U on the DEVICE: supernodal multifrontal factorisation (csrc/splu.hip, hx_splu_*), nested-dissection ordering from
+    the coordinates registered for the pattern (petsc.register_coords) or from its graph.  What PCLU / MUMPS is to the reference's
+    ST sinvert (eigensolvers.py:49-50,102-103): an answer at any target.  The host analysis is kept per sparsity pattern
+    (``_ANALYSES``): a new target re-factorises numerically only."""
 
     name = "lu"
+    _ANALYSES = __import__("collections").OrderedDict()      # pattern id -> handle (analysis + device plan + factor storage)
+    _MAX_ANALYSES = 2
+    REFINE_ABOVE = 1e-11          # a first solve with a larger relative residual switches iterative refinement on
+
+    def __init__(self, K_csr, coords=None):
+        import time
+        from .petsc import coords_of
+        t0 = time.perf_counter()
+        self.K = K_csr
+        n = self.n = K_csr.shape[0]
+        key = K_csr.pattern_id
+        self.handle = self._ANALYSES.pop(key, None)
+        self.analysis_reused = self.handle is not None
+        if self.handle is None:
+            rp, ci = K_csr.host_pattern()
+            rp, ci = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32)
+            xy = coords if coords is not None else coords_of(key)
+            dim = 0
+            if xy is not None and xy.shape[0] == n:
+                xy = np.ascontiguousarray(xy, np.float64)
+                dim = xy.shape[1]
+            else:
+                xy = None
+            h = C.c_void_p()
+            _hx.check(_hx.lib.hx_splu_analyse(C.byref(h), n, _hx.nptr(rp), _hx.nptr(ci), None if xy is None else _hx.nptr(xy),
+                                               dim, int(__import__("os").environ.get("HX_LU_LEAF", "0"))))
+            self.handle = h
+            self.ordering = "inertial" if xy is not None else "level-set"
+        else:
+            self.ordering = "cached"
+        self._key = key
+        t1 = time.perf_counter()
+        _hx.check(_hx.lib.hx_splu_factor(self.handle, _hx.ptr(K_csr.val), _hx.stream()))
+        self.tmp = torch.empty(n, dtype=torch.complex128, device=K_csr.val.device)
+        self.res = torch.empty(n, dtype=torch.complex128, device=K_csr.val.device)
+        self.analyse_s, self.factor_s = t1 - t0, time.perf_counter() - t1
+        self.setup_s = time.perf_counter() - t0
+        self.n_solves = 0
+        self.refine = None            # decided by the residual of the first solve
+        self.first_residual = None
+        io, _ = self.info()
+        if io[12] > 0:
+            info("! direct solver: %d tiny pivots replaced (static pivoting); solves are refined against the residual" % io[12])
+            self.refine = True
+
+    def info(self):
+        io, do = (C.c_int64 * 16)(), (C.c_double * 8)()
+        _hx.check(_hx.lib.hx_splu_info(self.handle, io, do))
+        return list(io), list(do)
+
+    def stats(self):
+        io, do = self.info()
+        return dict(setup_s=round(self.setup_s, 4), analyse_s=round(self.analyse_s, 4), factor_s=round(self.factor_s, 4),
+                    factor_device_s=round(do[2], 5), factor_tflops=round(do[0] / max(do[2], 1e-12) / 1e12, 2),
+                    ordering=self.ordering, solves=self.n_solves, fill=round(2.0 * io[3] / max(io[11], 1), 1), nnz_L=io[3],
+                    supernodes=io[1], levels=io[2], largest_front=io[8], replaced_pivots=io[12],
+                    factor_gib=round((io[4] + io[5]) * 16 / 2 ** 30, 3), launches_factor_fwd_bwd=io[13:16],
+                    refine=bool(self.refine), first_residual=self.first_residual)
+
+    def _residual(self, b, x, transposed):
+        """res = b - K x (K^T x); returns ||res|| / ||b||."""
+        self.res.copy_(b)
+        if transposed and not getattr(self.K, "symmetric", False):
+            raise NotImplementedError("residual of a transposed solve needs K^T")       # (never reached: see solve)
+        self.K.spmv(x, self.res, -1.0, 1.0)
+        return float(torch.linalg.vector_norm(self.res) / torch.linalg.vector_norm(b))
+
+    def solve(self, b, x, relax=1.0, transposed=False):
+        """x = K^-1 b (device tensors; may alias).  ``relax`` is ignored: the solve is direct."""
+        s = _hx.stream()
+        self.n_solves += 1
+        tr = 1 if transposed else 0
+        can_check = (not transposed) or getattr(self.K, "symmetric", False)
+        if self.refine is None and can_check and b.data_ptr() != x.data_ptr():
+            _hx.check(_hx.lib.hx_splu_solve(self.handle, _hx.ptr(b), _hx.ptr(x), tr, s))
+            self.first_residual = self._residual(b, x, transposed)
+            if not np.isfinite(self.first_residual) or self.first_residual > 1e-4:
+                raise ZeroDivisionError("singular factor (residual %.1e): the target coincides with an eigenvalue"
+                                        % self.first_residual)
+            self.refine = self.first_residual > self.REFINE_ABOVE
+            if self.refine:
+                _hx.check(_hx.lib.hx_splu_solve(self.handle, _hx.ptr(self.res), _hx.ptr(self.tmp), tr, s))
+                x.add_(self.tmp)
+            return
+        if self.refine and can_check and b.data_ptr() != x.data_ptr():
+            _hx.check(_hx.lib.hx_splu_solve(self.handle, _hx.ptr(b), _hx.ptr(x), tr, s))
+            self._residual(b, x, transposed)
+            _hx.check(_hx.lib.hx_splu_solve(self.handle, _hx.ptr(self.res), _hx.ptr(self.tmp), tr, s))
+            x.add_(self.tmp)
+            return
+        _hx.check(_hx.lib.hx_splu_solve(self.handle, _hx.ptr(b), _hx.ptr(x), tr, s))
+
+    def destroy(self):
+        h, self.handle = self.handle, None
+        if h is None:
+            return
+        if self._key is not None and not isinstance(self._key, tuple):
+            self._ANALYSES[self._key] = h                  # the next solver on this pattern re-factorises only
+            while len(self._ANALYSES) > self._MAX_ANALYSES:
+                _, old = self._ANALYSES.popitem(last=False)
+                _hx.lib.hx_splu_destroy(old)
+        else:
+            _hx.lib.hx_splu_destroy(h)
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class HostLUSolver:
+    """Round-1 route kept for comparison (``HX_LU=host``): Pr K Pc = L U by SciPy's SuperLU on one host core, level-scheduled
+    triangular solves on the device (hx_sptrsv_*)."""
+
+    name = "lu-host"
+
 
     def __init__(self, K_csr):
         import time
@@ -140,6 +260,8 @@ def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=
         # 0.16, 16 k 2.35 vs 0.14 -- the direct route only serves problems too small for a two-level hierarchy.
         st = "lu" if n <= DEFAULTS["lu_max_dofs"] else "amg"
     if st == "lu":
+        if __import__("os").environ.get("HX_LU", "device") == "host":
+            return HostLUSolver(K_csr)
         return LUSolver(K_csr)
     if st == "amg":
         from .amg import AMGSolver

@@ -223,18 +223,140 @@ def test_sptrsv_against_scipy(hx, n, lower):
 
 def test_lu_solver_matches_splu(hx):
     from helmholtz_x.petsc import CSR
-    from helmholtz_x.slepc import LUSolver
+    from helmholtz_x.slepc import HostLUSolver, LUSolver
     from oracle import fem, meshes
     m = meshes.rectangle(60, 20, 0.4, 0.1)
     c = np.full(m.x.shape[0], 450.0)
     K = (fem.assemble_A(m.x, m.cells, c) + (3000.0 + 200j) ** 2 * fem.assemble_C(m.x, m.cells)).tocsr()
     rng = np.random.default_rng(1)
     b = _rand_c(rng, K.shape[0])
-    S = LUSolver(CSR.from_scipy(K))
-    x, bd = _dev(np.zeros_like(b)), _dev(b)
-    S.solve(bd, x)
     ref = spla.splu(K.tocsc()).solve(b)
-    assert np.max(np.abs(x.cpu().numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))
+    for cls in (LUSolver, HostLUSolver):          # device multifrontal LU (the product route) / round-1 host SuperLU route
+        S = cls(CSR.from_scipy(K))
+        x, bd = _dev(np.zeros_like(b)), _dev(b)
+        S.solve(bd, x)
+        assert np.max(np.abs(x.cpu().numpy() - ref)) <= 1e-10 * np.max(np.abs(ref)), cls.__name__
+        S.destroy()
+
+
+def _micca_K(golden_dir, level):
+    """K = A + sigma B + sigma^2 C of the reference's MICCA case at its own target (oracle assembly on the host), mesh
+    refined ``level`` times; returns (K csr, coordinates)."""
+    import os
+    from cases import Micca
+    from helmholtz_x import synthetic
+    from helmholtz_x.io_utils import read_xdmf
+    from oracle import fem
+    mesh, sub, ft = read_xdmf(os.path.join(golden_dir, "meshes", "micca_full", "mesh"))
+    for _ in range(level):
+        mesh, sub, ft = synthetic.refine_tets(mesh, cell_tags=sub, facet_tags=ft)
+    x, cells = mesh.geometry.x, mesh.topology.cells
+    c = Micca.c_of_z(x[cells].mean(axis=1)[:, 2])
+    sel = ft.find(11)
+    B = fem.assemble_B(x, x.shape[0], [(mesh.facets[sel], fem.robin_Z(Micca.R_outlet), c, mesh.facet_cells[sel])])
+    s = Micca.target
+    K = (fem.assemble_A(x, cells, c, c_is_cellwise=True) + s * B + s * s * fem.assemble_C(x, cells)).tocsr()
+    K.sort_indices()
+    return K, x
+
+
+@pytest.mark.parametrize("level,with_coords", [(0, True), (0, False), (1, True)])
+def test_device_sparse_lu_on_the_real_micca_operator(hx, golden_dir, level, with_coords):
+    """hx_splu_* on the shifted operator of the reference's flagship case: 34,787 DOF against SciPy's SuperLU (solution and
+    transposed solution to 1e-10, both orderings), 249,497 DOF (one uniform refinement; SuperLU would need minutes and tens of
+    GB there) against a manufactured solution b = K x and its residual.  No refinement step is allowed to hide anything: the
+    raw solves of the C-ABI are compared."""
+    import torch
+    K, xyz = _micca_K(golden_dir, level)
+    n = K.shape[0]
+    assert n == (34787, 249497)[level]
+    rng = np.random.default_rng(level)
+    x_true = _rand_c(rng, n)
+    b = K @ x_true
+    rp, ci = K.indptr.astype(np.int32), K.indices.astype(np.int32)
+    xy = np.ascontiguousarray(xyz, np.float64)
+    h = C.c_void_p()
+    hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), hx.nptr(xy) if with_coords else None,
+                                    3 if with_coords else 0, 0))
+    val, bd = _dev(np.ascontiguousarray(K.data)), _dev(b)
+    xd = torch.empty_like(bd)
+    io, do = (C.c_int64 * 16)(), (C.c_double * 8)()
+    for rep in range(2):                               # the second factorisation reuses plan and storage
+        hx.check(hx.lib.hx_splu_factor(h, hx.ptr(val), hx.stream()))
+        hx.check(hx.lib.hx_splu_info(h, io, do))
+        assert io[12] == 0                              # no pivot had to be replaced
+        hx.check(hx.lib.hx_splu_solve(h, hx.ptr(bd), hx.ptr(xd), 0, hx.stream()))
+        x = xd.cpu().numpy()
+        assert np.linalg.norm(K @ x - b) <= 1e-12 * np.linalg.norm(b)
+        assert np.max(np.abs(x - x_true)) <= 1e-10 * np.max(np.abs(x_true))
+    print("device LU n = %d (%s): nnz(L) %.3e, fill %.1f, %.2e flops, factorisation %.1f ms = %.1f TFLOP/s"
+          % (n, "inertial" if with_coords else "level-set", io[3], 2 * io[3] / K.nnz, do[0], do[2] * 1e3, do[0] / do[2] / 1e12))
+    bt = K.T @ x_true
+    btd = _dev(bt)
+    hx.check(hx.lib.hx_splu_solve(h, hx.ptr(btd), hx.ptr(btd), 1, hx.stream()))        # transposed, in place
+    assert np.max(np.abs(btd.cpu().numpy() - x_true)) <= 1e-10 * np.max(np.abs(x_true))
+    if level == 0:
+        lu = spla.splu(K.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.1, options=dict(SymmetricMode=True))
+        g = _rand_c(rng, n)
+        gd = _dev(g)
+        hx.check(hx.lib.hx_splu_solve(h, hx.ptr(gd), hx.ptr(xd), 0, hx.stream()))
+        ref = lu.solve(g)
+        assert np.max(np.abs(xd.cpu().numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))
+        hx.check(hx.lib.hx_splu_solve(h, hx.ptr(gd), hx.ptr(xd), 1, hx.stream()))
+        ref = lu.solve(g, "T")
+        assert np.max(np.abs(xd.cpu().numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))
+    hx.check(hx.lib.hx_splu_destroy(h))
+
+
+@pytest.mark.parametrize("case", ["n1", "n2_swap", "diag", "n64", "n65", "n129_dense", "random_unsym", "two_components",
+                                  "unsymmetric_pattern"])
+def test_device_sparse_lu_edge_cases(hx, case):
+    """Sizes around the 64-column pivot block, a dense matrix (one supernode, several pivot blocks, left-looking updates), values
+    without symmetry, a pattern without symmetry, disconnected graphs, a pivot that only exists after a row exchange inside the
+    diagonal block -- against numpy / SciPy."""
+    import torch
+    rng = np.random.default_rng(7)
+    if case == "n1":
+        K = sp.csr_matrix(np.array([[2.0 - 3.0j]]))
+    elif case == "n2_swap":
+        K = sp.csr_matrix(np.array([[0.0, 2.0], [3.0 + 1j, 0.0]]))
+    elif case == "diag":
+        K = sp.diags(_rand_c(rng, 300) + 3.0).tocsr()
+    elif case in ("n64", "n65"):
+        n = int(case[1:])
+        K = sp.csr_matrix(sp.random(n, n, density=0.2, random_state=rng) + 1j * sp.random(n, n, density=0.2, random_state=rng)
+                          + sp.eye(n) * 2.0)
+    elif case == "n129_dense":
+        K = sp.csr_matrix(_rand_c(rng, 329, 329) + 10.0 * np.eye(329))
+    elif case == "random_unsym":
+        n = 3000
+        P = sp.random(n, n, density=0.0015, random_state=rng, format="csr")
+        P = ((P + P.T) != 0).astype(np.float64)
+        K = sp.csr_matrix(P.multiply(sp.csr_matrix(_rand_c(rng, n, 1)) @ sp.csr_matrix(np.ones((1, n)))) + sp.diags(4.0 + _rand_c(rng, n)))
+        K.data = K.data * (1.0 + 0.3 * rng.standard_normal(K.nnz))          # values without any symmetry
+    elif case == "two_components":
+        A = sp.random(500, 500, density=0.01, random_state=rng) + sp.eye(500) * 3
+        K = sp.csr_matrix(sp.block_diag([A, 2j * A.T + sp.eye(500)]))
+    else:
+        K = sp.csr_matrix(sp.triu(sp.random(800, 800, density=0.01, random_state=rng)) + sp.eye(800) * 2 +
+                          1j * sp.random(800, 800, density=0.001, random_state=rng))
+    K = sp.csr_matrix(K, dtype=np.complex128)
+    K.sort_indices()
+    n = K.shape[0]
+    rp, ci = K.indptr.astype(np.int32), K.indices.astype(np.int32)
+    h = C.c_void_p()
+    hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), None, 0, 0))
+    val = _dev(np.ascontiguousarray(K.data))
+    hx.check(hx.lib.hx_splu_factor(h, hx.ptr(val), hx.stream()))
+    b = _rand_c(rng, n)
+    bd = _dev(b)
+    xd = torch.empty_like(bd)
+    ref = np.linalg.solve(K.toarray(), b) if n <= 400 else spla.splu(K.tocsc()).solve(b)
+    reft = np.linalg.solve(K.toarray().T, b) if n <= 400 else spla.splu(K.tocsc()).solve(b, "T")
+    for tr, r in ((0, ref), (1, reft)):
+        hx.check(hx.lib.hx_splu_solve(h, hx.ptr(bd), hx.ptr(xd), tr, hx.stream()))
+        assert np.max(np.abs(xd.cpu().numpy() - r)) <= 1e-9 * np.max(np.abs(r)), (case, tr)
+    hx.check(hx.lib.hx_splu_destroy(h))
 
 
 @pytest.mark.parametrize("n,density", [(1, 1.0), (999, 0.02), (30000, 0.0006)])

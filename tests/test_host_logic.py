@@ -636,3 +636,95 @@ def test_set_from_options_maps_the_reference_option_names(monkeypatch):
         Q.setFromOptions()
     Options(prefix="st_").clear()
     assert not db.hasName("st_type") and db.hasName("eps_nev")
+
+
+# ------------------------------------------------------------------------------------------------- direct solver: host analysis
+def _splu_fields(hx, h):
+    out = {}
+    for name, dt in [("perm", np.int32), ("iperm", np.int32), ("sfirst", np.int32), ("sparent", np.int32), ("sptr", np.int64),
+                     ("srow", np.int32), ("rel", np.int32), ("slevel", np.int32), ("level_ptr", np.int32), ("level_list", np.int32),
+                     ("child_ptr", np.int32), ("child_list", np.int32), ("loff", np.int64), ("uoff", np.int64), ("soff", np.int64),
+                     ("amap", np.int64)]:
+        cnt = C.c_int64()
+        hx.check(hx.lib.hx_splu_symbolic(h, name.encode(), None, 0, C.byref(cnt)))
+        a = np.empty(cnt.value, dt)
+        hx.check(hx.lib.hx_splu_symbolic(h, name.encode(), hx.nptr(a), a.nbytes, C.byref(cnt)))
+        out[name] = a
+    return out
+
+
+@pytest.mark.parametrize("with_coords", [True, False])
+@pytest.mark.parametrize("case", ["box3d", "path", "two_components", "unsymmetric_pattern", "tiny"])
+def test_direct_solver_analysis_structure_contains_the_fill(case, with_coords):
+    """hx_splu_analyse (host only): the ordering is a permutation, supernodes tile the columns, every supernode's parent owns
+    its first border row, the extend-add positions point at the same global rows, every stored entry has its own slot in the
+    right panel, and the supernodal structure CONTAINS the fill of an elimination without pivoting (dense symbolic elimination of
+    the permuted pattern) -- with and without coordinates."""
+    from helmholtz_x import _hx as hx
+    from oracle import fem, meshes
+    rng = np.random.default_rng(3)
+    xy = None
+    if case == "box3d":
+        from helmholtz_x import synthetic
+        m = synthetic.annulus(3, 24, 4)[0]
+        x, cells = m.geometry.x, m.topology.cells
+        K = fem.assemble_C(x, cells).tocsr()
+        xy = x
+    elif case == "path":
+        n = 700
+        K = sp.diags([np.ones(n - 1), np.ones(n), np.ones(n - 1)], [-1, 0, 1]).tocsr()
+        xy = np.linspace(0, 1, n)[:, None]
+    elif case == "two_components":
+        m = meshes.rectangle(12, 9, 1.0, 1.0)
+        A = fem.assemble_C(m.x, m.cells).tocsr()
+        K = sp.block_diag([A, A]).tocsr()
+        xy = np.vstack([m.x[:, :2], m.x[:, :2] + [3.0, 0.0]])
+    elif case == "unsymmetric_pattern":
+        K = sp.random(400, 400, density=0.01, random_state=rng, format="csr") + sp.eye(400)
+        K = sp.csr_matrix(sp.triu(K) + sp.random(400, 400, density=0.002, random_state=rng))
+        xy = rng.random((400, 2))
+    else:
+        K = sp.csr_matrix(np.array([[2.0, 1.0], [0.0, 3.0]]))
+        xy = np.array([[0.0], [1.0]])
+    K = sp.csr_matrix(K)
+    K.sort_indices()
+    n = K.shape[0]
+    rp, ci = K.indptr.astype(np.int32), K.indices.astype(np.int32)
+    xyc = np.ascontiguousarray(xy, np.float64) if with_coords else None
+    h = C.c_void_p()
+    hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), None if xyc is None else hx.nptr(xyc),
+                                    0 if xyc is None else xyc.shape[1], 16))
+    try:
+        f = _splu_fields(hx, h)
+        io, do = (C.c_int64 * 16)(), (C.c_double * 8)()
+        hx.check(hx.lib.hx_splu_info(h, io, do))
+        assert io[0] == n and io[1] == len(f["sfirst"]) - 1
+        perm, iperm, sfirst, sptr, srow = f["perm"], f["iperm"], f["sfirst"], f["sptr"], f["srow"]
+        assert np.array_equal(np.sort(perm), np.arange(n)) and np.array_equal(iperm[perm], np.arange(n))
+        assert sfirst[0] == 0 and sfirst[-1] == n and np.all(np.diff(sfirst) > 0)
+        nsup = len(sfirst) - 1
+        super_of = np.repeat(np.arange(nsup), np.diff(sfirst))
+        for s in range(nsup):
+            rows = srow[sptr[s]:sptr[s + 1]]
+            assert np.all(np.diff(rows) > 0) and (len(rows) == 0 or rows[0] >= sfirst[s + 1])
+            p = f["sparent"][s]
+            assert (p == -1) == (len(rows) == 0)
+            if p >= 0:
+                assert super_of[rows[0]] == p and f["slevel"][p] > f["slevel"][s]
+                front_p = np.concatenate([np.arange(sfirst[p], sfirst[p + 1]), srow[sptr[p]:sptr[p + 1]]])
+                assert np.array_equal(front_p[f["rel"][sptr[s]:sptr[s + 1]]], rows)
+        assert len(np.unique(f["amap"])) == K.nnz and f["amap"].min() >= 0 and f["amap"].max() < io[4]
+        # dense symbolic elimination of the permuted, symmetrised pattern
+        P = ((abs(K) + abs(K).T) != 0).toarray()[np.ix_(perm, perm)]
+        np.fill_diagonal(P, True)
+        for k in range(n):
+            below = np.nonzero(P[k + 1:, k])[0] + k + 1
+            P[np.ix_(below, below)] = True
+        for s in range(nsup):
+            allowed = np.zeros(n, bool)
+            allowed[sfirst[s]:sfirst[s + 1]] = True
+            allowed[srow[sptr[s]:sptr[s + 1]]] = True
+            for j in range(sfirst[s], sfirst[s + 1]):
+                assert not np.any(P[j:, j] & ~allowed[j:]), (case, s, j)
+    finally:
+        hx.check(hx.lib.hx_splu_destroy(h))

@@ -5,11 +5,12 @@
 //
 // Numeric factorisation, level by level up the assembly tree (fronts of one level are independent and share every launch):
 //   zero the contribution blocks -> extend-add the children (round r adds the r-th child of every front: race-free, fixed order)
-//   -> per pivot block of 64 columns: k_diag (LU of the 64 x 64 diagonal block in LDS, partial pivoting INSIDE the block, explicit
-//   inverses W_L = L^-1 P and W_U = U^-1), k_gemm<PANEL> (L21 <- F21 W_U, U12^T <- F12^T W_L^T), k_gemm<INNER> (right-looking
-//   update of the rest of the current 256-column outer block) -- before an outer block starts k_gemm<LEFT> applies all earlier
-//   outer blocks at once (left-looking: K = hundreds, the rank-64 updates stay inside 256 columns) -> k_gemm<SUPD> F22 -= L21 U12.
-// Everything GEMM-shaped is ONE kernel: C (-)= A B^T on column-major complex128 operands, 64 x 64 tiles, 4 waves, each wave a
+//   -> per pivot block of 64 columns: k_diag (Gauss-Jordan inverse of the 64 x 64 diagonal block, partial pivoting INSIDE the
+//   block, one row of the block per lane in registers), k_gemm<PANEL> (L21 <- F21 D^-1), k_gemm<INNER> (right-looking update
+//   of the rest of the current 256-column outer block, L and U side) -- before an outer block starts k_gemm<LEFT> applies all
+//   earlier outer blocks at once (left-looking: K = hundreds, the rank-64 updates stay inside 256 columns) -> k_gemm<SUPD>
+//   F22 -= L21 U12.
+// Everything GEMM-shaped is ONE kernel: C (-)= A B on column-major complex128 operands, 64 x 64 tiles, 4 waves, each wave a
 // 32 x 32 block as 2 x 2 x (re, im) accumulators of v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex product block; operands
 // staged through LDS as interleaved complex so one ds_read_b128 feeds the re and im fragments).
 // No pivoting across blocks: K = A + sigma B + sigma^2 C of a Helmholtz problem is complex symmetric with a complex shift
@@ -17,8 +18,9 @@
 // residual and refines.
 //
 // Solves: forward up the levels, backward down, supernodal (dense panels): small fronts run whole in one workgroup per front and
-// level, large fronts step through their pivot blocks with row-tiled launches.  Child updates travel through per-front workspace
-// slices (no atomics: bitwise reproducible).  Transposed solves use the same factors (U^T L^T).
+// level, large fronts step through their pivot blocks with tiled launches.  Both sweeps are "rows of a panel times a vector"
+// with the 64 contiguous rows on the lanes (L is stored m x ns, U ns x m).  Child updates travel through per-front workspace
+// slices (no atomics: bitwise reproducible).  Transposed solves use the same factors (U^T L^T) through column-dot kernels.
 #include <algorithm>
 #include <string.h>
 #include <vector>
@@ -31,9 +33,10 @@
 #define GT 64                   // GEMM tile
 #define GK 16                   // GEMM k chunk
 #define GLD (GT + 1)            // LDS stride (complex elements) of a staged operand chunk
-#define DLD (NB + 1)            // LDS stride of the diagonal block
-#define BIG_FRONT_ELEMS (96 * 1024)   // a front whose panel has more entries than this steps through launches in the solves
-#define SOLVE_ROWS 512          // rows per workgroup of the large-front solve kernels
+#define BIG_FRONT_ELEMS (48 * 1024)   // a front whose panel has more entries than this steps through launches in the solves
+#define FWD_ROWS 64             // rows per workgroup of the large-front forward update
+#define BWD_COLS 256            // columns per workgroup of the large-front backward partial products
+#define SOLVE_ROWS 512          // rows per workgroup of the column-dot kernels (transposed solves)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -53,7 +56,7 @@ struct hx_splu {
   SpluSymbolic sym;
   int64_t nnz_in = 0;
   bool factored = false;
-  std::vector<Launch> fplan, fwd_plan, bwd_plan;
+  std::vector<Launch> fplan, fwd_plan[2], bwd_plan[2];
   std::vector<int64_t> poff;
   int64_t part_elems = 0;
   // device
@@ -74,17 +77,22 @@ __host__ __device__ static inline int trap_tiles(int tm, int tn) {      // tiles
 __host__ __device__ static inline int splu_tiles(int kind, int ns, int nr, int p0) {
   const int m = ns + nr;
   switch (kind) {
-    case K_PANEL: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return 2 * cdiv(m - c1, GT); }
+    case K_PANEL: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, GT); }
     case K_INNER: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB), cj1 = min(ns, (c0 / NBO + 1) * NBO);
                     return 2 * trap_tiles(cdiv(m - c1, GT), cdiv(cj1 - c1, GT)); }
     case K_LEFT: { const int cj0 = p0 * NBO, cj1 = min(ns, cj0 + NBO); return 2 * trap_tiles(cdiv(m - cj0, GT), cdiv(cj1 - cj0, GT)); }
     case K_SUPD: return cdiv(nr, GT) * cdiv(nr, GT);
     case K_ZERO: return cdiv(nr * nr, 256 * 16);     // nr <= 46 k: no overflow
     case K_EXTEND: return cdiv(nr, GT) * cdiv(nr, GT);
-    case S_FWD_UPD: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, SOLVE_ROWS); }
-    case S_BWD_DOT: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, SOLVE_ROWS); }
+    case S_FWD_UPD: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, FWD_ROWS); }
+    case S_BWD_DOT: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, BWD_COLS); }
     default: return 1;
   }
+}
+// transposed solves use other tilings of the same two launch kinds
+__host__ __device__ static inline int splu_tiles_trans(int kind, int ns, int nr, int p0) {
+  const int m = ns + nr, c0 = p0 * NB, c1 = min(ns, c0 + NB);
+  return cdiv(m - c1, SOLVE_ROWS);
 }
 
 // which front does workgroup b of a launch serve: prefix[f] <= b < prefix[f + 1]
@@ -147,135 +155,166 @@ __global__ void __launch_bounds__(256) k_splu_extend(SpluDev d, const int32_t* _
     const zc v = Sc[i + (int64_t)(tj * GT + jj) * nrc];
     zc* dst;
     if (b < nsp && a >= b) dst = Lp + a + b * mp;
-    else if (a < nsp && b > a) dst = Up + b + a * mp;
+    else if (a < nsp && b > a) dst = Up + a + b * nsp;
     else dst = Sp + (a - nsp) + (b - nsp) * nrp;
     dst->x += v.x; dst->y += v.y;
   }
 }
 
 // ------------------------------------------------------------------------------------------------- diagonal block
-// One workgroup per front: D = F[c0:c1, c0:c1] (lower + diagonal from Lp, strict upper from Utp) -> P D = L U in LDS ->
-// W_L = L^-1 P (stored column-major), W_U = U^-1 (stored ROW-major: both are then the "B^T" operand of k_gemm<PANEL>).
-__global__ void __launch_bounds__(256) k_splu_diag(SpluDev d, const int32_t* __restrict__ fronts, int kb) {
-  extern __shared__ zc lds[];
-  zc* D = lds;                     // NB x DLD, element (a, b) at a + b * DLD
-  zc* X = lds + NB * DLD;
-  __shared__ int piv_row;
-  __shared__ double scale_ref;
+// One workgroup (512 threads) per front: D = F[c0:c1, c0:c1] (lower + diagonal from Lp, strict upper from Up) -> D^-1 by
+// in-place Gauss-Jordan with threshold pivoting inside the block.  The chain of 64 dependent pivots bounds the critical path
+// of a whole factorisation, and both the LDS (a 16-byte store costs 13 cycles per wave) and a lone wave's dependent issue
+// (~8 cycles per instruction) are slow against it, so: the matrix lives in REGISTERS (thread (a = t >> 3, q = t & 7) holds
+// D[a, q + 8 j], j < 8), only the pivot row and the pivot column travel through LDS, run-time register indices are resolved
+// by wave-uniform switches, and a step is ONE barrier long when the diagonal entry is an acceptable pivot
+// (not small against the block's largest entry): while it eliminates with pivot k every thread already publishes what step k + 1 needs -- column
+// k + 1, the row holding the next diagonal entry (unscaled: every thread scales its own multiplier by 1 / pivot instead) and,
+// by one LDS atomic max per candidate row, the largest entry of column k + 1 (key = magnitude bits | row).  Only when the
+// diagonal entry fails the test rows are exchanged: by RENAMING (each thread carries the logical index of the row it holds)
+// plus one more barrier to publish that row.  The column permutation of the inverse is applied on the way out.  Blocks
+// narrower than 64 are padded with the identity.
+__device__ __forceinline__ unsigned long long pivot_key(double mag, int row) {   // mag >= 0 (NaN sorts above everything)
+  return ((unsigned long long)__double_as_longlong(mag) & ~63ull) | (unsigned long long)(63 - row);
+}
+__device__ __forceinline__ double fast_rcp(double x) {            // 1 / x for a normal x: v_rcp_f64 + two Newton steps
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+struct DiagShared {
+  zc col[2][NB], rowb[2][NB];
+  unsigned long long key;
+  int perm[NB];
+  double wmax[8];
+};
+
+// step k = 8 J + qk of the elimination: column k lives in register r[J] of the threads with q == qk, column k + 1 in r[JN]
+template <int J, int JN>
+__device__ __forceinline__ void diag_step(DiagShared& sh, zc (&r)[8], int& la, const int qk, const int w, const int q, const int tid,
+                                          const double small2, const double tiny2, const double scale_ref, int32_t* status) {
+  {
+    const int k = 8 * J + qk;
+    if (k >= w) return;                           // (uniform) the identity padding needs no elimination
+    const int cur = k & 1;
+    const zc f = sh.col[cur][la];                 // this row's entry in column k (multiplier of the elimination)
+    const zc dk = sh.col[cur][k];
+    zc pv = dk;
+    if (!(dk.x * dk.x + dk.y * dk.y >= small2)) { // (uniform, rare) small against the block: search column k, exchange rows by renaming
+      if (tid == 0) sh.key = 0ull;
+      __syncthreads();
+      if (q == 0 && la >= k && la < w) atomicMax(&sh.key, pivot_key(f.x * f.x + f.y * f.y, la));
+      __syncthreads();
+      const int p = 63 - (int)(sh.key & 63ull);
+      if (p != k) {
+        pv = sh.col[cur][p];
+        if (la == k) la = p; else if (la == p) la = k;
+        if (la == k) {                            // publish the new row k
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sh.rowb[cur][q + 8 * j] = r[j];
+        }
+        if (tid == 0) { const int tp = sh.perm[k]; sh.perm[k] = sh.perm[p]; sh.perm[p] = tp; }
+      }
+      __syncthreads();
+      const double mag = pv.x * pv.x + pv.y * pv.y;
+      if (!(mag > tiny2)) {                       // static pivoting (also catches NaN)
+        if (tid == 0) atomicAdd(status, 1);
+        const double nrm = sqrt(mag);
+        pv = nrm > 0.0 ? make_double2(pv.x / nrm * 1e-8 * scale_ref, pv.y / nrm * 1e-8 * scale_ref) : make_double2(1e-8 * scale_ref, 0.0);
+        if (!(scale_ref > 0.0)) pv = make_double2(1.0, 0.0);
+      }
+    }
+    const double inv = fast_rcp(pv.x * pv.x + pv.y * pv.y);
+    const zc pinv = make_double2(pv.x * inv, -pv.y * inv);
+    const zc fp = zmul(f, pinv);
+    zc u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = sh.rowb[cur][q + 8 * j];
+    if (la != k) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { r[j].x -= fp.x * u[j].x - fp.y * u[j].y; r[j].y -= fp.x * u[j].y + fp.y * u[j].x; }
+      if (q == qk) r[J] = make_double2(-fp.x, -fp.y);       // column k becomes a column of the inverse
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = zmul(r[j], pinv);
+      if (q == qk) r[J] = pinv;
+    }
+    if (k + 1 < w) {                              // what step k + 1 reads: column k + 1 and the row of the next diagonal entry
+      if (q == ((qk + 1) & 7)) sh.col[cur ^ 1][la] = r[JN];
+      if (la == k + 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh.rowb[cur ^ 1][q + 8 * j] = r[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int J>
+__device__ __forceinline__ void diag_steps(DiagShared& sh, zc (&r)[8], int& la, const int w, const int q, const int tid,
+                                           const double small2, const double tiny2, const double scale_ref, int32_t* status) {
+#pragma unroll 1
+  for (int qk = 0; qk < 7; ++qk) diag_step<J, J>(sh, r, la, qk, w, q, tid, small2, tiny2, scale_ref, status);
+  diag_step<J, (J < 7 ? J + 1 : 7)>(sh, r, la, 7, w, q, tid, small2, tiny2, scale_ref, status);
+}
+
+__global__ void __launch_bounds__(512) k_splu_diag(SpluDev d, const int32_t* __restrict__ fronts, int kb) {
+  __shared__ DiagShared sh;
   const int s = fronts[blockIdx.x];
   const int ns = d.sfirst[s + 1] - d.sfirst[s];
   const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
   const int c0 = kb * NB, w = min(ns, c0 + NB) - c0;
   const zc* Lp = d.F + d.loff[s];
   const zc* Up = d.F + d.uoff[s];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, a = tid >> 3, q = tid & 7;
+  int la = a;                                     // logical row held by this thread
+  zc r[8];
   double amax = 0.0;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int a = e & (NB - 1), b = e >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int b = q + 8 * j;
     zc v = make_double2(a == b ? 1.0 : 0.0, 0.0);
-    if (a < w && b < w) v = (a >= b) ? Lp[(c0 + a) + (int64_t)(c0 + b) * m] : Up[(c0 + b) + (int64_t)(c0 + a) * m];
-    D[a + b * DLD] = v;
-    X[a + b * DLD] = make_double2(a == b ? 1.0 : 0.0, 0.0);
-    amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
+    if (a < w && b < w) v = (a >= b) ? Lp[(c0 + a) + (int64_t)(c0 + b) * m] : Up[(c0 + a) + (int64_t)(c0 + b) * ns];
+    r[j] = v;
+    if (a < w && b < w) amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
   }
-  // block-wide max |entry| (reference magnitude of the static pivoting)
   for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
-  __shared__ double wmax[4];
-  if ((tid & 63) == 0) wmax[tid >> 6] = amax;
-  __syncthreads();
-  if (tid == 0) scale_ref = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
-  __syncthreads();
-  for (int k = 0; k < w; ++k) {
-    if (tid < 64) {                              // pivot search in column k, rows k .. w-1
-      double best = -1.0; int row = k;
-      if (tid >= k && tid < w) { const zc v = D[tid + k * DLD]; best = v.x * v.x + v.y * v.y; row = tid; }
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o); const int orow = __shfl_xor(row, o);
-        if (ob > best || (ob == best && orow < row)) { best = ob; row = orow; }
-      }
-      if (tid == 0) piv_row = row;
-    }
-    __syncthreads();
-    const int p = piv_row;
-    if (p != k && tid < 2 * NB) {                // swap rows k and p of D (all columns) and of X
-      zc* M = tid < NB ? D : X;
-      const int b = tid & (NB - 1);
-      const zc t = M[k + b * DLD]; M[k + b * DLD] = M[p + b * DLD]; M[p + b * DLD] = t;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      zc pv = D[k + k * DLD];
-      const double tiny = 1e-13 * scale_ref;
-      if (!(pv.x * pv.x + pv.y * pv.y > tiny * tiny)) {       // also catches NaN
-        atomicAdd(d.status, 1);
-        const double nrm = sqrt(pv.x * pv.x + pv.y * pv.y);
-        pv = nrm > 0.0 ? make_double2(pv.x / nrm * 1e-8 * scale_ref, pv.y / nrm * 1e-8 * scale_ref) : make_double2(1e-8 * scale_ref, 0.0);
-        if (!(scale_ref > 0.0)) pv = make_double2(1.0, 0.0);
-        D[k + k * DLD] = pv;
-      }
-    }
-    __syncthreads();
-    const zc inv = zdiv(make_double2(1.0, 0.0), D[k + k * DLD]);
-    __syncthreads();
-    if (tid > k && tid < w) D[tid + k * DLD] = zmul(D[tid + k * DLD], inv);
-    __syncthreads();
-    // trailing update D[a, b] -= l[a] u[b], a, b > k
-    const int rem = w - k - 1;
-    for (int e = tid; e < rem * rem; e += 256) {
-      const int a = k + 1 + e % rem, b = k + 1 + e / rem;
-      zc v = D[a + b * DLD];
-      const zc l = D[a + k * DLD], u = D[k + b * DLD];
-      v.x -= l.x * u.x - l.y * u.y; v.y -= l.x * u.y + l.y * u.x;
-      D[a + b * DLD] = v;
-    }
-    __syncthreads();
-  }
-  // X = P so far.  W_L = L^-1 P: forward substitution on all columns at once
-  for (int k = 0; k < w; ++k) {
-    const int rem = w - k - 1;
-    for (int e = tid; e < rem * w; e += 256) {
-      const int a = k + 1 + e % rem, b = e / rem;
-      const zc l = D[a + k * DLD], x = X[k + b * DLD];
-      zc v = X[a + b * DLD];
-      v.x -= l.x * x.x - l.y * x.y; v.y -= l.x * x.y + l.y * x.x;
-      X[a + b * DLD] = v;
-    }
-    __syncthreads();
-  }
-  zc* WL = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB;
-  zc* WU = WL + NB * NB;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int a = e & (NB - 1), b = e >> 6;
-    WL[a + b * NB] = (a < w && b < w) ? X[a + b * DLD] : make_double2(0.0, 0.0);
+  if ((tid & 63) == 0) sh.wmax[tid >> 6] = amax;
+  if (tid < NB) sh.perm[tid] = tid;
+  if (q == 0) sh.col[0][a] = r[0];
+  if (a == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh.rowb[0][q + 8 * j] = r[j];
   }
   __syncthreads();
-  // W_U = U^-1: backward substitution on the identity
-  for (int e = tid; e < NB * NB; e += 256) { const int a = e & (NB - 1), b = e >> 6; X[a + b * DLD] = make_double2(a == b ? 1.0 : 0.0, 0.0); }
-  __syncthreads();
-  for (int k = w - 1; k >= 0; --k) {
-    const zc inv = zdiv(make_double2(1.0, 0.0), D[k + k * DLD]);
-    if (tid < w) X[k + tid * DLD] = zmul(X[k + tid * DLD], inv);
-    __syncthreads();
-    for (int e = tid; e < k * w; e += 256) {
-      const int a = e % k, b = e / k;
-      const zc u = D[a + k * DLD], x = X[k + b * DLD];
-      zc v = X[a + b * DLD];
-      v.x -= u.x * x.x - u.y * x.y; v.y -= u.x * x.y + u.y * x.x;
-      X[a + b * DLD] = v;
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int b = e & (NB - 1), a = e >> 6;          // row-major: W_U[a, b] at a * NB + b
-    WU[a * NB + b] = (a < w && b < w) ? X[a + b * DLD] : make_double2(0.0, 0.0);
+  double scale_ref = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) scale_ref = fmax(scale_ref, sh.wmax[i]);
+  const double tiny2 = (1e-13 * scale_ref) * (1e-13 * scale_ref), small2 = (1e-5 * scale_ref) * (1e-5 * scale_ref);
+  diag_steps<0>(sh, r, la, w, q, tid, small2, tiny2, scale_ref, d.status);
+  diag_steps<1>(sh, r, la, w, q, tid, small2, tiny2, scale_ref, d.status);
+  diag_steps<2>(sh, r, la, w, q, tid, small2, tiny2, scale_ref, d.status);
+  diag_steps<3>(sh, r, la, w, q, tid, small2, tiny2, scale_ref, d.status);
+  diag_steps<4>(sh, r, la, w, q, tid, small2, tiny2, scale_ref, d.status);
+  diag_steps<5>(sh, r, la, w, q, tid, small2, tiny2, scale_ref, d.status);
+  diag_steps<6>(sh, r, la, w, q, tid, small2, tiny2, scale_ref, d.status);
+  diag_steps<7>(sh, r, la, w, q, tid, small2, tiny2, scale_ref, d.status);
+  // stored column b holds column perm[b] of D^-1 (in-place Gauss-Jordan with row exchanges)
+  zc* Wd = d.W + d.ioff[s] + (int64_t)kb * NB * NB;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int b = q + 8 * j;
+    const int cc = sh.perm[b];
+    Wd[la + cc * NB] = (la < w && cc < w) ? r[j] : make_double2(0.0, 0.0);
   }
 }
 
-// ------------------------------------------------------------------------------------------------- GEMM  C (-)= A B^T
-// A: M x K, B: N x K, C: M x N, all column-major complex128.  ASSIGN: C = A B^T (C may be A itself when N = K <= 64: every
+// ------------------------------------------------------------------------------------------------- GEMM  C (-)= A B
+// A: M x K, B: K x N, C: M x N, all column-major complex128.  ASSIGN: C = A B (C may be A itself when N = K <= 64: every
 // operand chunk is in LDS / registers before the first store).  One 64 x 64 tile per workgroup.
 // MFMA mapping: D[row][col] of v_mfma_f64_16x16x4_f64 has col = lane & 15, so the tile's ROW index i (contiguous in memory)
-// rides on lane & 15: the "a" operand is the B-matrix fragment (index j), the "b" operand the A-matrix fragment (index i).
+// rides on lane & 15: the "a" operand is the B-matrix fragment (k, j), the "b" operand the A-matrix fragment (i, k).
 struct GemmProb { const zc* A; const zc* B; zc* C; int64_t lda, ldb, ldc; int M, N, K; };
 
 template <bool ASSIGN>
@@ -283,17 +322,19 @@ __device__ __forceinline__ void gemm_tile(const GemmProb& p, int ti, int tj, zc*
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wi = wv & 1, wj = wv >> 1;
   const int row0 = ti * GT, col0 = tj * GT;
-  const int lr = tid & 63, lk = tid >> 6;           // staging: row lr, k offset lk + 4q
-  const bool a_ok = row0 + lr < p.M, b_ok = col0 + lr < p.N;
+  const int lr = tid & 63, lk = tid >> 6;           // staging of A: row lr, k offset lk + 4q
+  const int bk = tid & 15, bj = tid >> 4;           // staging of B: k offset bk, column bj + 16q (k is contiguous in memory)
+  const bool a_ok = row0 + lr < p.M;
   const zc* Ag = p.A + row0 + lr;
-  const zc* Bg = p.B + col0 + lr;
+  const zc* Bg = p.B + (int64_t)col0 * p.ldb;
   zc ra[4], rb[4];
   auto load = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int k = k0 + lk + 4 * q;
       ra[q] = (a_ok && k < p.K) ? Ag[(int64_t)k * p.lda] : make_double2(0.0, 0.0);
-      rb[q] = (b_ok && k < p.K) ? Bg[(int64_t)k * p.ldb] : make_double2(0.0, 0.0);
+      const int j = bj + 16 * q;
+      rb[q] = (col0 + j < p.N && k0 + bk < p.K) ? Bg[(k0 + bk) + (int64_t)j * p.ldb] : make_double2(0.0, 0.0);
     }
   };
   v4d cr[2][2], ci[2][2];
@@ -308,7 +349,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProb& p, int ti, int tj, zc*
     zc* sA = lds + buf * 2 * GK * GLD;
     zc* sB = sA + GK * GLD;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { sA[(lk + 4 * q) * GLD + lr] = ra[q]; sB[(lk + 4 * q) * GLD + lr] = rb[q]; }
+    for (int q = 0; q < 4; ++q) { sA[(lk + 4 * q) * GLD + lr] = ra[q]; sB[bk * GLD + bj + 16 * q] = rb[q]; }
     __syncthreads();
     if (k0 + GK < p.K) load(k0 + GK);
 #pragma unroll
@@ -372,51 +413,114 @@ __global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __r
   zc* Up = d.F + d.uoff[s];
   GemmProb p;
   int ti, tj;
-  if (KIND == K_PANEL) {
+  if (KIND == K_PANEL) {                         // Lp[c1:m, c0:c1] <- Lp[c1:m, c0:c1] D^-1
     const int c0 = p0 * NB, c1 = min(ns, c0 + NB);
-    const int tm = cdiv((int)m - c1, GT);
-    const int side = t / tm; ti = t % tm; tj = 0;
-    zc* P = side == 0 ? Lp : Up;
-    const zc* Wb = d.W + d.ioff[s] + (int64_t)p0 * 2 * NB * NB + (side == 0 ? NB * NB : 0);   // side 0: W_U (row-major), side 1: W_L
-    p.A = P + c1 + (int64_t)c0 * m; p.lda = m; p.C = (zc*)p.A; p.ldc = m; p.B = Wb; p.ldb = NB;
+    p.A = Lp + c1 + (int64_t)c0 * m; p.lda = m; p.C = (zc*)p.A; p.ldc = m;
+    p.B = d.W + d.ioff[s] + (int64_t)p0 * NB * NB; p.ldb = NB;
     p.M = (int)m - c1; p.N = p.K = c1 - c0;
-    gemm_tile<true>(p, ti, tj, lds);
+    gemm_tile<true>(p, t, 0, lds);
   } else if (KIND == K_INNER || KIND == K_LEFT) {
-    int r0, k0, k1, cj1;           // C = P[r0:m, r0:cj1] -= P[r0:m, k0:k1] Q[r0:cj1, k0:k1]^T
+    int r0, k0, k1, cj1;
     if (KIND == K_INNER) { k0 = p0 * NB; k1 = min(ns, k0 + NB); r0 = k1; cj1 = min(ns, (k0 / NBO + 1) * NBO); }
     else { k0 = 0; k1 = p0 * NBO; r0 = k1; cj1 = min(ns, r0 + NBO); }
-    const int tm = cdiv((int)m - r0, GT), tn = cdiv(cj1 - r0, GT);
-    const int per = trap_tiles(tm, tn);
+    const int tall = cdiv((int)m - r0, GT), wide = cdiv(cj1 - r0, GT);
+    const int per = trap_tiles(tall, wide);
     const int side = t / per; t -= side * per;
-    trap_decode(t, tm, tn, ti, tj);
-    zc* P = side == 0 ? Lp : Up;
-    zc* Q = side == 0 ? Up : Lp;
-    p.A = P + r0 + (int64_t)k0 * m; p.lda = m; p.B = Q + r0 + (int64_t)k0 * m; p.ldb = m;
-    p.C = P + r0 + (int64_t)r0 * m; p.ldc = m; p.M = (int)m - r0; p.N = cj1 - r0; p.K = k1 - k0;
+    int tl, ts;                                   // tile along the long / the short (outer block) direction, tl >= ts
+    trap_decode(t, tall, wide, tl, ts);
+    p.K = k1 - k0;
+    if (side == 0) {                              // Lp[r0:m, r0:cj1] -= Lp[r0:m, k0:k1] Up[k0:k1, r0:cj1]
+      p.A = Lp + r0 + (int64_t)k0 * m; p.lda = m; p.B = Up + k0 + (int64_t)r0 * ns; p.ldb = ns;
+      p.C = Lp + r0 + (int64_t)r0 * m; p.ldc = m; p.M = (int)m - r0; p.N = cj1 - r0;
+      ti = tl; tj = ts;
+    } else {                                      // Up[r0:cj1, r0:m] -= Lp[r0:cj1, k0:k1] Up[k0:k1, r0:m]
+      p.A = Lp + r0 + (int64_t)k0 * m; p.lda = m; p.B = Up + k0 + (int64_t)r0 * ns; p.ldb = ns;
+      p.C = Up + r0 + (int64_t)r0 * ns; p.ldc = ns; p.M = cj1 - r0; p.N = (int)m - r0;
+      ti = ts; tj = tl;
+    }
     gemm_tile<false>(p, ti, tj, lds);
-  } else {   // K_SUPD
+  } else {   // K_SUPD: S -= Lp[ns:m, 0:ns] Up[0:ns, ns:m]
     const int tm = cdiv(nr, GT);
     ti = t % tm; tj = t / tm;
-    p.A = Lp + ns; p.lda = m; p.B = Up + ns; p.ldb = m; p.C = d.T + d.soff[s]; p.ldc = nr; p.M = p.N = nr; p.K = ns;
+    p.A = Lp + ns; p.lda = m; p.B = Up + (int64_t)ns * ns; p.ldb = ns; p.C = d.T + d.soff[s]; p.ldc = nr; p.M = p.N = nr; p.K = ns;
     gemm_tile<false>(p, ti, tj, lds);
   }
 }
 
 // ------------------------------------------------------------------------------------------------- solves
-// y (length w) = W v for a 64 x 64 stored block; COLMAJOR: element (a, k) at a + k NB, else at a NB + k.  All 256 threads.
-template <bool COLMAJOR>
+// out[a] = sum_k M[a, k] v[k] for the stored 64 x 64 inverse (column-major); TRANS: M^T.  All 256 threads; sv, sy in LDS.
+template <bool TRANS>
 __device__ __forceinline__ void block_apply(const zc* __restrict__ Wb, int w, const zc* sv, zc* sy, zc* sred) {
   const int a = threadIdx.x & 63, q = threadIdx.x >> 6;
   zc acc = make_double2(0.0, 0.0);
   if (a < w)
-    for (int k = q * 16; k < min(w, q * 16 + 16); ++k) zfma(acc, COLMAJOR ? Wb[a + k * NB] : Wb[a * NB + k], sv[k]);
+    for (int k = q * 16; k < min(w, q * 16 + 16); ++k) zfma(acc, TRANS ? Wb[k + a * NB] : Wb[a + k * NB], sv[k]);
   sred[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    zc r = zadd(zadd(sred[a], sred[a + 64]), zadd(sred[a + 128], sred[a + 192]));
-    sy[a] = r;
-  }
+  if (threadIdx.x < 64) sy[a] = zadd(zadd(sred[a], sred[a + 64]), zadd(sred[a + 128], sred[a + 192]));
   __syncthreads();
+}
+
+// rows [r0, r1) of a column-major panel (leading dimension ld) times the 64-vector sy, columns c0 .. c0 + wd:
+// w[r] -= sum_k P[r, c0 + k] sy[k].  Thread (r = t & 63, q = t >> 6) takes a quarter of the columns; 64 rows per pass.
+__device__ __forceinline__ void rows_times_block(const zc* __restrict__ P, int64_t ld, int64_t r0, int64_t r1, int c0, int wd,
+                                                 const zc* sy, zc* w, zc* sred) {
+  const int lr = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int k0 = q * 16, k1 = min(wd, k0 + 16);
+  for (int64_t base = r0; base < r1; base += 64) {
+    const int64_t r = base + lr;
+    zc acc = make_double2(0.0, 0.0);
+    if (r < r1) {
+      const zc* pr = P + r + (int64_t)c0 * ld;
+#pragma unroll 8
+      for (int k = k0; k < k1; ++k) zfma(acc, pr[(int64_t)k * ld], sy[k]);
+    }
+    sred[threadIdx.x] = acc;
+    __syncthreads();
+    if (q == 0 && r < r1) {
+      const zc t = zadd(zadd(sred[lr], sred[lr + 64]), zadd(sred[lr + 128], sred[lr + 192]));
+      w[r].x -= t.x; w[r].y -= t.y;
+    }
+    __syncthreads();
+  }
+}
+
+// pivot rows c0 .. c0 + wd of the row panel U (ns x m, leading dimension ns) times w[a0:a1]: out[k] = sum_a U[c0 + k, a] w[a].
+// Thread (k = t & 63, q) takes every fourth column; the four partial sums are left in sred[q * 64 + k].
+__device__ __forceinline__ void block_times_cols(const zc* __restrict__ U, int64_t ld, int c0, int wd, int64_t a0, int64_t a1,
+                                                 const zc* __restrict__ w, zc* sred) {
+  const int k = threadIdx.x & 63, q = threadIdx.x >> 6;
+  zc acc = make_double2(0.0, 0.0);
+  if (k < wd) {
+    const zc* pu = U + c0 + k;
+#pragma unroll 4
+    for (int64_t a = a0 + q; a < a1; a += 4) zfma(acc, pu[a * ld], w[a]);
+  }
+  sred[threadIdx.x] = acc;
+  __syncthreads();
+}
+
+// column dots (transposed solves): out[k] = sum_a P[a, c0 + k] w[a] over a in [r0, r1); wave wv takes k = wv, wv + 4, ...
+__device__ __forceinline__ void block_dots(const zc* __restrict__ P, int64_t m, int c0, int wd, int64_t r0, int64_t r1, const zc* __restrict__ w, zc* out) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = wv; k < wd; k += 4) {
+    zc acc = make_double2(0.0, 0.0);
+    const zc* pc = P + (int64_t)(c0 + k) * m;
+    for (int64_t a = r0 + lane; a < r1; a += 64) zfma(acc, pc[a], w[a]);
+    acc = zreduce_sub<64>(acc);
+    if (lane == 0) out[k] = acc;
+  }
+}
+// w[a] -= sum_k U[c0 + k, a] sy[k] for a in [r0, r1) (transposed forward sweep): one wave per a, lanes over k
+__device__ __forceinline__ void cols_dot_block(const zc* __restrict__ U, int64_t ld, int c0, int wd, int64_t r0, int64_t r1, const zc* sy, zc* w) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const zc yk = lane < wd ? sy[lane] : make_double2(0.0, 0.0);
+  for (int64_t a = r0 + wv; a < r1; a += 4) {
+    zc acc = make_double2(0.0, 0.0);
+    if (lane < wd) zfma(acc, U[c0 + lane + a * ld], yk);
+    acc = zreduce_sub<64>(acc);
+    if (lane == 0) { w[a].x -= acc.x; w[a].y -= acc.y; }
+  }
 }
 
 __device__ __forceinline__ void fwd_gather(const SpluDev& d, int s, int ns, int64_t m, const zc* __restrict__ pb, zc* w) {
@@ -434,33 +538,28 @@ __device__ __forceinline__ void fwd_gather(const SpluDev& d, int s, int ns, int6
   }
 }
 
-// forward: w[0:ns] <- block-forward-substituted right-hand side (= y of this supernode), w[ns:m] <- update for the ancestors
-__global__ void __launch_bounds__(256) k_splu_fwd_small(SpluDev d, const int32_t* __restrict__ fronts, int trans,
-                                                        const zc* __restrict__ pb, zc* __restrict__ y) {
+// forward sweep of one front: w[0:ns] <- y of this supernode (stays in the workspace for the backward sweep),
+// w[ns:m] <- update for the ancestors.  L has unit diagonal blocks; the transposed sweep runs on U^T (diagonal blocks D^T).
+__global__ void __launch_bounds__(256) k_splu_fwd_small(SpluDev d, const int32_t* __restrict__ fronts, int trans, const zc* __restrict__ pb) {
   __shared__ zc sv[NB], sy[NB], sred[256];
   const int s = fronts[blockIdx.x];
   const int ns = d.sfirst[s + 1] - d.sfirst[s];
   const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
   zc* w = d.wk + d.woff[s];
-  const zc* P = d.F + (trans ? d.uoff[s] : d.loff[s]);
   fwd_gather(d, s, ns, m, pb, w);
   for (int kb = 0; kb * NB < ns; ++kb) {
     const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
-    const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB + (trans ? NB * NB : 0);
     if (threadIdx.x < wd) sv[threadIdx.x] = w[c0 + threadIdx.x];
     __syncthreads();
-    block_apply<true>(Wb, wd, sv, sy, sred);
-    if (threadIdx.x < wd) w[c0 + threadIdx.x] = sy[threadIdx.x];
-    for (int64_t r = c1 + threadIdx.x; r < m; r += 256) {
-      zc acc = make_double2(0.0, 0.0);
-      const zc* pr = P + r + (int64_t)c0 * m;
-      for (int k = 0; k < wd; ++k) zfma(acc, pr[(int64_t)k * m], sy[k]);
-      w[r].x -= acc.x; w[r].y -= acc.y;
+    if (!trans) {
+      rows_times_block(d.F + d.loff[s], m, c1, m, c0, wd, sv, w, sred);
+    } else {
+      block_apply<true>(d.W + d.ioff[s] + (int64_t)kb * NB * NB, wd, sv, sy, sred);
+      if (threadIdx.x < wd) w[c0 + threadIdx.x] = sy[threadIdx.x];
+      cols_dot_block(d.F + d.uoff[s], ns, c0, wd, c1, m, sy, w);
+      __syncthreads();
     }
-    __syncthreads();
   }
-  const int first = d.sfirst[s];
-  for (int i = threadIdx.x; i < ns; i += 256) y[first + i] = w[i];
 }
 
 __global__ void __launch_bounds__(256) k_splu_fwd_gather(SpluDev d, const int32_t* __restrict__ fronts, const zc* __restrict__ pb) {
@@ -470,24 +569,23 @@ __global__ void __launch_bounds__(256) k_splu_fwd_gather(SpluDev d, const int32_
   fwd_gather(d, s, ns, m, pb, d.wk + d.woff[s]);
 }
 
-// large fronts, pivot block kb: w[c0:c1] <- W w[c0:c1]  (also written to y)
-__global__ void __launch_bounds__(256) k_splu_fwd_diag(SpluDev d, const int32_t* __restrict__ fronts, int kb, int trans, zc* __restrict__ y) {
+// large fronts, transposed sweep only, pivot block kb: w[c0:c1] <- D^-T w[c0:c1]
+__global__ void __launch_bounds__(256) k_splu_fwd_diag(SpluDev d, const int32_t* __restrict__ fronts, int kb) {
   __shared__ zc sv[NB], sy[NB], sred[256];
   const int s = fronts[blockIdx.x];
   const int ns = d.sfirst[s + 1] - d.sfirst[s];
   const int c0 = kb * NB, wd = min(ns, c0 + NB) - c0;
   zc* w = d.wk + d.woff[s];
-  const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB + (trans ? NB * NB : 0);
   if (threadIdx.x < wd) sv[threadIdx.x] = w[c0 + threadIdx.x];
   __syncthreads();
-  block_apply<true>(Wb, wd, sv, sy, sred);
-  if (threadIdx.x < wd) { w[c0 + threadIdx.x] = sy[threadIdx.x]; y[d.sfirst[s] + c0 + threadIdx.x] = sy[threadIdx.x]; }
+  block_apply<true>(d.W + d.ioff[s] + (int64_t)kb * NB * NB, wd, sv, sy, sred);
+  if (threadIdx.x < wd) w[c0 + threadIdx.x] = sy[threadIdx.x];
 }
 
-// large fronts, pivot block kb: w[c1:m] -= P[c1:m, c0:c1] w[c0:c1]; SOLVE_ROWS rows per workgroup
+// large fronts, pivot block kb: w[c1:m] -= L[c1:m, c0:c1] w[c0:c1] (transposed: U[c0:c1, c1:m]^T)
 __global__ void __launch_bounds__(256) k_splu_fwd_upd(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf,
                                                       int kb, int trans) {
-  __shared__ zc sy[NB];
+  __shared__ zc sy[NB], sred[256];
   const int f = find_front(prefix, nf, blockIdx.x);
   const int s = fronts[f];
   const int t = blockIdx.x - prefix[f];
@@ -495,81 +593,87 @@ __global__ void __launch_bounds__(256) k_splu_fwd_upd(SpluDev d, const int32_t* 
   const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
   const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
   zc* w = d.wk + d.woff[s];
-  const zc* P = d.F + (trans ? d.uoff[s] : d.loff[s]);
   if (threadIdx.x < wd) sy[threadIdx.x] = w[c0 + threadIdx.x];
   __syncthreads();
-  const int64_t rend = min(m, (int64_t)c1 + (int64_t)(t + 1) * SOLVE_ROWS);
-  for (int64_t r = c1 + (int64_t)t * SOLVE_ROWS + threadIdx.x; r < rend; r += 256) {
-    zc acc = make_double2(0.0, 0.0);
-    const zc* pr = P + r + (int64_t)c0 * m;
-    for (int k = 0; k < wd; ++k) zfma(acc, pr[(int64_t)k * m], sy[k]);
-    w[r].x -= acc.x; w[r].y -= acc.y;
+  if (!trans) {
+    const int64_t r0 = c1 + (int64_t)t * FWD_ROWS;
+    rows_times_block(d.F + d.loff[s], m, r0, min(m, r0 + FWD_ROWS), c0, wd, sy, w, sred);
+  } else {
+    const int64_t r0 = c1 + (int64_t)t * SOLVE_ROWS;
+    cols_dot_block(d.F + d.uoff[s], ns, c0, wd, r0, min(m, r0 + SOLVE_ROWS), sy, w);
   }
 }
 
-__device__ __forceinline__ void bwd_gather(const SpluDev& d, int s, int ns, int64_t m, const zc* __restrict__ y, const zc* __restrict__ x, zc* w) {
-  const int first = d.sfirst[s];
-  const int32_t* rows = d.srow + d.sptr[s];
-  for (int64_t i = threadIdx.x; i < m; i += blockDim.x) w[i] = i < ns ? y[first + i] : x[rows[i - ns]];
-  __syncthreads();
-}
-
-// column dots of one pivot block against w[r0:r1]: out[k] = sum_a P[a, c0 + k] w[a]; wave wv takes k = wv, wv + 4, ...
-__device__ __forceinline__ void block_dots(const zc* __restrict__ P, int64_t m, int c0, int wd, int64_t r0, int64_t r1, const zc* __restrict__ w, zc* out) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = wv; k < wd; k += 4) {
-    zc acc = make_double2(0.0, 0.0);
-    const zc* pc = P + (int64_t)(c0 + k) * m;
-    for (int64_t a = r0 + lane; a < r1; a += 64) zfma(acc, pc[a], w[a]);
-    acc = zreduce_sub<64>(acc);
-    if (lane == 0) out[k] = acc;
-  }
-}
-
-__global__ void __launch_bounds__(256) k_splu_bwd_small(SpluDev d, const int32_t* __restrict__ fronts, int trans,
-                                                        const zc* __restrict__ y, zc* __restrict__ x) {
+// backward sweep of one front: w[ns:m] <- x of the border rows, then pivot blocks from last to first
+__global__ void __launch_bounds__(256) k_splu_bwd_small(SpluDev d, const int32_t* __restrict__ fronts, int trans, zc* __restrict__ x) {
   __shared__ zc sv[NB], sy[NB], sred[256];
   const int s = fronts[blockIdx.x];
   const int ns = d.sfirst[s + 1] - d.sfirst[s];
   const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
   zc* w = d.wk + d.woff[s];
-  const zc* P = d.F + (trans ? d.loff[s] : d.uoff[s]);
-  bwd_gather(d, s, ns, m, y, x, w);
+  {
+    const int32_t* rows = d.srow + d.sptr[s];
+    for (int64_t i = ns + threadIdx.x; i < m; i += 256) w[i] = x[rows[i - ns]];
+    __syncthreads();
+  }
   for (int kb = (ns - 1) / NB; kb >= 0; --kb) {
     const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
-    const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB + (trans ? 0 : NB * NB);
-    block_dots(P, m, c0, wd, c1, m, w, sy);
-    __syncthreads();
-    if (threadIdx.x < wd) sv[threadIdx.x] = zsub(w[c0 + threadIdx.x], sy[threadIdx.x]);
-    __syncthreads();
-    block_apply<false>(Wb, wd, sv, sy, sred);
-    if (threadIdx.x < wd) w[c0 + threadIdx.x] = sy[threadIdx.x];
+    if (!trans) {
+      block_times_cols(d.F + d.uoff[s], ns, c0, wd, c1, m, w, sred);
+      if (threadIdx.x < wd) {
+        const int k = threadIdx.x;
+        const zc t = zadd(zadd(sred[k], sred[k + 64]), zadd(sred[k + 128], sred[k + 192]));
+        sv[k] = zsub(w[c0 + k], t);
+      }
+      __syncthreads();
+      block_apply<false>(d.W + d.ioff[s] + (int64_t)kb * NB * NB, wd, sv, sy, sred);
+      if (threadIdx.x < wd) w[c0 + threadIdx.x] = sy[threadIdx.x];
+    } else {
+      block_dots(d.F + d.loff[s], m, c0, wd, c1, m, w, sy);
+      __syncthreads();
+      if (threadIdx.x < wd) w[c0 + threadIdx.x] = zsub(w[c0 + threadIdx.x], sy[threadIdx.x]);
+    }
     __syncthreads();
   }
   const int first = d.sfirst[s];
   for (int i = threadIdx.x; i < ns; i += 256) x[first + i] = w[i];
 }
 
-__global__ void __launch_bounds__(256) k_splu_bwd_gather(SpluDev d, const int32_t* __restrict__ fronts, const zc* __restrict__ y, const zc* __restrict__ x) {
+__global__ void __launch_bounds__(256) k_splu_bwd_gather(SpluDev d, const int32_t* __restrict__ fronts, const zc* __restrict__ x) {
   const int s = fronts[blockIdx.x];
   const int ns = d.sfirst[s + 1] - d.sfirst[s];
   const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
-  bwd_gather(d, s, ns, m, y, x, d.wk + d.woff[s]);
+  zc* w = d.wk + d.woff[s];
+  const int32_t* rows = d.srow + d.sptr[s];
+  for (int64_t i = ns + threadIdx.x; i < m; i += 256) w[i] = x[rows[i - ns]];
 }
 
+// large fronts, pivot block kb: partial products of U[c0:c1, c1:m] w[c1:m] (transposed: L[c1:m, c0:c1]^T w[c1:m]) per tile
 __global__ void __launch_bounds__(256) k_splu_bwd_dot(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf,
                                                       int kb, int trans) {
+  __shared__ zc sred[256];
   const int f = find_front(prefix, nf, blockIdx.x);
   const int s = fronts[f];
   const int t = blockIdx.x - prefix[f];
   const int ns = d.sfirst[s + 1] - d.sfirst[s];
   const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
   const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
-  const zc* P = d.F + (trans ? d.loff[s] : d.uoff[s]);
-  const int64_t r0 = c1 + (int64_t)t * SOLVE_ROWS, r1 = min(m, r0 + SOLVE_ROWS);
-  block_dots(P, m, c0, wd, r0, r1, d.wk + d.woff[s], d.part + d.poff[s] + (int64_t)t * NB);
+  const zc* w = d.wk + d.woff[s];
+  zc* out = d.part + d.poff[s] + (int64_t)t * NB;
+  if (!trans) {
+    const int64_t a0 = c1 + (int64_t)t * BWD_COLS;
+    block_times_cols(d.F + d.uoff[s], ns, c0, wd, a0, min(m, a0 + BWD_COLS), w, sred);
+    if (threadIdx.x < wd) {
+      const int k = threadIdx.x;
+      out[k] = zadd(zadd(sred[k], sred[k + 64]), zadd(sred[k + 128], sred[k + 192]));
+    }
+  } else {
+    const int64_t r0 = c1 + (int64_t)t * SOLVE_ROWS;
+    block_dots(d.F + d.loff[s], m, c0, wd, r0, min(m, r0 + SOLVE_ROWS), w, out);
+  }
 }
 
+// large fronts, pivot block kb: w[c0:c1] <- D^-1 (w[c0:c1] - sum of the partial products)   (transposed: no D)
 __global__ void __launch_bounds__(256) k_splu_bwd_diag(SpluDev d, const int32_t* __restrict__ fronts, int kb, int trans, zc* __restrict__ x) {
   __shared__ zc sv[NB], sy[NB], sred[256];
   const int s = fronts[blockIdx.x];
@@ -577,8 +681,7 @@ __global__ void __launch_bounds__(256) k_splu_bwd_diag(SpluDev d, const int32_t*
   const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
   const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
   zc* w = d.wk + d.woff[s];
-  const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * 2 * NB * NB + (trans ? 0 : NB * NB);
-  const int ntile = cdiv((int)(m - c1), SOLVE_ROWS);
+  const int ntile = cdiv((int)(m - c1), trans ? SOLVE_ROWS : BWD_COLS);
   if (threadIdx.x < wd) {
     zc acc = make_double2(0.0, 0.0);
     const zc* pp = d.part + d.poff[s] + threadIdx.x;
@@ -586,8 +689,11 @@ __global__ void __launch_bounds__(256) k_splu_bwd_diag(SpluDev d, const int32_t*
     sv[threadIdx.x] = zsub(w[c0 + threadIdx.x], acc);
   }
   __syncthreads();
-  block_apply<false>(Wb, wd, sv, sy, sred);
-  if (threadIdx.x < wd) { w[c0 + threadIdx.x] = sy[threadIdx.x]; x[d.sfirst[s] + c0 + threadIdx.x] = sy[threadIdx.x]; }
+  if (!trans) block_apply<false>(d.W + d.ioff[s] + (int64_t)kb * NB * NB, wd, sv, sy, sred);
+  if (threadIdx.x < wd) {
+    const zc v = trans ? sv[threadIdx.x] : sy[threadIdx.x];
+    w[c0 + threadIdx.x] = v; x[d.sfirst[s] + c0 + threadIdx.x] = v;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_splu_permute(int32_t n, const int32_t* __restrict__ perm, const zc* __restrict__ in, zc* __restrict__ out, int scatter) {
@@ -597,17 +703,19 @@ __global__ void __launch_bounds__(256) k_splu_permute(int32_t n, const int32_t* 
 }
 
 // ------------------------------------------------------------------------------------------------- host side
+typedef int (*tile_fn)(int, int, int, int);
+
 static void add_launch(std::vector<Launch>& plan, std::vector<int32_t>& lists, int kind, const std::vector<int32_t>& fronts,
-                       const SpluSymbolic& S, int p0, bool tiled) {
+                       const SpluSymbolic& S, int p0, tile_fn tiles) {
   if (fronts.empty()) return;
   Launch L; L.kind = kind; L.list = (int64_t)lists.size(); L.nf = (int32_t)fronts.size(); L.p0 = p0;
   lists.insert(lists.end(), fronts.begin(), fronts.end());
-  if (tiled) {
+  if (tiles) {
     int32_t acc = 0;
     lists.push_back(0);
     for (int32_t s : fronts) {
       const int ns = S.sfirst[s + 1] - S.sfirst[s], nr = (int)(S.sptr[s + 1] - S.sptr[s]);
-      acc += splu_tiles(kind, ns, nr, p0);
+      acc += tiles(kind, ns, nr, p0);
       lists.push_back(acc);
     }
     L.grid = acc;
@@ -626,74 +734,74 @@ static void build_plans(hx_splu* h, std::vector<int32_t>& lists) {
   std::vector<char> big(S.nsuper, 0);
   for (int s = 0; s < S.nsuper; ++s) {
     const int64_t ns = ns_of(s), m = ns + nr_of(s);
-    if (m * ns > BIG_FRONT_ELEMS) { big[s] = 1; h->poff[s] = pcur; pcur += (int64_t)cdiv((int)m, SOLVE_ROWS) * NB; }
+    if (m * ns > BIG_FRONT_ELEMS) { big[s] = 1; h->poff[s] = pcur; pcur += (int64_t)cdiv((int)m, BWD_COLS) * NB; }
   }
   h->part_elems = pcur;
-  std::vector<std::vector<int32_t>> fwd_by_level(S.nlevels);
   for (int l = 0; l < S.nlevels; ++l) {
     std::vector<int32_t> fr(S.level_list.begin() + S.level_ptr[l], S.level_list.begin() + S.level_ptr[l + 1]);
     // ---- factorisation
     std::vector<int32_t> sel;
     for (int s : fr) if (nr_of(s) > 0) sel.push_back(s);
-    add_launch(h->fplan, lists, K_ZERO, sel, S, 0, true);
+    add_launch(h->fplan, lists, K_ZERO, sel, S, 0, splu_tiles);
     for (int r = 0;; ++r) {
       sel.clear();
       for (int s : fr) if (S.child_ptr[s + 1] - S.child_ptr[s] > r) sel.push_back(S.child_list[S.child_ptr[s] + r]);
       if (sel.empty()) break;
-      add_launch(h->fplan, lists, K_EXTEND, sel, S, 0, true);
+      add_launch(h->fplan, lists, K_EXTEND, sel, S, 0, splu_tiles);
     }
     int max_ns = 0;
     for (int s : fr) max_ns = std::max(max_ns, ns_of(s));
     for (int kb = 0; kb * NB < max_ns; ++kb) {
       const int c0 = kb * NB;
-      if (c0 % NBO == 0 && c0 > 0) {
-        sel.clear();
-        for (int s : fr) if (ns_of(s) > c0) sel.push_back(s);
-        add_launch(h->fplan, lists, K_LEFT, sel, S, c0 / NBO, true);
-      }
       sel.clear();
       for (int s : fr) if (ns_of(s) > c0) sel.push_back(s);
-      add_launch(h->fplan, lists, K_DIAG, sel, S, kb, false);
+      if (c0 % NBO == 0 && c0 > 0) add_launch(h->fplan, lists, K_LEFT, sel, S, c0 / NBO, splu_tiles);
+      add_launch(h->fplan, lists, K_DIAG, sel, S, kb, nullptr);
       std::vector<int32_t> sp, si;
       for (int s : sel) {
         const int ns = ns_of(s), m = ns + nr_of(s), c1 = std::min(ns, c0 + NB), cj1 = std::min(ns, (c0 / NBO + 1) * NBO);
         if (m > c1) sp.push_back(s);
         if (cj1 > c1) si.push_back(s);
       }
-      add_launch(h->fplan, lists, K_PANEL, sp, S, kb, true);
-      add_launch(h->fplan, lists, K_INNER, si, S, kb, true);
+      add_launch(h->fplan, lists, K_PANEL, sp, S, kb, splu_tiles);
+      add_launch(h->fplan, lists, K_INNER, si, S, kb, splu_tiles);
     }
     sel.clear();
     for (int s : fr) if (nr_of(s) > 0) sel.push_back(s);
-    add_launch(h->fplan, lists, K_SUPD, sel, S, 0, true);
-    // ---- solves
-    std::vector<int32_t> small, large;
-    for (int s : fr) (big[s] ? large : small).push_back(s);
-    add_launch(h->fwd_plan, lists, S_FWD_SMALL, small, S, 0, false);
-    add_launch(h->fwd_plan, lists, S_FWD_GATHER, large, S, 0, false);
-    int max_big = 0;
-    for (int s : large) max_big = std::max(max_big, ns_of(s));
-    for (int kb = 0; kb * NB < max_big; ++kb) {
-      sel.clear();
-      std::vector<int32_t> su;
-      for (int s : large) if (ns_of(s) > kb * NB) { sel.push_back(s); if (ns_of(s) + nr_of(s) > std::min(ns_of(s), kb * NB + NB)) su.push_back(s); }
-      add_launch(h->fwd_plan, lists, S_FWD_DIAG, sel, S, kb, false);
-      add_launch(h->fwd_plan, lists, S_FWD_UPD, su, S, kb, true);
-    }
+    add_launch(h->fplan, lists, K_SUPD, sel, S, 0, splu_tiles);
   }
-  for (int l = S.nlevels - 1; l >= 0; --l) {
-    std::vector<int32_t> small, large, sel;
-    for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) { const int s = S.level_list[k]; (big[s] ? large : small).push_back(s); }
-    add_launch(h->bwd_plan, lists, S_BWD_SMALL, small, S, 0, false);
-    add_launch(h->bwd_plan, lists, S_BWD_GATHER, large, S, 0, false);
-    int max_big = 0;
-    for (int s : large) max_big = std::max(max_big, ns_of(s));
-    for (int kb = (max_big - 1) / NB; kb >= 0 && max_big > 0; --kb) {
-      sel.clear();
-      std::vector<int32_t> sd;
-      for (int s : large) if (ns_of(s) > kb * NB) { sel.push_back(s); if (ns_of(s) + nr_of(s) > std::min(ns_of(s), kb * NB + NB)) sd.push_back(s); }
-      add_launch(h->bwd_plan, lists, S_BWD_DOT, sd, S, kb, true);
-      add_launch(h->bwd_plan, lists, S_BWD_DIAG, sel, S, kb, false);
+  // ---- solves: [0] = A x = b, [1] = A^T x = b
+  for (int tr = 0; tr < 2; ++tr) {
+    tile_fn tiles = tr ? splu_tiles_trans : splu_tiles;
+    for (int l = 0; l < S.nlevels; ++l) {
+      std::vector<int32_t> small, large, sel;
+      for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) { const int s = S.level_list[k]; (big[s] ? large : small).push_back(s); }
+      add_launch(h->fwd_plan[tr], lists, S_FWD_SMALL, small, S, 0, nullptr);
+      add_launch(h->fwd_plan[tr], lists, S_FWD_GATHER, large, S, 0, nullptr);
+      int max_big = 0;
+      for (int s : large) max_big = std::max(max_big, ns_of(s));
+      for (int kb = 0; kb * NB < max_big; ++kb) {
+        sel.clear();
+        std::vector<int32_t> su;
+        for (int s : large) if (ns_of(s) > kb * NB) { sel.push_back(s); if (ns_of(s) + nr_of(s) > std::min(ns_of(s), kb * NB + NB)) su.push_back(s); }
+        if (tr) add_launch(h->fwd_plan[tr], lists, S_FWD_DIAG, sel, S, kb, nullptr);
+        add_launch(h->fwd_plan[tr], lists, S_FWD_UPD, su, S, kb, tiles);
+      }
+    }
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+      std::vector<int32_t> small, large, sel;
+      for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) { const int s = S.level_list[k]; (big[s] ? large : small).push_back(s); }
+      add_launch(h->bwd_plan[tr], lists, S_BWD_SMALL, small, S, 0, nullptr);
+      add_launch(h->bwd_plan[tr], lists, S_BWD_GATHER, large, S, 0, nullptr);
+      int max_big = 0;
+      for (int s : large) max_big = std::max(max_big, ns_of(s));
+      for (int kb = (max_big - 1) / NB; kb >= 0 && max_big > 0; --kb) {
+        sel.clear();
+        std::vector<int32_t> sd;
+        for (int s : large) if (ns_of(s) > kb * NB) { sel.push_back(s); if (ns_of(s) + nr_of(s) > std::min(ns_of(s), kb * NB + NB)) sd.push_back(s); }
+        add_launch(h->bwd_plan[tr], lists, S_BWD_DOT, sd, S, kb, tiles);
+        add_launch(h->bwd_plan[tr], lists, S_BWD_DIAG, sel, S, kb, nullptr);
+      }
     }
   }
 }
@@ -707,8 +815,8 @@ static hipError_t upload(T** dst, const std::vector<T>& v) {
 }
 
 static void splu_release(hx_splu* h) {
-  hx_free(h->d_i32); hx_free(h->d_i64); hx_free(h->d_lists); hx_free(h->d_amap); hx_free(h->d_perm); hx_free(h->d_status);
-  hx_free(h->F); hx_free(h->W); hx_free(h->T); hx_free(h->wk); hx_free(h->part); hx_free(h->pb); hx_free(h->xp);
+  void* blocks[] = {h->d_i32, h->d_i64, h->d_lists, h->d_amap, h->d_perm, h->d_status, h->F, h->W, h->T, h->wk, h->part, h->pb, h->xp};
+  for (void* b : blocks) (void)hx_free(b);
   h->d_i32 = h->d_lists = h->d_perm = h->d_status = nullptr; h->d_i64 = h->d_amap = nullptr;
   h->F = h->W = h->T = h->wk = h->part = h->pb = h->xp = nullptr;
 }
@@ -775,10 +883,9 @@ extern "C" int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream stream) 
   HX_HIP(hipMemsetAsync(h->d_status, 0, 4 * sizeof(int32_t), st));
   k_splu_scatter<<<hx_grid(h->nnz_in, 256), 256, 0, st>>>(h->nnz_in, h->d_amap, (const zc*)val, h->F);
   HX_LAUNCH_CHECK("k_splu_scatter");
-  const size_t gemm_lds = 2 * 2 * GK * GLD * sizeof(zc), diag_lds = 2 * NB * DLD * sizeof(zc);
+  const size_t gemm_lds = 2 * 2 * GK * GLD * sizeof(zc);
   static bool attr_done = false;
   if (!attr_done) {
-    HX_HIP(hipFuncSetAttribute((const void*)k_splu_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
     HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_PANEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
     HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_INNER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
     HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_LEFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
@@ -791,7 +898,7 @@ extern "C" int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream stream) 
     switch (L.kind) {
       case K_ZERO: k_splu_zero<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf); break;
       case K_EXTEND: k_splu_extend<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf); break;
-      case K_DIAG: k_splu_diag<<<L.grid, 256, diag_lds, st>>>(h->dev, fr, L.p0); break;
+      case K_DIAG: k_splu_diag<<<L.grid, 512, 0, st>>>(h->dev, fr, L.p0); break;
       case K_PANEL: k_splu_gemm<K_PANEL><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
       case K_INNER: k_splu_gemm<K_INNER><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
       case K_LEFT: k_splu_gemm<K_LEFT><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
@@ -806,10 +913,10 @@ extern "C" int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream stream) 
   HX_HIP(hipStreamSynchronize(st));
   float ms = 0.f;
   HX_HIP(hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   h->factor_seconds = ms * 1e-3;
   h->tiny_pivots = status[0];
-  hx_free(h->T); h->T = nullptr; h->dev.T = nullptr;      // the contribution blocks are dead: back to the pool
+  (void)hx_free(h->T); h->T = nullptr; h->dev.T = nullptr;      // the contribution blocks are dead: back to the pool
   h->factored = true;
   return HX_OK;
 }
@@ -821,25 +928,25 @@ extern "C" int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int trans
   const SpluSymbolic& S = h->sym;
   const int tr = transposed ? 1 : 0;
   k_splu_permute<<<hx_grid(S.n, 256), 256, 0, st>>>(S.n, h->d_perm, (const zc*)b, h->pb, 0);
-  // forward writes y into xp, backward overwrites it with x supernode by supernode (a front reads y of its own columns only)
+  // forward leaves y of every supernode in its workspace slice, backward turns it into x and writes the permuted solution
   zc* y = h->xp;
-  for (const Launch& L : h->fwd_plan) {
+  for (const Launch& L : h->fwd_plan[tr]) {
     const int32_t* fr = h->d_lists + L.list;
     const int32_t* px = fr + L.nf;
     switch (L.kind) {
-      case S_FWD_SMALL: k_splu_fwd_small<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, h->pb, y); break;
+      case S_FWD_SMALL: k_splu_fwd_small<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, h->pb); break;
       case S_FWD_GATHER: k_splu_fwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, h->pb); break;
-      case S_FWD_DIAG: k_splu_fwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0, tr, y); break;
+      case S_FWD_DIAG: k_splu_fwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0); break;
       case S_FWD_UPD: k_splu_fwd_upd<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
       default: break;
     }
   }
-  for (const Launch& L : h->bwd_plan) {
+  for (const Launch& L : h->bwd_plan[tr]) {
     const int32_t* fr = h->d_lists + L.list;
     const int32_t* px = fr + L.nf;
     switch (L.kind) {
-      case S_BWD_SMALL: k_splu_bwd_small<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, y, y); break;
-      case S_BWD_GATHER: k_splu_bwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, y, y); break;
+      case S_BWD_SMALL: k_splu_bwd_small<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, y); break;
+      case S_BWD_GATHER: k_splu_bwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, y); break;
       case S_BWD_DOT: k_splu_bwd_dot<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
       case S_BWD_DIAG: k_splu_bwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0, tr, y); break;
       default: break;
@@ -856,7 +963,7 @@ extern "C" int hx_splu_info(const hx_splu* h, int64_t* iout, double* dout) {
   iout[0] = S.n; iout[1] = S.nsuper; iout[2] = S.nlevels; iout[3] = S.nnz_L; iout[4] = S.factor_elems;
   iout[5] = S.inverse_elems; iout[6] = S.temp_elems; iout[7] = S.work_elems; iout[8] = S.max_front; iout[9] = S.max_ns;
   iout[10] = (int64_t)S.srow.size(); iout[11] = h->nnz_in; iout[12] = h->tiny_pivots;
-  iout[13] = (int64_t)h->fplan.size(); iout[14] = (int64_t)h->fwd_plan.size(); iout[15] = (int64_t)h->bwd_plan.size();
+  iout[13] = (int64_t)h->fplan.size(); iout[14] = (int64_t)h->fwd_plan[0].size(); iout[15] = (int64_t)h->bwd_plan[0].size();
   dout[0] = S.flops; dout[1] = S.analyse_seconds; dout[2] = h->factor_seconds;
   return HX_OK;
 }

@@ -323,7 +323,7 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
     const int64_t ns = S.sfirst[s + 1] - S.sfirst[s], nr = S.sptr[s + 1] - S.sptr[s], m = ns + nr;
     S.loff[s] = fcur; fcur += m * ns;
     S.uoff[s] = fcur; fcur += m * ns;
-    S.ioff[s] = icur; icur += 2 * (int64_t)SPLU_NB * SPLU_NB * ((ns + SPLU_NB - 1) / SPLU_NB);
+    S.ioff[s] = icur; icur += (int64_t)SPLU_NB * SPLU_NB * ((ns + SPLU_NB - 1) / SPLU_NB);
     S.woff[s] = wcur; wcur += m;
     S.nnz_L += ns * (ns + 1) / 2 + nr * ns;
     S.flops += 8.0 * ((double)ns * ns * ns / 3.0 + (double)nr * ns * ns + (double)nr * nr * ns);
@@ -403,7 +403,8 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
         if (p == e || *p != oth) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: entry outside its front");
         a = ns + (p - b);
       }
-      S.amap[k] = (lower ? S.loff[s] : S.uoff[s]) + a + (int64_t)(piv - S.sfirst[s]) * m;
+      S.amap[k] = lower ? S.loff[s] + a + (int64_t)(piv - S.sfirst[s]) * m          // Lp[a, pivot]: m x ns, ld m
+                        : S.uoff[s] + (int64_t)(piv - S.sfirst[s]) + a * ns;        // Up[pivot, a]: ns x m, ld ns
     }
   }
   S.analyse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

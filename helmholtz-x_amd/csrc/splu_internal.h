@@ -3,10 +3,12 @@
 // Supernodal multifrontal LU of a structurally symmetric(ised) complex128 matrix, nested-dissection ordered:
 //   * a supernode s owns the pivot columns [first, first + ns) of the permuted matrix and a sorted list of nr border rows;
 //     its front is the (ns + nr)^2 matrix [F11 F12; F21 F22] over (own columns ++ border);
-//   * the factor keeps two column-major panels of m = ns + nr rows and ns columns per supernode:
-//       Lp [a, b] = L(front row a, pivot b)   for a >= b   (the strict upper triangle of its top block is unused space),
-//       Utp[a, b] = U(pivot b, front column a) for a >  b   (U stored transposed: both panels are "tall"),
-//     the inverses of the SB x SB diagonal blocks (block-local partial pivoting folded in) live in a separate array;
+//   * block elimination with 64 x 64 pivot blocks: F = L U with unit diagonal BLOCKS in L and the (updated) diagonal blocks D_k
+//     themselves on the diagonal of U, so L[r, k] = F[r, k] D_k^-1 and U[k, j] = F[k, j] is never transformed.  The factor
+//     keeps two column-major panels per supernode:
+//       Lp[a, b] (m x ns, leading dimension m)  = L(front row a, pivot b)     for a >= b (strict upper triangle of the top block unused),
+//       Up[b, a] (ns x m, leading dimension ns) = U(pivot b, front column a)  for a >  b (lower triangle + diagonal of its left block unused),
+//     and D_k^-1 (Gauss-Jordan with partial pivoting inside the block), NB x NB column-major per pivot block, in a separate array;
 //   * F22 (the contribution block) is temporary: it lives in an arena until the parent front has absorbed it.
 #pragma once
 #include <stdint.h>
@@ -25,8 +27,8 @@ struct SpluSymbolic {
   std::vector<int32_t> slevel;               // height above the leaves
   std::vector<int32_t> level_ptr, level_list;  // supernodes grouped by level
   std::vector<int32_t> child_ptr, child_list;  // children in ascending order (the order of the extend-add)
-  std::vector<int64_t> loff, uoff;           // element offsets of Lp / Utp in the factor arena
-  std::vector<int64_t> ioff;                 // element offset of the diagonal-block inverses (2 * NB*NB per pivot block)
+  std::vector<int64_t> loff, uoff;           // element offsets of Lp / Up in the factor arena
+  std::vector<int64_t> ioff;                 // element offset of the diagonal-block inverses (NB * NB per pivot block)
   std::vector<int64_t> soff;                 // element offset of the contribution block in the temporary arena
   std::vector<int64_t> woff;                 // offset of the front's slice of the solve workspace (m entries)
   int64_t factor_elems = 0, inverse_elems = 0, temp_elems = 0, work_elems = 0;

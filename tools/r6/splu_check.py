@@ -1,5 +1,5 @@
 """Device sparse LU (hx_splu_*) on K = A + sigma B + sigma^2 C of the reference's MICCA mesh (refined `level` times):
-residuals, agreement with SciPy's SuperLU, factorisation / solve times.  usage: splu_check.py [max_level] [--no-scipy]"""
+residuals, agreement with SciPy's SuperLU, factorisation / solve times.  usage: splu_check.py [max_level] [--only level] [--graph] [--no-scipy]"""
 import ctypes as C
 import os
 import sys
@@ -43,12 +43,16 @@ def build(levels):
 def main():
     levels = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 0
     use_scipy = "--no-scipy" not in sys.argv
+    only = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else None
+    graph_too = "--graph" in sys.argv
     for lvl, (K, x) in enumerate(build(levels)):
+        if only is not None and lvl != only:
+            continue
         n = K.shape[0]
         rp = np.ascontiguousarray(K.indptr, np.int32)
         ci = np.ascontiguousarray(K.indices, np.int32)
         xy = np.ascontiguousarray(x, np.float64)
-        for coords in (xy, None):
+        for coords in ((xy, None) if graph_too else (xy,)):
             h = C.c_void_p()
             t0 = time.perf_counter()
             _hx.check(_hx.lib.hx_splu_analyse(C.byref(h), n, _hx.nptr(rp), _hx.nptr(ci), None if coords is None else _hx.nptr(coords),
@@ -71,7 +75,7 @@ def main():
             b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
             bd = to_device(b)
             xd = torch.empty_like(bd)
-            for tr in (0, 1):
+            for tr in ((0,) if "--no-trans" in sys.argv else (0, 1)):
                 _hx.check(_hx.lib.hx_splu_solve(h, _hx.ptr(bd), _hx.ptr(xd), tr, _hx.stream()))
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()

@@ -37,17 +37,20 @@
 #define FWD_ROWS 64             // rows per workgroup of the large-front forward update
 #define BWD_COLS 256            // columns per workgroup of the large-front backward partial products
 #define SOLVE_ROWS 512          // rows per workgroup of the column-dot kernels (transposed solves)
+#define GV_K 256                // columns per workgroup of the large-front matrix-vector products (64 rows x GV_K columns)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 enum { K_ZERO = 0, K_EXTEND, K_DIAG, K_PANEL, K_INNER, K_LEFT, K_SUPD,
-       S_FWD_SMALL, S_FWD_GATHER, S_FWD_DIAG, S_FWD_UPD, S_BWD_SMALL, S_BWD_GATHER, S_BWD_DOT, S_BWD_DIAG };
+       S_FWD_SMALL, S_FWD_GATHER, S_FWD_DIAG, S_FWD_UPD, S_BWD_SMALL, S_BWD_GATHER, S_BWD_DOT, S_BWD_DIAG,
+       K_INV_INIT, K_INVU_SCALE, K_INVL, K_INVU, S_GV_PART, S_GV_REDUCE };
+enum { GV_IL = 0, GV_L21, GV_U12, GV_IU };
 
 struct SpluDev {
   const int32_t* sfirst; const int64_t* sptr; const int32_t* srow; const int32_t* rel; const int32_t* sparent;
-  const int64_t* loff; const int64_t* uoff; const int64_t* ioff; const int64_t* soff; const int64_t* woff; const int64_t* poff;
+  const int64_t* loff; const int64_t* uoff; const int64_t* ioff; const int64_t* soff; const int64_t* woff; const int64_t* poff; const int64_t* voff;
   const int32_t* child_ptr; const int32_t* child_list;
-  zc* F; zc* W; zc* T; zc* wk; zc* part; int32_t* status;
+  zc* F; zc* W; zc* T; zc* wk; zc* part; zc* V; int32_t* status;
 };
 
 struct Launch { int kind; int64_t list; int32_t nf; int32_t grid; int32_t p0; };
@@ -56,13 +59,14 @@ struct hx_splu {
   SpluSymbolic sym;
   int64_t nnz_in = 0;
   bool factored = false;
-  std::vector<Launch> fplan, fwd_plan[2], bwd_plan[2];
-  std::vector<int64_t> poff;
-  int64_t part_elems = 0;
+  std::vector<Launch> fplan, iplan, fwd_plan[2], bwd_plan[2];
+  std::vector<int64_t> poff, voff;      // per supernode: partial sums of the large-front products / inverted diagonal blocks (-1: none)
+  int64_t part_elems = 0, inv_elems = 0;
+  double inv_flops = 0.0;
   // device
   int32_t *d_i32 = nullptr; int64_t* d_i64 = nullptr; int32_t* d_lists = nullptr; int64_t* d_amap = nullptr;
   int32_t *d_perm = nullptr, *d_status = nullptr;
-  zc *F = nullptr, *W = nullptr, *T = nullptr, *wk = nullptr, *part = nullptr, *pb = nullptr, *xp = nullptr;
+  zc *F = nullptr, *W = nullptr, *T = nullptr, *wk = nullptr, *part = nullptr, *pb = nullptr, *xp = nullptr, *V = nullptr;
   SpluDev dev{};
   int32_t tiny_pivots = 0;
   double factor_seconds = 0.0;
@@ -86,6 +90,14 @@ __host__ __device__ static inline int splu_tiles(int kind, int ns, int nr, int p
     case K_EXTEND: return cdiv(nr, GT) * cdiv(nr, GT);
     case S_FWD_UPD: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, FWD_ROWS); }
     case S_BWD_DOT: { const int c0 = p0 * NB, c1 = min(ns, c0 + NB); return cdiv(m - c1, BWD_COLS); }
+    case K_INV_INIT: return cdiv(ns, NB);
+    case K_INVU_SCALE: { int c = 0; for (int c1 = NB; c1 < ns; c1 += NB) c += cdiv(ns - c1, GT); return c; }
+    case K_INVL: return p0;                                               // row block p0: columns 0 .. p0 * 64
+    case K_INVU: { const int k = cdiv(ns, NB) - 1 - p0; return cdiv(ns - (k + 1) * NB, GT); }
+    case S_GV_PART: switch (p0) { case GV_IL: case GV_IU: return cdiv(ns, 64) * cdiv(ns, GV_K);
+                                  case GV_L21: return cdiv(nr, 64) * cdiv(ns, GV_K);
+                                  default: return cdiv(ns, 64) * cdiv(nr, GV_K); }
+    case S_GV_REDUCE: return cdiv(p0 == GV_L21 ? nr : ns, 256);
     default: return 1;
   }
 }
@@ -315,9 +327,10 @@ __global__ void __launch_bounds__(512) k_splu_diag(SpluDev d, const int32_t* __r
 // operand chunk is in LDS / registers before the first store).  One 64 x 64 tile per workgroup.
 // MFMA mapping: D[row][col] of v_mfma_f64_16x16x4_f64 has col = lane & 15, so the tile's ROW index i (contiguous in memory)
 // rides on lane & 15: the "a" operand is the B-matrix fragment (k, j), the "b" operand the A-matrix fragment (i, k).
-struct GemmProb { const zc* A; const zc* B; zc* C; int64_t lda, ldb, ldc; int M, N, K; };
+struct GemmProb { const zc* A; const zc* B; zc* C; int64_t lda, ldb, ldc; int M, N, K, K0 = 0; };   // k runs over [K0, K)
+enum { G_SUB = 0, G_ASSIGN = 1, G_NEG = 2 };     // C -= A B, C = A B, C = -A B
 
-template <bool ASSIGN>
+template <int MODE>
 __device__ __forceinline__ void gemm_tile(const GemmProb& p, int ti, int tj, zc* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wi = wv & 1, wj = wv >> 1;
@@ -342,10 +355,10 @@ __device__ __forceinline__ void gemm_tile(const GemmProb& p, int ti, int tj, zc*
   for (int x = 0; x < 2; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y) { cr[x][y] = (v4d){0, 0, 0, 0}; ci[x][y] = (v4d){0, 0, 0, 0}; }
-  load(0);
+  load(p.K0);
   int buf = 0;
   const int fi = lane & 15, fk = lane >> 4;
-  for (int k0 = 0; k0 < p.K; k0 += GK) {
+  for (int k0 = p.K0; k0 < p.K; k0 += GK) {
     zc* sA = lds + buf * 2 * GK * GLD;
     zc* sB = sA + GK * GLD;
 #pragma unroll
@@ -383,7 +396,8 @@ __device__ __forceinline__ void gemm_tile(const GemmProb& p, int ti, int tj, zc*
         const int j = col0 + 32 * wj + 16 * y + fk + 4 * r;
         if (i < p.M && j < p.N) {
           zc* c = p.C + i + (int64_t)j * p.ldc;
-          if (ASSIGN) *c = make_double2(cr[x][y][r], ci[x][y][r]);
+          if (MODE == G_ASSIGN) *c = make_double2(cr[x][y][r], ci[x][y][r]);
+          else if (MODE == G_NEG) *c = make_double2(-cr[x][y][r], -ci[x][y][r]);
           else { zc v = *c; v.x -= cr[x][y][r]; v.y -= ci[x][y][r]; *c = v; }
         }
       }
@@ -418,7 +432,7 @@ __global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __r
     p.A = Lp + c1 + (int64_t)c0 * m; p.lda = m; p.C = (zc*)p.A; p.ldc = m;
     p.B = d.W + d.ioff[s] + (int64_t)p0 * NB * NB; p.ldb = NB;
     p.M = (int)m - c1; p.N = p.K = c1 - c0;
-    gemm_tile<true>(p, t, 0, lds);
+    gemm_tile<G_ASSIGN>(p, t, 0, lds);
   } else if (KIND == K_INNER || KIND == K_LEFT) {
     int r0, k0, k1, cj1;
     if (KIND == K_INNER) { k0 = p0 * NB; k1 = min(ns, k0 + NB); r0 = k1; cj1 = min(ns, (k0 / NBO + 1) * NBO); }
@@ -438,12 +452,55 @@ __global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __r
       p.C = Up + r0 + (int64_t)r0 * ns; p.ldc = ns; p.M = cj1 - r0; p.N = (int)m - r0;
       ti = ts; tj = tl;
     }
-    gemm_tile<false>(p, ti, tj, lds);
-  } else {   // K_SUPD: S -= Lp[ns:m, 0:ns] Up[0:ns, ns:m]
+    gemm_tile<G_SUB>(p, ti, tj, lds);
+  } else if (KIND == K_SUPD) {   // K_SUPD: S -= Lp[ns:m, 0:ns] Up[0:ns, ns:m]
     const int tm = cdiv(nr, GT);
     ti = t % tm; tj = t / tm;
     p.A = Lp + ns; p.lda = m; p.B = Up + (int64_t)ns * ns; p.ldb = ns; p.C = d.T + d.soff[s]; p.ldc = nr; p.M = p.N = nr; p.K = ns;
-    gemm_tile<false>(p, ti, tj, lds);
+    gemm_tile<G_SUB>(p, ti, tj, lds);
+  } else {
+    // selective inversion of a large supernode: IL = L11^-1 (unit block lower triangular) and IU = U11^-1 (block upper
+    // triangular, diagonal blocks D_k^-1), ns x ns each at d.V + voff; the strictly upper BLOCKS of IL carry D_k^-1 U[k, :]
+    // while IU is being built (the products never touch them)
+    zc* IL = d.V + d.voff[s];
+    zc* IU = IL + (int64_t)ns * ns;
+    if (KIND == K_INVU_SCALE) {                  // IL[k, c1:ns] = D_k^-1 U[k, c1:ns] for every pivot block k but the last
+      int k = 0, c1 = NB;
+      for (; c1 < ns; c1 += NB, ++k) { const int c = cdiv(ns - c1, GT); if (t < c) break; t -= c; }
+      const int c0 = k * NB;
+      p.A = d.W + d.ioff[s] + (int64_t)k * NB * NB; p.lda = NB; p.B = Up + c0 + (int64_t)c1 * ns; p.ldb = ns;
+      p.C = IL + c0 + (int64_t)c1 * ns; p.ldc = ns; p.M = NB; p.N = ns - c1; p.K = NB;
+      gemm_tile<G_ASSIGN>(p, 0, t, lds);
+    } else if (KIND == K_INVL) {                 // row block i = p0: IL[i, 0:c0] = -L[i, 0:c0] IL[0:c0, 0:c0]   (IL lower triangular)
+      const int c0 = p0 * NB;
+      p.A = Lp + c0; p.lda = m; p.B = IL; p.ldb = ns; p.C = IL + c0; p.ldc = ns;
+      p.M = min(NB, ns - c0); p.N = c0; p.K = c0; p.K0 = t * GT;
+      gemm_tile<G_NEG>(p, 0, t, lds);
+    } else {                                     // row block k = nb - 1 - p0: IU[k, c1:ns] = -(D_k^-1 U[k, c1:ns]) IU[c1:ns, c1:ns]   (upper triangular)
+      const int k = cdiv(ns, NB) - 1 - p0, c0 = k * NB, c1 = c0 + NB;
+      p.A = IL + c0 + (int64_t)c1 * ns; p.lda = ns; p.B = IU + c1 + (int64_t)c1 * ns; p.ldb = ns; p.C = IU + c0 + (int64_t)c1 * ns; p.ldc = ns;
+      p.M = NB; p.N = ns - c1; p.K = min(ns - c1, (t + 1) * GT);
+      gemm_tile<G_NEG>(p, 0, t, lds);
+    }
+  }
+}
+
+// diagonal blocks of the inverted supernode: IL[k, k] = I, IU[k, k] = D_k^-1; one workgroup per (front, pivot block)
+__global__ void __launch_bounds__(256) k_splu_inv_init(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf) {
+  const int f = find_front(prefix, nf, blockIdx.x);
+  const int s = fronts[f];
+  const int k = blockIdx.x - prefix[f];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int c0 = k * NB, wd = min(ns, c0 + NB) - c0;
+  zc* IL = d.V + d.voff[s];
+  zc* IU = IL + (int64_t)ns * ns;
+  const zc* Wd = d.W + d.ioff[s] + (int64_t)k * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int a = e & (NB - 1), b = e >> 6;
+    if (a < wd && b < wd) {
+      IL[(c0 + a) + (int64_t)(c0 + b) * ns] = make_double2(a == b ? 1.0 : 0.0, 0.0);
+      IU[(c0 + a) + (int64_t)(c0 + b) * ns] = Wd[a + b * NB];
+    }
   }
 }
 
@@ -696,6 +753,71 @@ __global__ void __launch_bounds__(256) k_splu_bwd_diag(SpluDev d, const int32_t*
   }
 }
 
+// ---- large fronts, A x = b: every product is "64 rows of a column-major matrix times a vector", tiled 64 rows x GV_K columns;
+// the partial sums of a row's tiles are added in a fixed order by k_splu_gv_reduce (no atomics).  Per front and sweep:
+//   forward   y = IL w[0:ns]            (GV_IL, lower triangular: tiles right of the diagonal are skipped)
+//             w[ns:m] -= L21 y          (GV_L21)
+//   backward  t = y - U12 w[ns:m]       (GV_U12)
+//             x = IU t                  (GV_IU, upper triangular)
+// y / t live in the ns entries behind the front's m workspace entries.
+__global__ void __launch_bounds__(256) k_splu_gv_part(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf, int what) {
+  __shared__ zc sred[256];
+  const int f = find_front(prefix, nf, blockIdx.x);
+  const int s = fronts[f];
+  const int t = blockIdx.x - prefix[f];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int nr = (int)(d.sptr[s + 1] - d.sptr[s]);
+  const int64_t m = ns + nr;
+  const zc* w = d.wk + d.woff[s];
+  const zc* P; const zc* v; int64_t ld; int R, C;
+  if (what == GV_IL) { P = d.V + d.voff[s]; ld = ns; R = ns; C = ns; v = w; }
+  else if (what == GV_L21) { P = d.F + d.loff[s] + ns; ld = m; R = nr; C = ns; v = w + m; }
+  else if (what == GV_U12) { P = d.F + d.uoff[s] + (int64_t)ns * ns; ld = ns; R = ns; C = nr; v = w + ns; }
+  else { P = d.V + d.voff[s] + (int64_t)ns * ns; ld = ns; R = ns; C = ns; v = w + m; }
+  const int tr = cdiv(R, 64);
+  const int ti = t % tr, c = t / tr;
+  int k0 = c * GV_K, k1 = min(C, k0 + GV_K);
+  if (what == GV_IL) k1 = min(k1, min(ns, (ti + 1) * 64));      // columns beyond the row tile's diagonal block are zero
+  if (what == GV_IU) k0 = max(k0, ti * 64);
+  if (k0 >= k1) return;                                          // (the reduction skips this tile too)
+  const int lr = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int r = ti * 64 + lr;
+  zc acc = make_double2(0.0, 0.0);
+  if (r < R) {
+    const zc* pr = P + r;
+#pragma unroll 16
+    for (int k = k0 + q; k < k1; k += 4) zfma(acc, pr[(int64_t)k * ld], v[k]);
+  }
+  sred[threadIdx.x] = acc;
+  __syncthreads();
+  if (q == 0 && r < R)
+    d.part[d.poff[s] + (int64_t)c * R + r] = zadd(zadd(sred[lr], sred[lr + 64]), zadd(sred[lr + 128], sred[lr + 192]));
+}
+
+__global__ void __launch_bounds__(256) k_splu_gv_reduce(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf, int what,
+                                                        zc* __restrict__ x) {
+  const int f = find_front(prefix, nf, blockIdx.x);
+  const int s = fronts[f];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int nr = (int)(d.sptr[s + 1] - d.sptr[s]);
+  const int64_t m = ns + nr;
+  zc* w = d.wk + d.woff[s];
+  const int R = what == GV_L21 ? nr : ns, C = what == GV_U12 ? nr : ns;
+  const int r = (blockIdx.x - prefix[f]) * 256 + threadIdx.x;
+  if (r >= R) return;
+  const int ti = r >> 6;
+  int ca = 0, cb = cdiv(C, GV_K);
+  if (what == GV_IL) cb = min(cb, (min(ns, (ti + 1) * 64) - 1) / GV_K + 1);
+  if (what == GV_IU) ca = (ti * 64) / GV_K;
+  zc acc = make_double2(0.0, 0.0);
+  const zc* pp = d.part + d.poff[s] + r;
+  for (int c = ca; c < cb; ++c) acc = zadd(acc, pp[(int64_t)c * R]);
+  if (what == GV_IL) w[m + r] = acc;
+  else if (what == GV_L21) w[ns + r] = zsub(w[ns + r], acc);
+  else if (what == GV_U12) w[m + r] = zsub(w[m + r], acc);
+  else { w[r] = acc; x[d.sfirst[s] + r] = acc; }
+}
+
 __global__ void __launch_bounds__(256) k_splu_permute(int32_t n, const int32_t* __restrict__ perm, const zc* __restrict__ in, zc* __restrict__ out, int scatter) {
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     if (scatter) out[perm[i]] = in[i]; else out[i] = in[perm[i]];
@@ -730,13 +852,37 @@ static void build_plans(hx_splu* h, std::vector<int32_t>& lists) {
   auto ns_of = [&](int s) { return S.sfirst[s + 1] - S.sfirst[s]; };
   auto nr_of = [&](int s) { return (int)(S.sptr[s + 1] - S.sptr[s]); };
   h->poff.assign(S.nsuper, 0);
-  int64_t pcur = 0;
+  h->voff.assign(S.nsuper, -1);
+  int64_t pcur = 0, vcur = 0;
   std::vector<char> big(S.nsuper, 0);
+  std::vector<int32_t> all_big;
+  h->inv_flops = 0.0;
   for (int s = 0; s < S.nsuper; ++s) {
-    const int64_t ns = ns_of(s), m = ns + nr_of(s);
-    if (m * ns > BIG_FRONT_ELEMS) { big[s] = 1; h->poff[s] = pcur; pcur += (int64_t)cdiv((int)m, BWD_COLS) * NB; }
+    const int64_t ns = ns_of(s), nr = nr_of(s), m = ns + nr;
+    if (m * ns > BIG_FRONT_ELEMS) {
+      big[s] = 1; all_big.push_back(s);
+      const int64_t big_dim = std::max(ns, nr);
+      h->poff[s] = pcur; pcur += std::max<int64_t>(big_dim * cdiv((int)big_dim, GV_K), (int64_t)cdiv((int)m, BWD_COLS) * NB);
+      h->voff[s] = vcur; vcur += 2 * ns * ns;
+      h->inv_flops += 8.0 * ((double)ns * ns * ns / 3.0 + (double)NB * ns * ns / 2.0);
+    }
   }
-  h->part_elems = pcur;
+  h->part_elems = pcur; h->inv_elems = vcur;
+  // ---- selective inversion of the large supernodes (all levels together: the inverses only serve the solves)
+  {
+    int max_nb = 0;
+    for (int s : all_big) max_nb = std::max(max_nb, cdiv(ns_of(s), NB));
+    add_launch(h->iplan, lists, K_INV_INIT, all_big, S, 0, splu_tiles);
+    std::vector<int32_t> sel;
+    for (int s : all_big) if (ns_of(s) > NB) sel.push_back(s);
+    add_launch(h->iplan, lists, K_INVU_SCALE, sel, S, 0, splu_tiles);
+    for (int t = 1; t < max_nb; ++t) {
+      sel.clear();
+      for (int s : all_big) if (cdiv(ns_of(s), NB) > t) sel.push_back(s);
+      add_launch(h->iplan, lists, K_INVL, sel, S, t, splu_tiles);
+      add_launch(h->iplan, lists, K_INVU, sel, S, t, splu_tiles);
+    }
+  }
   for (int l = 0; l < S.nlevels; ++l) {
     std::vector<int32_t> fr(S.level_list.begin() + S.level_ptr[l], S.level_list.begin() + S.level_ptr[l + 1]);
     // ---- factorisation
@@ -778,6 +924,15 @@ static void build_plans(hx_splu* h, std::vector<int32_t>& lists) {
       for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) { const int s = S.level_list[k]; (big[s] ? large : small).push_back(s); }
       add_launch(h->fwd_plan[tr], lists, S_FWD_SMALL, small, S, 0, nullptr);
       add_launch(h->fwd_plan[tr], lists, S_FWD_GATHER, large, S, 0, nullptr);
+      if (!tr) {
+        std::vector<int32_t> with_border;
+        for (int s : large) if (nr_of(s) > 0) with_border.push_back(s);
+        add_launch(h->fwd_plan[0], lists, S_GV_PART, large, S, GV_IL, splu_tiles);
+        add_launch(h->fwd_plan[0], lists, S_GV_REDUCE, large, S, GV_IL, splu_tiles);
+        add_launch(h->fwd_plan[0], lists, S_GV_PART, with_border, S, GV_L21, splu_tiles);
+        add_launch(h->fwd_plan[0], lists, S_GV_REDUCE, with_border, S, GV_L21, splu_tiles);
+        continue;
+      }
       int max_big = 0;
       for (int s : large) max_big = std::max(max_big, ns_of(s));
       for (int kb = 0; kb * NB < max_big; ++kb) {
@@ -793,6 +948,15 @@ static void build_plans(hx_splu* h, std::vector<int32_t>& lists) {
       for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) { const int s = S.level_list[k]; (big[s] ? large : small).push_back(s); }
       add_launch(h->bwd_plan[tr], lists, S_BWD_SMALL, small, S, 0, nullptr);
       add_launch(h->bwd_plan[tr], lists, S_BWD_GATHER, large, S, 0, nullptr);
+      if (!tr) {
+        std::vector<int32_t> with_border;
+        for (int s : large) if (nr_of(s) > 0) with_border.push_back(s);
+        add_launch(h->bwd_plan[0], lists, S_GV_PART, with_border, S, GV_U12, splu_tiles);
+        add_launch(h->bwd_plan[0], lists, S_GV_REDUCE, large, S, GV_U12, splu_tiles);
+        add_launch(h->bwd_plan[0], lists, S_GV_PART, large, S, GV_IU, splu_tiles);
+        add_launch(h->bwd_plan[0], lists, S_GV_REDUCE, large, S, GV_IU, splu_tiles);
+        continue;
+      }
       int max_big = 0;
       for (int s : large) max_big = std::max(max_big, ns_of(s));
       for (int kb = (max_big - 1) / NB; kb >= 0 && max_big > 0; --kb) {
@@ -815,10 +979,10 @@ static hipError_t upload(T** dst, const std::vector<T>& v) {
 }
 
 static void splu_release(hx_splu* h) {
-  void* blocks[] = {h->d_i32, h->d_i64, h->d_lists, h->d_amap, h->d_perm, h->d_status, h->F, h->W, h->T, h->wk, h->part, h->pb, h->xp};
+  void* blocks[] = {h->d_i32, h->d_i64, h->d_lists, h->d_amap, h->d_perm, h->d_status, h->F, h->W, h->T, h->wk, h->part, h->pb, h->xp, h->V};
   for (void* b : blocks) (void)hx_free(b);
   h->d_i32 = h->d_lists = h->d_perm = h->d_status = nullptr; h->d_i64 = h->d_amap = nullptr;
-  h->F = h->W = h->T = h->wk = h->part = h->pb = h->xp = nullptr;
+  h->F = h->W = h->T = h->wk = h->part = h->pb = h->xp = h->V = nullptr;
 }
 
 extern "C" int hx_splu_analyse(hx_splu** out, int32_t n, const int32_t* h_rowptr, const int32_t* h_col,
@@ -846,7 +1010,7 @@ static int splu_prepare_device(hx_splu* h) {
   const size_t o_sfirst = put32(S.sfirst), o_srow = put32(S.srow), o_rel = put32(S.rel), o_par = put32(S.sparent),
                o_cp = put32(S.child_ptr), o_cl = put32(S.child_list);
   const size_t o_sptr = put64(S.sptr), o_loff = put64(S.loff), o_uoff = put64(S.uoff), o_ioff = put64(S.ioff), o_soff = put64(S.soff),
-               o_woff = put64(S.woff), o_poff = put64(h->poff);
+               o_woff = put64(S.woff), o_poff = put64(h->poff), o_voff = put64(h->voff);
   HX_HIP(upload(&h->d_i32, i32));
   HX_HIP(upload(&h->d_i64, i64));
   HX_HIP(upload(&h->d_lists, lists));
@@ -857,14 +1021,15 @@ static int splu_prepare_device(hx_splu* h) {
   HX_HIP(hx_malloc(&h->W, std::max<int64_t>(S.inverse_elems, 1) * sizeof(zc)));
   HX_HIP(hx_malloc(&h->wk, std::max<int64_t>(S.work_elems, 1) * sizeof(zc)));
   HX_HIP(hx_malloc(&h->part, std::max<int64_t>(h->part_elems, 1) * sizeof(zc)));
+  HX_HIP(hx_malloc(&h->V, std::max<int64_t>(h->inv_elems, 1) * sizeof(zc)));
   HX_HIP(hx_malloc(&h->pb, (size_t)S.n * sizeof(zc)));
   HX_HIP(hx_malloc(&h->xp, (size_t)S.n * sizeof(zc)));
   SpluDev& d = h->dev;
   d.sfirst = h->d_i32 + o_sfirst; d.srow = h->d_i32 + o_srow; d.rel = h->d_i32 + o_rel; d.sparent = h->d_i32 + o_par;
   d.child_ptr = h->d_i32 + o_cp; d.child_list = h->d_i32 + o_cl;
   d.sptr = h->d_i64 + o_sptr; d.loff = h->d_i64 + o_loff; d.uoff = h->d_i64 + o_uoff; d.ioff = h->d_i64 + o_ioff;
-  d.soff = h->d_i64 + o_soff; d.woff = h->d_i64 + o_woff; d.poff = h->d_i64 + o_poff;
-  d.F = h->F; d.W = h->W; d.T = nullptr; d.wk = h->wk; d.part = h->part; d.status = h->d_status;
+  d.soff = h->d_i64 + o_soff; d.woff = h->d_i64 + o_woff; d.poff = h->d_i64 + o_poff; d.voff = h->d_i64 + o_voff;
+  d.F = h->F; d.W = h->W; d.T = nullptr; d.wk = h->wk; d.part = h->part; d.V = h->V; d.status = h->d_status;
   return HX_OK;
 }
 
@@ -890,6 +1055,9 @@ extern "C" int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream stream) 
     HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_INNER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
     HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_LEFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
     HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_SUPD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_INVU_SCALE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_INVL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
+    HX_HIP(hipFuncSetAttribute((const void*)k_splu_gemm<K_INVU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds));
     attr_done = true;
   }
   for (const Launch& L : h->fplan) {
@@ -906,6 +1074,18 @@ extern "C" int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream stream) 
       default: break;
     }
     HX_LAUNCH_CHECK("hx_splu_factor");
+  }
+  for (const Launch& L : h->iplan) {
+    const int32_t* fr = h->d_lists + L.list;
+    const int32_t* px = fr + L.nf;
+    switch (L.kind) {
+      case K_INV_INIT: k_splu_inv_init<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf); break;
+      case K_INVU_SCALE: k_splu_gemm<K_INVU_SCALE><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      case K_INVL: k_splu_gemm<K_INVL><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      case K_INVU: k_splu_gemm<K_INVU><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      default: break;
+    }
+    HX_LAUNCH_CHECK("hx_splu_factor (selective inversion)");
   }
   HX_HIP(hipEventRecord(e1, st));
   int32_t status[4] = {0, 0, 0, 0};
@@ -938,6 +1118,8 @@ extern "C" int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int trans
       case S_FWD_GATHER: k_splu_fwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, h->pb); break;
       case S_FWD_DIAG: k_splu_fwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0); break;
       case S_FWD_UPD: k_splu_fwd_upd<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
+      case S_GV_PART: k_splu_gv_part<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      case S_GV_REDUCE: k_splu_gv_reduce<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, y); break;
       default: break;
     }
   }
@@ -949,6 +1131,8 @@ extern "C" int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int trans
       case S_BWD_GATHER: k_splu_bwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, y); break;
       case S_BWD_DOT: k_splu_bwd_dot<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
       case S_BWD_DIAG: k_splu_bwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0, tr, y); break;
+      case S_GV_PART: k_splu_gv_part<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      case S_GV_REDUCE: k_splu_gv_reduce<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, y); break;
       default: break;
     }
   }
@@ -964,7 +1148,8 @@ extern "C" int hx_splu_info(const hx_splu* h, int64_t* iout, double* dout) {
   iout[5] = S.inverse_elems; iout[6] = S.temp_elems; iout[7] = S.work_elems; iout[8] = S.max_front; iout[9] = S.max_ns;
   iout[10] = (int64_t)S.srow.size(); iout[11] = h->nnz_in; iout[12] = h->tiny_pivots;
   iout[13] = (int64_t)h->fplan.size(); iout[14] = (int64_t)h->fwd_plan[0].size(); iout[15] = (int64_t)h->bwd_plan[0].size();
-  dout[0] = S.flops; dout[1] = S.analyse_seconds; dout[2] = h->factor_seconds;
+  dout[0] = S.flops; dout[1] = S.analyse_seconds; dout[2] = h->factor_seconds; dout[3] = h->inv_flops;
+  iout[5] = S.inverse_elems + h->inv_elems;
   return HX_OK;
 }
 

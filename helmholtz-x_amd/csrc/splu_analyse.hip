@@ -324,7 +324,7 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
     S.loff[s] = fcur; fcur += m * ns;
     S.uoff[s] = fcur; fcur += m * ns;
     S.ioff[s] = icur; icur += (int64_t)SPLU_NB * SPLU_NB * ((ns + SPLU_NB - 1) / SPLU_NB);
-    S.woff[s] = wcur; wcur += m;
+    S.woff[s] = wcur; wcur += m + ns;            // m front entries + ns more (y / t of a large front's sweeps)
     S.nnz_L += ns * (ns + 1) / 2 + nr * ns;
     S.flops += 8.0 * ((double)ns * ns * ns / 3.0 + (double)nr * ns * ns + (double)nr * nr * ns);
     S.max_front = std::max<int32_t>(S.max_front, (int32_t)m);

@@ -30,7 +30,7 @@ struct SpluSymbolic {
   std::vector<int64_t> loff, uoff;           // element offsets of Lp / Up in the factor arena
   std::vector<int64_t> ioff;                 // element offset of the diagonal-block inverses (NB * NB per pivot block)
   std::vector<int64_t> soff;                 // element offset of the contribution block in the temporary arena
-  std::vector<int64_t> woff;                 // offset of the front's slice of the solve workspace (m entries)
+  std::vector<int64_t> woff;                 // offset of the front's slice of the solve workspace (m + ns entries)
   int64_t factor_elems = 0, inverse_elems = 0, temp_elems = 0, work_elems = 0;
   int64_t nnz_L = 0;                         // entries of L incl. diagonal (= entries of U)
   double flops = 0.0;                        // real flops of the numeric factorisation (complex multiply-add = 8)

@@ -345,9 +345,10 @@ def cpu_baseline(sample="micca-real", gpu_same_sample=True):
         D = Df if D is None else D + Df
     E, hist = eigen.fixed_point_iteration(A, B, C, eigen.OracleFlame(D, case["ftf"]), P.target, nev=4, i=0, tol=1e-3)
     dt = time.perf_counter() - t0
-    out = dict(value=round(4 / dt, 5), unit="eigenpairs/s", cores=BLAS_THREADS, blas_threads=BLAS_THREADS, kind="port",
-               note="SciPy SuperLU factorises on one core (sequential library); BLAS / LAPACK pools capped at %d threads"
-                    % BLAS_THREADS,
+    out = dict(value=round(4 / dt, 5), unit="eigenpairs/s", cores=BLAS_THREADS, blas_threads=BLAS_THREADS,
+               host_cores=os.cpu_count(), kind="port",
+               note="SciPy SuperLU factorises on one core (sequential library); BLAS / LAPACK pools capped at %d threads "
+                    "(cores = threads actually used; host_cores = os.cpu_count() of the box)" % BLAS_THREADS,
                sample="%s (%d DOF, %d tets), 1 full fixed_point_iteration (nev=4, tol=1e-3, %d iterations), "
                       "SciPy SuperLU + ARPACK, %.1f s" % (sample, n, cells.shape[0], len(hist) - 1, dt),
                seconds=round(dt, 2), omega=[hist[-1].real, hist[-1].imag])

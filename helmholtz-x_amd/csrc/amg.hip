@@ -990,7 +990,14 @@ static int gmres_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, 
 extern "C" int hx_amg_enable_recycling(hx_amg* h, int64_t n, int k_max, int restart) {
   HX_REQUIRE(h && n > 0 && k_max >= 1 && k_max <= 32 && restart >= 2 && restart <= 120, "bad argument");
   Recycle& R = h->rec;
-  HX_REQUIRE(R.kmax == 0, "recycling already enabled");
+  if (R.kmax > 0) {          // called again: another panel size (the escalation ladder widens the Krylov space; the hierarchy stays)
+    HX_REQUIRE(R.n == n, "recycling workspace was sized for another n");
+    HX_HIP(hipStreamSynchronize(hx_last_stream.load(std::memory_order_relaxed)));
+    (void)hx_free(R.U); (void)hx_free(R.CV); (void)hx_free(R.CVf); (void)hx_free(R.Uf); (void)hx_free(R.Cd); (void)hx_free(R.Einv);
+    R.U = R.CV = R.Cd = R.Einv = nullptr; R.CVf = R.Uf = nullptr;
+    R.kmax = 0;
+    h->normK_val = nullptr;
+  }
   HX_HIP(hx_malloc((void**)&R.U, sizeof(hx_c128) * (size_t)k_max * (size_t)n));
   HX_HIP(hx_malloc((void**)&R.CV, sizeof(hx_c128) * (size_t)(k_max + restart + 1) * (size_t)n));
   HX_HIP(hx_malloc((void**)&R.CVf, sizeof(hx_c64) * (size_t)(k_max + restart + 1) * (size_t)n));

@@ -22,6 +22,7 @@
 // which RCCL itself refuses).
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -98,6 +99,12 @@ struct Plan {
   int32_t* d_idx = nullptr;                // concatenated owned indices of the gathered lists (device)
   int64_t n_gather = 0;
   void* stage = nullptr;                   // n_gather * 16 bytes
+  // a peer whose entries fill SEVERAL separate ranges (the layers of a deep-halo plan) still gets ONE message: it lands in
+  // `rstage` and k_comm_scatter moves entry i to dst[d_ridx[i]]
+  std::vector<int64_t> recv_stage;         // >= 0: offset in rstage (else the message lands in dst at recv_off)
+  int32_t* d_ridx = nullptr;
+  int64_t n_scatter = 0;
+  void* rstage = nullptr;
 };
 }  // namespace
 
@@ -140,6 +147,12 @@ __global__ void k_comm_gather(int64_t n, const int32_t* __restrict__ idx, const 
     dst[i] = src[idx[i]];
 }
 
+template <typename T>
+__global__ void k_comm_scatter(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ src, T* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[idx[i]] = src[i];
+}
+
 extern "C" int hx_comm_unique_id(void* out, int nbytes) {
   HX_REQUIRE(out && nbytes >= (int)sizeof(ncclUniqueId), "need a buffer of HX_COMM_ID_BYTES bytes");
   int rc = load_rccl();
@@ -169,7 +182,7 @@ extern "C" int hx_comm_destroy(hx_comm* c) {
   // nothing of this communicator may still be in flight when its staging buffers go back to the pool
   if (c->istream) (void)hipStreamSynchronize(c->istream);
   if (c->op_stream || c->n_exchange + c->n_allreduce > 0) (void)hipStreamSynchronize(c->op_stream);
-  for (Plan& p : c->plans) { (void)hx_free(p.d_idx); (void)hx_free(p.stage); }
+  for (Plan& p : c->plans) { (void)hx_free(p.d_idx); (void)hx_free(p.stage); (void)hx_free(p.d_ridx); (void)hx_free(p.rstage); }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->istream) { hx_pool_register_stream(c->istream, false); (void)hipStreamDestroy(c->istream); }
@@ -204,25 +217,60 @@ extern "C" int hx_comm_set_plan(hx_comm* c, int plan, int ns, const int32_t* sen
   HX_REQUIRE(nr == 0 || (recv_peer && recv_off && recv_cnt), "missing receive ranges");
   if ((int)c->plans.size() <= plan) c->plans.resize(plan + 1);
   Plan& P = c->plans[plan];
-  (void)hx_free(P.d_idx); (void)hx_free(P.stage);
+  (void)hx_free(P.d_idx); (void)hx_free(P.stage); (void)hx_free(P.d_ridx); (void)hx_free(P.rstage);
   P = Plan();
-  std::vector<int32_t> gathered;
-  for (int q = 0; q < ns; ++q) {
-    HX_REQUIRE(send_peer[q] >= 0 && send_peer[q] < c->world && send_ptr[q + 1] >= send_ptr[q], "bad send list");
-    const int64_t a = send_ptr[q], b = send_ptr[q + 1];
-    bool run = b > a;
-    for (int64_t i = a + 1; i < b && run; ++i) run = send_idx[i] == send_idx[i - 1] + 1;
-    P.send_peer.push_back(send_peer[q]);
-    P.send_cnt.push_back(b - a);
-    P.send_lo.push_back(run ? (int64_t)send_idx[a] : -1);
-    P.send_stage.push_back((int64_t)gathered.size());
-    if (!run) gathered.insert(gathered.end(), send_idx + a, send_idx + b);
+  // ONE message per peer and direction: lists / ranges of a peer that is named several times (per peer one entry per layer of a
+  // deep-halo plan, in layer order on both sides) are concatenated in the order given -- nothing rests on how the
+  // communication library matches several messages between one pair of ranks
+  std::vector<int32_t> gathered, scattered;
+  {
+    std::vector<int> peers;
+    for (int q = 0; q < ns; ++q) {
+      HX_REQUIRE(send_peer[q] >= 0 && send_peer[q] < c->world && send_ptr[q + 1] >= send_ptr[q], "bad send list");
+      if (std::find(peers.begin(), peers.end(), (int)send_peer[q]) == peers.end()) peers.push_back(send_peer[q]);
+    }
+    for (int peer : peers) {
+      std::vector<int32_t> list;
+      for (int q = 0; q < ns; ++q)
+        if (send_peer[q] == peer) list.insert(list.end(), send_idx + send_ptr[q], send_idx + send_ptr[q + 1]);
+      bool run = !list.empty();
+      for (size_t i = 1; i < list.size() && run; ++i) run = list[i] == list[i - 1] + 1;
+      P.send_peer.push_back(peer);
+      P.send_cnt.push_back((int64_t)list.size());
+      P.send_lo.push_back(run ? (int64_t)list[0] : -1);
+      P.send_stage.push_back((int64_t)gathered.size());
+      if (!run) gathered.insert(gathered.end(), list.begin(), list.end());
+    }
+    peers.clear();
+    for (int q = 0; q < nr; ++q) {
+      HX_REQUIRE(recv_peer[q] >= 0 && recv_peer[q] < c->world && recv_off[q] >= 0 && recv_cnt[q] >= 0, "bad receive range");
+      HX_REQUIRE(recv_off[q] + recv_cnt[q] < ((int64_t)1 << 31), "receive range beyond int32 positions");
+      if (std::find(peers.begin(), peers.end(), (int)recv_peer[q]) == peers.end()) peers.push_back(recv_peer[q]);
+    }
+    for (int peer : peers) {
+      int64_t first = -1, next = -1, total = 0;
+      bool one_range = true;
+      for (int q = 0; q < nr; ++q)
+        if (recv_peer[q] == peer && recv_cnt[q] > 0) {
+          if (first < 0) first = recv_off[q]; else if (recv_off[q] != next) one_range = false;
+          next = recv_off[q] + recv_cnt[q];
+          total += recv_cnt[q];
+        }
+      P.recv_peer.push_back(peer);
+      P.recv_cnt.push_back(total);
+      P.recv_off.push_back(first < 0 ? 0 : first);
+      if (one_range) { P.recv_stage.push_back(-1); continue; }
+      P.recv_stage.push_back((int64_t)scattered.size());
+      for (int q = 0; q < nr; ++q)
+        if (recv_peer[q] == peer)
+          for (int64_t i = 0; i < recv_cnt[q]; ++i) scattered.push_back((int32_t)(recv_off[q] + i));
+    }
   }
-  for (int q = 0; q < nr; ++q) {
-    HX_REQUIRE(recv_peer[q] >= 0 && recv_peer[q] < c->world && recv_off[q] >= 0 && recv_cnt[q] >= 0, "bad receive range");
-    P.recv_peer.push_back(recv_peer[q]);
-    P.recv_off.push_back(recv_off[q]);
-    P.recv_cnt.push_back(recv_cnt[q]);
+  P.n_scatter = (int64_t)scattered.size();
+  if (P.n_scatter > 0) {
+    HX_HIP(hx_malloc((void**)&P.d_ridx, sizeof(int32_t) * (size_t)P.n_scatter));
+    HX_HIP(hipMemcpy(P.d_ridx, scattered.data(), sizeof(int32_t) * (size_t)P.n_scatter, hipMemcpyHostToDevice));
+    HX_HIP(hx_malloc(&P.rstage, 16 * (size_t)P.n_scatter));
   }
   P.n_gather = (int64_t)gathered.size();
   if (P.n_gather > 0) {
@@ -248,6 +296,8 @@ extern "C" int hx_comm_exchange(hx_comm* c, int plan, const void* src, void* dst
   if (ns == 0 && nr == 0) return HX_OK;
   const int64_t* stage_off = P.send_stage.data();
   const int64_t* cnt = P.send_cnt.data();
+  if (P.n_gather > 0) HX_DEBUG_BOUNDS("hx_comm_exchange (send lists of the plan)", P.d_idx, P.n_gather, nullptr, 0, src, elem_bytes, hx_s(s));
+  if (P.n_scatter > 0) HX_DEBUG_BOUNDS("hx_comm_exchange (receive ranges of the plan)", P.d_ridx, P.n_scatter, nullptr, 0, dst, elem_bytes, hx_s(s));
   if (P.n_gather > 0) {
     const int g = hx_grid(P.n_gather, 256);
     if (elem_bytes == 16) k_comm_gather<double2><<<g, 256, 0, hx_s(s)>>>(P.n_gather, P.d_idx, (const double2*)src, (double2*)P.stage);
@@ -262,12 +312,20 @@ extern "C" int hx_comm_exchange(hx_comm* c, int plan, const void* src, void* dst
                                       : (const char*)P.stage + (size_t)stage_off[q] * elem_bytes;
     bad = g_rccl.Send(p, (size_t)cnt[q] * elem_bytes, ncclChar, P.send_peer[q], c->comm, hx_s(s));
   }
-  for (int q = 0; q < nr && bad == ncclSuccess; ++q)
-    bad = g_rccl.Recv((char*)dst + (size_t)P.recv_off[q] * elem_bytes, (size_t)P.recv_cnt[q] * elem_bytes, ncclChar,
-                      P.recv_peer[q], c->comm, hx_s(s));
+  for (int q = 0; q < nr && bad == ncclSuccess; ++q) {
+    char* p = P.recv_stage[q] >= 0 ? (char*)P.rstage + (size_t)P.recv_stage[q] * elem_bytes : (char*)dst + (size_t)P.recv_off[q] * elem_bytes;
+    bad = g_rccl.Recv(p, (size_t)P.recv_cnt[q] * elem_bytes, ncclChar, P.recv_peer[q], c->comm, hx_s(s));
+  }
   const ncclResult_t ge = g_rccl.GroupEnd();
   if (bad != ncclSuccess) return hx_fail(HX_ERR_COMM, "ncclSend/ncclRecv", g_rccl.GetErrorString(bad));
   HX_NCCL(ge);
+  if (P.n_scatter > 0) {        // messages that fill several separate ranges: from the staging buffer to their places
+    const int g = hx_grid(P.n_scatter, 256);
+    if (elem_bytes == 16) k_comm_scatter<double2><<<g, 256, 0, hx_s(s)>>>(P.n_scatter, P.d_ridx, (const double2*)P.rstage, (double2*)dst);
+    else if (elem_bytes == 8) k_comm_scatter<float2><<<g, 256, 0, hx_s(s)>>>(P.n_scatter, P.d_ridx, (const float2*)P.rstage, (float2*)dst);
+    else k_comm_scatter<float><<<g, 256, 0, hx_s(s)>>>(P.n_scatter, P.d_ridx, (const float*)P.rstage, (float*)dst);
+    HX_LAUNCH_CHECK("k_comm_scatter");
+  }
   return HX_OK;
 }
 

@@ -105,13 +105,23 @@ static inline int hx_grid(int64_t work_items, int block, int max_blocks = 256 * 
 // every launch converts its stream argument here: the pool notes which caller streams may still touch a block it caches
 #include <atomic>
 extern std::atomic<hipStream_t> hx_last_stream;
+extern std::atomic<int> hx_stream_epoch;
 void hx_pool_register_stream(hipStream_t s, bool add);      // side streams of the library (see pool.hip)
 void hx_pool_note_stream(hipStream_t s);                    // (slow path: takes the pool's lock)
 static inline hipStream_t hx_s(hx_stream s) {
   hipStream_t st = (hipStream_t)s;
   if (hx_last_stream.load(std::memory_order_relaxed) != st) {   // a stream other than the previous call's: remember it where it is USED
     hx_last_stream.store(st, std::memory_order_relaxed);
-    hx_pool_note_stream(st);
+    // the split exchanges alternate between the caller's stream and the communicator's side stream on every launch: the two
+    // streams seen last by this thread are known to the pool already (no lock on that path); only a NEW stream takes it
+    static thread_local hipStream_t noted[2] = {(hipStream_t)-1, (hipStream_t)-1};
+    static thread_local int epoch = -1;
+    const int now = hx_stream_epoch.load(std::memory_order_relaxed);
+    if (epoch != now) { epoch = now; noted[0] = noted[1] = (hipStream_t)-1; }
+    if (noted[0] != st && noted[1] != st) {
+      noted[1] = noted[0]; noted[0] = st;
+      hx_pool_note_stream(st);
+    }
   }
   return st;
 }
@@ -138,3 +148,16 @@ struct HxOpt { int gen = -1; long i = 0; double d = 0.0; };
   ([]() -> bool { static HxOpt o_; const int g_ = hx_option_generation.load(std::memory_order_relaxed);   \
                   if (o_.gen != g_) { o_.i = hx_option_lookup_set(name) ? 1 : 0; o_.gen = g_; } return o_.i != 0; }())
 static inline long hx_option_int(const char* name, long dflt) { return hx_option_lookup_int(name, dflt); }
+
+// ---- option "debug_bounds" (HX_DEBUG_BOUNDS=1; off by default): entry points that follow caller-supplied index arrays check
+// them on the device first -- every indexed access must stay inside the ALLOCATION that holds the indexed vector
+// (hipMemGetAddressRange), so a stale or foreign index array gives HX_ERR_ARG with the offending position instead of a fault of
+// the device.  One reduction + one synchronising read-back per call: for test suites and bug hunts.  (vecops.hip)
+//   idx: device array of `count` int32 indices (or pointer positions ptr[0] .. ptr[nvec] when `via_ptr` != null: count is then
+//   read from ptr[nvec]); `vec` / `elem_bytes`: the vector they index.
+int hx_debug_check_indices(const char* who, const int32_t* idx, int64_t count, const int32_t* via_ptr, int nvec,
+                           const void* vec, int elem_bytes, hipStream_t st);
+#define HX_DEBUG_BOUNDS(who, idx, count, via_ptr, nvec, vec, elem_bytes, st)                                         \
+  do { if (HX_OPT_SET("debug_bounds") && HX_OPT_INT("debug_bounds", 0) != 0) {                                     \
+         const int rc_ = hx_debug_check_indices(who, idx, count, via_ptr, nvec, vec, elem_bytes, st);                \
+         if (rc_ != HX_OK) return rc_; } } while (0)

@@ -34,6 +34,7 @@
 // the caller streams recently passed to the library (hx_s notes them) and the library's own side streams
 static hipStream_t const HX_NO_STREAM = (hipStream_t)(intptr_t)-1;    // "none seen yet" (nullptr is the null stream, a real one)
 std::atomic<hipStream_t> hx_last_stream{(hipStream_t)(intptr_t)-1};
+std::atomic<int> hx_stream_epoch{0};          // bumped whenever the pool forgets noted streams: hx_s() then notes them again
 
 namespace {
 struct Pool {
@@ -46,10 +47,12 @@ struct Pool {
   int64_t n_events = 0, n_waits = 0;
   void note(hipStream_t s) {                                      // (lock held)
     if (s == HX_NO_STREAM) return;
+    for (hipStream_t in : internal_streams)
+      if (in == s) return;                                        // a side stream of the library: marked through its own list already
     for (size_t i = 0; i < caller_streams.size(); ++i)
       if (caller_streams[i] == s) { caller_streams.erase(caller_streams.begin() + i); break; }
     caller_streams.push_back(s);
-    if (caller_streams.size() > 8) caller_streams.erase(caller_streams.begin());
+    if (caller_streams.size() > 8) { caller_streams.erase(caller_streams.begin()); hx_stream_epoch.fetch_add(1, std::memory_order_relaxed); }
   }
   void mark(Free& f) {                                            // (lock held) one event per stream that may still use the block
     note(hx_last_stream.load(std::memory_order_relaxed));
@@ -208,6 +211,7 @@ void hx_pool_register_stream(hipStream_t s, bool add) {
     hx_last_stream.compare_exchange_strong(cur, HX_NO_STREAM);
     for (size_t i = 0; i < P.caller_streams.size(); ++i)
       if (P.caller_streams[i] == s) { P.caller_streams.erase(P.caller_streams.begin() + i); break; }
+    hx_stream_epoch.fetch_add(1, std::memory_order_relaxed);
   }
 }
 // events recorded on release / waited for on reuse (bookkeeping of the ordering above; tests)
@@ -239,7 +243,7 @@ extern "C" int hx_pool_trim(void) {
   Pool& P = g_pool;
   std::lock_guard<std::mutex> lock(P.mu);
   while (!P.lru.empty()) P.drop(P.lru.begin());
-  P.caller_streams.clear();                                       // (a caller about to destroy its stream: forget it)
+  P.caller_streams.clear(); hx_stream_epoch.fetch_add(1, std::memory_order_relaxed);                                       // (a caller about to destroy its stream: forget it)
   hx_last_stream.store(HX_NO_STREAM);
   return HX_OK;
 }

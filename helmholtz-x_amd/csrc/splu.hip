@@ -986,10 +986,10 @@ static void splu_release(hx_splu* h) {
 }
 
 extern "C" int hx_splu_analyse(hx_splu** out, int32_t n, const int32_t* h_rowptr, const int32_t* h_col,
-                               const double* h_coords, int dim, int leaf_size) {
+                               const double* h_coords, int dim, int leaf_size, int flags) {
   HX_REQUIRE(out && h_rowptr && h_col, "null argument");
   hx_splu* h = new hx_splu();
-  const int rc = splu_analyse_host(h->sym, n, h_rowptr, h_col, h_coords, dim, leaf_size > 0 ? leaf_size : SPLU_NB);
+  const int rc = splu_analyse_host(h->sym, n, h_rowptr, h_col, h_coords, dim, leaf_size > 0 ? leaf_size : SPLU_NB, flags);
   if (rc != HX_OK) { delete h; return rc; }
   h->nnz_in = h_rowptr[n];
   *out = h;

@@ -18,7 +18,10 @@
 #include <chrono>
 #include <cmath>
 #include <map>
+#include <atomic>
 #include <numeric>
+#include <stdlib.h>
+#include <thread>
 
 #include "hx_common.h"
 #include "splu_internal.h"
@@ -31,8 +34,20 @@ struct Graph {
   std::vector<int32_t> adj;
 };
 
-void build_graph(Graph& g, int32_t n, const int32_t* rowptr, const int32_t* col) {
+void build_graph(Graph& g, int32_t n, const int32_t* rowptr, const int32_t* col, bool symmetric) {
   g.n = n;
+  if (symmetric) {                          // the pattern is its own transpose: the rows are the adjacency lists
+    g.xadj.assign((size_t)n + 1, 0);
+    g.adj.resize((size_t)rowptr[n]);
+    int64_t w = 0;
+    for (int32_t i = 0; i < n; ++i) {
+      for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+        if (col[k] != i) g.adj[w++] = col[k];
+      g.xadj[i + 1] = w;
+    }
+    g.adj.resize((size_t)w);
+    return;
+  }
   g.xadj.assign((size_t)n + 1, 0);
   for (int32_t i = 0; i < n; ++i)
     for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
@@ -69,15 +84,15 @@ struct Dissector {
   const double* xy;          // n x dim or null
   int dim;
   int leaf;
-  std::vector<int32_t> verts;        // permuted in place: every call owns a contiguous slice
-  std::vector<int32_t> mark;         // which call / side a vertex currently belongs to
-  std::vector<int32_t> order;        // emitted vertices (new -> old)
-  std::vector<int32_t> sfirst;       // supernode boundaries in `order`
+  int threads;
+  std::vector<int32_t> verts;        // permuted in place: every call owns a contiguous slice; at the end: new -> old
+  std::vector<int32_t> mark;         // which call / side a vertex currently belongs to (ids are unique across threads)
   std::vector<double> proj;
-  std::vector<int32_t> queue, lvl, scratch;
-  int32_t stamp = 0;
+  std::vector<int32_t> queue, lvl, scratch;      // indexed by POSITION in verts: calls on disjoint slices never collide
+  std::atomic<int32_t> stamp{0};
 
-  Dissector(const Graph& g_, const double* xy_, int dim_, int leaf_) : g(g_), xy(xy_), dim(dim_), leaf(leaf_) {
+  Dissector(const Graph& g_, const double* xy_, int dim_, int leaf_, int threads_)
+      : g(g_), xy(xy_), dim(dim_), leaf(leaf_), threads(threads_) {
     verts.resize(g.n);
     std::iota(verts.begin(), verts.end(), 0);
     mark.assign(g.n, -1);
@@ -85,14 +100,6 @@ struct Dissector {
     queue.resize(g.n);
     lvl.resize(g.n);
     scratch.resize(g.n);
-    order.reserve(g.n);
-    sfirst.push_back(0);
-  }
-
-  void emit(int32_t lo, int32_t hi) {
-    if (hi <= lo) return;
-    for (int32_t i = lo; i < hi; ++i) order.push_back(verts[i]);
-    sfirst.push_back((int32_t)order.size());
   }
 
   // splits verts[lo, hi) into [lo, mid) and [mid, hi) by the median plane perpendicular to the principal axis; false: degenerate
@@ -126,12 +133,12 @@ struct Dissector {
       for (int d = 0; d < dim; ++d) p += v[d] * (xy[(size_t)verts[i] * dim + d] - c[d]);
       proj[verts[i]] = p;
     }
-    for (int32_t i = 0; i < cnt; ++i) scratch[i] = verts[lo + i];
-    std::nth_element(scratch.begin(), scratch.begin() + cnt / 2, scratch.begin() + cnt,
-                     [&](int32_t a, int32_t b) { return proj[a] < proj[b]; });
-    const double t = proj[scratch[cnt / 2]];
+    int32_t* sc = scratch.data() + lo;
+    for (int32_t i = 0; i < cnt; ++i) sc[i] = verts[lo + i];
+    std::nth_element(sc, sc + cnt / 2, sc + cnt, [&](int32_t a, int32_t b) { return proj[a] < proj[b]; });
+    const double t = proj[sc[cnt / 2]];
     double span = 0;
-    for (int32_t i = 0; i < cnt; ++i) span = std::max(span, std::fabs(proj[scratch[i]]));
+    for (int32_t i = 0; i < cnt; ++i) span = std::max(span, std::fabs(proj[sc[i]]));
     const double eps = 1e-9 * (span > 0 ? span : 1.0);
     auto below = [&](int32_t u) { return proj[u] < t - eps; };
     int32_t* b = verts.data() + lo;
@@ -169,32 +176,33 @@ struct Dissector {
     int32_t root = verts[lo];
     for (int sweep = 0; sweep < 2; ++sweep) {
       const int32_t vis = ++stamp;
-      const int32_t end = bfs(root, id, vis, 0, 0);
+      const int32_t end = bfs(root, id, vis, lo, 0);
       root = queue[end - 1];
-      for (int32_t i = 0; i < end; ++i) mark[queue[i]] = id;
+      for (int32_t i = lo; i < end; ++i) mark[queue[i]] = id;
     }
     const int32_t vis = ++stamp;
-    int32_t end = bfs(root, id, vis, 0, 0);
-    for (int32_t i = lo; i < hi && end < cnt; ++i)          // further components, each starting a new level
+    int32_t end = bfs(root, id, vis, lo, 0);
+    for (int32_t i = lo; i < hi && end < hi; ++i)          // further components, each starting a new level
       if (mark[verts[i]] == id) end = bfs(verts[i], id, vis, end, lvl[end - 1] + 1);
     // cut at the level boundary closest to the middle
     int32_t best = -1;
     for (int32_t i = 1; i < cnt; ++i)
-      if (lvl[i] != lvl[i - 1] && (best < 0 || std::abs(i - cnt / 2) < std::abs(best - cnt / 2))) best = i;
+      if (lvl[lo + i] != lvl[lo + i - 1] && (best < 0 || std::abs(i - cnt / 2) < std::abs(best - cnt / 2))) best = i;
     if (best < 0) best = cnt / 2;
-    for (int32_t i = 0; i < cnt; ++i) scratch[i] = queue[i];
-    for (int32_t i = 0; i < cnt; ++i) verts[lo + i] = scratch[i];
+    for (int32_t i = lo; i < hi; ++i) verts[i] = queue[i];
     mid = lo + best;
     return mid > lo && mid < hi;
   }
 
-  void dissect(int32_t lo, int32_t hi) {
+  // `ends`: end positions of the supernodes emitted by this call tree (every emitted slice is final in verts)
+  void dissect(int32_t lo, int32_t hi, int depth, std::vector<int32_t>& ends) {
     const int32_t cnt = hi - lo;
-    if (cnt <= leaf) { emit(lo, hi); return; }
+    if (cnt <= 0) return;
+    if (cnt <= leaf) { ends.push_back(hi); return; }
     int32_t mid = lo;
     bool ok = (xy != nullptr) && split_inertial(lo, hi, mid);
     if (!ok) ok = split_levelset(lo, hi, mid);
-    if (!ok) { emit(lo, hi); return; }
+    if (!ok) { ends.push_back(hi); return; }
     const int32_t idA = ++stamp, idB = ++stamp;
     for (int32_t i = lo; i < mid; ++i) mark[verts[i]] = idA;
     for (int32_t i = mid; i < hi; ++i) mark[verts[i]] = idB;
@@ -216,33 +224,49 @@ struct Dissector {
       int32_t* m = std::stable_partition(verts.data() + mid, verts.data() + hi, [&](int32_t v) { return !touches(v, idA); });
       a_end = mid; b_end = (int32_t)(m - verts.data());
     }
-    if (a_end - lo == 0 && b_end - a_end == 0) { emit(lo, hi); return; }
-    dissect(lo, a_end);
-    dissect(a_end, b_end);
-    emit(b_end, hi);
+    if (a_end - lo == 0 && b_end - a_end == 0) { ends.push_back(hi); return; }
+    // the two parts share no edge: independent from here on (threads on the first levels of a large problem)
+    if (threads > 1 && (1 << depth) < threads && a_end - lo > 8192 && b_end - a_end > 8192) {
+      std::vector<int32_t> other;
+      std::thread th([&]() { dissect(lo, a_end, depth + 1, other); });
+      dissect(a_end, b_end, depth + 1, ends);
+      th.join();
+      ends.insert(ends.end(), other.begin(), other.end());
+    } else {
+      dissect(lo, a_end, depth + 1, ends);
+      dissect(a_end, b_end, depth + 1, ends);
+    }
+    if (hi > b_end) ends.push_back(hi);
   }
 };
 
 }  // namespace
 
 int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const int32_t* col, const double* coords, int dim,
-                      int leaf_size) {
+                      int leaf_size, int flags) {
   const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (getenv("HX_SPLU_TRACE")) fprintf(stderr, "  splu analyse: %-22s %.4f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); };
   if (n <= 0) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "n <= 0");
   if (coords && (dim < 1 || dim > 3)) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "dim must be 1, 2 or 3");
   for (int32_t i = 0; i < n; ++i)
     for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
       if (col[k] < 0 || col[k] >= n) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "column index out of range");
   Graph g;
-  build_graph(g, n, rowptr, col);
-  Dissector D(g, coords, dim, leaf_size < 8 ? 8 : leaf_size);
-  D.dissect(0, n);
-  if ((int32_t)D.order.size() != n) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: ordering lost vertices");
+  build_graph(g, n, rowptr, col, (flags & 1) != 0);
+  lap("graph");
+  const int threads = (int)std::max<long>(1, std::min<long>(hx_option_int("host_threads", 8), (long)std::thread::hardware_concurrency()));
+  Dissector D(g, coords, dim, leaf_size < 8 ? 8 : leaf_size, threads);
+  std::vector<int32_t> ends;
+  D.dissect(0, n, 0, ends);
+  lap("dissection");
+  std::sort(ends.begin(), ends.end());
+  if (ends.empty() || ends.back() != n) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: ordering lost vertices");
   S.n = n;
-  S.perm.swap(D.order);
+  S.perm.swap(D.verts);
   S.iperm.assign(n, 0);
   for (int32_t i = 0; i < n; ++i) S.iperm[S.perm[i]] = i;
-  S.sfirst.swap(D.sfirst);
+  S.sfirst.assign(1, 0);
+  S.sfirst.insert(S.sfirst.end(), ends.begin(), ends.end());
   const int32_t ns_ = S.nsuper = (int32_t)S.sfirst.size() - 1;
   std::vector<int32_t> super_of(n);
   for (int32_t s = 0; s < ns_; ++s)
@@ -278,6 +302,7 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
       tail[p] = s;
     }
   }
+  lap("symbolic");
   S.child_ptr.assign((size_t)ns_ + 1, 0);
   S.child_list.clear();
   for (int32_t s = 0; s < ns_; ++s) {
@@ -315,6 +340,7 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
     std::vector<int32_t> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
     for (int32_t s = 0; s < ns_; ++s) S.level_list[pos[S.slevel[s]]++] = s;
   }
+  lap("children, rel, levels");
   // ---- storage plan
   S.loff.assign(ns_, 0); S.uoff.assign(ns_, 0); S.ioff.assign(ns_, 0); S.soff.assign(ns_, -1); S.woff.assign(ns_, 0);
   int64_t fcur = 0, icur = 0, wcur = 0;
@@ -384,9 +410,12 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
     }
     S.temp_elems = top;
   }
+  lap("storage plan");
   // ---- destination of every stored entry of the input
   S.amap.assign((size_t)rowptr[n], -1);
-  for (int32_t i = 0; i < n; ++i) {
+  std::atomic<int> bad{0};
+  auto map_rows = [&](int32_t i0, int32_t i1) {
+  for (int32_t i = i0; i < i1; ++i) {
     const int32_t pi = S.iperm[i];
     for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
       const int32_t pj = S.iperm[col[k]];
@@ -400,13 +429,23 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
         const int32_t* b = S.srow.data() + S.sptr[s];
         const int32_t* e = S.srow.data() + S.sptr[s + 1];
         const int32_t* p = std::lower_bound(b, e, oth);
-        if (p == e || *p != oth) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: entry outside its front");
+        if (p == e || *p != oth) { bad = 1; continue; }
         a = ns + (p - b);
       }
       S.amap[k] = lower ? S.loff[s] + a + (int64_t)(piv - S.sfirst[s]) * m          // Lp[a, pivot]: m x ns, ld m
                         : S.uoff[s] + (int64_t)(piv - S.sfirst[s]) + a * ns;        // Up[pivot, a]: ns x m, ld ns
     }
   }
+  };
+  {
+    std::vector<std::thread> pool;
+    const int nt = n > 50000 ? threads : 1;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(map_rows, (int32_t)((int64_t)n * t / nt), (int32_t)((int64_t)n * (t + 1) / nt));
+    map_rows(0, (int32_t)((int64_t)n / nt));
+    for (auto& th : pool) th.join();
+  }
+  if (bad) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: entry outside its front");
+  lap("entry map");
   S.analyse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return HX_OK;
 }

@@ -40,5 +40,6 @@ struct SpluSymbolic {
 };
 
 // splu_analyse.hip (host only)
+// flags: bit 0 = the pattern is structurally symmetric with sorted rows (skips forming A + A^T)
 int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const int32_t* col, const double* coords, int dim,
-                      int leaf_size);
+                      int leaf_size, int flags);

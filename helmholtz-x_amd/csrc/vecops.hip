@@ -80,10 +80,56 @@ __global__ void k_zscatter_axpy(int64_t m, zc a, const zc* __restrict__ src, con
     dst[k] = d;
   }
 }
+// ---------------------------------------------------------------- option debug_bounds (hx_common.h)
+__global__ void k_first_bad_index(int64_t n, const int32_t* __restrict__ idx, int64_t lo, int64_t hi, unsigned long long* __restrict__ first) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = idx[i];
+    if (v < lo || v >= hi) atomicMin(first, (unsigned long long)i);
+  }
+}
+
+int hx_debug_check_indices(const char* who, const int32_t* idx, int64_t count, const int32_t* via_ptr, int nvec,
+                           const void* vec, int elem_bytes, hipStream_t st) {
+  if (via_ptr) {                                  // packed vectors: the number of indices is ptr[nvec]
+    int32_t last = 0;
+    HX_HIP(hipMemcpyAsync(&last, via_ptr + nvec, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HX_HIP(hipStreamSynchronize(st));
+    count = last;
+  }
+  if (count <= 0) return HX_OK;
+  if (!idx) return hx_fail(HX_ERR_ARG, who, "debug_bounds: null index array");
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)vec) != hipSuccess) {
+    (void)hipGetLastError();
+    return hx_fail(HX_ERR_ARG, who, "debug_bounds: the indexed vector is not a device allocation");
+  }
+  const int64_t lo = -(int64_t)(((const char*)vec - (const char*)base) / elem_bytes);
+  const int64_t hi = (int64_t)(((const char*)base + size - (const char*)vec) / elem_bytes);
+  static unsigned long long* d_first = nullptr;
+  if (!d_first) HX_HIP(hipMalloc((void**)&d_first, sizeof(unsigned long long)));
+  unsigned long long first = ~0ull;
+  HX_HIP(hipMemcpyAsync(d_first, &first, sizeof(first), hipMemcpyHostToDevice, st));
+  k_first_bad_index<<<hx_grid(count, 256), 256, 0, st>>>(count, idx, lo, hi, d_first);
+  HX_LAUNCH_CHECK("k_first_bad_index");
+  HX_HIP(hipMemcpyAsync(&first, d_first, sizeof(first), hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  if (first != ~0ull) {
+    int32_t bad = 0;
+    HX_HIP(hipMemcpy(&bad, idx + first, sizeof(int32_t), hipMemcpyDeviceToHost));
+    char msg[256];
+    snprintf(msg, sizeof(msg), "debug_bounds: index array entry %llu is %d, outside the allocation of the indexed vector "
+             "(elements %lld .. %lld from its start)", first, (int)bad, (long long)lo, (long long)hi - 1);
+    return hx_fail(HX_ERR_ARG, who, msg);
+  }
+  return HX_OK;
+}
+
 extern "C" int hx_zscatter_axpy(int64_t m, const double alpha[2], const hx_c128* src, const int32_t* slot,
                                 hx_c128* dst, hx_stream s) {
   HX_REQUIRE(m >= 0 && alpha && src && slot && dst, "bad argument");
   if (m == 0) return HX_OK;
+  HX_DEBUG_BOUNDS("hx_zscatter_axpy", slot, m, nullptr, 0, dst, 16, hx_s(s));
   k_zscatter_axpy<<<hx_grid(m, 256), 256, 0, hx_s(s)>>>(m, hx_z(alpha), (const zc*)src, slot, (zc*)dst);
   HX_LAUNCH_CHECK("k_zscatter_axpy");
   return HX_OK;
@@ -124,6 +170,7 @@ __global__ void k_zgather(int64_t m, const zc* __restrict__ x, const int32_t* __
 extern "C" int hx_zgather(int64_t m, const hx_c128* x, const int32_t* idx, hx_c128* y, hx_stream s) {
   HX_REQUIRE(m >= 0 && x && idx && y, "bad argument");
   if (m == 0) return HX_OK;
+  HX_DEBUG_BOUNDS("hx_zgather", idx, m, nullptr, 0, x, 16, hx_s(s));
   k_zgather<<<hx_grid(m, 256), 256, 0, hx_s(s)>>>(m, (const zc*)x, idx, (zc*)y);
   HX_LAUNCH_CHECK("k_zgather");
   return HX_OK;
@@ -351,6 +398,7 @@ extern "C" int hx_zsparse_dots(int nvec, const int32_t* ptr, const int32_t* idx,
                                const hx_c128* y, hx_c128* out, hx_stream s) {
   HX_REQUIRE(nvec >= 0 && ptr && y && out, "bad argument");
   if (nvec == 0) return HX_OK;
+  HX_DEBUG_BOUNDS("hx_zsparse_dots", idx, 0, ptr, nvec, y, 16, hx_s(s));
   k_sparse_dots<<<nvec, HX_WAVE, 0, hx_s(s)>>>(nvec, ptr, idx, (const zc*)vals, (const zc*)y, (zc*)out);
   HX_LAUNCH_CHECK("k_sparse_dots");
   return HX_OK;
@@ -377,6 +425,7 @@ extern "C" int hx_zsparse_axpys(int nvec, const int32_t* ptr, const int32_t* idx
   HX_REQUIRE(nvec >= 0 && ptr && t && coef && y, "bad argument");
   if (nvec == 0) return HX_OK;
   HX_REQUIRE(idx && vals, "bad argument");
+  HX_DEBUG_BOUNDS("hx_zsparse_axpys", idx, 0, ptr, nvec, y, 16, hx_s(s));
   if (disjoint) k_sparse_axpys<<<nvec, 256, 0, hx_s(s)>>>(0, ptr, idx, (const zc*)vals, (const zc*)t, hx_z(coef), (zc*)y);
   else for (int f = 0; f < nvec; ++f) k_sparse_axpys<<<1, 256, 0, hx_s(s)>>>(f, ptr, idx, (const zc*)vals, (const zc*)t, hx_z(coef), (zc*)y);
   HX_LAUNCH_CHECK("k_sparse_axpys");

@@ -78,7 +78,7 @@ SIGNATURES = {
     "hx_sptrsv_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "hx_sptrsv_solve": (C.c_int, [_vp, _vp, _vp, _vp]),
     "hx_sptrsv_destroy": (C.c_int, [_vp]),
-    "hx_splu_analyse": (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _vp, _int, _int]),
+    "hx_splu_analyse": (C.c_int, [C.POINTER(_vp), _i32, _vp, _vp, _vp, _int, _int, _int]),
     "hx_splu_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "hx_splu_symbolic": (C.c_int, [_vp, C.c_char_p, _vp, _i64, C.POINTER(_i64)]),
     "hx_splu_factor": (C.c_int, [_vp, _vp, _vp]),

@@ -745,7 +745,12 @@ class AMGSolver:
         self.last = (0, 0.0)
         self.max_iters_in_a_solve = 0
         self.ladder = []                              # [{rung, after_solve, reason}]: the steps taken so far
+        self.direct = None                            # the last rung: slepc.LUSolver once every iterative rung has stalled
+        self.direct_refused = None
         self.rung = int(os.environ.get("HX_AMG_RUNG", "0"))      # (experiment hook: start on a later rung)
+        if not 0 <= self.rung < len(self.LADDER):
+            raise ValueError("HX_AMG_RUNG=%d: the escalation ladder has the rungs %s"
+                             % (self.rung, ", ".join("%d (%s)" % (i, r["name"]) for i, r in enumerate(self.LADDER))))
         self._apply_rung()
         self._build()
 
@@ -766,7 +771,8 @@ class AMGSolver:
     LADDER = (dict(name="default"),
               dict(name="wide", max_it_factor=3, restart=100, recycle=32),
               dict(name="shifted", max_it_factor=4, restart=100, recycle=32, beta=0.5, graph=True))
-    REBUILD_KEYS = ("beta", "graph", "sweeps", "restart", "recycle")
+    REBUILD_KEYS = ("beta", "graph", "sweeps")            # a rung that changes one of these builds another hierarchy
+    RESIZE_KEYS = ("restart", "recycle")                  # ... one of these only re-sizes the Krylov workspace and the deflation panel
 
     def _apply_rung(self):
         import os
@@ -790,6 +796,7 @@ class AMGSolver:
         if nxt >= len(self.LADDER) or (self.LADDER[nxt].get("beta") and self._shifted is None):
             return False
         rebuild = any(self.LADDER[nxt].get(k) != self.LADDER[self.rung].get(k) for k in self.REBUILD_KEYS)
+        resize = any(self.LADDER[nxt].get(k) != self.LADDER[self.rung].get(k) for k in self.RESIZE_KEYS)
         self.rung = nxt
         self.ladder.append(dict(rung=self.LADDER[nxt]["name"], after_solve=self.n_solves, reason=reason))
         info("! inner solver: %s -- moving to rung %r of the escalation ladder" % (reason, self.LADDER[nxt]["name"]))
@@ -797,7 +804,28 @@ class AMGSolver:
         if rebuild:
             self._teardown()
             self._build()
+        elif resize:
+            self._size_krylov()                   # aggregation, Galerkin products, exchange plans and SELL copies stay as they are
         return True
+
+    def _size_krylov(self):
+        """Deflation panel (inside the handle) and Krylov workspace for the rung's restart length / number of recycled pairs;
+        drops the harvested pairs -- the next solve harvests again, from the larger space."""
+        dev = self.tmp.device
+        levels = self.levels
+        n_glob = self.n if self.shard is None else self.shard.n_global
+        self.recycle_k = int(os.environ.get("HX_AMG_RECYCLE", self.params["recycle"])) if len(levels) > 1 else 0
+        if n_glob < self.params["recycle_min_rows"] and "HX_AMG_RECYCLE" not in os.environ:
+            self.recycle_k = 0
+        self.recycled = 0
+        if self.recycle_k > 0:
+            _hx.check(_hx.lib.hx_amg_enable_recycling(self.handle, self.n, self.recycle_k, self.params["restart"]))
+        # Krylov workspace: with the recycling workspace in the handle the Arnoldi vectors live there (51 x n entries less here)
+        gmres_ws = (_hx.lib.hx_gmres_ws_recycling if self.recycle_k > 0 else _hx.lib.hx_gmres_ws)(self.n, self.params["restart"])
+        self.ws = None
+        self.ws = torch.empty(max(gmres_ws, _hx.lib.hx_cocg_ws(self.n)), dtype=torch.complex128, device=dev)
+        if self.shard is not None:
+            self._hbuf = torch.zeros(max(self.params["restart"] + 2 + 32, 80), dtype=torch.complex128, device=dev)
 
     def _build(self):
         import os
@@ -1003,16 +1031,7 @@ class AMGSolver:
         # with COCG a deflation vector costs bytes, not launches, and small problems are launch-bound: 34,787-DOF MICCA mesh
         # 0.45 -> 0.35 s per call (25.1 -> 17.3 iterations per solve), 66 k DOF 0.27 -> 0.25, 16 k / 34 k unchanged
         # (tools/r3_small.sh): recycle_min_rows is 0.
-        n_glob = self.n if shard is None else shard.n_global
-        self.recycle_k = int(os.environ.get("HX_AMG_RECYCLE", self.params["recycle"])) if len(levels) > 1 else 0
-        if n_glob < self.params["recycle_min_rows"] and "HX_AMG_RECYCLE" not in os.environ:
-            self.recycle_k = 0
-        self.recycled = 0
-        if self.recycle_k > 0:
-            _hx.check(_hx.lib.hx_amg_enable_recycling(h, self.n, self.recycle_k, self.params["restart"]))
-        # Krylov workspace: with the recycling workspace in the handle the Arnoldi vectors live there (51 x n entries less here)
-        gmres_ws = (_hx.lib.hx_gmres_ws_recycling if self.recycle_k > 0 else _hx.lib.hx_gmres_ws)(self.n, self.params["restart"])
-        self.ws = torch.empty(max(gmres_ws, _hx.lib.hx_cocg_ws(self.n)), dtype=torch.complex128, device=dev)
+        self._size_krylov()
         self.krylov_tol_floor = 10.0 * self.params["rtol"]
         torch.cuda.synchronize()
         self.setup_s += time.perf_counter() - t_setup
@@ -1044,17 +1063,41 @@ class AMGSolver:
         A solve that ends above 100x its tolerance (and not at a rounding-level backward error) moves the solver up its
         escalation ladder and is repeated there; only the last rung raises -- with the operator's label in the message."""
         while True:
+            if self.direct is not None:
+                self.n_solves += 1
+                return self.direct.solve(b, x)
             it, rr = self._solve_once(b, x, relax, x0)
             rtol = self.params["rtol"] * max(float(relax), 1.0)
             if not (rr > 100 * rtol and not getattr(self, "backward_stable", False)):
                 return
             reason = "inner solve %d stalled at relative residual %.2e after %d iterations" % (self.n_solves, rr, it)
             x0 = False
-            if not self._escalate(reason):
-                raise ArithmeticError("%s on the last rung (%r) of the escalation ladder%s; steps taken: %s"
+            if not self._escalate(reason) and not self._go_direct(reason):
+                raise ArithmeticError("%s on the last rung (%r) of the escalation ladder%s; steps taken: %s%s"
                                       % (reason, self.LADDER[self.rung]["name"],
                                          " -- operator: %s" % self.label if self.label else "",
-                                         [st["rung"] for st in self.ladder] or "none"))
+                                         [st["rung"] for st in self.ladder] or "none",
+                                         "; direct factorisation: %s" % self.direct_refused if self.direct_refused else ""))
+
+    def _go_direct(self, reason):
+        """Beyond the last iterative rung: factorise K on the device (slepc.LUSolver, csrc/splu.hip) when the factor fits in HBM --
+        what PCLU / MUMPS is to the reference: an answer at any target.  Single GPU only."""
+        if self.shard is not None or os.environ.get("HX_AMG_DIRECT_RUNG", "1") == "0":
+            self.direct_refused = "not available on the row-sharded path" if self.shard is not None else "switched off"
+            return False
+        from .slepc import LUSolver
+        self._teardown()                              # the hierarchy's memory goes to the factor
+        _hx.check(_hx.lib.hx_pool_trim())
+        try:
+            self.direct = LUSolver(self._K_in)
+        except MemoryError as e:
+            self.direct_refused = str(e)
+            self._build()
+            return False
+        self.ladder.append(dict(rung="direct", after_solve=self.n_solves, reason=reason))
+        info("! inner solver: %s -- moving to the direct factorisation (nnz(L) = %.3g, %.2f s)"
+             % (reason, self.direct.info()[0][3], self.direct.setup_s))
+        return True
 
     def _solve_once(self, b, x, relax, x0):
         import time
@@ -1102,7 +1145,7 @@ class AMGSolver:
     def block_ready(self):
         """The batched route: single GPU, SELL-64 fine level with complex128 values, complex64 V-cycle, COCG in use and its
         deflation pairs prepared by an earlier solve (or none wanted)."""
-        return (self.shard is None and self.sell is not None and self.use_cocg and self.params["precision"] == "mixed"
+        return (self.direct is None and self.shard is None and self.sell is not None and self.use_cocg and self.params["precision"] == "mixed"
                 and os.environ.get("HX_BLOCK_SOLVES", "1") != "0"
                 and (self.recycle_k == 0 or (self.recycled and self.cocg_solves > 0)))
 
@@ -1242,6 +1285,10 @@ class AMGSolver:
         self.harmonic_ritz = theta
 
     def stats(self):
+        if self.direct is not None:               # the hierarchy is gone: what the direct rung reports, under the same keys
+            out = dict(rung="direct", ladder=list(self.ladder), solves=self.n_solves, setup_s=round(self.setup_s, 3),
+                       iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1), direct=self.direct.stats())
+            return out
         return dict(rung=self.LADDER[self.rung]["name"], ladder=list(self.ladder), shift_beta=self.beta,
                     transfers_from="A" if (self.use_graph and self._graph is not None) else "K",
                     recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)),
@@ -1289,6 +1336,9 @@ class AMGSolver:
 
     def destroy(self):
         self._teardown()
+        if getattr(self, "direct", None) is not None:
+            self.direct.destroy()
+            self.direct = None
         self._K_in = self._hierarchy_in = self._shifted = self._graph = None
 
     def __del__(self):

@@ -447,8 +447,10 @@ class DeepHaloPlan:
         self.n_exchanges += 1
 
     def native_arrays(self):
-        """All layers as ONE plan of hx_comm_set_plan: the peers of layer 1, then those of layer 2, ... (a peer may appear several
-        times: its messages are matched in issue order on both sides, as NCCL does for one pair of ranks)."""
+        """All layers as ONE plan of hx_comm_set_plan: the peers of layer 1, then those of layer 2, ...  A peer appears once per
+        layer; hx_comm_set_plan concatenates its lists in this order on both sides into ONE message per peer and direction (the
+        receiving side scatters it to the layers' ranges), so nothing rests on how the communication library matches several
+        messages between one pair of ranks."""
         parts = [pl.native_arrays() for pl in self.layers]
         send_peer = np.concatenate([a[0] for a in parts])
         send_ptr, off = [np.zeros(1, np.int64)], 0

@@ -650,6 +650,9 @@ class P1Assembler:
         self.v2c_ptr, self.v2c_idx = self._adjacency(self.cells, self.nc, self.dim + 1)
         self.rowptr, self.col = self._pattern(self.cells, self.nc, self.dim + 1, self.v2c_ptr, self.v2c_idx)
         self.pattern_id = new_pattern_id()
+        self._h_pattern = None
+        if getattr(self.mesh, "part", None) is None:
+            register_coords(self.pattern_id, self.mesh.geometry.x)
 
     def lumped(self):
         """m_j = int phi_j dx, so that int f dx = m . f for nodal P1 f."""

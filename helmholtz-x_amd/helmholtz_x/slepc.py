@@ -59,9 +59,22 @@ class LUSolver:
     (``_ANALYSES``): a new target re-factorises numerically only."""
 
     name = "lu"
-    _ANALYSES = __import__("collections").OrderedDict()      # pattern id -> handle (analysis + device plan + factor storage)
+    # analyses kept by sparsity pattern: [(n, nnz, device rowptr, device col, handle)], most recent last.  A pattern is recognised
+    # by its CONTENT (a driver that rebuilds its integer maps gets new tensors with the same entries): two device compares.
+    _ANALYSES = []
     _MAX_ANALYSES = 2
+    REUSE = __import__("os").environ.get("HX_LU_REUSE_ANALYSIS", "1") != "0"
     REFINE_ABOVE = 1e-11          # a first solve with a larger relative residual switches iterative refinement on
+
+    @classmethod
+    def _cached_analysis(cls, K_csr):
+        n, nnz = K_csr.shape[0], K_csr.nnz
+        for i, (cn, cnnz, rp, ci, h) in enumerate(cls._ANALYSES):
+            if cn == n and cnnz == nnz and (rp is K_csr.rowptr or torch.equal(rp, K_csr.rowptr)) \
+                    and (ci is K_csr.col or torch.equal(ci, K_csr.col)):
+                cls._ANALYSES.pop(i)
+                return h
+        return None
 
     def __init__(self, K_csr, coords=None):
         import time
@@ -70,7 +83,7 @@ class LUSolver:
         self.K = K_csr
         n = self.n = K_csr.shape[0]
         key = K_csr.pattern_id
-        self.handle = self._ANALYSES.pop(key, None)
+        self.handle = self._cached_analysis(K_csr) if self.REUSE else None
         self.analysis_reused = self.handle is not None
         if self.handle is None:
             rp, ci = K_csr.host_pattern()
@@ -83,14 +96,30 @@ class LUSolver:
             else:
                 xy = None
             h = C.c_void_p()
+            flags = 1 if getattr(K_csr, "symmetric", False) else 0       # Galerkin operators: the pattern is its own transpose
             _hx.check(_hx.lib.hx_splu_analyse(C.byref(h), n, _hx.nptr(rp), _hx.nptr(ci), None if xy is None else _hx.nptr(xy),
-                                               dim, int(__import__("os").environ.get("HX_LU_LEAF", "0"))))
+                                               dim, int(__import__("os").environ.get("HX_LU_LEAF", "0")), flags))
             self.handle = h
             self.ordering = "inertial" if xy is not None else "level-set"
         else:
             self.ordering = "cached"
         self._key = key
         t1 = time.perf_counter()
+        if not self.analysis_reused:
+            # does the factor fit?  (panels + inverted diagonal blocks + contribution-block arena + workspaces; torch's cache and the
+            # library's pool are given back first when it is tight)
+            io, _ = self.info()
+            need = 16 * (io[4] + io[5] + io[6] + io[7]) * 1.25 + 64 * n
+            free = torch.cuda.mem_get_info()[0]
+            if need > 0.9 * free:
+                torch.cuda.empty_cache()
+                _hx.check(_hx.lib.hx_pool_trim())
+                free = torch.cuda.mem_get_info()[0]
+            if need > 0.9 * free:
+                _hx.lib.hx_splu_destroy(self.handle)
+                self.handle = None
+                raise MemoryError("direct factorisation of %d unknowns needs %.1f GiB (nnz(L) = %.3g), %.1f GiB are free"
+                                  % (n, need / 2 ** 30, io[3], free / 2 ** 30))
         _hx.check(_hx.lib.hx_splu_factor(self.handle, _hx.ptr(K_csr.val), _hx.stream()))
         self.tmp = torch.empty(n, dtype=torch.complex128, device=K_csr.val.device)
         self.res = torch.empty(n, dtype=torch.complex128, device=K_csr.val.device)
@@ -155,11 +184,11 @@ class LUSolver:
         h, self.handle = self.handle, None
         if h is None:
             return
-        if self._key is not None and not isinstance(self._key, tuple):
-            self._ANALYSES[self._key] = h                  # the next solver on this pattern re-factorises only
+        if self.REUSE and not isinstance(self._key, tuple):
+            K = self.K                                     # the next solver on this pattern re-factorises only
+            self._ANALYSES.append((K.shape[0], K.nnz, K.rowptr, K.col, h))
             while len(self._ANALYSES) > self._MAX_ANALYSES:
-                _, old = self._ANALYSES.popitem(last=False)
-                _hx.lib.hx_splu_destroy(old)
+                _hx.lib.hx_splu_destroy(self._ANALYSES.pop(0)[4])
         else:
             _hx.lib.hx_splu_destroy(h)
 

@@ -61,7 +61,11 @@ enum hx_status {
  *   HX_AMG_GRAPH_PRIVATE_STREAM                               hipGraph replay of the V-cycle on a private stream
  *   HX_GMRES_TRACE=1                                          residual histories of hx_gmres / hx_cocg on stderr
  *   HX_HOST_THREADS                                           threads of the hx_host_* set-up passes
- *   HX_RCCL_LIB                                               librccl to bind in hx_comm_* (default: the loaded one / librccl.so.1) */
+ *   HX_RCCL_LIB                                               librccl to bind in hx_comm_* (default: the loaded one / librccl.so.1)
+ *   HX_DEBUG_BOUNDS=1                                         entry points that follow caller-supplied index arrays (hx_zgather, hx_zscatter_axpy, hx_zsparse_dots,
+ *                                                             hx_zsparse_axpys, the send / receive lists of hx_comm_exchange) first check on the device that every
+ *                                                             indexed access stays inside the allocation holding the indexed vector: HX_ERR_ARG with the offending
+ *                                                             position instead of a device fault.  One reduction + a synchronising read-back per call (tests) */
 /* Run-time options (csrc/options.hip).  Every switch listed above is ALSO an option: its name is the environment variable's
  * without the HX_ prefix, in lower case ("sell_stencil", "cocg_lag", "cocg_single_reduction", ...).  hx_set_option(name, value)
  * overrides the environment from the next library call on (value NULL or "" removes the override); nothing is latched at first
@@ -326,9 +330,11 @@ int hx_sptrsv_destroy(hx_sptrsv* t);
  * (dense panels), bitwise reproducible; the transposed solve uses the same factors. */
 typedef struct hx_splu hx_splu;
 /* HOST analysis (no device needed): h_rowptr / h_col = CSR pattern, h_coords = n x dim vertex coordinates of the unknowns
- * (inertial nested dissection) or NULL (level-set nested dissection on the graph); leaf_size <= 0: default 64.  SYNC. */
+ * (inertial nested dissection) or NULL (level-set nested dissection on the graph); leaf_size <= 0: default 64;
+ * flags bit 0: the pattern is structurally symmetric with sorted rows (the analysis then skips forming A + A^T).  The first
+ * levels of the dissection and the entry map run on HX_HOST_THREADS host threads (default 8).  SYNC. */
 int hx_splu_analyse(hx_splu** out, int32_t n, const int32_t* h_rowptr, const int32_t* h_col, const double* h_coords,
-                    int dim, int leaf_size);
+                    int dim, int leaf_size, int flags);
 /* iout[16]: n, supernodes, levels, nnz(L) (= nnz(U), diagonal included), factor / inverse / temporary / workspace elements,
  * largest front, widest supernode, border rows, nnz of the input, replaced pivots of the last factorisation, launches of
  * the factorisation / forward / backward sweeps;  dout[8]: real flops of the factorisation, seconds of the analysis (host),
@@ -415,7 +421,8 @@ int hx_gmres(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, const int
  * K U = C, C^H C = I, harvested once as the harmonic Ritz vectors of the first solve.  hx_gmres / hx_gmres_sharded
  * then start every cycle from the Galerkin guess on span(U) and keep the Arnoldi vectors orthogonal to C, which
  * removes the initial plateau caused by the few near-null modes of the preconditioned operator.
- *   hx_amg_enable_recycling  allocate the [C; V] panel and U inside the handle (n = rows of the local operator)
+ *   hx_amg_enable_recycling  allocate the [C; V] panel and U inside the handle (n = rows of the local operator); called again it
+ *                            re-sizes them for another k_max / restart and drops the harvested pairs (the hierarchy stays). SYNC then.
  *   hx_gmres_hessenberg      raw (m+1) x m Hessenberg of the last cycle of the last solve (column-major, ld m+1);
  *                            *m = 0 if that solve already used recycled pairs.  Call with H = NULL to query m.
  *   hx_amg_set_recycle       U = Z_m Ucoef, C = V_{m+1} Ccoef (HOST coefficients, column-major m x k and (m+1) x k);

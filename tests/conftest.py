@@ -10,6 +10,10 @@ for p in (ROOT, os.path.join(ROOT, "helmholtz-x_amd"), os.path.join(ROOT, "tests
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the library checks every caller-supplied index array on the device before it follows it (include/hx.h: HX_DEBUG_BOUNDS): a
+# lifetime bug of a test's temporaries then fails with an error code instead of faulting the GPU of a shared machine
+os.environ.setdefault("HX_DEBUG_BOUNDS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -277,7 +277,7 @@ def test_device_sparse_lu_on_the_real_micca_operator(hx, golden_dir, level, with
     xy = np.ascontiguousarray(xyz, np.float64)
     h = C.c_void_p()
     hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), hx.nptr(xy) if with_coords else None,
-                                    3 if with_coords else 0, 0))
+                                    3 if with_coords else 0, 0, 0))
     val, bd = _dev(np.ascontiguousarray(K.data)), _dev(b)
     xd = torch.empty_like(bd)
     io, do = (C.c_int64 * 16)(), (C.c_double * 8)()
@@ -345,7 +345,7 @@ def test_device_sparse_lu_edge_cases(hx, case):
     n = K.shape[0]
     rp, ci = K.indptr.astype(np.int32), K.indices.astype(np.int32)
     h = C.c_void_p()
-    hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), None, 0, 0))
+    hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), None, 0, 0, 0))
     val = _dev(np.ascontiguousarray(K.data))
     hx.check(hx.lib.hx_splu_factor(h, hx.ptr(val), hx.stream()))
     b = _rand_c(rng, n)
@@ -1146,9 +1146,42 @@ def test_factored_flame_term_scatter_with_device_coefficients(hx):
         xv = _rand_c(rng, n)
         out = Vec.zeros(n)
         M.mult(Vec(xv), out)
-        D = np.zeros((n, n), dtype=np.complex128) if n <= 6000 else None
         expl = S @ xv
         for f in range(r):
             expl[sup[f]] += coef * vals[f] * (rval[f] @ xv[rsup[f]])
         assert _rel(out.array, expl) < 1e-13
-        del D
+
+
+def test_debug_bounds_turns_a_wild_index_into_an_error_code(hx):
+    """HX_DEBUG_BOUNDS (on for this suite, conftest.py): an index array pointing outside the allocation of the vector it indexes
+    -- what a stale or recycled temporary looks like to a kernel -- is refused with HX_ERR_ARG naming the position, for every entry
+    point that follows caller-supplied indices; nothing is launched, the device stays healthy (the last call of the test runs)."""
+    import torch
+    assert hx.get_option("debug_bounds") == "1"
+    n = 1000
+    rng = np.random.default_rng(0)
+    x = _dev(_rand_c(rng, n))
+    y = torch.zeros_like(x)
+    good = _dev(rng.permutation(n).astype(np.int32))
+    wild = good.clone()
+    wild[137] = 2 ** 30                              # ~16 GiB past the start of a 16 kB vector
+    hx.check(hx.lib.hx_zgather(n, hx.ptr(x), hx.ptr(good), hx.ptr(y), hx.stream()))
+    for call in (lambda: hx.lib.hx_zgather(n, hx.ptr(x), hx.ptr(wild), hx.ptr(y), hx.stream()),
+                 lambda: hx.lib.hx_zscatter_axpy(n, hx.z2(1.0), hx.ptr(x), hx.ptr(wild), hx.ptr(y), hx.stream())):
+        rc = call()
+        assert rc == -1, rc                           # HX_ERR_ARG
+        msg = hx.lib.hx_last_error().decode()
+        assert "debug_bounds" in msg and "entry 137" in msg, msg
+    ptr = _dev(np.array([0, 400, n], np.int32))
+    vals, t, out = _dev(_rand_c(rng, n)), _dev(_rand_c(rng, 2)), _dev(np.zeros(2, np.complex128))
+    for call in (lambda idx: hx.lib.hx_zsparse_dots(2, hx.ptr(ptr), hx.ptr(idx), hx.ptr(vals), hx.ptr(x), hx.ptr(out), hx.stream()),
+                 lambda idx: hx.lib.hx_zsparse_axpys(2, hx.ptr(ptr), hx.ptr(idx), hx.ptr(vals), hx.ptr(t), hx.z2(0.5), hx.ptr(y), 1, hx.stream())):
+        assert call(good) == 0
+        assert call(wild) == -1 and "entry 137" in hx.lib.hx_last_error().decode()
+    hx.set_option("debug_bounds", "0")               # off: the same call is not inspected (not made here: it would fault)
+    try:
+        hx.check(hx.lib.hx_zgather(n, hx.ptr(x), hx.ptr(good), hx.ptr(y), hx.stream()))
+    finally:
+        hx.set_option("debug_bounds", None)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), x.cpu().numpy()[good.cpu().numpy()])

@@ -693,7 +693,7 @@ def test_direct_solver_analysis_structure_contains_the_fill(case, with_coords):
     xyc = np.ascontiguousarray(xy, np.float64) if with_coords else None
     h = C.c_void_p()
     hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), None if xyc is None else hx.nptr(xyc),
-                                    0 if xyc is None else xyc.shape[1], 16))
+                                    0 if xyc is None else xyc.shape[1], 16, 0))
     try:
         f = _splu_fields(hx, h)
         io, do = (C.c_int64 * 16)(), (C.c_double * 8)()

@@ -56,7 +56,7 @@ def main():
             h = C.c_void_p()
             t0 = time.perf_counter()
             _hx.check(_hx.lib.hx_splu_analyse(C.byref(h), n, _hx.nptr(rp), _hx.nptr(ci), None if coords is None else _hx.nptr(coords),
-                                               0 if coords is None else 3, 0))
+                                               0 if coords is None else 3, 0, 0))
             ta = time.perf_counter() - t0
             val = to_device(np.ascontiguousarray(K.data, np.complex128))
             io, do = (C.c_int64 * 16)(), (C.c_double * 8)()

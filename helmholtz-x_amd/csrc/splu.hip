@@ -70,6 +70,8 @@ struct hx_splu {
   SpluDev dev{};
   int32_t tiny_pivots = 0;
   double factor_seconds = 0.0;
+  hipGraphExec_t sweep_graph[2] = {nullptr, nullptr};   // the two sweeps of a solve (A x = b / A^T x = b), captured at the first solve
+  bool graph_failed = false;
 };
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -595,9 +597,9 @@ __device__ __forceinline__ void fwd_gather(const SpluDev& d, int s, int ns, int6
   }
 }
 
-// forward sweep of one front: w[0:ns] <- y of this supernode (stays in the workspace for the backward sweep),
+// (256-thread form, used by the transposed sweeps) forward sweep of one front: w[0:ns] <- y of this supernode (stays in the workspace for the backward sweep),
 // w[ns:m] <- update for the ancestors.  L has unit diagonal blocks; the transposed sweep runs on U^T (diagonal blocks D^T).
-__global__ void __launch_bounds__(256) k_splu_fwd_small(SpluDev d, const int32_t* __restrict__ fronts, int trans, const zc* __restrict__ pb) {
+__global__ void __launch_bounds__(256) k_splu_fwd_small_256(SpluDev d, const int32_t* __restrict__ fronts, int trans, const zc* __restrict__ pb) {
   __shared__ zc sv[NB], sy[NB], sred[256];
   const int s = fronts[blockIdx.x];
   const int ns = d.sfirst[s + 1] - d.sfirst[s];
@@ -616,6 +618,38 @@ __global__ void __launch_bounds__(256) k_splu_fwd_small(SpluDev d, const int32_t
       cols_dot_block(d.F + d.uoff[s], ns, c0, wd, c1, m, sy, w);
       __syncthreads();
     }
+  }
+}
+
+// forward sweep of one front: w[0:ns] <- y of this supernode (stays in the workspace for the backward sweep),
+// w[ns:m] <- update for the ancestors.  L has unit diagonal blocks; the transposed sweep runs on U^T (diagonal blocks D^T).
+// 512 threads: a wave takes whole 64-row tiles (every load of a tile's 64 columns in flight at once, no reduction).
+#define SM_T 512
+#define SM_W (SM_T / 64)
+__global__ void __launch_bounds__(SM_T) k_splu_fwd_small(SpluDev d, const int32_t* __restrict__ fronts, const zc* __restrict__ pb) {
+  __shared__ zc sv[NB];
+  const bool trans = false;
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  zc* w = d.wk + d.woff[s];
+  fwd_gather(d, s, ns, m, pb, w);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int kb = 0; kb * NB < ns; ++kb) {
+    const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
+    if (threadIdx.x < wd) sv[threadIdx.x] = w[c0 + threadIdx.x];
+    __syncthreads();
+    if (!trans) {
+      const zc* P = d.F + d.loff[s] + (int64_t)c0 * m;
+      for (int64_t r = c1 + (int64_t)wv * 64 + lane; r < m; r += SM_T) {
+        zc acc = make_double2(0.0, 0.0);
+        const zc* pr = P + r;
+#pragma unroll 16
+        for (int k = 0; k < wd; ++k) zfma(acc, pr[(int64_t)k * m], sv[k]);
+        w[r].x -= acc.x; w[r].y -= acc.y;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -661,8 +695,8 @@ __global__ void __launch_bounds__(256) k_splu_fwd_upd(SpluDev d, const int32_t* 
   }
 }
 
-// backward sweep of one front: w[ns:m] <- x of the border rows, then pivot blocks from last to first
-__global__ void __launch_bounds__(256) k_splu_bwd_small(SpluDev d, const int32_t* __restrict__ fronts, int trans, zc* __restrict__ x) {
+// (256-thread form, used by the transposed sweeps) backward sweep of one front: w[ns:m] <- x of the border rows, then pivot blocks from last to first
+__global__ void __launch_bounds__(256) k_splu_bwd_small_256(SpluDev d, const int32_t* __restrict__ fronts, int trans, zc* __restrict__ x) {
   __shared__ zc sv[NB], sy[NB], sred[256];
   const int s = fronts[blockIdx.x];
   const int ns = d.sfirst[s + 1] - d.sfirst[s];
@@ -694,6 +728,59 @@ __global__ void __launch_bounds__(256) k_splu_bwd_small(SpluDev d, const int32_t
   }
   const int first = d.sfirst[s];
   for (int i = threadIdx.x; i < ns; i += 256) x[first + i] = w[i];
+}
+
+// backward sweep of one front: w[ns:m] <- x of the border rows, then pivot blocks from last to first
+__global__ void __launch_bounds__(SM_T) k_splu_bwd_small(SpluDev d, const int32_t* __restrict__ fronts, zc* __restrict__ x) {
+  __shared__ zc sv[NB], sred[SM_T];
+  const bool trans = false;
+  const int s = fronts[blockIdx.x];
+  const int ns = d.sfirst[s + 1] - d.sfirst[s];
+  const int64_t m = ns + (d.sptr[s + 1] - d.sptr[s]);
+  zc* w = d.wk + d.woff[s];
+  {
+    const int32_t* rows = d.srow + d.sptr[s];
+    for (int64_t i = ns + threadIdx.x; i < m; i += SM_T) w[i] = x[rows[i - ns]];
+    __syncthreads();
+  }
+  const int k = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (int kb = (ns - 1) / NB; kb >= 0; --kb) {
+    const int c0 = kb * NB, c1 = min(ns, c0 + NB), wd = c1 - c0;
+    if (!trans) {
+      // t = w[c0:c1] - U[c0:c1, c1:m] w[c1:m]: lane = pivot row, wave q takes every 8th column
+      zc acc = make_double2(0.0, 0.0);
+      if (k < wd) {
+        const zc* pu = d.F + d.uoff[s] + c0 + k;
+#pragma unroll 8
+        for (int64_t a = c1 + q; a < m; a += SM_W) zfma(acc, pu[a * ns], w[a]);
+      }
+      sred[threadIdx.x] = acc;
+      __syncthreads();
+      if (threadIdx.x < wd) {
+        zc t = sred[k];
+#pragma unroll
+        for (int i = 1; i < SM_W; ++i) t = zadd(t, sred[k + 64 * i]);
+        sv[k] = zsub(w[c0 + k], t);
+      }
+      __syncthreads();
+      // x = D^-1 t: row a = lane, wave q takes 8 columns
+      const zc* Wb = d.W + d.ioff[s] + (int64_t)kb * NB * NB;
+      zc y = make_double2(0.0, 0.0);
+      if (k < wd)
+        for (int j = q * 8; j < min(wd, q * 8 + 8); ++j) zfma(y, Wb[k + j * NB], sv[j]);
+      sred[threadIdx.x] = y;
+      __syncthreads();
+      if (threadIdx.x < wd) {
+        zc t = sred[k];
+#pragma unroll
+        for (int i = 1; i < SM_W; ++i) t = zadd(t, sred[k + 64 * i]);
+        w[c0 + k] = t;
+      }
+    }
+    __syncthreads();
+  }
+  const int first = d.sfirst[s];
+  for (int i = threadIdx.x; i < ns; i += SM_T) x[first + i] = w[i];
 }
 
 __global__ void __launch_bounds__(256) k_splu_bwd_gather(SpluDev d, const int32_t* __restrict__ fronts, const zc* __restrict__ x) {
@@ -979,6 +1066,7 @@ static hipError_t upload(T** dst, const std::vector<T>& v) {
 }
 
 static void splu_release(hx_splu* h) {
+  for (int t = 0; t < 2; ++t) if (h->sweep_graph[t]) { (void)hipGraphExecDestroy(h->sweep_graph[t]); h->sweep_graph[t] = nullptr; }
   void* blocks[] = {h->d_i32, h->d_i64, h->d_lists, h->d_amap, h->d_perm, h->d_status, h->F, h->W, h->T, h->wk, h->part, h->pb, h->xp, h->V};
   for (void* b : blocks) (void)hx_free(b);
   h->d_i32 = h->d_lists = h->d_perm = h->d_status = nullptr; h->d_i64 = h->d_amap = nullptr;
@@ -1108,34 +1196,61 @@ extern "C" int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int trans
   const SpluSymbolic& S = h->sym;
   const int tr = transposed ? 1 : 0;
   k_splu_permute<<<hx_grid(S.n, 256), 256, 0, st>>>(S.n, h->d_perm, (const zc*)b, h->pb, 0);
-  // forward leaves y of every supernode in its workspace slice, backward turns it into x and writes the permuted solution
+  // The two sweeps are ~100 small launches on fixed internal buffers: captured once into a hipGraph and replayed (option
+  // splu_graph=0: plain launches).  Only the two permutation kernels around them see the caller's vectors.
   zc* y = h->xp;
-  for (const Launch& L : h->fwd_plan[tr]) {
-    const int32_t* fr = h->d_lists + L.list;
-    const int32_t* px = fr + L.nf;
-    switch (L.kind) {
-      case S_FWD_SMALL: k_splu_fwd_small<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, h->pb); break;
-      case S_FWD_GATHER: k_splu_fwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, h->pb); break;
-      case S_FWD_DIAG: k_splu_fwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0); break;
-      case S_FWD_UPD: k_splu_fwd_upd<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
-      case S_GV_PART: k_splu_gv_part<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0); break;
-      case S_GV_REDUCE: k_splu_gv_reduce<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, y); break;
-      default: break;
+  auto sweeps = [&](hipStream_t st) -> int {
+  // forward leaves y of every supernode in its workspace slice, backward turns it into x and writes the permuted solution
+    for (const Launch& L : h->fwd_plan[tr]) {
+      const int32_t* fr = h->d_lists + L.list;
+      const int32_t* px = fr + L.nf;
+      switch (L.kind) {
+        case S_FWD_SMALL: if (tr) k_splu_fwd_small_256<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, h->pb);
+                        else k_splu_fwd_small<<<L.grid, SM_T, 0, st>>>(h->dev, fr, h->pb);
+                        break;
+        case S_FWD_GATHER: k_splu_fwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, h->pb); break;
+        case S_FWD_DIAG: k_splu_fwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0); break;
+        case S_FWD_UPD: k_splu_fwd_upd<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
+        case S_GV_PART: k_splu_gv_part<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+        case S_GV_REDUCE: k_splu_gv_reduce<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, y); break;
+        default: break;
+      }
     }
-  }
-  for (const Launch& L : h->bwd_plan[tr]) {
-    const int32_t* fr = h->d_lists + L.list;
-    const int32_t* px = fr + L.nf;
-    switch (L.kind) {
-      case S_BWD_SMALL: k_splu_bwd_small<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, y); break;
-      case S_BWD_GATHER: k_splu_bwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, y); break;
-      case S_BWD_DOT: k_splu_bwd_dot<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
-      case S_BWD_DIAG: k_splu_bwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0, tr, y); break;
-      case S_GV_PART: k_splu_gv_part<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0); break;
-      case S_GV_REDUCE: k_splu_gv_reduce<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, y); break;
-      default: break;
+    for (const Launch& L : h->bwd_plan[tr]) {
+      const int32_t* fr = h->d_lists + L.list;
+      const int32_t* px = fr + L.nf;
+      switch (L.kind) {
+        case S_BWD_SMALL: if (tr) k_splu_bwd_small_256<<<L.grid, 256, 0, st>>>(h->dev, fr, tr, y);
+                        else k_splu_bwd_small<<<L.grid, SM_T, 0, st>>>(h->dev, fr, y);
+                        break;
+        case S_BWD_GATHER: k_splu_bwd_gather<<<L.grid, 256, 0, st>>>(h->dev, fr, y); break;
+        case S_BWD_DOT: k_splu_bwd_dot<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, tr); break;
+        case S_BWD_DIAG: k_splu_bwd_diag<<<L.grid, 256, 0, st>>>(h->dev, fr, L.p0, tr, y); break;
+        case S_GV_PART: k_splu_gv_part<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+        case S_GV_REDUCE: k_splu_gv_reduce<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf, L.p0, y); break;
+        default: break;
+      }
     }
+  return HX_OK;
+  };
+  const bool want_graph = HX_OPT_INT("splu_graph", 1) != 0 && !h->graph_failed;
+  if (want_graph && !h->sweep_graph[tr]) {
+    // captured on a private stream (the caller's may be the null stream, which cannot capture), replayed on the caller's
+    hipGraph_t g = nullptr;
+    hipStream_t cs = nullptr;
+    bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+    if (ok) ok = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      const int rc = sweeps(cs);
+      ok = hipStreamEndCapture(cs, &g) == hipSuccess && rc == HX_OK && g != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&h->sweep_graph[tr], g, nullptr, nullptr, 0) == hipSuccess;
+    if (g) (void)hipGraphDestroy(g);
+    if (cs) (void)hipStreamDestroy(cs);
+    if (!ok) { (void)hipGetLastError(); h->sweep_graph[tr] = nullptr; h->graph_failed = true; }
   }
+  if (want_graph && h->sweep_graph[tr]) HX_HIP(hipGraphLaunch(h->sweep_graph[tr], st));
+  else { const int rc = sweeps(st); if (rc != HX_OK) return rc; }
   k_splu_permute<<<hx_grid(S.n, 256), 256, 0, st>>>(S.n, h->d_perm, y, (zc*)x, 1);
   HX_LAUNCH_CHECK("hx_splu_solve");
   return HX_OK;

@@ -838,6 +838,13 @@ class AMGSolver:
         # the operator the HIERARCHY is built on: K itself, or its complex-shifted companion (same pattern)
         Kp = K_csr if not self.beta else self._shifted(self.beta)
         G = self._graph() if (self.use_graph and self._graph is not None) else None
+        host_setup = os.environ.get("HX_AMG_SETUP", self.params["setup"]) == "host"
+        # transfers from the Laplacian part exist in the single-GPU device set-up only: say so where the rung asks for them
+        self.graph_ignored = bool(self.use_graph and (G is None or shard is not None or hierarchy is not None or host_setup))
+        if self.graph_ignored:
+            info("! inner solver: rung %r asks for transfer operators from the stiffness part; %s builds them from the operator itself"
+                 % (self.LADDER[self.rung]["name"], "the row-sharded set-up" if shard is not None else
+                    ("the host set-up" if host_setup else "this caller (no stiffness part supplied)")))
         if shard is not None:
             # row-sharded: K_csr is this rank's rows (distributed assembly) or the global operator (cut to the rank's rows
             # here); either way the hierarchy is BUILT sharded -- every rank its slab of every large level
@@ -1290,7 +1297,8 @@ class AMGSolver:
                        iters_per_solve=round(self.total_iters / max(self.n_solves, 1), 1), direct=self.direct.stats())
             return out
         return dict(rung=self.LADDER[self.rung]["name"], ladder=list(self.ladder), shift_beta=self.beta,
-                    transfers_from="A" if (self.use_graph and self._graph is not None) else "K",
+                    transfers_from="A" if (self.use_graph and self._graph is not None and not getattr(self, "graph_ignored", False)) else "K",
+                    graph_transfers_ignored=bool(getattr(self, "graph_ignored", False)),
                     recycled_pairs=self.recycled, vcycle_graph=bool(_hx.lib.hx_amg_graph_active(self.handle)),
                     levels=[lv.get("n_global", lv["n"]) for lv in self.levels],
                     operator_complexity=getattr(self, "operator_complexity", None), level_nnz=getattr(self, "level_nnz", None),

@@ -27,7 +27,12 @@ from .krylov import default_ncv, krylov_schur
 from .petsc import combine_csr, to_device
 from .solver_utils import info
 
-DEFAULTS = {"st_type": "auto", "lu_max_dofs": 1_000}
+# st_type "auto": the direct factorisation (device multifrontal LU) up to lu_max_dofs unknowns, AMG-preconditioned Krylov beyond.
+# Measured on one MI355X (round 6, profiles/r06_lu_amg_crossover.txt; one fixed-point call, ms, LU / AMG): 2 k DOF 84 / 93, 16 k 110 /
+# 131, the reference's MICCA mesh (34,787) 177 / 265, 66 k 163 / 177, MICCA refined once (249 k) 370 / 412 (455 with the analysis
+# redone in the call), structured 255 k annulus 324 / 245: the direct route wins up to ~1e5 unknowns on every mesh tried and ties
+# around 2.5e5; beyond, its factor (4.6 GiB at 249 k, growing like n^(4/3)) and flops (n^2) lose to the O(n) hierarchy.
+DEFAULTS = {"st_type": "auto", "lu_max_dofs": 100_000}
 # Tolerance factor of the Woodbury columns W = K^-1 U (inner tolerance 1e-11 -> 3e-10).  Larger factors were measured: at
 # 5 M DOF 300 and 1000 give the same four eigenvalues to the printed 1e-6 (3e-10 relative) with 2 % / 3 % fewer inner
 # iterations, but on the Bloch sector (config 5) a factor of 300 moves the adjoint eigenvalue away from the conjugate of
@@ -283,10 +288,6 @@ def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=
         from .amg import AMGSolver
         return AMGSolver(K_csr, hierarchy=hierarchy, shard=shard, shifted=shifted, label=label)
     if st == "auto":
-        # measured (MI355X, round 1): 2-D 103 k DOF PEP solve 3.8 s with LU (host SuperLU 2.5 s + latency-bound
-        # triangular solves) vs 0.29 s with AMG-GMRES; 3-D 34 k DOF fixed point 20.8 s vs < 3 s.  Round 3, with COCG at every
-        # size (one fixed-point call of the 3-D annulus): 2.2 k DOF 0.35 s (LU) vs 0.15 s (AMG), 4 k 0.59 vs 0.16, 8 k 1.38 vs
-        # 0.16, 16 k 2.35 vs 0.14 -- the direct route only serves problems too small for a two-level hierarchy.
         st = "lu" if n <= DEFAULTS["lu_max_dofs"] else "amg"
     if st == "lu":
         if __import__("os").environ.get("HX_LU", "device") == "host":

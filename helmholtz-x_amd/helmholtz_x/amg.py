@@ -1101,6 +1101,7 @@ class AMGSolver:
             self.direct_refused = str(e)
             self._build()
             return False
+        self.tmp = self.direct.tmp                    # (callers size their work vectors after the inner solver's)
         self.ladder.append(dict(rung="direct", after_solve=self.n_solves, reason=reason))
         info("! inner solver: %s -- moving to the direct factorisation (nnz(L) = %.3g, %.2f s)"
              % (reason, self.direct.info()[0][3], self.direct.setup_s))

@@ -1250,6 +1250,61 @@ def test_wide_rung_is_entered_before_anything_fails_at_15000_rad_s_5M():
     E.destroy()
 
 
+def test_direct_factorisation_answers_beyond_the_wall_of_the_iterative_route_260k():
+    """`annulus-260k` at 25 000 and 30 000 rad/s -- 2.3 / 2.7 times the reference's highest target, where the
+    iterative route needs 350 - 770 inner iterations per solve (4 - 10 s per passive solve, profiles/r06_envelope_260k.txt) -- with
+    st_type = 'lu': the device multifrontal factorisation answers in a fraction of a second at any target, as the reference's
+    PCLU does (eigensolvers.py:49-50,102-103).  Each returned pair is checked by its own residual (A + w B + w^2 C) p computed with
+    the assembled operators, the factorisation by the residual of its first solve; the 25 000 rad/s pair also against the
+    iterative route (wide rung)."""
+    import time
+    import torch
+    import bench
+    from helmholtz_x.acoustic_matrices import AcousticMatrices
+    from helmholtz_x.eigensolvers import pep_solver
+    from helmholtz_x.petsc import Vec
+    case = bench.build_case(bench.WORKLOADS["annulus-260k"])
+    P = case["P"]
+    M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
+    n = case["mesh"].num_vertices
+    found = {}
+    for target in (25000.0, 30000.0):
+        caches = ({}, {}, {})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        E = pep_solver(M.A, M.B, M.C, target, nev=2, st_type="lu", _caches=caches)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = next(v for v in caches[0].values() if hasattr(v, "stats")).stats()
+        assert E.getConverged() >= 2 and st["replaced_pivots"] == 0 and st["first_residual"] < 1e-11, st
+        for i in range(2):
+            w = E.getEigenvalue(i)
+            p, t = Vec.zeros(n), Vec.zeros(n)
+            E.getEigenvector(i, p)
+            r = Vec.zeros(n)
+            M.A.mult(p, r)
+            M.B.mult(p, t)
+            r.t.add_(t.t, alpha=w)
+            M.C.mult(p, t)
+            r.t.add_(t.t, alpha=w * w)
+            scale = float(torch.linalg.vector_norm(t.t)) * abs(w) ** 2
+            assert float(torch.linalg.vector_norm(r.t)) < 1e-8 * scale, (target, i, w)
+            assert abs(w - target) < 800.0
+        found[target] = E.getEigenvalue(0)
+        print("annulus-260k, target %g rad/s, st_type lu: %.2f s (factorisation %.0f ms on the device, nnz(L) %.3g, %d solves)"
+              % (target, dt, 1e3 * st["factor_device_s"], st["nnz_L"], st["solves"]))
+        assert dt < 3.0
+        E._owns_caches = True
+        E.destroy()
+    caches = ({}, {}, {})
+    E = pep_solver(M.A, M.B, M.C, 25000.0, nev=2, st_type="amg", _caches=caches)
+    assert abs(E.getEigenvalue(0) - found[25000.0]) < 1e-8 * abs(found[25000.0])
+    st = next(v for v in caches[0].values() if hasattr(v, "stats")).stats()
+    assert st["iters_per_solve"] > 100, st            # (the iterative route's price here)
+    E._owns_caches = True
+    E.destroy()
+
+
 def test_escalation_ladder_of_the_iterative_inner_solve(monkeypatch):
     """A stalled inner solve no longer ends the call (the reference's PCLU answers for any target,
     eigensolvers.py:49-50,102-103): the solver climbs its ladder -- default -> wide (FGMRES(100), up to 32 recycled vectors, 3x the
@@ -1268,7 +1323,7 @@ def test_escalation_ladder_of_the_iterative_inner_solve(monkeypatch):
 
     def solve():
         caches = ({}, {}, {})
-        E = pep_solver(M.A, M.B, M.C, P.target, nev=2, _caches=caches)
+        E = pep_solver(M.A, M.B, M.C, P.target, nev=2, st_type="amg", _caches=caches)     # (auto would factorise 25 k unknowns directly)
         inner = next(v for v in caches[0].values() if hasattr(v, "stats"))
         eigs, st = [E.getEigenvalue(i) for i in range(2)], inner.stats()
         E._owns_caches = True
@@ -1289,11 +1344,20 @@ def test_escalation_ladder_of_the_iterative_inner_solve(monkeypatch):
     assert st2["rung"] == "shifted" and st2["shift_beta"] == 0.5 and st2["transfers_from"] == "A", st2
     assert max(abs(a - b) / abs(b) for a, b in zip(eigs2, ref)) < 1e-9, (eigs2, ref)
     monkeypatch.delenv("HX_AMG_RUNG")
+    # 2 iterations are too few for every iterative rung: the ladder ends in the DIRECT factorisation (round 6: device multifrontal
+    # LU, what PCLU is to the reference) and the call still answers, with the same eigenvalues ...
     Options()["st_ksp_max_it"] = 2
+    eigs3, st3 = solve()
+    assert st3["rung"] == "direct" and [s["rung"] for s in st3["ladder"]] == ["wide", "shifted", "direct"], st3
+    assert st3["direct"]["replaced_pivots"] == 0 and st3["direct"]["first_residual"] < 1e-12, st3
+    assert max(abs(a - b) / abs(b) for a, b in zip(eigs3, ref)) < 1e-9, (eigs3, ref)
+    # ... and only with that rung switched off the last iterative rung raises, naming the operator
+    monkeypatch.setenv("HX_AMG_DIRECT_RUNG", "0")
     with pytest.raises(ArithmeticError) as err:
         solve()
     msg = str(err.value)
     assert "last rung ('shifted')" in msg and "PEP shift-invert at target 3225.12+481j" in msg and "['wide', 'shifted']" in msg, msg
+    assert "direct factorisation: switched off" in msg, msg
 
 
 def test_rijke3d_logged_trajectory_with_iterative_inner_solver(ref_logs, golden_dir):

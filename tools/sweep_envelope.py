@@ -29,7 +29,8 @@ def inner_of(caches):
 
 def pick(stats):
     keep = ("levels", "solves", "iters_per_solve", "gmres_iters", "setup_s", "solve_s", "recycled_pairs", "krylov", "cocg_fallbacks",
-            "attainable_stops", "harmonic_ritz", "ladder", "rung")
+            "attainable_stops", "harmonic_ritz", "ladder", "rung", "direct", "factor_device_s", "analyse_s", "nnz_L", "fill", "factor_gib",
+            "first_residual", "refine", "replaced_pivots", "ordering")
     return {k: stats[k] for k in keep if k in stats}
 
 
@@ -41,6 +42,7 @@ def main():
     ap.add_argument("--targets", default=None)
     ap.add_argument("--legs", default="passive,active")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--st-type", default=None, help="inner solver: lu | amg | auto (default: the library's choice)")
     ap.add_argument("--stop-after-failures", type=int, default=2, help="stop the sweep after this many consecutive failing targets")
     args = ap.parse_args()
     from helmholtz_x.acoustic_matrices import AcousticMatrices
@@ -72,7 +74,7 @@ def main():
             caches = ({}, {}, {})
             t0 = time.perf_counter()
             try:
-                E = pep_solver(M.A, M.B, M.C, target, nev=2, _caches=caches)
+                E = pep_solver(M.A, M.B, M.C, target, nev=2, st_type=args.st_type, _caches=caches)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 emit(dict(target=tt, leg="passive", ok=True, seconds=round(dt, 3),
@@ -93,7 +95,7 @@ def main():
             t0 = time.perf_counter()
             E = None
             try:
-                E = fixed_point_iteration(M, D, target, i=0, nev=4, tol=1e-3, history=hist)
+                E = fixed_point_iteration(M, D, target, i=0, nev=4, tol=1e-3, st_type=args.st_type, history=hist)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 inner = next((v for v in (E.inner_cache or {}).values() if hasattr(v, "stats")), None)

@@ -72,7 +72,7 @@ HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec
 METRIC = "converged eigenpairs/sec + SpMV GB/s (% HBM roofline), AnnularCombustor 5M DOF"
 
 
-def build_case(shape, numbering="native", jitter=0.0, resident=True):
+def build_case(shape, numbering="native", jitter=0.0, resident=True, slab_only=False):
     """The synthetic annular combustor.  ``numbering``: "native" = theta-major grid numbering of the generator (periodic,
     extruded: what a structured mesher writes); "rcm" = a random numbering passed through reverse Cuthill-McKee (what a
     bandwidth-reducing reader such as DOLFINx's leaves of an unstructured mesh file); "morton" = vertices renumbered along
@@ -86,6 +86,12 @@ def build_case(shape, numbering="native", jitter=0.0, resident=True):
     from helmholtz_x.synthetic import annulus, micca_sound_speed
     if shape[0] == "real":
         return build_case_real(shape[1], resident)
+    if slab_only and numbering == "native" and jitter == 0.0:
+        # N > 1 ranks on the analytic annulus: no rank builds the global mesh; helmholtz_x.sharded.distributed_case lets every
+        # rank generate its own theta-slab (synthetic.annulus_part)
+        mat = loadmat(os.path.join(ROOT, "tests", "golden", "micca_ftf.mat"))
+        return dict(mesh=None, subdomains=None, facet_tags=None, c=None, ftf=stateSpace(mat['A'], mat['b'], mat['c'], mat['d']),
+                    P=Micca, np=np, numbering="native", jitter=0.0, generator=tuple(shape))
     mesh, subdomains, facet_tags = annulus(*shape)
     if jitter > 0.0:
         x = mesh.geometry.x.copy()
@@ -493,7 +499,7 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     shape = WORKLOADS[args.workload]
-    case = build_case(shape, args.numbering, args.jitter, resident=(world == 1))   # N > 1: only the rank's part goes to HBM
+    case = build_case(shape, args.numbering, args.jitter, resident=(world == 1), slab_only=(world > 1))   # N > 1: only the rank's part goes to HBM
     args.numbering = case["numbering"]         # (the real-mesh workloads: "file" / "rcm")
     if world > 1:
         rc = run_sharded(args, case, shape, rank, world, backend, n_dev, barrier)
@@ -606,15 +612,21 @@ def run_sharded(args, case, shape, rank, world, backend, n_dev, barrier):
     import torch.distributed as dist
     from helmholtz_x import _hx
     budget = float(os.environ.get("HX_BENCH_SHARDED_TIMEOUT", "900"))
+    if backend == "nccl":
+        # on real GPUs the exchanges of the solves are the library's own RCCL calls or the run is void: no silent fall-back to
+        # host-driven torch.distributed (a communicator that cannot be created ends the run with the reason in the record)
+        os.environ.setdefault("HX_NATIVE_COMM", "1")
     out = {"metric": METRIC, "value": None, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "c128", "data": "synthetic",
            "config": {"workload": args.workload, "grid_nr_ntheta_nz": list(shape), "numbering": args.numbering,
                       "jitter": args.jitter, "parallelism": "row-sharded x%d" % world, "backend": backend,
                       "devices_visible": n_dev,
-                      "host_setup": "every rank builds the GLOBAL host mesh (build_case) before it cuts its part: N x the host work and "
-                                    "memory of one mesh on the node (5 M DOF: 29 M tets, ~1 GB per rank); a distributing reader is not "
-                                    "part of the hot path",
+                      "host_setup": ("every rank generates its own theta-slab (+ one plane either side) from the grid formulas: host work and "
+                                     "memory per rank shrink like 1 / N (config.partition.per_rank: host_setup_s, host_rss_gib)"
+                                     if case.get("generator") is not None else
+                                     "every rank builds the GLOBAL host mesh (build_case) before it cuts its part (mesh read from a file / "
+                                     "renumbered: no distributing reader in the hot path)"),
                       "rehearsal": None if n_dev >= world else
                       "%d ranks share %d GPU(s): gloo stages every exchange through the host" % (world, n_dev)}}
 
@@ -672,7 +684,10 @@ def run_sharded(args, case, shape, rank, world, backend, n_dev, barrier):
                 if roof is not None:
                     roof["scope"] = "rank 0's rows of the shifted operator over [owned | ghost] columns"
                     roof["dominant_by_time"] = smoother_roofline(inner, sh.n_own, in_situ_smoother)
-            out.update({"value": round(pairs / dt, 5), "ms_per_step": round(1e3 * dt / max(args.steps, 1), 2)})
+            out.update({"value": round(pairs / dt, 5), "ms_per_step": round(1e3 * dt / max(args.steps, 1), 2),
+                        "exchanges_issued_by": sh.counters()["issued_by"]})
+            if backend == "nccl" and sh.comm is None:
+                raise RuntimeError("nccl backend without the library's own communicator: the exchanges went through torch.distributed")
             out["config"].update({
                 "dofs": sh.n_global, "nev": 4, "fpi_tol": 1e-3, "fpi_iterations": len(hist) - 1, "flames": 16,
                 "partition": "%s: %d rows + %d ghost rows on rank 0" % (

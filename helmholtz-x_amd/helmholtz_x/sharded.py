@@ -385,6 +385,34 @@ def distributed_case(case, group=None):
     d = case.get("dist")
     if d is not None:
         return d
+    if case.get("generator") is not None:
+        # the analytic annulus in its generator's numbering: every rank GENERATES its theta-slab (+ the one plane either side),
+        # nobody holds the global mesh (synthetic.annulus_part = distribute_mesh of the global mesh, bit for bit)
+        import time
+        from .synthetic import annulus_part, micca_sound_speed
+        t0 = time.perf_counter()
+        nr, nth, nz = case["generator"]
+        plane = (nr + 1) * (nz + 1)
+        shard = ShardContext(nth * plane, group=group, align=plane)
+        local, sub_l, ft_l = annulus_part(nr, nth, nz, shard.ranges, shard.rank, group)
+        c_l = micca_sound_speed(local)
+        mine = dict(rows=int(local.part["n_own"]), ghosts=int(local.num_vertices - local.part["n_own"]),
+                    neighbours=int(len({(shard.rank - 1) % shard.world, (shard.rank + 1) % shard.world} - {shard.rank})),
+                    host_setup_s=round(time.perf_counter() - t0, 3))
+        try:
+            import resource
+            mine["host_rss_gib"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20, 2)
+        except Exception:
+            pass
+        per_rank = [None] * shard.world
+        dist.all_gather_object(per_rank, mine, group=group)
+        case["partition"] = dict(kind="theta-slabs of the generator's numbering, every rank generates its own slab", per_rank=per_rank)
+        local.assembler()
+        c_l.resident()
+        h_l = Q_multiple(local, sub_l, case["P"].N_sector).resident()
+        d = case["dist"] = dict(shard=shard, mesh=local, subdomains=sub_l, facet_tags=ft_l, c=c_l, h=h_l)
+        case["shard"] = shard
+        return d
     mesh = case["mesh"]
     x = mesh.geometry.x
     world = dist.get_world_size(group)

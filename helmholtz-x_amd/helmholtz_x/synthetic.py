@@ -100,6 +100,95 @@ def annulus(nr, ntheta, nz, r_in=0.14, r_out=0.21, z0=-0.09, z1=0.2, n_flames=16
     return mesh, subdomains, facet_tags
 
 
+def annulus_part(nr, ntheta, nz, ranges, rank, group=None, r_in=0.14, r_out=0.21, z0=-0.09, z1=0.2, n_flames=16, r_f=0.175,
+                 flame_radius=0.0175, flame_z=(0.0, 0.02)):
+    """This rank's part of the welded annulus WITHOUT the global mesh: exactly what
+    ``distributed.distribute_mesh(annulus(nr, ntheta, nz)[0], ranges, rank, subdomains, facet_tags)`` returns -- the cells touching
+    an owned vertex (ascending global cell id), vertices [owned | ghost] in ascending global id, the outlet facets with an owned
+    vertex, flame tags, ``mesh.part`` with the same maps -- generated from the grid formulas for the rank's theta-planes and the
+    one plane either side of them.  ``ranges``: the ranks' row ranges, cut between theta-planes (``distributed.partition_rows``
+    with align = (nr + 1)(nz + 1)).  The reference's counterpart: XDMFFile.read_mesh on N ranks hands every rank its cells and
+    one ghost layer (io_utils.py:149-155); the synthetic workload is analytic, so a rank needs no reader and no N-fold host copy.
+    Returns (local_mesh, local_subdomains, local_facet_tags)."""
+    from .distributed import DistComm
+    plane = (nr + 1) * (nz + 1)
+    r0, r1 = ranges[rank]
+    n_global = ntheta * plane
+    if r0 % plane or r1 % plane or not (0 <= r0 < r1 <= n_global):
+        raise ValueError("the row range of a rank must be cut between theta-planes (multiples of %d)" % plane)
+    p0, p1 = r0 // plane, r1 // plane
+    hex_planes = np.arange(p0 - 1, p1) % ntheta if p1 - p0 < ntheta else np.arange(ntheta)      # hexes with a vertex in [p0, p1)
+    hex_planes = np.unique(hex_planes)
+    it, ir, iz = np.meshgrid(hex_planes, np.arange(nr), np.arange(nz), indexing="ij")
+    it, ir, iz = it.ravel(), ir.ravel(), iz.ravel()
+    hex_id = (it * nr + ir) * nz + iz                          # global hex index, ascending (hex_planes ascending)
+
+    def nid(jt, jr, jz):
+        return ((jt % ntheta) * (nr + 1) + jr) * (nz + 1) + jz
+
+    v = np.empty((it.size, 2, 2, 2), dtype=np.int64)
+    for a in range(2):
+        for b in range(2):
+            for c in range(2):
+                v[:, a, b, c] = nid(it + a, ir + b, iz + c)
+    gcells = _kuhn_tets(v).astype(np.int64)                    # every tet of a hex holds its 000 and 111 corners: both planes
+    keep = (hex_id[:, None] * 6 + np.arange(6)[None, :]).ravel()
+    verts = np.unique(gcells)
+    owned = np.arange(r0, r1, dtype=np.int64)
+    ghost = verts[(verts < r0) | (verts >= r1)]
+    l2g = np.concatenate([owned, ghost])
+    order = np.argsort(l2g, kind="stable")
+    lcells = order[np.searchsorted(l2g[order], gcells.ravel())].reshape(gcells.shape)
+    # coordinates of the local vertices from the grid formulas (the same arithmetic as annulus(): bitwise the same numbers)
+    th = np.arange(ntheta) * (2 * np.pi / ntheta)
+    rr = np.linspace(r_in, r_out, nr + 1)
+    zz = np.linspace(z0, z1, nz + 1)
+    jt, rem = np.divmod(l2g, plane)
+    jr, jz = np.divmod(rem, nz + 1)
+    x = np.stack([rr[jr] * np.cos(th[jt]), rr[jr] * np.sin(th[jt]), zz[jz]], axis=-1)
+    # outlet facets of the kept hexes (both triangles of a top face hold vertices of both planes): global ids as in annulus()
+    n_top = ntheta * nr                                        # top hexes of the whole ring, in hex order
+    top = np.flatnonzero(iz == nz - 1)
+    top_rank = (it[top] * nr + ir[top])                        # position of the hex among the ring's top hexes
+    f1 = np.stack([v[top, 0, 0, 1], v[top, 1, 0, 1], v[top, 1, 1, 1]], axis=1)
+    f2 = np.stack([v[top, 0, 0, 1], v[top, 0, 1, 1], v[top, 1, 1, 1]], axis=1)
+    p201 = int(np.flatnonzero((_KUHN == (2, 0, 1)).all(axis=1))[0])
+    p210 = int(np.flatnonzero((_KUHN == (2, 1, 0)).all(axis=1))[0])
+    gf = np.sort(np.concatenate([f1, f2]), axis=1)
+    gf_id = np.concatenate([top_rank, n_top + top_rank])
+    gf_cell = np.concatenate([hex_id[top] * 6 + p201, hex_id[top] * 6 + p210])
+    fo = np.argsort(gf_id, kind="stable")
+    gf, gf_id, gf_cell = gf[fo], gf_id[fo], gf_cell[fo]
+    g2l = np.full(n_global, -1, dtype=np.int64) if n_global <= 4 * l2g.size else None
+    if g2l is not None:
+        g2l[l2g] = np.arange(l2g.size)
+        lf = np.sort(g2l[gf], axis=1)
+    else:
+        lf = np.sort(order[np.searchsorted(l2g[order], gf.ravel())].reshape(gf.shape), axis=1)
+    fcell = np.searchsorted(keep, gf_cell)
+    local = Mesh(x, lcells.astype(np.int32), facets=lf.astype(np.int32), facet_cells=fcell.astype(np.int32))
+    low = gcells.min(axis=1)
+    flow = gf.min(axis=1) if gf.size else np.zeros(0, np.int64)
+    local.part = dict(r0=r0, r1=r1, n_own=int(owned.size), n_global=n_global, local_to_global=l2g, cell_ids=keep,
+                      cell_owned=(low >= r0) & (low < r1), facet_ids=gf_id, ranges=list(ranges), rank=rank,
+                      n_cells_global=ntheta * nr * nz * 6, facet_owned=(flow >= r0) & (flow < r1))
+    local.comm = DistComm(group)
+    facet_tags = MeshTags(local, 2, np.arange(lf.shape[0]), np.full(lf.shape[0], 11))
+    cent = x[lcells].mean(axis=1)
+    tags = np.full(lcells.shape[0], -1, dtype=np.int32)
+    band = (cent[:, 2] >= flame_z[0]) & (cent[:, 2] <= flame_z[1])
+    idx = np.flatnonzero(band)
+    for f in range(n_flames):
+        ang = f * 2 * np.pi / 16
+        cx, cy = r_f * np.cos(ang), r_f * np.sin(ang)
+        hit = idx[(cent[idx, 0] - cx) ** 2 + (cent[idx, 1] - cy) ** 2 <= flame_radius ** 2]
+        tags[hit] = f
+    marked = np.flatnonzero(tags >= 0)
+    subdomains = MeshTags(local, 3, marked, tags[marked])
+    local._centroids = cent
+    return local, subdomains, facet_tags
+
+
 def micca_sound_speed(mesh, gamma=1.4, r=287.0, T_amb=300.0, T_a=1521.0, T_b=1200.0, l_cc=0.2):
     """DG0 axial sound-speed field of Micca/fullAnnulus/params.py:53-70 (cell-midpoint rule)."""
     c = Function(FunctionSpace(mesh, "DG", 0), "soundspeed")

@@ -1363,6 +1363,59 @@ def test_config4_annulus_5M_split_over_four_ranks_library_issued_exchanges():
                                            d0["stats"]["sharded_levels"], d0["eigs"][0]))
 
 
+def _generated_slab_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "helmholtz-x_amd"), os.path.join(root, "tests")]
+    os.environ["HX_QUIET"] = "1"
+    os.environ["HX_NATIVE_COMM"] = "1"
+    os.environ["HX_RCCL_LIB"] = os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import contextlib
+        import io
+        import bench
+        res = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            for how in ("cut from the global mesh", "generated"):
+                case = bench.build_case(bench.WORKLOADS["annulus-66k"], resident=False, slab_only=(how == "generated"))
+                assert (case["mesh"] is None) == (how == "generated")
+                hist = []
+                E, _ = bench.hot_path(case, st_type="amg", nev=4, tol=1e-3, history=hist, sharded=True)
+                res[how] = dict(hist=list(hist), eigs=[E.getEigenvalue(i) for i in range(2)], partition=case["partition"])
+                E.destroy()
+                case["shard"].destroy()
+                dist.barrier()
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_ranks_generate_their_own_slabs_three_ranks():
+    """`bench.py --gpus N` on the analytic annulus: every rank generates its theta-slab instead of building the
+    global mesh and cutting it.  Three ranks, 64,896 DOF: the fixed-point trajectory and the eigenvalues of the run on generated slabs
+    equal those of the run on parts cut from the global mesh BITWISE (same local meshes, test_host_logic: same arithmetic); the
+    partition record carries per-rank rows / ghosts / neighbours and the host set-up time."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "fake_rccl")])
+    world, port = 3, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_generated_slab_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for rank in range(world):
+        a, b = out[rank]["cut from the global mesh"], out[rank]["generated"]
+        assert a["hist"] == b["hist"] and a["eigs"] == b["eigs"], (a["hist"], b["hist"])
+        pa, pb = a["partition"]["per_rank"], b["partition"]["per_rank"]
+        assert [(q["rows"], q["ghosts"], q["neighbours"]) for q in pa] == [(q["rows"], q["ghosts"], q["neighbours"]) for q in pb]
+        assert all("host_setup_s" in q for q in pb) and "generates its own slab" in b["partition"]["kind"]
+    assert sum(q["rows"] for q in out[0]["generated"]["partition"]["per_rank"]) == 64896
+
+
 def _rcb_worker(rank, world, port, out, golden_dir):
     """RCB partition of the reference's real (unstructured) MICCA mesh over `world` ranks: distribute, exchange, check."""
     import sys

@@ -728,3 +728,36 @@ def test_direct_solver_analysis_structure_contains_the_fill(case, with_coords):
                 assert not np.any(P[j:, j] & ~allowed[j:]), (case, s, j)
     finally:
         hx.check(hx.lib.hx_splu_destroy(h))
+
+
+def test_every_rank_generates_its_own_slab_of_the_annulus():
+    """synthetic.annulus_part (what `bench.py --gpus N` uses on the analytic workload: no rank holds the global mesh) equals
+    distributed.distribute_mesh of the global mesh BIT FOR BIT -- coordinates, cells, facets, maps, flame tags, sound speed -- for
+    1, 2, 4 and 5 ranks; the owned ranges tile the vertex set and the owned cells tile the cell set."""
+    from helmholtz_x import synthetic
+    from helmholtz_x.distributed import distribute_mesh, partition_rows
+    shape = (3, 24, 4)
+    mesh, sub, ft = synthetic.annulus(*shape)
+    c = synthetic.micca_sound_speed(mesh)
+    plane = (shape[0] + 1) * (shape[2] + 1)
+    for world in (1, 2, 4, 5):
+        ranges = partition_rows(mesh.num_vertices, world, plane)
+        owned_cells = np.zeros(mesh.num_cells, dtype=int)
+        rows = 0
+        for rank in range(world):
+            a, sa, fa, (ca,) = distribute_mesh(mesh, ranges, rank, sub, ft, [c])
+            b, sb, fb = synthetic.annulus_part(*shape, ranges, rank)
+            cb = synthetic.micca_sound_speed(b)
+            assert np.array_equal(a.geometry.x, b.geometry.x) and np.array_equal(a.topology.cells, b.topology.cells)
+            assert np.array_equal(a.facets, b.facets) and np.array_equal(a.facet_cells, b.facet_cells)
+            assert sorted(a.part) == sorted(b.part)
+            for k in a.part:
+                assert np.array_equal(np.asarray(a.part[k]), np.asarray(b.part[k])), (k, world, rank)
+            assert np.array_equal(sa.indices, sb.indices) and np.array_equal(sa.values, sb.values)
+            assert np.array_equal(fa.indices, fb.indices) and np.array_equal(fa.values, fb.values)
+            assert np.array_equal(ca.x.array, cb.x.array)
+            owned_cells[b.part["cell_ids"][b.part["cell_owned"]]] += 1
+            rows += b.part["n_own"]
+        assert rows == mesh.num_vertices and np.all(owned_cells == 1)
+    with pytest.raises(ValueError):
+        synthetic.annulus_part(*shape, [(0, 7), (7, mesh.num_vertices)], 0)        # not cut between theta-planes

@@ -395,6 +395,8 @@ def distributed_case(case, group=None):
         plane = (nr + 1) * (nz + 1)
         shard = ShardContext(nth * plane, group=group, align=plane)
         local, sub_l, ft_l = annulus_part(nr, nth, nz, shard.ranges, shard.rank, group)
+        shard.set_ghosts(local.part["local_to_global"][local.part["n_own"]:])      # level-0 exchange plan = the mesh's ghost layer
+        local.shard = shard
         c_l = micca_sound_speed(local)
         mine = dict(rows=int(local.part["n_own"]), ghosts=int(local.num_vertices - local.part["n_own"]),
                     neighbours=int(len({(shard.rank - 1) % shard.world, (shard.rank + 1) % shard.world} - {shard.rank})),

@@ -1,21 +1,24 @@
 // Bare v_mfma_f64_16x16x4_f64 rate on the device: every wave issues the instruction back to back on 8 independent accumulators;
 // 4 waves per workgroup (one per SIMD), `wg_per_cu` workgroups per CU.  Prints TFLOP/s (2 * 16 * 16 * 4 flops per instruction).
-// build: hipcc -O3 --offload-arch=gfx950 mfma_f64_peak.hip -o bin/mfma_f64_peak
+// build: hipcc -O3 --offload-arch=gfx950 [-DNACC=16] mfma_f64_peak.hip -o bin/mfma_f64_peak
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 typedef double v4d __attribute__((ext_vector_type(4)));
+#ifndef NACC
+#define NACC 8          // independent accumulators per wave
+#endif
 
 __global__ void __launch_bounds__(256) k_mfma(double* out, int iters, double a0, double b0) {
-  v4d acc[8];
-  for (int i = 0; i < 8; ++i) acc[i] = (v4d){0, 0, 0, 0};
+  v4d acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0, 0, 0, 0};
   double a = a0 + threadIdx.x * 1e-3, b = b0 - threadIdx.x * 1e-3;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
   }
   double s = 0;
-  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -31,8 +34,8 @@ int main(int argc, char** argv) {
   k_mfma<<<grid, 256>>>(out, iters, 1.0, 2.0);
   hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  const double flops = (double)grid * 4 * iters * 8 * 2048.0;
-  printf("%d CUs x %d workgroup(s) of 4 waves: %.1f TFLOP/s f64 MFMA (%.3f ms); per CU and clock at 2.4 GHz: %.1f flop\n", p.multiProcessorCount,
-         wg_per_cu, flops / ms / 1e9, ms, flops / (ms * 1e-3) / p.multiProcessorCount / 2.4e9);
+  const double flops = (double)grid * 4 * iters * NACC * 2048.0;
+  printf("%d CUs x %d workgroup(s) of 4 waves, %d accumulators per wave: %.1f TFLOP/s f64 MFMA (%.3f ms); per CU and clock at 2.4 GHz: %.1f flop\n", p.multiProcessorCount,
+         wg_per_cu, NACC, flops / ms / 1e9, ms, flops / (ms * 1e-3) / p.multiProcessorCount / 2.4e9);
   return 0;
 }

@@ -69,6 +69,7 @@ class LUSolver:
     _ANALYSES = []
     _MAX_ANALYSES = 2
     REUSE = __import__("os").environ.get("HX_LU_REUSE_ANALYSIS", "1") != "0"
+    CACHE_MAX_BYTES = float(__import__("os").environ.get("HX_LU_CACHE_MAX_GIB", "8")) * 2 ** 30     # kept handles keep their factor storage
     REFINE_ABOVE = 1e-11          # a first solve with a larger relative residual switches iterative refinement on
 
     @classmethod
@@ -139,8 +140,12 @@ class LUSolver:
             self.refine = True
 
     def info(self):
+        return self.info_of(self.handle)
+
+    @staticmethod
+    def info_of(handle):
         io, do = (C.c_int64 * 16)(), (C.c_double * 8)()
-        _hx.check(_hx.lib.hx_splu_info(self.handle, io, do))
+        _hx.check(_hx.lib.hx_splu_info(handle, io, do))
         return list(io), list(do)
 
     def stats(self):
@@ -190,6 +195,10 @@ class LUSolver:
         if h is None:
             return
         if self.REUSE and not isinstance(self._key, tuple):
+            io, _ = self.info_of(h)
+            if 16 * (io[4] + io[5]) > self.CACHE_MAX_BYTES:        # a large factor does not stay allocated behind the caller's back
+                _hx.lib.hx_splu_destroy(h)
+                return
             K = self.K                                     # the next solver on this pattern re-factorises only
             self._ANALYSES.append((K.shape[0], K.nnz, K.rowptr, K.col, h))
             while len(self._ANALYSES) > self._MAX_ANALYSES:

@@ -4,7 +4,7 @@
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
-TAG="${1:-r05}"
+TAG="${1:-r06}"
 mkdir -p gpurun_out/final
 python bench.py --warmup 1 --steps 3 > gpurun_out/final/bench_5M.json 2> gpurun_out/final/bench_5M.err || exit 1
 python bench.py --workload annulus-1M --no-cpu-baseline --warmup 1 --steps 3 > gpurun_out/final/bench_1M.json 2> /dev/null || exit 1

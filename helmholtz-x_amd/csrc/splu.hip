@@ -51,6 +51,7 @@ struct SpluDev {
   const int64_t* loff; const int64_t* uoff; const int64_t* ioff; const int64_t* soff; const int64_t* woff; const int64_t* poff; const int64_t* voff;
   const int32_t* child_ptr; const int32_t* child_list;
   zc* F; zc* W; zc* T; zc* wk; zc* part; zc* V; int32_t* status;
+  int sym;          // this factorisation runs in symmetric mode (A = A^T): U panels are transposed copies of the unscaled L panels
 };
 
 struct Launch { int kind; int64_t list; int32_t nf; int32_t grid; int32_t p0; };
@@ -70,6 +71,10 @@ struct hx_splu {
   SpluDev dev{};
   int32_t tiny_pivots = 0;
   double factor_seconds = 0.0;
+  int32_t* d_mirror = nullptr;
+  double* d_symcheck = nullptr;
+  bool symmetric = false;
+  double flops_done = 0.0;
   hipGraphExec_t sweep_graph[2] = {nullptr, nullptr};   // the two sweeps of a solve (A x = b / A^T x = b), captured at the first solve
   bool graph_failed = false;
 };
@@ -120,11 +125,31 @@ __device__ __forceinline__ int find_front(const int32_t* __restrict__ prefix, in
 }
 
 // ------------------------------------------------------------------------------------------------- assembly of the fronts
-__global__ void __launch_bounds__(256) k_splu_scatter(int64_t nnz, const int64_t* __restrict__ amap, const zc* __restrict__ val,
-                                                      zc* __restrict__ F) {
+// max |a_ij - a_ji| and max |a_ij| over the upper entries of a matrix with a symmetric pattern (out[0], out[1]: doubles >= 0, so
+// their bit patterns order like integers)
+__global__ void __launch_bounds__(256) k_splu_symcheck(int64_t nnz, const int32_t* __restrict__ mirror, const zc* __restrict__ val,
+                                                       unsigned long long* __restrict__ out) {
+  double dmax = 0.0, vmax = 0.0;
   for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
     const zc v = val[k];
-    zc* d = F + amap[k];
+    vmax = fmax(vmax, fmax(fabs(v.x), fabs(v.y)));
+    const int32_t mk = mirror[k];
+    if (mk >= 0) { const zc u = val[mk]; dmax = fmax(dmax, fmax(fabs(v.x - u.x), fabs(v.y - u.y))); }
+  }
+  for (int o = 32; o > 0; o >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, o)); vmax = fmax(vmax, __shfl_xor(vmax, o)); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, (unsigned long long)__double_as_longlong(dmax));
+    atomicMax(out + 1, (unsigned long long)__double_as_longlong(vmax));
+  }
+}
+
+__global__ void __launch_bounds__(256) k_splu_scatter(int64_t nnz, const int64_t* __restrict__ amap, const zc* __restrict__ val,
+                                                      zc* __restrict__ F, int sym) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+    const zc v = val[k];
+    int64_t dest = amap[k];
+    if (dest < 0) { if (sym) continue; dest = -dest - 1; }       // an entry of a U panel: symmetric mode copies those from L
+    zc* d = F + dest;
     d->x += v.x; d->y += v.y;        // duplicates of a (row, col) pair do not occur in a CSR matrix: plain add
   }
 }
@@ -160,12 +185,14 @@ __global__ void __launch_bounds__(256) k_splu_extend(SpluDev d, const int32_t* _
   __shared__ int32_t rj[GT];
   if (threadIdx.x < GT) rj[threadIdx.x] = (tj * GT + (int)threadIdx.x < nrc) ? rel[tj * GT + threadIdx.x] : -1;
   __syncthreads();
+  if (d.sym && ti < tj) return;                   // symmetric mode: the lower triangle only (rel is increasing: i >= j <=> a >= b)
   const int i = ti * GT + (threadIdx.x & 63);
   if (i >= nrc) return;
   const int64_t a = rel[i];
   for (int jj = threadIdx.x >> 6; jj < GT; jj += 4) {
     const int64_t b = rj[jj];
     if (b < 0) break;
+    if (d.sym && b > a) continue;
     const zc v = Sc[i + (int64_t)(tj * GT + jj) * nrc];
     zc* dst;
     if (b < nsp && a >= b) dst = Lp + a + b * mp;
@@ -289,7 +316,8 @@ __global__ void __launch_bounds__(512) k_splu_diag(SpluDev d, const int32_t* __r
   for (int j = 0; j < 8; ++j) {
     const int b = q + 8 * j;
     zc v = make_double2(a == b ? 1.0 : 0.0, 0.0);
-    if (a < w && b < w) v = (a >= b) ? Lp[(c0 + a) + (int64_t)(c0 + b) * m] : Up[(c0 + a) + (int64_t)(c0 + b) * ns];
+    if (a < w && b < w) v = (a >= b) ? Lp[(c0 + a) + (int64_t)(c0 + b) * m]
+                                     : (d.sym ? Lp[(c0 + b) + (int64_t)(c0 + a) * m] : Up[(c0 + a) + (int64_t)(c0 + b) * ns]);
     r[j] = v;
     if (a < w && b < w) amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
   }
@@ -329,7 +357,8 @@ __global__ void __launch_bounds__(512) k_splu_diag(SpluDev d, const int32_t* __r
 // operand chunk is in LDS / registers before the first store).  One 64 x 64 tile per workgroup.
 // MFMA mapping: D[row][col] of v_mfma_f64_16x16x4_f64 has col = lane & 15, so the tile's ROW index i (contiguous in memory)
 // rides on lane & 15: the "a" operand is the B-matrix fragment (k, j), the "b" operand the A-matrix fragment (i, k).
-struct GemmProb { const zc* A; const zc* B; zc* C; int64_t lda, ldb, ldc; int M, N, K, K0 = 0; };   // k runs over [K0, K)
+struct GemmProb { const zc* A; const zc* B; zc* C; int64_t lda, ldb, ldc; int M, N, K, K0 = 0;    // k runs over [K0, K)
+                  zc* T = nullptr; int64_t ldt = 0; };       // T != null: the A tile is also written TRANSPOSED, T[k + i ldt] = A[i, k]
 enum { G_SUB = 0, G_ASSIGN = 1, G_NEG = 2 };     // C -= A B, C = A B, C = -A B
 
 template <int MODE>
@@ -366,6 +395,13 @@ __device__ __forceinline__ void gemm_tile(const GemmProb& p, int ti, int tj, zc*
 #pragma unroll
     for (int q = 0; q < 4; ++q) { sA[(lk + 4 * q) * GLD + lr] = ra[q]; sB[bk * GLD + bj + 16 * q] = rb[q]; }
     __syncthreads();
+    if (p.T) {                                      // transposed copy of this chunk of A (16 consecutive k per 16 lanes: 256-byte runs)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = bj + 16 * q;
+        if (row0 + i < p.M && k0 + bk < p.K) p.T[(k0 + bk) + (int64_t)(row0 + i) * p.ldt] = sA[bk * GLD + i];
+      }
+    }
     if (k0 + GK < p.K) load(k0 + GK);
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 4) {
@@ -434,6 +470,7 @@ __global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __r
     p.A = Lp + c1 + (int64_t)c0 * m; p.lda = m; p.C = (zc*)p.A; p.ldc = m;
     p.B = d.W + d.ioff[s] + (int64_t)p0 * NB * NB; p.ldb = NB;
     p.M = (int)m - c1; p.N = p.K = c1 - c0;
+    if (d.sym) { p.T = Up + c0 + (int64_t)c1 * ns; p.ldt = ns; }       // U[c0:c1, c1:m] = (unscaled L[c1:m, c0:c1])^T
     gemm_tile<G_ASSIGN>(p, t, 0, lds);
   } else if (KIND == K_INNER || KIND == K_LEFT) {
     int r0, k0, k1, cj1;
@@ -442,6 +479,7 @@ __global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __r
     const int tall = cdiv((int)m - r0, GT), wide = cdiv(cj1 - r0, GT);
     const int per = trap_tiles(tall, wide);
     const int side = t / per; t -= side * per;
+    if (side == 1 && d.sym) return;               // symmetric mode: the U panels are copies, nothing to update
     int tl, ts;                                   // tile along the long / the short (outer block) direction, tl >= ts
     trap_decode(t, tall, wide, tl, ts);
     p.K = k1 - k0;
@@ -458,6 +496,7 @@ __global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __r
   } else if (KIND == K_SUPD) {   // K_SUPD: S -= Lp[ns:m, 0:ns] Up[0:ns, ns:m]
     const int tm = cdiv(nr, GT);
     ti = t % tm; tj = t / tm;
+    if (d.sym && ti < tj) return;                 // symmetric mode: F22 is symmetric, its lower triangle is all the parent reads
     p.A = Lp + ns; p.lda = m; p.B = Up + (int64_t)ns * ns; p.ldb = ns; p.C = d.T + d.soff[s]; p.ldc = nr; p.M = p.N = nr; p.K = ns;
     gemm_tile<G_SUB>(p, ti, tj, lds);
   } else {
@@ -1067,10 +1106,10 @@ static hipError_t upload(T** dst, const std::vector<T>& v) {
 
 static void splu_release(hx_splu* h) {
   for (int t = 0; t < 2; ++t) if (h->sweep_graph[t]) { (void)hipGraphExecDestroy(h->sweep_graph[t]); h->sweep_graph[t] = nullptr; }
-  void* blocks[] = {h->d_i32, h->d_i64, h->d_lists, h->d_amap, h->d_perm, h->d_status, h->F, h->W, h->T, h->wk, h->part, h->pb, h->xp, h->V};
+  void* blocks[] = {h->d_i32, h->d_i64, h->d_lists, h->d_amap, h->d_perm, h->d_status, h->F, h->W, h->T, h->wk, h->part, h->pb, h->xp, h->V, h->d_mirror, h->d_symcheck};
   for (void* b : blocks) (void)hx_free(b);
   h->d_i32 = h->d_lists = h->d_perm = h->d_status = nullptr; h->d_i64 = h->d_amap = nullptr;
-  h->F = h->W = h->T = h->wk = h->part = h->pb = h->xp = h->V = nullptr;
+  h->F = h->W = h->T = h->wk = h->part = h->pb = h->xp = h->V = nullptr; h->d_mirror = nullptr; h->d_symcheck = nullptr;
 }
 
 extern "C" int hx_splu_analyse(hx_splu** out, int32_t n, const int32_t* h_rowptr, const int32_t* h_col,
@@ -1104,6 +1143,8 @@ static int splu_prepare_device(hx_splu* h) {
   HX_HIP(upload(&h->d_lists, lists));
   HX_HIP(upload(&h->d_amap, S.amap));
   HX_HIP(upload(&h->d_perm, S.perm));
+  if (!S.mirror.empty()) HX_HIP(upload(&h->d_mirror, S.mirror));
+  HX_HIP(hx_malloc(&h->d_symcheck, 2 * sizeof(double)));
   HX_HIP(hx_malloc(&h->d_status, 4 * sizeof(int32_t)));
   HX_HIP(hx_malloc(&h->F, std::max<int64_t>(S.factor_elems, 1) * sizeof(zc)));
   HX_HIP(hx_malloc(&h->W, std::max<int64_t>(S.inverse_elems, 1) * sizeof(zc)));
@@ -1130,11 +1171,32 @@ extern "C" int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream stream) 
   hipEvent_t e0, e1;
   HX_HIP(hipEventCreate(&e0)); HX_HIP(hipEventCreate(&e1));
   HX_HIP(hipEventRecord(e0, st));
+  // symmetric mode (A = A^T, checked on the values: complex symmetric Helmholtz operators): the U side of the factorisation is
+  // not computed but copied -- half the in-panel products, half of F22, half the extend-add (option splu_symmetric=0: never)
+  h->symmetric = false;
+  if (h->d_mirror && HX_OPT_INT("splu_symmetric", 1) != 0) {
+    HX_HIP(hipMemsetAsync(h->d_symcheck, 0, 2 * sizeof(double), st));
+    k_splu_symcheck<<<hx_grid(h->nnz_in, 256), 256, 0, st>>>(h->nnz_in, h->d_mirror, (const zc*)val, (unsigned long long*)h->d_symcheck);
+    HX_LAUNCH_CHECK("k_splu_symcheck");
+    double chk[2] = {0.0, 0.0};
+    HX_HIP(hipMemcpyAsync(chk, h->d_symcheck, sizeof(chk), hipMemcpyDeviceToHost, st));
+    HX_HIP(hipStreamSynchronize(st));
+    h->symmetric = chk[0] <= 1e-13 * chk[1];
+  }
+  h->dev.sym = h->symmetric ? 1 : 0;
+  {
+    double done = 0.0;
+    for (int32_t q = 0; q < S.nsuper; ++q) {
+      const double ns = S.sfirst[q + 1] - S.sfirst[q], nr = (double)(S.sptr[q + 1] - S.sptr[q]);
+      done += h->symmetric ? 8.0 * (ns * ns * ns / 6.0 + nr * ns * ns / 2.0 + nr * nr * ns / 2.0) : 8.0 * (ns * ns * ns / 3.0 + nr * ns * ns + nr * nr * ns);
+    }
+    h->flops_done = done + h->inv_flops;
+  }
   HX_HIP(hx_malloc(&h->T, std::max<int64_t>(S.temp_elems, 1) * sizeof(zc)));
   h->dev.T = h->T;
   HX_HIP(hipMemsetAsync(h->F, 0, S.factor_elems * sizeof(zc), st));
   HX_HIP(hipMemsetAsync(h->d_status, 0, 4 * sizeof(int32_t), st));
-  k_splu_scatter<<<hx_grid(h->nnz_in, 256), 256, 0, st>>>(h->nnz_in, h->d_amap, (const zc*)val, h->F);
+  k_splu_scatter<<<hx_grid(h->nnz_in, 256), 256, 0, st>>>(h->nnz_in, h->d_amap, (const zc*)val, h->F, h->dev.sym);
   HX_LAUNCH_CHECK("k_splu_scatter");
   const size_t gemm_lds = 2 * 2 * GK * GLD * sizeof(zc);
   static bool attr_done = false;
@@ -1264,6 +1326,7 @@ extern "C" int hx_splu_info(const hx_splu* h, int64_t* iout, double* dout) {
   iout[10] = (int64_t)S.srow.size(); iout[11] = h->nnz_in; iout[12] = h->tiny_pivots;
   iout[13] = (int64_t)h->fplan.size(); iout[14] = (int64_t)h->fwd_plan[0].size(); iout[15] = (int64_t)h->bwd_plan[0].size();
   dout[0] = S.flops; dout[1] = S.analyse_seconds; dout[2] = h->factor_seconds; dout[3] = h->inv_flops;
+  dout[4] = h->flops_done; dout[5] = h->symmetric ? 1.0 : 0.0;
   iout[5] = S.inverse_elems + h->inv_elems;
   return HX_OK;
 }

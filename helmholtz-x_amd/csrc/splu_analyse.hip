@@ -487,7 +487,9 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
   lap("storage plan");
   // ---- destination of every stored entry of the input
   S.amap.assign((size_t)rowptr[n], -1);
-  std::atomic<int> bad{0};
+  S.mirror.clear();
+  if (flags & 1) S.mirror.assign((size_t)rowptr[n], -1);
+  std::atomic<int> bad{0}, nomirror{0};
   auto map_rows = [&](int32_t i0, int32_t i1) {
   for (int32_t i = i0; i < i1; ++i) {
     const int32_t pi = S.iperm[i];
@@ -507,7 +509,14 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
         a = ns + (p - b);
       }
       S.amap[k] = lower ? S.loff[s] + a + (int64_t)(piv - S.sfirst[s]) * m          // Lp[a, pivot]: m x ns, ld m
-                        : S.uoff[s] + (int64_t)(piv - S.sfirst[s]) + a * ns;        // Up[pivot, a]: ns x m, ld ns
+                        : -(S.uoff[s] + (int64_t)(piv - S.sfirst[s]) + a * ns) - 1;  // Up[pivot, a]: ns x m, ld ns; stored as -(dest + 1)
+      if ((flags & 1) && !lower) {                 // position of the mirrored entry (col[k], i): values are compared on the device
+        const int32_t j = col[k];
+        const int32_t* b = col + rowptr[j];
+        const int32_t* e = col + rowptr[j + 1];
+        const int32_t* p = std::lower_bound(b, e, i);
+        if (p == e || *p != i) nomirror = 1; else S.mirror[k] = (int32_t)(rowptr[j] + (p - b));
+      }
     }
   }
   };
@@ -519,6 +528,7 @@ int splu_analyse_host(SpluSymbolic& S, int32_t n, const int32_t* rowptr, const i
     for (auto& th : pool) th.join();
   }
   if (bad) return hx_fail(HX_ERR_ARG, "hx_splu_analyse", "internal: entry outside its front");
+  if (nomirror) S.mirror.clear();                  // (the pattern was not its own transpose after all: no symmetric mode)
   lap("entry map");
   S.analyse_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return HX_OK;

@@ -36,7 +36,9 @@ struct SpluSymbolic {
   double flops = 0.0;                        // real flops of the numeric factorisation (complex multiply-add = 8)
   int32_t max_front = 0, max_ns = 0;
   double analyse_seconds = 0.0;
-  std::vector<int64_t> amap;                 // per stored entry of the input CSR: destination in the factor arena
+  std::vector<int64_t> amap;                 // per stored entry of the input CSR: destination in the factor arena (>= 0: in an L panel;
+                                             // < 0: -(destination + 1) in a U panel)
+  std::vector<int32_t> mirror;               // symmetric pattern: per UPPER entry (i, j) the position of (j, i); empty otherwise
 };
 
 // splu_analyse.hip (host only)

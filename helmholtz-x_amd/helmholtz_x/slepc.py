@@ -151,7 +151,8 @@ class LUSolver:
     def stats(self):
         io, do = self.info()
         return dict(setup_s=round(self.setup_s, 4), analyse_s=round(self.analyse_s, 4), factor_s=round(self.factor_s, 4),
-                    factor_device_s=round(do[2], 5), factor_tflops=round(do[0] / max(do[2], 1e-12) / 1e12, 2),
+                    factor_device_s=round(do[2], 5), factor_tflops=round(do[4] / max(do[2], 1e-12) / 1e12, 2), symmetric_mode=bool(do[5]),
+                    factor_tflops_nominal=round(do[0] / max(do[2], 1e-12) / 1e12, 2),
                     ordering=self.ordering, solves=self.n_solves, fill=round(2.0 * io[3] / max(io[11], 1), 1), nnz_L=io[3],
                     supernodes=io[1], levels=io[2], largest_front=io[8], replaced_pivots=io[12],
                     factor_gib=round((io[4] + io[5]) * 16 / 2 ** 30, 3), launches_factor_fwd_bwd=io[13:16],

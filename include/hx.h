@@ -337,14 +337,17 @@ int hx_splu_analyse(hx_splu** out, int32_t n, const int32_t* h_rowptr, const int
                     int dim, int leaf_size, int flags);
 /* iout[16]: n, supernodes, levels, nnz(L) (= nnz(U), diagonal included), factor / inverse / temporary / workspace elements,
  * largest front, widest supernode, border rows, nnz of the input, replaced pivots of the last factorisation, launches of
- * the factorisation / forward / backward sweeps;  dout[8]: real flops of the factorisation, seconds of the analysis (host),
- * seconds of the last numeric factorisation (HIP events). */
+ * the factorisation / forward / backward sweeps;  dout[8]: real flops of the (unsymmetric) factorisation, seconds of the analysis
+ * (host), seconds of the last numeric factorisation (HIP events), flops of the selective inversion, flops the last
+ * factorisation actually executed, 1.0 when it ran in symmetric mode. */
 int hx_splu_info(const hx_splu* h, int64_t* iout, double* dout);
 /* the symbolic structure by field name (tests, diagnostics): perm, iperm, sfirst, sparent, sptr, srow, rel, slevel, level_ptr,
  * level_list, child_ptr, child_list, loff, uoff, ioff, soff, woff, amap.  h_out NULL: only *count.  HOST buffers. */
 int hx_splu_symbolic(const hx_splu* h, const char* name, void* h_out, int64_t capacity_bytes, int64_t* count);
 /* numeric factorisation of the values `val` (device, in the CSR order of the analysed pattern).  May be repeated with new
- * values.  SYNC (reads back the pivot counter). */
+ * values.  A matrix with a symmetric pattern (flags bit 0 of the analysis) whose VALUES are symmetric too (checked on the device,
+ * 1e-13 relative: the complex symmetric K = A + sigma B + sigma^2 C) is factorised in symmetric mode: the U panels are transposed
+ * copies of the unscaled L panels, half the products (option splu_symmetric=0: never).  SYNC (reads back the pivot counter). */
 int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream s);
 /* x = A^-1 b (transposed != 0: A^-T b); b, x device vectors of length n, may alias. */
 int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int transposed, hx_stream s);

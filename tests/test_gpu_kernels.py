@@ -260,12 +260,13 @@ def _micca_K(golden_dir, level):
     return K, x
 
 
-@pytest.mark.parametrize("level,with_coords", [(0, True), (0, False), (1, True)])
-def test_device_sparse_lu_on_the_real_micca_operator(hx, golden_dir, level, with_coords):
+@pytest.mark.parametrize("level,with_coords,flags", [(0, True, 1), (0, True, 0), (0, False, 1), (1, True, 1)])
+def test_device_sparse_lu_on_the_real_micca_operator(hx, golden_dir, level, with_coords, flags):
     """hx_splu_* on the shifted operator of the reference's flagship case: 34,787 DOF against SciPy's SuperLU (solution and
     transposed solution to 1e-10, both orderings), 249,497 DOF (one uniform refinement; SuperLU would need minutes and tens of
     GB there) against a manufactured solution b = K x and its residual.  No refinement step is allowed to hide anything: the
-    raw solves of the C-ABI are compared."""
+    raw solves of the C-ABI are compared.  flags = 1 (the pattern is symmetric; what LUSolver passes for Galerkin operators): the
+    values are found symmetric on the device and the factorisation runs in symmetric mode; flags = 0: the general algorithm."""
     import torch
     K, xyz = _micca_K(golden_dir, level)
     n = K.shape[0]
@@ -277,7 +278,7 @@ def test_device_sparse_lu_on_the_real_micca_operator(hx, golden_dir, level, with
     xy = np.ascontiguousarray(xyz, np.float64)
     h = C.c_void_p()
     hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), hx.nptr(xy) if with_coords else None,
-                                    3 if with_coords else 0, 0, 0))
+                                    3 if with_coords else 0, 0, flags))
     val, bd = _dev(np.ascontiguousarray(K.data)), _dev(b)
     xd = torch.empty_like(bd)
     io, do = (C.c_int64 * 16)(), (C.c_double * 8)()
@@ -285,12 +286,14 @@ def test_device_sparse_lu_on_the_real_micca_operator(hx, golden_dir, level, with
         hx.check(hx.lib.hx_splu_factor(h, hx.ptr(val), hx.stream()))
         hx.check(hx.lib.hx_splu_info(h, io, do))
         assert io[12] == 0                              # no pivot had to be replaced
+        assert bool(do[5]) == bool(flags)               # symmetric mode exactly when the caller vouched for the pattern
         hx.check(hx.lib.hx_splu_solve(h, hx.ptr(bd), hx.ptr(xd), 0, hx.stream()))
         x = xd.cpu().numpy()
         assert np.linalg.norm(K @ x - b) <= 1e-12 * np.linalg.norm(b)
         assert np.max(np.abs(x - x_true)) <= 1e-10 * np.max(np.abs(x_true))
-    print("device LU n = %d (%s): nnz(L) %.3e, fill %.1f, %.2e flops, factorisation %.1f ms = %.1f TFLOP/s"
-          % (n, "inertial" if with_coords else "level-set", io[3], 2 * io[3] / K.nnz, do[0], do[2] * 1e3, do[0] / do[2] / 1e12))
+    print("device LU n = %d (%s, %s mode): nnz(L) %.3e, fill %.1f, %.2e flops executed, factorisation %.1f ms = %.1f TFLOP/s"
+          % (n, "inertial" if with_coords else "level-set", "symmetric" if do[5] else "general", io[3], 2 * io[3] / K.nnz, do[4],
+             do[2] * 1e3, do[4] / do[2] / 1e12))
     bt = K.T @ x_true
     btd = _dev(bt)
     hx.check(hx.lib.hx_splu_solve(h, hx.ptr(btd), hx.ptr(btd), 1, hx.stream()))        # transposed, in place
@@ -309,7 +312,7 @@ def test_device_sparse_lu_on_the_real_micca_operator(hx, golden_dir, level, with
 
 
 @pytest.mark.parametrize("case", ["n1", "n2_swap", "diag", "n64", "n65", "n129_dense", "random_unsym", "two_components",
-                                  "unsymmetric_pattern"])
+                                  "unsymmetric_pattern", "complex_symmetric", "symmetric_pattern_only"])
 def test_device_sparse_lu_edge_cases(hx, case):
     """Sizes around the 64-column pivot block, a dense matrix (one supernode, several pivot blocks, left-looking updates), values
     without symmetry, a pattern without symmetry, disconnected graphs, a pivot that only exists after a row exchange inside the
@@ -334,6 +337,14 @@ def test_device_sparse_lu_edge_cases(hx, case):
         P = ((P + P.T) != 0).astype(np.float64)
         K = sp.csr_matrix(P.multiply(sp.csr_matrix(_rand_c(rng, n, 1)) @ sp.csr_matrix(np.ones((1, n)))) + sp.diags(4.0 + _rand_c(rng, n)))
         K.data = K.data * (1.0 + 0.3 * rng.standard_normal(K.nnz))          # values without any symmetry
+    elif case in ("complex_symmetric", "symmetric_pattern_only"):
+        n = 2500                                     # flags = 1 below: symmetric mode / its refusal when only the PATTERN is symmetric
+        P = sp.random(n, n, density=0.002, random_state=rng, format="csr")
+        P = sp.triu(P, 1)
+        Pc = P + 1j * sp.triu(sp.random(n, n, density=0.002, random_state=rng, format="csr"), 1).multiply(P != 0)
+        K = sp.csr_matrix(Pc + Pc.T + sp.diags(4.0 + _rand_c(rng, n)))
+        if case == "symmetric_pattern_only":
+            K.data = K.data * (1.0 + 0.2 * rng.standard_normal(K.nnz))
     elif case == "two_components":
         A = sp.random(500, 500, density=0.01, random_state=rng) + sp.eye(500) * 3
         K = sp.csr_matrix(sp.block_diag([A, 2j * A.T + sp.eye(500)]))
@@ -345,9 +356,13 @@ def test_device_sparse_lu_edge_cases(hx, case):
     n = K.shape[0]
     rp, ci = K.indptr.astype(np.int32), K.indices.astype(np.int32)
     h = C.c_void_p()
-    hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), None, 0, 0, 0))
+    sym_flag = 1 if case in ("complex_symmetric", "symmetric_pattern_only", "diag") else 0
+    hx.check(hx.lib.hx_splu_analyse(C.byref(h), n, hx.nptr(rp), hx.nptr(ci), None, 0, 0, sym_flag))
     val = _dev(np.ascontiguousarray(K.data))
     hx.check(hx.lib.hx_splu_factor(h, hx.ptr(val), hx.stream()))
+    io, do = (C.c_int64 * 16)(), (C.c_double * 8)()
+    hx.check(hx.lib.hx_splu_info(h, io, do))
+    assert bool(do[5]) == (case in ("complex_symmetric", "diag")), (case, do[5])
     b = _rand_c(rng, n)
     bd = _dev(b)
     xd = torch.empty_like(bd)

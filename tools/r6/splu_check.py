@@ -67,9 +67,9 @@ def main():
                 torch.cuda.synchronize()
                 tf = time.perf_counter() - t0
                 _hx.check(_hx.lib.hx_splu_info(h, io, do))
-                print("level %d n %d %s: analyse %.3f s, factor wall %.4f s (events %.4f s) = %.2f TFLOP/s, nnz(L) %.3e, fronts %d, levels %d, "
+                print("level %d n %d %s: analyse %.3f s, factor wall %.4f s (events %.4f s) = %.2f TFLOP/s executed (%s mode), nnz(L) %.3e, fronts %d, levels %d, "
                       "launches f/fw/bw %d/%d/%d, tiny pivots %d, factor %.2f GB temp %.2f GB"
-                      % (lvl, n, "coords" if coords is not None else "graph", ta, tf, do[2], do[0] / max(do[2], 1e-9) / 1e12, io[3], io[1], io[2],
+                      % (lvl, n, "coords" if coords is not None else "graph", ta, tf, do[2], do[4] / max(do[2], 1e-9) / 1e12, "symmetric" if do[5] else "general", io[3], io[1], io[2],
                          io[13], io[14], io[15], io[12], io[4] * 16 / 1e9, io[6] * 16 / 1e9), flush=True)
             rng = np.random.default_rng(0)
             b = rng.standard_normal(n) + 1j * rng.standard_normal(n)

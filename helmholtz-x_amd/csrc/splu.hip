@@ -54,7 +54,7 @@ struct SpluDev {
   int sym;          // this factorisation runs in symmetric mode (A = A^T): U panels are transposed copies of the unscaled L panels
 };
 
-struct Launch { int kind; int64_t list; int32_t nf; int32_t grid; int32_t p0; };
+struct Launch { int kind; int64_t list; int32_t nf; int32_t grid; int32_t p0; int64_t list_sym = -1; int32_t grid_sym = 0; };   // list_sym: prefix of the symmetric-mode tiling
 
 struct hx_splu {
   SpluSymbolic sym;
@@ -124,6 +124,17 @@ __device__ __forceinline__ int find_front(const int32_t* __restrict__ prefix, in
   return lo;
 }
 
+// trapezoid decode: t-th tile (ti >= tj) of a tm x tn tile grid, column by column
+__device__ __forceinline__ void trap_decode(int t, int tm, int tn, int& ti, int& tj) {
+  tj = 0;
+  for (; tj < tn; ++tj) {
+    const int c = tm > tj ? tm - tj : 0;
+    if (t < c) break;
+    t -= c;
+  }
+  ti = tj + t;
+}
+
 // ------------------------------------------------------------------------------------------------- assembly of the fronts
 // max |a_ij - a_ji| and max |a_ij| over the upper entries of a matrix with a symmetric pattern (out[0], out[1]: doubles >= 0, so
 // their bit patterns order like integers)
@@ -173,7 +184,9 @@ __global__ void __launch_bounds__(256) k_splu_extend(SpluDev d, const int32_t* _
   const int t = blockIdx.x - prefix[f];
   const int nrc = (int)(d.sptr[c + 1] - d.sptr[c]);
   const int tm = cdiv(nrc, GT);
-  const int ti = t % tm, tj = t / tm;
+  int ti, tj;
+  if (d.sym) trap_decode(t, tm, tm, ti, tj);      // symmetric mode: the launch holds the lower triangle of tiles only
+  else { ti = t % tm; tj = t / tm; }
   const int p = d.sparent[c];
   const int nsp = d.sfirst[p + 1] - d.sfirst[p];
   const int64_t nrp = d.sptr[p + 1] - d.sptr[p], mp = nsp + nrp;
@@ -185,7 +198,6 @@ __global__ void __launch_bounds__(256) k_splu_extend(SpluDev d, const int32_t* _
   __shared__ int32_t rj[GT];
   if (threadIdx.x < GT) rj[threadIdx.x] = (tj * GT + (int)threadIdx.x < nrc) ? rel[tj * GT + threadIdx.x] : -1;
   __syncthreads();
-  if (d.sym && ti < tj) return;                   // symmetric mode: the lower triangle only (rel is increasing: i >= j <=> a >= b)
   const int i = ti * GT + (threadIdx.x & 63);
   if (i >= nrc) return;
   const int64_t a = rel[i];
@@ -441,17 +453,6 @@ __device__ __forceinline__ void gemm_tile(const GemmProb& p, int ti, int tj, zc*
       }
 }
 
-// trapezoid decode: t-th tile (ti >= tj) of a tm x tn tile grid, column by column
-__device__ __forceinline__ void trap_decode(int t, int tm, int tn, int& ti, int& tj) {
-  tj = 0;
-  for (; tj < tn; ++tj) {
-    const int c = tm > tj ? tm - tj : 0;
-    if (t < c) break;
-    t -= c;
-  }
-  ti = tj + t;
-}
-
 template <int KIND>
 __global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __restrict__ fronts, const int32_t* __restrict__ prefix, int nf, int p0) {
   extern __shared__ zc lds[];
@@ -495,8 +496,8 @@ __global__ void __launch_bounds__(256) k_splu_gemm(SpluDev d, const int32_t* __r
     gemm_tile<G_SUB>(p, ti, tj, lds);
   } else if (KIND == K_SUPD) {   // K_SUPD: S -= Lp[ns:m, 0:ns] Up[0:ns, ns:m]
     const int tm = cdiv(nr, GT);
-    ti = t % tm; tj = t / tm;
-    if (d.sym && ti < tj) return;                 // symmetric mode: F22 is symmetric, its lower triangle is all the parent reads
+    if (d.sym) trap_decode(t, tm, tm, ti, tj);    // symmetric mode: F22 is symmetric, its lower triangle is all the parent reads
+    else { ti = t % tm; tj = t / tm; }
     p.A = Lp + ns; p.lda = m; p.B = Up + (int64_t)ns * ns; p.ldb = ns; p.C = d.T + d.soff[s]; p.ldc = nr; p.M = p.N = nr; p.K = ns;
     gemm_tile<G_SUB>(p, ti, tj, lds);
   } else {
@@ -967,6 +968,17 @@ static void add_launch(std::vector<Launch>& plan, std::vector<int32_t>& lists, i
       lists.push_back(acc);
     }
     L.grid = acc;
+    if (kind == K_SUPD || kind == K_EXTEND) {       // symmetric mode: the lower triangle of tiles only
+      L.list_sym = (int64_t)lists.size();
+      int32_t a2 = 0;
+      lists.push_back(0);
+      for (int32_t s : fronts) {
+        const int tm = cdiv((int)(S.sptr[s + 1] - S.sptr[s]), GT);
+        a2 += tm * (tm + 1) / 2;
+        lists.push_back(a2);
+      }
+      L.grid_sym = a2;
+    }
   } else {
     L.grid = L.nf;
   }
@@ -1212,15 +1224,17 @@ extern "C" int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream stream) 
   }
   for (const Launch& L : h->fplan) {
     const int32_t* fr = h->d_lists + L.list;
-    const int32_t* px = fr + L.nf;
+    const bool alt = h->symmetric && L.list_sym >= 0;
+    const int32_t* px = alt ? h->d_lists + L.list_sym : fr + L.nf;
+    const int32_t grid = alt ? L.grid_sym : L.grid;
     switch (L.kind) {
       case K_ZERO: k_splu_zero<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf); break;
-      case K_EXTEND: k_splu_extend<<<L.grid, 256, 0, st>>>(h->dev, fr, px, L.nf); break;
+      case K_EXTEND: k_splu_extend<<<grid, 256, 0, st>>>(h->dev, fr, px, L.nf); break;
       case K_DIAG: k_splu_diag<<<L.grid, 512, 0, st>>>(h->dev, fr, L.p0); break;
       case K_PANEL: k_splu_gemm<K_PANEL><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
       case K_INNER: k_splu_gemm<K_INNER><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
       case K_LEFT: k_splu_gemm<K_LEFT><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
-      case K_SUPD: k_splu_gemm<K_SUPD><<<L.grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
+      case K_SUPD: k_splu_gemm<K_SUPD><<<grid, 256, gemm_lds, st>>>(h->dev, fr, px, L.nf, L.p0); break;
       default: break;
     }
     HX_LAUNCH_CHECK("hx_splu_factor");

@@ -1,5 +1,5 @@
 """Device sparse LU (hx_splu_*) on K = A + sigma B + sigma^2 C of the reference's MICCA mesh (refined `level` times):
-residuals, agreement with SciPy's SuperLU, factorisation / solve times.  usage: splu_check.py [max_level] [--only level] [--graph] [--no-scipy]"""
+residuals, agreement with SciPy's SuperLU, factorisation / solve times.  usage: splu_check.py [max_level] [--only level] [--graph] [--general] [--no-scipy]  (--general: no symmetric mode)"""
 import ctypes as C
 import os
 import sys
@@ -56,7 +56,7 @@ def main():
             h = C.c_void_p()
             t0 = time.perf_counter()
             _hx.check(_hx.lib.hx_splu_analyse(C.byref(h), n, _hx.nptr(rp), _hx.nptr(ci), None if coords is None else _hx.nptr(coords),
-                                               0 if coords is None else 3, 0, 0))
+                                               0 if coords is None else 3, 0, 0 if "--general" in sys.argv else 1))
             ta = time.perf_counter() - t0
             val = to_device(np.ascontiguousarray(K.data, np.complex128))
             io, do = (C.c_int64 * 16)(), (C.c_double * 8)()

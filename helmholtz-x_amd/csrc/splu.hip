@@ -37,7 +37,7 @@
 #define FWD_ROWS 64             // rows per workgroup of the large-front forward update
 #define BWD_COLS 256            // columns per workgroup of the large-front backward partial products
 #define SOLVE_ROWS 512          // rows per workgroup of the column-dot kernels (transposed solves)
-#define GV_K 256                // columns per workgroup of the large-front matrix-vector products (64 rows x GV_K columns)
+#define GV_K 64                // columns per workgroup of the large-front matrix-vector products (64 rows x GV_K columns)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 

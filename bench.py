@@ -240,9 +240,12 @@ def spmv_roofline(K, reps=50, in_situ=None, pmc=None):
     idx_bytes = _hx.lib.hx_sell_index_bits(sell) // 8
     stencil_entries = _hx.lib.hx_sell_stencil_entries(sell)
     stencil_slices = _hx.lib.hx_sell_stencil_slices(sell)
+    tail, split = C.c_int64(0), C.c_int32(0)
+    _hx.check(_hx.lib.hx_sell_tail_info(sell, C.byref(tail), C.byref(split)))
     _hx.lib.hx_sell_destroy(sell)
     alg_bytes = nnz * 20 + n * 36
-    fmt_bytes = padded.value * 16 + (padded.value - stencil_entries) * idx_bytes + n * 32
+    # (overflow tails: value + 32-bit column per entry, 2 bytes per row of a split slice)
+    fmt_bytes = padded.value * 16 + (padded.value - stencil_entries) * idx_bytes + n * 32 + tail.value * 20 + split.value * 128
     loop_ms = ms
     if in_situ is not None and in_situ[0] > 0:
         ms = in_situ[1] / in_situ[0]
@@ -261,8 +264,9 @@ def spmv_roofline(K, reps=50, in_situ=None, pmc=None):
                 traffic=traffic, n_rows=n, nnz=nnz,
                 bytes_per_launch=alg_bytes, bytes_model="CSR-algorithmic: nnz*20 + n*36 (SURVEY 8d)",
                 format_bytes_per_launch=fmt_bytes,
-                format="SELL-64: %d slices (%d index-free stencil slices), %d padded entries, %d-bit indices elsewhere"
-                       % (ns.value, stencil_slices, padded.value, 8 * idx_bytes),
+                format="SELL-64: %d slices (%d index-free stencil slices), %d padded entries, %d-bit indices elsewhere%s"
+                       % (ns.value, stencil_slices, padded.value, 8 * idx_bytes,
+                          "; %d entries in the overflow tails of %d slices" % (tail.value, split.value) if tail.value else ""),
                 achieved_format=round(gbs_fmt, 1), frac_format_bytes=round(gbs_fmt / HBM_PEAK_GBS, 4),
                 traffic_ratio_vs_algorithmic=None if not traffic else round(traffic / alg_bytes, 3),
                 traffic_ratio_vs_format=None if not traffic else round(traffic / fmt_bytes, 3),
@@ -292,7 +296,9 @@ def smoother_roofline(inner, n, in_situ, numbering="native"):
     idx_bytes = _hx.lib.hx_sell_index_bits(sell) // 8
     val_bytes = {"fp16": 4, "c64": 8, "c128": 16}.get(getattr(inner, "fine_values", "fp16"), 4)
     indexed = padded.value - _hx.lib.hx_sell_stencil_entries(sell)        # stencil slices carry no per-entry index
-    nbytes = padded.value * val_bytes + indexed * idx_bytes + n * 5 * 8
+    tail, split = C.c_int64(0), C.c_int32(0)
+    _hx.check(_hx.lib.hx_sell_tail_info(sell, C.byref(tail), C.byref(split)))
+    nbytes = padded.value * val_bytes + indexed * idx_bytes + n * 5 * 8 + tail.value * (val_bytes + 4) + split.value * 128
     ms = in_situ[1] / in_situ[0]
     gbs = nbytes / (ms * 1e-3) / 1e9
     traffic = measured_traffic(n, None, numbering, kernel="k_sell<c64,1,half>")

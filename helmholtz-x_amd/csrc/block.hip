@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(256)
 k_sell_blk(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
            const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
            const int32_t* __restrict__ st_delta, int32_t n_cols, const MV* __restrict__ val, const XT* __restrict__ x, V* y,
-           const V* yin, const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev, const BlkOp<V> a) {
+           const V* yin, const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev, const BlkOp<V> a,
+           const SellTail<MV> tl) {
   const int lane = threadIdx.x & 63;
   const int32_t slice = __builtin_amdgcn_readfirstlane((int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6));
   if (slice >= n_slices) return;
@@ -134,6 +135,23 @@ k_sell_blk(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, c
   if (stw > 0) blk_row_dot<V, MV, XT, NB, G, 0>(acc, u, nullptr, vb, lane, x, width, row, n_cols);
   else if (dcol && !wide[slice]) blk_row_dot<V, MV, XT, NB, G, 1>(acc, 0, dcol + base, vb, lane, x, width, row, n_cols);
   else blk_row_dot<V, MV, XT, NB, G, 2>(acc, 0, col + base, vb, lane, x, width, row, n_cols);
+  if (tl.tptr && stw == 0) {                          // overflow tail of a split slice (hx_sell::tptr): the lane's own entries
+    const int32_t t0 = tl.tptr[slice];
+    if (tl.tptr[slice + 1] > t0) {
+      const uint32_t pk = tl.trow[row];
+      const int cnt = (int)(pk & 63u);
+      const int32_t* tc = tl.tcol + t0 + (pk >> 6);
+      const MV* tv = tl.tval + t0 + (pk >> 6);
+      for (int j = 0; __any(j < cnt); ++j)
+        if (j < cnt) {
+          V xv[NB];
+          blk_load<V, XT, NB>(x + (int64_t)tc[j] * NB, xv);
+          const MV v = tv[j];
+#pragma unroll
+          for (int c = 0; c < NB; ++c) b_acc(acc[c], v, xv[c]);
+        }
+    }
+  }
   if (!live) return;
   const int64_t o = (int64_t)row * NB;
   if constexpr (sizeof(MV) != sizeof(V)) {
@@ -179,7 +197,7 @@ int launch_sell_blk(const hx_sell* h, const MV* val, const XT* x, V* y, V alpha,
   constexpr int G = sizeof(V) == 16 ? 2 : 4;
   k_sell_blk<V, MODE, MV, NB, G, XT><<<(h->n_slices + 3) / 4, 256, 0, hx_s(s)>>>(h->n, h->n_slices, h->slice_ptr, h->col, h->dcol, h->wide,
                                                                            h->st_ptr, h->st_delta, h->n_cols, val, x, y,
-                                                                           yin ? yin : y, dinv, b, xprev, op);
+                                                                           yin ? yin : y, dinv, b, xprev, op, sell_tail_of<MV>(h));
   HX_LAUNCH_CHECK("k_sell_blk");
   return HX_OK;
 }

@@ -84,11 +84,59 @@ __global__ void k_sell_stencil_pack(int32_t n_slices, const int32_t* __restrict_
   if (lane < w) st_delta[b + lane] = tmp[(int64_t)slice * 64 + lane];
 }
 
+// Body width and overflow tail of the slices that are no stencil slices (see hx_sell::tptr).  Candidates: the longest row (no
+// tail) and every multiple of 8 below it; cost in lane-slots of the row-sum loop: 64 (8 ceil(w / 8) + w) for the body's issue slots
+// and bytes, 128 per tail step (the longest overflow decides how often the wave goes round), 3 per tail entry.
+__global__ void k_sell_tail_plan(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ wu,
+                                 int64_t* __restrict__ slice_sz, int32_t* __restrict__ tail_sz, uint16_t* __restrict__ trow,
+                                 int step_cost, int gran) {
+  const int lane = threadIdx.x & 63;
+  const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  if (slice >= n_slices) return;
+  const int32_t row = slice * SELL_C + lane;
+  const int len = row < n ? rowptr[row + 1] - rowptr[row] : 0;
+  int M = len;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) M = max(M, __shfl_xor(M, o, 64));
+  int best_w = M;
+  if (!(wu && wu[slice] > 0)) {
+    long best = 64l * (8 * ((M + 7) / 8) + M);
+    for (int w = 8; w < M; w += gran) {
+      int T = max(len - w, 0);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) T += __shfl_xor(T, o, 64);
+      const int trip = M - w;
+      if (trip > 63 || T > 1023) continue;
+      const long cost = 64l * (8 * ((w + 7) / 8) + w) + (long)step_cost * trip + 3l * T;
+      if (cost < best) { best = cost; best_w = w; }
+    }
+  }
+  const int ex = max(len - best_w, 0);
+  int incl = ex;                                   // inclusive prefix sum over the lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  trow[(int64_t)slice * SELL_C + lane] = (uint16_t)(((incl - ex) << 6) | ex);
+  if (lane == 63) tail_sz[slice] = incl;
+  if (lane == 0 && best_w != M) slice_sz[slice] = (int64_t)best_w * SELL_C;
+}
+__global__ void k_count_positive(int32_t n, const int32_t* __restrict__ v, int32_t* __restrict__ out) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (v[i + 1] > v[i]) atomicAdd(out, 1);
+}
+
+template <typename VOUT>
+__device__ __forceinline__ VOUT sell_store_value(zc v, float inv_scale) {
+  if constexpr (sizeof(VOUT) == sizeof(zc)) return v;
+  else if constexpr (sizeof(VOUT) == sizeof(cc)) return make_float2((float)v.x, (float)v.y);
+  else return __floats2half2_rn((float)v.x * inv_scale, (float)v.y * inv_scale);
+}
+
 template <typename VOUT>
 __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                             const zc* __restrict__ val, const int64_t* __restrict__ slice_ptr, int32_t* __restrict__ scol,
                             VOUT* __restrict__ sval, float inv_scale, const int32_t* __restrict__ st_ptr,
-                            const int32_t* __restrict__ st_delta, int32_t n_cols) {
+                            const int32_t* __restrict__ st_delta, int32_t n_cols, const int32_t* __restrict__ tptr,
+                            const uint16_t* __restrict__ trow, int32_t* __restrict__ tcol, VOUT* __restrict__ tval) {
   const int lane = threadIdx.x & 63;
   const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
   if (slice >= n_slices) return;
@@ -130,6 +178,13 @@ __global__ void k_sell_fill(int32_t n, int32_t n_slices, const int32_t* __restri
       sval[o] = czero<VOUT>();
     }
   }
+  if (tptr && len > width) {                          // what the row has beyond the body: packed into the slice's tail
+    const int64_t t0 = (int64_t)tptr[slice] + (trow[(int64_t)slice * SELL_C + lane] >> 6);
+    for (int k = width; k < len; ++k) {
+      if (scol) tcol[t0 + k - width] = col[s + k];
+      tval[t0 + k - width] = sell_store_value<VOUT>(val[s + k], inv_scale);
+    }
+  }
 }
 
 // per slice: do all stored (padded) entries fit a 16-bit delta?  If so write them, else flag the slice as wide.
@@ -160,7 +215,8 @@ __global__ void k_sell_narrow(int32_t n_slices, const int64_t* __restrict__ slic
 // flag[slice] = 1 when a stored entry of the slice (padding and the zero entries of stencil slices included: their clamped
 // columns are read too) addresses a column >= n_rows, i.e. the ghost block of a row-sharded operand
 __global__ void k_sell_ghost_flags(int32_t n_rows, int32_t n_slices, const int64_t* __restrict__ slice_ptr,
-                                   const int32_t* __restrict__ scol, uint8_t* __restrict__ flag) {
+                                   const int32_t* __restrict__ scol, uint8_t* __restrict__ flag,
+                                   const int32_t* __restrict__ tptr, const int32_t* __restrict__ tcol) {
   const int lane = threadIdx.x & 63;
   const int32_t slice = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
   if (slice >= n_slices) return;
@@ -168,6 +224,8 @@ __global__ void k_sell_ghost_flags(int32_t n_rows, int32_t n_slices, const int64
   const int width = (int)((slice_ptr[slice + 1] - base) / SELL_C);
   bool g = false;
   for (int k = 0; k < width; ++k) g = g || scol[base + (int64_t)k * SELL_C + lane] >= n_rows;
+  if (tptr)
+    for (int32_t t = tptr[slice] + lane; t < tptr[slice + 1]; t += SELL_C) g = g || tcol[t] >= n_rows;
   const bool any = __any(g);
   if (lane == 0) flag[slice] = any ? 1 : 0;
 }
@@ -177,6 +235,7 @@ extern "C" int hx_sell_destroy(hx_sell* h) {
   (void)hx_free(h->slice_ptr); (void)hx_free(h->col); (void)hx_free(h->dcol); (void)hx_free(h->wide); (void)hx_free(h->val_z); (void)hx_free(h->val_c);
   (void)hx_free(h->val_h); (void)hx_free(h->st_ptr); (void)hx_free(h->st_delta);
   (void)hx_free(h->list_interior); (void)hx_free(h->list_boundary); (void)hx_free(h->dot_ws);
+  (void)hx_free(h->tptr); (void)hx_free(h->trow); (void)hx_free(h->tcol); (void)hx_free(h->tval_z); (void)hx_free(h->tval_c); (void)hx_free(h->tval_h);
   delete h;
   return HX_OK;
 }
@@ -237,12 +296,23 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
       k_sell_stencil_sizes<<<hx_grid(h->n_slices, 256), 256, 0, s>>>(h->n_slices, d_wu, h->slice_ptr);
     }
   } else { (void)hx_free(d_wu); (void)hx_free(d_tmpU); d_wu = nullptr; d_tmpU = nullptr; (void)hipGetLastError(); }
+  // overflow tails of the slices that are no stencil slices (HX_SELL_TAIL=0: every slice as wide as its longest row).  An
+  // allocation failure only skips them: the format is complete without.
+  int32_t* d_tsz = nullptr;
+  if (HX_OPT_INT("sell_tail", 1) != 0 && h->n_slices > 0) {
+    if (hx_malloc((void**)&d_tsz, sizeof(int32_t) * np) == hipSuccess &&
+        hx_malloc((void**)&h->trow, sizeof(uint16_t) * SELL_C * (size_t)h->n_slices) == hipSuccess &&
+        hipMemsetAsync(d_tsz, 0, sizeof(int32_t) * np, s) == hipSuccess) {
+      k_sell_tail_plan<<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, d_wu, h->slice_ptr, d_tsz, h->trow,
+                                           (int)HX_OPT_INT("sell_tail_step", 128), (int)(HX_OPT_INT("sell_tail_gran", 8) > 0 ? HX_OPT_INT("sell_tail_gran", 8) : 8));
+    } else { (void)hx_free(d_tsz); (void)hx_free(h->trow); d_tsz = nullptr; h->trow = nullptr; (void)hipGetLastError(); }
+  }
   size_t bytes = 0;
-  hipError_t e = hipGetLastError();               // the width / stencil launches above
+  hipError_t e = hipGetLastError();               // the width / stencil / tail launches above
   if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, h->slice_ptr, h->slice_ptr, (int)np, s);
   void* tmp = nullptr;
   if (e != hipSuccess || hx_malloc(&tmp, bytes ? bytes : 16) != hipSuccess) {
-    (void)hx_free(d_wu); (void)hx_free(d_tmpU);
+    (void)hx_free(d_wu); (void)hx_free(d_tmpU); (void)hx_free(d_tsz);
     hx_sell_destroy(h);
     return hx_fail(e != hipSuccess ? HX_ERR_HIP : HX_ERR_ALLOC, "hx_sell_create: slice scan", e != hipSuccess ? hipGetErrorString(e) : "workspace");
   }
@@ -271,7 +341,32 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     (void)hx_free(d_wu); (void)hx_free(d_tmpU);
     d_wu = nullptr; d_tmpU = nullptr;
   }
-  if (e != hipSuccess) { (void)hx_free(d_wu); (void)hx_free(d_tmpU); hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
+  if (e == hipSuccess && d_tsz) {       // tptr = exclusive scan of the tail lengths; kept only if some slice was split
+    size_t b3 = 0;
+    void* t3 = nullptr;
+    int32_t n_tl = 0;
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, b3, d_tsz, d_tsz, (int)np, s);
+    if (e == hipSuccess) e = hx_malloc(&t3, b3 ? b3 : 16);
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(t3, b3, d_tsz, d_tsz, (int)np, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_tl, d_tsz + h->n_slices, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hx_free(t3);
+    if (e == hipSuccess && n_tl > 0) {
+      h->tptr = d_tsz;
+      d_tsz = nullptr;
+      h->n_tail = n_tl;
+      int32_t* d_ns = nullptr;
+      if (hx_malloc((void**)&d_ns, sizeof(int32_t)) == hipSuccess && hipMemsetAsync(d_ns, 0, sizeof(int32_t), s) == hipSuccess) {
+        k_count_positive<<<hx_grid(h->n_slices, 256), 256, 0, s>>>(h->n_slices, h->tptr, d_ns);
+        (void)hipMemcpyAsync(&h->n_split, d_ns, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        e = hipStreamSynchronize(s);
+      }
+      (void)hx_free(d_ns);
+    } else { (void)hx_free(h->trow); h->trow = nullptr; }
+    (void)hx_free(d_tsz);
+    d_tsz = nullptr;
+  }
+  if (e != hipSuccess) { (void)hx_free(d_wu); (void)hx_free(d_tmpU); (void)hx_free(d_tsz); hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
   h->padded = total;
   const size_t ne = (size_t)(total > 0 ? total : 1);
   if (hx_malloc((void**)&h->col, sizeof(int32_t) * ne) != hipSuccess ||
@@ -281,9 +376,21 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     hx_sell_destroy(h);
     return hx_fail(HX_ERR_ALLOC, __func__, "SELL arrays");
   }
-  if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f, h->st_ptr, h->st_delta, h->n_cols);
+  if (h->tptr) {
+    const size_t nt = (size_t)h->n_tail;
+    if (hx_malloc((void**)&h->tcol, sizeof(int32_t) * nt) != hipSuccess ||
+        (want_z && hx_malloc((void**)&h->tval_z, sizeof(zc) * nt) != hipSuccess) ||
+        (want_c == 1 && hx_malloc((void**)&h->tval_c, sizeof(cc) * nt) != hipSuccess) ||
+        (want_c == 2 && hx_malloc((void**)&h->tval_h, sizeof(ch) * nt) != hipSuccess)) {
+      hx_sell_destroy(h);
+      return hx_fail(HX_ERR_ALLOC, __func__, "SELL tail arrays");
+    }
+  }
+  if (want_z) k_sell_fill<zc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr, h->col, h->val_z, 1.f, h->st_ptr, h->st_delta, h->n_cols,
+                                                    h->tptr, h->trow, h->tcol, h->tval_z);
   if (want_c == 1) k_sell_fill<cc><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
-                                                          want_z ? nullptr : h->col, h->val_c, 1.f, h->st_ptr, h->st_delta, h->n_cols);
+                                                          want_z ? nullptr : h->col, h->val_c, 1.f, h->st_ptr, h->st_delta, h->n_cols,
+                                                          h->tptr, h->trow, h->tcol, h->tval_c);
   if (want_c == 2) {
     // scale so that the largest component maps to 2^14: five binary orders of head-room below the fp16 maximum, and
     // entries down to ~4e-9 of the largest stay normal numbers
@@ -305,7 +412,8 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     memcpy(&vmax, &hmax, sizeof(float));
     h->h_scale = vmax > 0.f ? vmax / 16384.f : 1.f;
     k_sell_fill<ch><<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, col, (const zc*)val, h->slice_ptr,
-                                           want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale, h->st_ptr, h->st_delta, h->n_cols);
+                                           want_z ? nullptr : h->col, h->val_h, 1.f / h->h_scale, h->st_ptr, h->st_delta, h->n_cols,
+                                           h->tptr, h->trow, h->tcol, h->tval_h);
   }
   e = hipStreamSynchronize(s);
   if (e != hipSuccess) { hx_sell_destroy(h); return hx_fail(HX_ERR_HIP, __func__, hipGetErrorString(e)); }
@@ -336,7 +444,7 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     std::vector<uint8_t> hf((size_t)h->n_slices);
     hipError_t ef = hx_malloc((void**)&d_flag, (size_t)h->n_slices);
     if (ef == hipSuccess) {
-      k_sell_ghost_flags<<<grid, 256, 0, s>>>(n, h->n_slices, h->slice_ptr, h->col, d_flag);
+      k_sell_ghost_flags<<<grid, 256, 0, s>>>(n, h->n_slices, h->slice_ptr, h->col, d_flag, h->tptr, h->tcol);
       ef = hipMemcpyAsync(hf.data(), d_flag, (size_t)h->n_slices, hipMemcpyDeviceToHost, s);
       if (ef == hipSuccess) ef = hipStreamSynchronize(s);
     }
@@ -386,6 +494,13 @@ extern "C" int hx_sell_info(const hx_sell* h, int32_t* n_slices, int64_t* padded
   HX_REQUIRE(h, "null handle");
   if (n_slices) *n_slices = h->n_slices;
   if (padded_entries) *padded_entries = h->padded;
+  return HX_OK;
+}
+
+extern "C" int hx_sell_tail_info(const hx_sell* h, int64_t* tail_entries, int32_t* split_slices) {
+  HX_REQUIRE(h, "null handle");
+  if (tail_entries) *tail_entries = h->n_tail;
+  if (split_slices) *split_slices = h->n_split;
   return HX_OK;
 }
 
@@ -586,12 +701,61 @@ __device__ __forceinline__ bool sell_row_dot_stencil_lds(int32_t u, int32_t stw,
 // dcol / wide: 16-bit column deltas for the slices flagged narrow (wave-uniform branch); both null -> 32-bit everywhere.
 // One wave = one slice.  The slice offsets are wave-uniform (scalar loads); the row-wise operands of the update (b, x, dinv,
 // xprev / yin) are requested BEFORE the row sum so that they travel with its first group of loads.
+// The row's share of the slice's overflow tail (hx_sell::tptr): every lane walks its own cnt entries, two at a time; the wave
+// goes round as often as its longest overflow needs.  The first pair's index and value loads are issued BEFORE the body of the
+// row sum (sell_tail_begin) so that they travel with its first group; sell_tail_end gathers their operands and does the rest.
+template <typename MV>
+struct SellTailRow {
+  uint32_t off; int cnt;
+  int32_t c0, c1;
+  MV v0, v1;
+  const int32_t* tc; const MV* tv;
+};
+template <typename MV>
+__device__ __forceinline__ SellTailRow<MV> sell_tail_begin(const SellTail<MV>& tl, int32_t t0, int32_t row) {
+  SellTailRow<MV> r;
+  const uint32_t packed = tl.trow[row];
+  r.cnt = (int)(packed & 63u);
+  r.off = packed >> 6;
+  r.tc = tl.tcol + t0;
+  r.tv = tl.tval + t0;
+  r.c0 = r.c1 = 0;
+  r.v0 = r.v1 = czero<MV>();
+  if (r.cnt > 0) { r.c0 = r.tc[r.off]; r.v0 = r.tv[r.off]; }
+  if (r.cnt > 1) { r.c1 = r.tc[r.off + 1]; r.v1 = r.tv[r.off + 1]; }
+  return r;
+}
+template <typename V, typename MV>
+__device__ __forceinline__ V sell_tail_end(const SellTailRow<MV>& r, const V* __restrict__ x) {
+  V a0 = czero<V>(), a1 = czero<V>();
+  {
+    V x0 = czero<V>(), x1 = czero<V>();
+    if (r.cnt > 0) x0 = ld32<V>(x, (uint32_t)r.c0 * (uint32_t)sizeof(V));
+    if (r.cnt > 1) x1 = ld32<V>(x, (uint32_t)r.c1 * (uint32_t)sizeof(V));
+    cmul_acc(a0, r.v0, x0);
+    cmul_acc(a1, r.v1, x1);
+  }
+  for (int j = 2; __any(j < r.cnt); j += 2) {
+    const bool on0 = j < r.cnt, on1 = j + 1 < r.cnt;
+    int32_t c0 = 0, c1 = 0;
+    MV v0 = czero<MV>(), v1 = czero<MV>();
+    if (on0) { c0 = r.tc[r.off + j]; v0 = r.tv[r.off + j]; }
+    if (on1) { c1 = r.tc[r.off + j + 1]; v1 = r.tv[r.off + j + 1]; }
+    V x0 = czero<V>(), x1 = czero<V>();
+    if (on0) x0 = ld32<V>(x, (uint32_t)c0 * (uint32_t)sizeof(V));
+    if (on1) x1 = ld32<V>(x, (uint32_t)c1 * (uint32_t)sizeof(V));
+    cmul_acc(a0, v0, x0);
+    cmul_acc(a1, v1, x1);
+  }
+  return zadd(a0, a1);
+}
+
 template <typename V>
 struct SellOp {            // the scalars of the update
   V alpha, beta;
   int beta_is_zero;
   typename real_of<V>::type omega, mom, vscale;
-  int ablate;              // timing-only experiment hook (HX_SELL_ABLATE; results are WRONG): bit 0 no D^-1 stream, bit 1 one entry fewer per row
+  int ablate;              // timing-only experiment hook (HX_SELL_ABLATE; results are WRONG): bit 0 no D^-1 stream, bit 1 one entry fewer per row, bits 2..5 = q: only (16 - q) / 16 of each slice's width
 };
 
 template <typename V, int MODE, typename MV, int G, bool LDSX>
@@ -600,7 +764,8 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
        const int32_t* __restrict__ st_delta, int32_t n_cols, const MV* __restrict__ val, const V* __restrict__ x, V* y,
        const V* yin, const V* __restrict__ dinv, const V* __restrict__ b, const V* __restrict__ xprev, const SellOp<V> a,
-       const int32_t* __restrict__ slice_list, int32_t xcd_chunk, V* __restrict__ dot_out /* MODE 0: x^T y per slice, or NULL */) {
+       const int32_t* __restrict__ slice_list, int32_t xcd_chunk, V* __restrict__ dot_out /* MODE 0: x^T y per slice, or NULL */,
+       const SellTail<MV> tl) {
   const int lane = threadIdx.x & 63;
   // n_slices counts the waves of this launch: all slices, or the entries of slice_list (interior / boundary part)
   // xcd_chunk > 0: workgroups are dealt round-robin to the eight XCDs, so workgroup g of XCD k = blockIdx.x % 8 takes the
@@ -615,7 +780,8 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
   if (wv >= n_slices) return;
   const int32_t slice = slice_list ? __builtin_amdgcn_readfirstlane(slice_list[wv]) : wv;
   const int64_t base = slice_ptr[slice];
-  const int32_t width = (int32_t)((slice_ptr[slice + 1] - base) >> 6) - ((a.ablate >> 1) & 1);
+  int32_t width = (int32_t)((slice_ptr[slice + 1] - base) >> 6) - ((a.ablate >> 1) & 1);
+  if (a.ablate >> 2) width = (width * (16 - ((a.ablate >> 2) & 15))) >> 4;
   int32_t st0 = 0, stw = 0;
   if (st_ptr) { st0 = st_ptr[slice]; stw = st_ptr[slice + 1] - st0; }
   const int32_t u = lane < stw ? st_delta[st0 + lane] : 0;       // the slice's delta list, one entry per lane
@@ -634,6 +800,13 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     }
   }
   const MV* vb = val + base;
+  bool has_tail = false;                               // overflow tail of a split slice (wave-uniform)
+  SellTailRow<MV> tr;
+  if (tl.tptr && stw == 0) {
+    const int32_t t0 = tl.tptr[slice];
+    has_tail = tl.tptr[slice + 1] > t0;
+    if (has_tail) tr = sell_tail_begin<MV>(tl, t0, row);
+  }
   V acc;
   bool staged = false;
   if constexpr (LDSX) {
@@ -645,6 +818,7 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     acc = stw > 0 ? sell_row_dot_stencil<V, MV, G>(u, vb, lane, x, width, row, n_cols)
           : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t, G>(dcol + base, vb, lane, x, width, row)
                                    : sell_row_dot<V, MV, int32_t, G>(col + base, vb, lane, x, width, row);
+  if (has_tail) acc = zadd(acc, sell_tail_end<V, MV>(tr, x));
   if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(a.vscale, acc);
   if (MODE == 0) {
     V r = zmul(a.alpha, acc);
@@ -673,7 +847,7 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
                         const V* b, const V* xprev, typename real_of<V>::type omega, typename real_of<V>::type mom,
                         typename real_of<V>::type vscale, hx_stream s, const V* yin = nullptr, int part = 0, V* dot_out = nullptr) {
   const int ablate = (int)HX_OPT_INT("sell_ablate", 0);
-  const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale, MODE == 1 || sizeof(V) == 8 ? ablate : 0};
+  const SellOp<V> op{alpha, beta, beta_is_zero, omega, mom, vscale, MODE == 1 || sizeof(V) == 8 || (ablate >> 2) ? ablate : 0};
   // x windows of the stencil slices through LDS (HX_SELL_LDS=0: gathers everywhere; =2: also for complex128 values)
   const int lds_mode = (int)HX_OPT_INT("sell_lds", 1);
   const bool use_lds = h->st_ptr && (lds_mode == 2 || (lds_mode == 1 && sizeof(MV) == 4));
@@ -701,7 +875,8 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
   const int32_t chunk = xcd ? (want > 0 && want < (sell_grid(nw) + 7) / 8 ? want : (sell_grid(nw) + 7) / 8) : 0;
   const int32_t xgrid = xcd ? (int32_t)(((int64_t)sell_grid(nw) + 8 * chunk - 1) / (8 * chunk)) * 8 * chunk : 0;
   kern<<<xcd ? xgrid : sell_grid(nw), 256, 0, hx_s(s)>>>(h->n, nw, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
-                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list, chunk, dot_out);
+                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list, chunk, dot_out,
+                                           sell_tail_of<MV>(h));
 }
 
 

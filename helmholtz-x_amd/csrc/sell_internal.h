@@ -40,9 +40,29 @@ struct hx_sell {
   int32_t* list_interior = nullptr;
   int32_t* list_boundary = nullptr;
   int32_t n_interior = 0, n_boundary = 0;
+  // OVERFLOW TAIL: on an unstructured mesh the longest of 64 rows sets the slice's width (24 % padding on tetrahedra).  A slice
+  // may instead keep a BODY of `width` entries per row (a multiple of the kernels' group of 8) and store what its longer rows
+  // have beyond that packed, row after row, in the tail arrays: entries tptr[s] .. tptr[s+1] belong to slice s, row r of the
+  // slice owns (trow >> 6) .. + (trow & 63) of them.  The kernel that owns the slice adds them right after the body (each lane
+  // walks its own few entries): no second launch, no second pass over y.  Null when no slice was split (structured meshes).
+  int32_t* tptr = nullptr;           // n_slices + 1
+  uint16_t* trow = nullptr;          // 64 per slice
+  int32_t* tcol = nullptr;           // absolute columns
+  zc* tval_z = nullptr;
+  cc* tval_c = nullptr;
+  __half2* tval_h = nullptr;         // (same scale as val_h)
+  int64_t n_tail = 0;
+  int32_t n_split = 0;               // slices with a tail
   zc* dot_ws = nullptr;              // one partial sum per slice (hx_sell_spmv_z_dot; allocated on first use)
 };
 typedef __half2 ch;
+template <typename MV> struct SellTail {   // kernel argument (all null: no tails)
+  const int32_t* tptr; const uint16_t* trow; const int32_t* tcol; const MV* tval;
+};
+template <typename MV> inline SellTail<MV> sell_tail_of(const hx_sell* h);
+template <> inline SellTail<zc> sell_tail_of<zc>(const hx_sell* h) { return {h->tval_z ? h->tptr : nullptr, h->trow, h->tcol, h->tval_z}; }
+template <> inline SellTail<cc> sell_tail_of<cc>(const hx_sell* h) { return {h->tval_c ? h->tptr : nullptr, h->trow, h->tcol, h->tval_c}; }
+template <> inline SellTail<__half2> sell_tail_of<__half2>(const hx_sell* h) { return {h->tval_h ? h->tptr : nullptr, h->trow, h->tcol, h->tval_h}; }
 __device__ __forceinline__ zc mload(const zc* p) { return *p; }
 __device__ __forceinline__ cc mload(const cc* p) { return *p; }
 __device__ __forceinline__ cc mload(const ch* p) { return __half22float2(*p); }

@@ -51,6 +51,7 @@ SIGNATURES = {
     "hx_sell_stencil_slices": (C.c_int, [_vp]),
     "hx_sell_stencil_entries": (_i64, [_vp]),
     "hx_sell_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64)]),
+    "hx_sell_tail_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32)]),
     "hx_sell_spmv_z": (C.c_int, [_vp, _vp, _vp, _dp, _dp, _vp]),
     "hx_sell_spmv_c64": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
     "hx_sell_smooth_z": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, _vp, C.c_double, _vp]),

@@ -200,6 +200,11 @@ int hx_sell_wide_slices(const hx_sell* h);
  * lacks it holds a zero).  Lossless; hx_sell_stencil_slices: number of such slices (SYNC). */
 int hx_sell_stencil_slices(const hx_sell* h);
 int64_t hx_sell_stencil_entries(const hx_sell* h);      /* stored entries that carry no index */
+/* Overflow tails (unstructured meshes): a slice may keep a body narrower than its longest row and store the longer rows'
+ * remaining entries packed in a tail that the same kernel adds after the body (option sell_tail / HX_SELL_TAIL, default 1).
+ * tail_entries: entries stored in tails (with 32-bit columns; hx_sell_info counts the bodies only); split_slices: slices
+ * that have one.  Either pointer may be NULL. */
+int hx_sell_tail_info(const hx_sell* h, int64_t* tail_entries, int32_t* split_slices);
 int hx_sell_spmv_z(const hx_sell* h, const hx_c128* x, hx_c128* y, const double alpha[2], const double beta[2],
                    hx_stream s);
 int hx_sell_spmv_c64(const hx_sell* h, const hx_c64* x, hx_c64* y, float alpha, float beta, hx_stream s);

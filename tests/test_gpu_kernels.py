@@ -425,7 +425,9 @@ def test_sell64_products_match_csr(hx, n, density):
     hx.check(hx.lib.hx_sell_create(C.byref(h), n, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), 1, 1, hx.stream()))
     ns, pad = C.c_int32(), C.c_int64()
     hx.check(hx.lib.hx_sell_info(h, C.byref(ns), C.byref(pad)))
-    assert ns.value == (n + 63) // 64 and pad.value >= M.nnz and pad.value % 64 == 0
+    tail = C.c_int64()
+    hx.check(hx.lib.hx_sell_tail_info(h, C.byref(tail), None))
+    assert ns.value == (n + 63) // 64 and pad.value + tail.value >= M.nnz and pad.value % 64 == 0
     # index compression is decided per slice of 64 rows: count the slices that must stay on 32-bit columns
     coo = M.tocoo()
     far = np.zeros((n + 63) // 64, dtype=bool)
@@ -457,6 +459,64 @@ def test_sell64_products_match_csr(hx, n, density):
     assert np.max(np.abs(o32.cpu().numpy() - refs32)) <= 3e-5 * max(np.max(np.abs(refs32)), 1.0)
     hx.check(hx.lib.hx_sell_destroy(h))
 
+
+
+@pytest.mark.parametrize("want,tails", [((1, 1), 1), ((1, 2), 1), ((0, 2), 1), ((1, 2), 0)])
+def test_sell64_overflow_tails_of_ragged_slices(hx, want, tails):
+    """Unstructured row lengths (14.5 +- 1.8 entries, as on tetrahedra): slices keep a body of 8 / 16 entries per row and the longer
+    rows' remaining entries in a packed tail that the same kernel adds (hx_sell_tail_info); products, residual and smoother
+    step in every value type agree with SciPy exactly as without tails; the stored entries shrink."""
+    import torch
+    rng = np.random.default_rng(11)
+    n = 20_000 + 37
+    lens = np.clip(np.rint(rng.normal(13.5, 1.8, n)).astype(np.int64), 8, 22)
+    lens[100:164] = 15                                   # one uniform slice: no tail there
+    lens[300] = 90                                       # one very long row: its slice keeps its width or a long tail
+    rows = np.repeat(np.arange(n), lens)
+    cols = (rows + rng.integers(-400, 400, rows.size)) % n
+    M = sp.csr_matrix((_rand_c(rng, rows.size), (rows, cols)), shape=(n, n))
+    M = sp.csr_matrix(M + sp.diags(6.0 + rng.random(n)))
+    M.sort_indices()
+    rp, ci, va = _dev(M.indptr.astype(np.int32)), _dev(M.indices.astype(np.int32)), _dev(M.data.astype(np.complex128))
+    hx.check(hx.lib.hx_set_option(b"sell_tail", str(tails).encode()))
+    try:
+        h = C.c_void_p()
+        hx.check(hx.lib.hx_sell_create(C.byref(h), n, hx.ptr(rp), hx.ptr(ci), hx.ptr(va), want[0], want[1], hx.stream()))
+    finally:
+        hx.check(hx.lib.hx_set_option(b"sell_tail", None))
+    ns, pad, tail, split = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
+    hx.check(hx.lib.hx_sell_info(h, C.byref(ns), C.byref(pad)))
+    hx.check(hx.lib.hx_sell_tail_info(h, C.byref(tail), C.byref(split)))
+    row_len = np.diff(M.indptr)
+    full = 64 * int(sum(row_len[i:i + 64].max() for i in range(0, n, 64)))       # every slice as wide as its longest row
+    if tails:
+        assert split.value > 0.8 * ns.value and 0 < tail.value < 0.1 * M.nnz
+        assert pad.value + tail.value >= M.nnz and pad.value + tail.value < 0.92 * full
+    else:
+        assert split.value == 0 and tail.value == 0 and pad.value == full
+    x, y0 = _rand_c(rng, n), _rand_c(rng, n)
+    d = M.diagonal()
+    if want[0]:
+        xd, yd = _dev(x), _dev(y0.copy())
+        a, b = 0.7 - 0.2j, -1.3 + 0.4j
+        hx.check(hx.lib.hx_sell_spmv_z(h, hx.ptr(xd), hx.ptr(yd), hx.z2(a), hx.z2(b), hx.stream()))
+        ref = a * (M @ x) + b * y0
+        assert np.max(np.abs(yd.cpu().numpy() - ref)) <= 1e-13 * np.max(np.abs(ref))
+        dinv, bb, xprev = _dev(1.0 / d), _dev(y0), _dev(_rand_c(rng, n))
+        out = torch.empty_like(xd)
+        hx.check(hx.lib.hx_sell_smooth_z(h, hx.ptr(dinv), hx.ptr(bb), hx.ptr(xd), hx.ptr(out), 0.7, hx.ptr(xprev), 0.3, hx.stream()))
+        refs = x + 0.7 * (1.0 / d) * (y0 - M @ x) + 0.3 * (x - xprev.cpu().numpy())
+        assert np.max(np.abs(out.cpu().numpy() - refs)) <= 1e-13 * np.max(np.abs(refs))
+    tol = 3e-5 if want[1] == 1 else 2e-3                 # complex64 values / complex-half storage of the values
+    x32, y32 = _dev(x.astype(np.complex64)), _dev(y0.astype(np.complex64))
+    hx.check(hx.lib.hx_sell_spmv_c64(h, hx.ptr(x32), hx.ptr(y32), -1.0, 1.0, hx.stream()))
+    ref32 = y0 - M @ x
+    assert np.max(np.abs(y32.cpu().numpy() - ref32)) <= tol * np.max(np.abs(ref32))
+    d32, b32, o32 = _dev((1.0 / d).astype(np.complex64)), _dev(y0.astype(np.complex64)), torch.empty_like(x32)
+    hx.check(hx.lib.hx_sell_smooth_c64(h, hx.ptr(d32), hx.ptr(b32), hx.ptr(x32), hx.ptr(o32), 0.7, None, 0.25, hx.stream()))
+    refs32 = x + 0.7 * (1.0 / d) * (y0 - M @ x) + 0.25 * x
+    assert np.max(np.abs(o32.cpu().numpy() - refs32)) <= tol * np.max(np.abs(refs32))
+    hx.check(hx.lib.hx_sell_destroy(h))
 
 
 def test_device_buffer_pool_reuses_released_blocks(hx):

@@ -20,7 +20,7 @@ name, reps = sys.argv[1], int(sys.argv[2])
 numbering = sys.argv[3] if len(sys.argv) > 3 else "native"
 jitter = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 shape = bench.WORKLOADS[name] if name in bench.WORKLOADS else tuple(int(v) for v in name.split("x"))   # or NRxNTxNZ
-case = bench.build_case(shape, numbering, jitter)
+case = bench.build_case_real(shape[1]) if shape[0] == "real" else bench.build_case(shape, numbering, jitter)
 P = case["P"]
 M = AcousticMatrices(case["mesh"], case["facet_tags"], {11: {'Robin': P.R_outlet}}, case["c"])
 K = combine_csr(M.A.shape, M.A.csr_terms + [(P.target * c, m) for c, m in M.B.csr_terms]
@@ -39,7 +39,11 @@ calls = {
                                                                             _hx.ptr(p32), 0.2, _hx.stream()),
 }
 
-print("n=%d nnz=%d stencil slices %d" % (n, K.nnz, _hx.lib.hx_sell_stencil_slices(h)))
+_ns, _pad, _tail, _split = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
+_hx.lib.hx_sell_info(h, C.byref(_ns), C.byref(_pad))
+_hx.lib.hx_sell_tail_info(h, C.byref(_tail), C.byref(_split))
+print("n=%d nnz=%d stencil slices %d; stored %d + tail %d entries in %d of %d slices" % (
+    n, K.nnz, _hx.lib.hx_sell_stencil_slices(h), _pad.value, _tail.value, _split.value, _ns.value))
 for label, fn in calls.items():          # back-to-back launches between two events: average time per launch
     for _ in range(3):
         fn()

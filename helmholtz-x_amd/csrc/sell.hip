@@ -800,12 +800,15 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     }
   }
   const MV* vb = val + base;
-  bool has_tail = false;                               // overflow tail of a split slice (wave-uniform)
+  // overflow tail of a split slice (wave-uniform).  The kernels of operators WITH stencil slices (LDSX: structured meshes, where
+  // a handful of slices may still be split) start their tails after the body: the early loads would cost them a wave of occupancy.
+  bool has_tail = false;
+  int32_t t0 = 0;
   SellTailRow<MV> tr;
   if (tl.tptr && stw == 0) {
-    const int32_t t0 = tl.tptr[slice];
+    t0 = tl.tptr[slice];
     has_tail = tl.tptr[slice + 1] > t0;
-    if (has_tail) tr = sell_tail_begin<MV>(tl, t0, row);
+    if constexpr (!LDSX) { if (has_tail) tr = sell_tail_begin<MV>(tl, t0, row); }
   }
   V acc;
   bool staged = false;
@@ -818,7 +821,10 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     acc = stw > 0 ? sell_row_dot_stencil<V, MV, G>(u, vb, lane, x, width, row, n_cols)
           : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t, G>(dcol + base, vb, lane, x, width, row)
                                    : sell_row_dot<V, MV, int32_t, G>(col + base, vb, lane, x, width, row);
-  if (has_tail) acc = zadd(acc, sell_tail_end<V, MV>(tr, x));
+  if (has_tail) {
+    if constexpr (LDSX) tr = sell_tail_begin<MV>(tl, t0, row);
+    acc = zadd(acc, sell_tail_end<V, MV>(tr, x));
+  }
   if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(a.vscale, acc);
   if (MODE == 0) {
     V r = zmul(a.alpha, acc);

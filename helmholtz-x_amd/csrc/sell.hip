@@ -866,18 +866,16 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
   // a solve re-reads the same operator): the x windows refetched through eight L2s are then a fifth of the fabric traffic
   // (1.9 M rows: smoother step 35.4 -> 29.0 us, residual 33.5 -> 26.1; 1 M rows: operator product 45.4 -> 41.5 us).  Beyond
   // that size the pass streams from HBM, the refetches come from the cache beside it and the interleaved schedule is as fast or
-  // faster (5 M rows: 95 vs 98 us) -- unless the XCDs stay close together, see the chunks below.  HX_SELL_XCD = 0 / 3: never / always (bit 0 complex64 kernels, bit 1 complex128).
+  // faster (5 M rows: 95 vs 98 us).  HX_SELL_XCD = 0 / 3: never / always (bit 0 complex64 kernels, bit 1 complex128).
   const int xcd_mode = (int)HX_OPT_INT("sell_xcd", -1);
   const double footprint = (double)h->padded * sizeof(MV) + (double)h->n * sizeof(V) * (MODE == 1 ? 5 : 3);
-  const bool big = footprint > 288e6;
   const bool xcd = sell_grid(nw) >= 64 &&
-                   (xcd_mode < 0 ? (!big || sizeof(V) == 8) : (xcd_mode & (sizeof(V) == 8 ? 1 : 2)) != 0);
-  // HX_SELL_XCD_CHUNK = c > 0: the launch is cut into super-chunks of 8 c workgroups and each XCD takes c consecutive ones of
-  // every super-chunk (the eight XCDs then stay within 8 c workgroups of each other instead of an eighth of the operator apart).
-  // Complex64 kernels beyond the cache-resident size, 5 M rows (profiles/r06_xcd_chunks_annulus5M.txt): smoother step 0.662 of
-  // the HBM peak interleaved, 0.661 in eighths, 0.688 with c = 4 .. 16, 0.679 with 64, 0.580 with 1024 -> c = 16 there.
-  int32_t want = (int32_t)HX_OPT_INT("sell_xcd_chunk", -1);
-  if (want < 0) want = big && xcd_mode < 0 ? 16 : 0;
+                   (xcd_mode < 0 ? footprint <= 288e6 : (xcd_mode & (sizeof(V) == 8 ? 1 : 2)) != 0);
+  // HX_SELL_XCD_CHUNK = c > 0 (experiment knob): the launch is cut into super-chunks of 8 c workgroups and each XCD takes c
+  // consecutive ones of every super-chunk.  5 M rows, complex64 smoother step, same box, every setting twice
+  // (profiles/r06_xcd_chunks_annulus5M.txt): interleaved 0.649 of the HBM peak, c = 4 and 16 0.648, eighths 0.614 - 0.621 -- small
+  // chunks ARE the interleaved schedule as far as the memory system can tell; nothing to adopt beyond the cache-resident size.
+  const int32_t want = (int32_t)HX_OPT_INT("sell_xcd_chunk", 0);
   const int32_t chunk = xcd ? (want > 0 && want < (sell_grid(nw) + 7) / 8 ? want : (sell_grid(nw) + 7) / 8) : 0;
   const int32_t xgrid = xcd ? (int32_t)(((int64_t)sell_grid(nw) + 8 * chunk - 1) / (8 * chunk)) * 8 * chunk : 0;
   kern<<<xcd ? xgrid : sell_grid(nw), 256, 0, hx_s(s)>>>(h->n, nw, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,

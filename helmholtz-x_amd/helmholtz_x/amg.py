@@ -1088,15 +1088,15 @@ class AMGSolver:
 
     def _go_direct(self, reason):
         """Beyond the last iterative rung: factorise K on the device (slepc.LUSolver, csrc/splu.hip) when the factor fits in HBM --
-        what PCLU / MUMPS is to the reference: an answer at any target.  Single GPU only."""
-        if self.shard is not None or os.environ.get("HX_AMG_DIRECT_RUNG", "1") == "0":
-            self.direct_refused = "not available on the row-sharded path" if self.shard is not None else "switched off"
+        what PCLU / MUMPS is to the reference: an answer at any target.  Row-sharded runs replicate the factor (slepc.ReplicatedLUSolver)."""
+        if os.environ.get("HX_AMG_DIRECT_RUNG", "1") == "0":
+            self.direct_refused = "switched off"
             return False
-        from .slepc import LUSolver
+        from .slepc import LUSolver, ReplicatedLUSolver
         self._teardown()                              # the hierarchy's memory goes to the factor
         _hx.check(_hx.lib.hx_pool_trim())
-        try:
-            self.direct = LUSolver(self._K_in)
+        try:                                          # (row-sharded: every rank holds the factor of the GLOBAL operator; collective)
+            self.direct = LUSolver(self._K_in) if self.shard is None else ReplicatedLUSolver(self._K_in, self.shard)
         except MemoryError as e:
             self.direct_refused = str(e)
             self._build()

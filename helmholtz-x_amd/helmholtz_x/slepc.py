@@ -12,8 +12,10 @@ followed by classical Gram-Schmidt with one re-orthogonalisation (hx_zpanel_dot 
 K^-1 is applied by ``K^-1 + W (I - F V^T W)^-1 F V^T K^-1`` (Woodbury) when the operator carries the
 rank-r flame term ``- sum_f F u_f v_f^T``; K itself never contains the dense outer-product block.
 The inner solver for the sparse K is pluggable (``st_type``):
-  'lu'   host SuperLU factorisation -> device level-scheduled triangular solves (hx_sptrsv_*)
-  'amg'  device AMG-preconditioned GMRES (amg.py) for 3-D problems where a direct factorisation does not fit
+  'lu'   device sparse LU (csrc/splu.hip: multifrontal factorisation on f64 MFMA, supernodal solves); replicated over the ranks
+         of a row-sharded run (ReplicatedLUSolver); HX_LU=host: the round-1 route (host SuperLU + device triangular solves)
+  'amg'  device AMG-preconditioned COCG / GMRES (amg.py) for 3-D problems where a direct factorisation does not fit
+  'auto' (default) 'lu' up to DEFAULTS['lu_max_dofs'] (global) unknowns, 'amg' beyond
 """
 import ctypes as C
 
@@ -288,13 +290,130 @@ class HostLUSolver:
             pass
 
 
+class ReplicatedLUSolver:
+    """st_type='lu' on the ROW-SHARDED path ("replicas only for the solve -- each GPU holds full factors -- with
+    sharded SpMV / CGS"): the ranks' row blocks of K are all-gathered ONCE, every rank factorises the global operator with the
+    device LU (the same analysis, the same arithmetic: identical factors everywhere) and a solve is one all-gather of the
+    right-hand side (n_global x 16 bytes), the local sweeps, and the owned slice of the solution.  What MUMPS / PCLU is to the
+    reference's ``mpirun -np 8`` runs (eigensolvers.py:49-50): an answer at any target, at the sizes a replicated factor fits
+    (the memory check of LUSolver applies; a refusal is agreed between the ranks before anybody raises)."""
+
+    name = "lu"
+
+    def __init__(self, K_local, shard):
+        import time
+        import torch.distributed as dist
+        from .amg import _all_gather_var
+        from .petsc import CSR, coords_of
+        t0 = time.perf_counter()
+        self.shard = shard
+        dev = K_local.val.device
+        n_own, n = shard.n_own, shard.n_global
+        if K_local.shape[0] == n and n != n_own and not getattr(K_local, "local", False):
+            K_local = shard.localize(K_local)                # a GLOBAL operator was passed: this rank's rows of it
+        if K_local.shape[0] != n_own:
+            raise ValueError("ReplicatedLUSolver takes this rank's rows of the operator")
+        col = K_local.col.long()
+        if getattr(K_local, "local", False) or K_local.shape[1] != n:
+            ghost = shard.ghost if shard.ghost is not None and shard.ghost.numel() else torch.zeros(1, dtype=torch.int64, device=dev)
+            gcol = torch.where(col < n_own, col + shard.r0, ghost[(col - n_own).clamp(min=0, max=ghost.numel() - 1)])
+        else:
+            gcol = col                                       # (rows of a GLOBAL operator: columns are global already)
+        counts = (K_local.rowptr[1:] - K_local.rowptr[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(n_own, device=dev, dtype=torch.int64) + shard.r0, counts)
+        key = _all_gather_var(shard, rows * n + gcol)
+        val = _all_gather_var(shard, K_local.val)
+        key, order = torch.sort(key)
+        val = val[order].contiguous()
+        rows, cols = key // n, key % n
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+        K = CSR((n, n), rowptr.to(torch.int32), cols.to(torch.int32).contiguous(), val)
+        K.symmetric = bool(torch.equal(torch.sort(cols * n + rows)[0], key))       # (of the PATTERN; the values are checked on the device)
+        xy = coords_of(K_local.pattern_id)                   # vertex coordinates of the local mesh: [owned | ghost]
+        flag = torch.tensor([0.0 if xy is not None and xy.shape[0] >= n_own else 1.0], device=dev)       # 1: this rank has none
+        shard.all_reduce_(flag, op="max")
+        coords = None
+        if float(flag[0]) == 0.0:
+            own = torch.from_numpy(np.ascontiguousarray(xy[:n_own], np.float64)).to(dev)
+            coords = _all_gather_var(shard, own.reshape(-1)).reshape(n, -1).cpu().numpy()
+        self.sizes = [r1 - r0 for r0, r1 in shard.ranges]
+        cap = max(max(self.sizes), 1)
+        self._send = torch.zeros(cap, dtype=torch.complex128, device=dev)
+        self._recv = torch.zeros(shard.world * cap, dtype=torch.complex128, device=dev)
+        self._pick = torch.cat([torch.arange(m, device=dev, dtype=torch.int64) + r * cap for r, m in enumerate(self.sizes)])
+        self._stage = shard.backend == "gloo" and dev.type == "cuda"
+        self.bg = torch.empty(n, dtype=torch.complex128, device=dev)
+        self.xg = torch.empty(n, dtype=torch.complex128, device=dev)
+        self.n = n_own
+        self.tmp = torch.empty(n_own, dtype=torch.complex128, device=dev)
+        self.lu, err = None, None
+        try:
+            self.lu = LUSolver(K, coords=coords)
+        except MemoryError as e:
+            err = e
+        bad = torch.tensor([1.0 if err is not None else 0.0], device=dev)
+        shard.all_reduce_(bad, op="max")
+        if float(bad[0]) > 0.0:                              # somebody's card is too full: nobody factorises
+            if self.lu is not None:
+                self.lu.destroy()
+                self.lu = None
+            raise MemoryError(str(err) if err is not None else "direct factorisation refused on another rank")
+        self.setup_s = time.perf_counter() - t0
+        self.n_solves = 0
+        self.n_gathers = 0
+        self._dist = dist
+
+    def _gather(self, b):
+        """Global right-hand side from the ranks' owned blocks (equal-sized slots, then compacted)."""
+        self._send[:self.n].copy_(b)
+        if self._stage:                                      # gloo with device tensors: through the host (tests, rehearsals)
+            src = torch.view_as_real(self._send).cpu()
+            outs = [torch.empty_like(src) for _ in range(self.shard.world)]
+            self._dist.all_gather(outs, src, group=self.shard.group)
+            self._recv.copy_(torch.view_as_complex(torch.cat(outs).contiguous()).to(self._recv.device))
+        else:
+            self._dist.all_gather_into_tensor(torch.view_as_real(self._recv), torch.view_as_real(self._send), group=self.shard.group)
+            if self.shard.comm is not None:                  # the library's own communicator is in use beside torch's: NCCL does
+                torch.cuda.current_stream().synchronize()    # not order two communicators -- this one is finished before the next
+        torch.index_select(self._recv, 0, self._pick, out=self.bg)
+        self.n_gathers += 1
+
+    def solve(self, b, x, relax=1.0, transposed=False):
+        self.n_solves += 1
+        self._gather(b)
+        self.lu.solve(self.bg, self.xg, transposed=transposed)
+        x.copy_(self.xg[self.shard.r0:self.shard.r1])
+
+    def stats(self):
+        out = self.lu.stats()
+        out.update(replicated_over=self.shard.world, rhs_all_gathers=self.n_gathers, setup_s=round(self.setup_s, 4), solves=self.n_solves)
+        return out
+
+    def info(self):
+        return self.lu.info()
+
+    def destroy(self):
+        lu, self.lu = self.lu, None
+        if lu is not None:
+            lu.destroy()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 def make_inner_solver(K_csr, dim_hint=None, st_type=None, hierarchy=None, shard=None, shifted=None, graph=None, label=None):
     """``shifted`` / ``graph`` / ``label``: what the iterative solver's escalation ladder needs (amg.AMGSolver)."""
     st = st_type or DEFAULTS["st_type"]
     n = K_csr.shape[0]
     if shard is not None:
+        if st == "auto":                      # a replicated factor while the GLOBAL problem is in the direct route's range
+            st = "lu" if shard.n_global <= DEFAULTS["lu_max_dofs"] else "amg"
         if st == "lu":
-            raise NotImplementedError("the direct inner solver is single-GPU; the row-sharded path uses st_type='amg'")
+            return ReplicatedLUSolver(K_csr, shard)
         from .amg import AMGSolver
         return AMGSolver(K_csr, hierarchy=hierarchy, shard=shard, shifted=shifted, label=label)
     if st == "auto":

@@ -791,8 +791,16 @@ def _micca_distributed_worker(rank, world, port, out, golden_dir, mode="fpi"):
                                  p_own=p.x.array[:n_own].copy(), x_own=local.geometry.x[:n_own].copy())
                 return
             hist = []
-            E = fixed_point_iteration(matrices, D, Micca.target, i=0, nev=4, tol=1e-3, st_type="amg", history=hist, shard=ctx)
+            st = "lu" if mode == "lu" else ("auto" if mode == "auto" else "amg")
+            if mode == "ladder":                 # two iterations are too few for every iterative rung (the reference's own option name)
+                from helmholtz_x.petsc import Options
+                Options()["st_ksp_max_it"] = 2
+            E = fixed_point_iteration(matrices, D, Micca.target, i=0, nev=4, tol=1e-3, st_type=st, history=hist, shard=ctx)
         inner = [v for v in E.inner_cache.values() if hasattr(v, "stats")][0]
+        if mode in ("lu", "auto", "ladder"):
+            out[rank] = dict(hist=list(hist), eigs=[E.getEigenvalue(i) for i in range(2)], stats=inner.stats(),
+                             solver=type(getattr(inner, "inner", inner)).__name__)
+            return
         # the adjoint problem as active_fpi.py:64-69 runs it: transposed flame factors, B^H, conjugate target (default nev = 2)
         with contextlib.redirect_stdout(io.StringIO()):
             D.assemble_submatrices('adjoint')
@@ -838,6 +846,37 @@ def test_micca_real_mesh_distributed_over_three_ranks(ref_logs, golden_dir):
         assert len(r["peers"][0]) >= 1 and not all(r["contiguous_sends"])
     assert sum(out[r]["sizes"][0] for r in range(world)) == out[0]["sizes"][3]
     print("micca distributed:", out[0]["stats"], [out[r]["peers"] for r in range(world)], [out[r]["sizes"] for r in range(world)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("st_type", ["lu", "auto", "ladder"])
+def test_micca_real_mesh_direct_solver_replicated_over_three_ranks(ref_logs, golden_dir, st_type):
+    """st_type='lu' on the row-sharded path (what MUMPS / PCLU is to the reference's `mpirun -np 8` runs; SURVEY 8(e): "replicas only
+    for the solve"): the ranks' row blocks of K are all-gathered once, every rank factorises the global operator on the device and
+    a solve is one all-gather of the right-hand side + the local sweeps.  The reference's flagship case on its real mesh over
+    three ranks: the logged trajectory and the stored 16-digit eigenvalues to 1e-8, identical on every rank; 'auto' picks the
+    replicated factor too at this size (34,787 <= lu_max_dofs); "ladder": st_type='amg' with -st_ksp_max_it 2 -- every iterative
+    rung stalls on every rank at once and the ladder ends in the replicated factor (amg.AMGSolver._go_direct, collective)."""
+    world, port = 3, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_micca_distributed_worker, args=(world, port, out, golden_dir, st_type), nprocs=world, join=True)
+    assert len(out) == world
+    g = ref_logs["micca_full"]
+    for rank in range(world):
+        r = out[rank]
+        assert len(r["hist"]) - 1 == len(g["trajectory_3dec"])
+        for z, ref in zip(r["hist"][1:], g["trajectory_3dec"]):
+            assert abs(z - complex(*ref)) < 7.5e-4
+        for i, ref in enumerate(g["direct"]):
+            ref = complex(*ref)
+            assert abs(r["eigs"][i] - ref) / abs(ref) < 1e-8, (i, r["eigs"][i], ref)
+        st = r["stats"]
+        if st_type == "ladder":
+            assert st["rung"] == "direct" and [q["rung"] for q in st["ladder"]] == ["wide", "shifted", "direct"], st
+            st = st["direct"]
+        assert st["replicated_over"] == world and st["rhs_all_gathers"] == st["solves"] > 0 and st["nnz_L"] > 0, st
+        assert r["eigs"] == out[0]["eigs"]                      # the same factors, the same sweeps: the same bits on every rank
+    print("micca replicated LU:", out[0]["stats"])
 
 
 def _rijke_distributed_worker(rank, world, port, out, golden_dir):

@@ -290,6 +290,34 @@ class HostLUSolver:
             pass
 
 
+def replicated_operator(K_local, shard):
+    """The GLOBAL operator on every rank from the ranks' row blocks (rows [r0, r1) over [owned | ghost] columns, or rows of a
+    global operator): one all-gather of (global row * n + global column) keys and of the values, sorted by key.  Collective.
+    ``symmetric`` is set when the PATTERN is its own transpose (what the analysis of the direct solver may assume then)."""
+    from .amg import _all_gather_var
+    from .petsc import CSR
+    dev = K_local.val.device
+    n_own, n = shard.n_own, shard.n_global
+    col = K_local.col.long()
+    if getattr(K_local, "local", False) or K_local.shape[1] != n:
+        ghost = shard.ghost if shard.ghost is not None and shard.ghost.numel() else torch.zeros(1, dtype=torch.int64, device=dev)
+        gcol = torch.where(col < n_own, col + shard.r0, ghost[(col - n_own).clamp(min=0, max=ghost.numel() - 1)])
+    else:
+        gcol = col                                       # (rows of a GLOBAL operator: columns are global already)
+    counts = (K_local.rowptr[1:] - K_local.rowptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n_own, device=dev, dtype=torch.int64) + shard.r0, counts)
+    key = _all_gather_var(shard, rows * n + gcol)
+    val = _all_gather_var(shard, K_local.val)
+    key, order = torch.sort(key)
+    val = val[order].contiguous()
+    rows, cols = key // n, key % n
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    K = CSR((n, n), rowptr.to(torch.int32), cols.to(torch.int32).contiguous(), val)
+    K.symmetric = bool(torch.equal(torch.sort(cols * n + rows)[0], key))       # (the values are checked on the device)
+    return K
+
+
 class ReplicatedLUSolver:
     """st_type='lu' on the ROW-SHARDED path ("replicas only for the solve -- each GPU holds full factors -- with
     sharded SpMV / CGS"): the ranks' row blocks of K are all-gathered ONCE, every rank factorises the global operator with the
@@ -304,7 +332,7 @@ class ReplicatedLUSolver:
         import time
         import torch.distributed as dist
         from .amg import _all_gather_var
-        from .petsc import CSR, coords_of
+        from .petsc import coords_of
         t0 = time.perf_counter()
         self.shard = shard
         dev = K_local.val.device
@@ -313,23 +341,7 @@ class ReplicatedLUSolver:
             K_local = shard.localize(K_local)                # a GLOBAL operator was passed: this rank's rows of it
         if K_local.shape[0] != n_own:
             raise ValueError("ReplicatedLUSolver takes this rank's rows of the operator")
-        col = K_local.col.long()
-        if getattr(K_local, "local", False) or K_local.shape[1] != n:
-            ghost = shard.ghost if shard.ghost is not None and shard.ghost.numel() else torch.zeros(1, dtype=torch.int64, device=dev)
-            gcol = torch.where(col < n_own, col + shard.r0, ghost[(col - n_own).clamp(min=0, max=ghost.numel() - 1)])
-        else:
-            gcol = col                                       # (rows of a GLOBAL operator: columns are global already)
-        counts = (K_local.rowptr[1:] - K_local.rowptr[:-1]).long()
-        rows = torch.repeat_interleave(torch.arange(n_own, device=dev, dtype=torch.int64) + shard.r0, counts)
-        key = _all_gather_var(shard, rows * n + gcol)
-        val = _all_gather_var(shard, K_local.val)
-        key, order = torch.sort(key)
-        val = val[order].contiguous()
-        rows, cols = key // n, key % n
-        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-        rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
-        K = CSR((n, n), rowptr.to(torch.int32), cols.to(torch.int32).contiguous(), val)
-        K.symmetric = bool(torch.equal(torch.sort(cols * n + rows)[0], key))       # (of the PATTERN; the values are checked on the device)
+        K = replicated_operator(K_local, shard)
         xy = coords_of(K_local.pattern_id)                   # vertex coordinates of the local mesh: [owned | ghost]
         flag = torch.tensor([0.0 if xy is not None and xy.shape[0] >= n_own else 1.0], device=dev)       # 1: this rank has none
         shard.all_reduce_(flag, op="max")

@@ -95,6 +95,13 @@ def _worker(rank, world, port, case, out):
         t = torch.tensor([complex(rank + 1, -rank)], dtype=torch.complex128)
         ctx.all_reduce_(t)
         assert t[0].item() == complex(sum(range(1, world + 1)), -sum(range(world)))
+        # the replicated operator of the direct route (slepc.ReplicatedLUSolver): every rank rebuilds the GLOBAL matrix from the
+        # ranks' row blocks -- entry for entry the matrix the rows were cut from, and recognised as structurally symmetric
+        from helmholtz_x.slepc import replicated_operator
+        R = replicated_operator(L, ctx)
+        assert R.shape == Ag.shape and R.symmetric
+        assert np.array_equal(R.rowptr.numpy(), Ag.indptr) and np.array_equal(R.col.numpy(), Ag.indices)
+        assert np.array_equal(R.val.numpy(), Ag.data.astype(np.complex128))
         out[rank] = (n_own, len(ghosts), sorted(plan.send_to), sorted(plan.recv_from))
     finally:
         dist.destroy_process_group()

@@ -47,7 +47,10 @@ enum hx_status {
  * an option is set or removed.
  *   HX_SELL_STENCIL=0 / HX_SELL_INDEX=i32 / HX_SELL_LDS=0|2   SELL-64 format and kernel variants (hx_sell_create, k_sell)
  *   HX_POOL=0, HX_POOL_MAX_GIB, HX_POOL_MIN_BYTES                 device-buffer pool off / cap of the cached bytes / smallest pooled block
- *   HX_SELL_XCD=0|3, HX_SELL_ABLATE                            XCD-contiguous slice schedule never / always (default: by footprint); timing-only ablations
+ *   HX_SELL_TAIL=0, HX_SELL_TAIL_STEP, HX_SELL_TAIL_GRAN       overflow tails of ragged slices off (every slice as wide as its longest row) / cost of a tail step
+ *                                                             in the split's model (128) / granularity of the body widths it may choose (8)
+ *   HX_SELL_XCD=0|3, HX_SELL_XCD_CHUNK, HX_SELL_ABLATE         XCD-contiguous slice schedule never / always (default: by footprint) / in chunks of that many workgroups;
+ *                                                             timing-only ablations
  *   HX_COCG_PQ_IN_PRODUCT=0|2                                 hx_cocg: p^T K p from the product itself (SELL-64: default up to 2 M rows; CSR operators: always) never / at every size
  *   HX_AMG_FOLD_DIAG=0                                        the first smoothing step of a level (x1 = a0 D^-1 b) as a launch of its own again (default: written by the
  *                                                             restriction that produced b, on the fine level by hx_cocg's update kernel)

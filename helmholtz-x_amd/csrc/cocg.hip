@@ -763,12 +763,13 @@ static int cocg_impl(hx_amg* M, int32_t n, int64_t nnz, const int32_t* rowptr, c
       HX_LAUNCH_CHECK("k_cocg_direction");
       first = false;
       // q = K p ;  alpha = rho / p^T q ;  x += alpha p, r -= alpha q, |r|^2
-      // single GPU with a SELL-64 operator of up to 2 M rows: p^T q comes out of the product itself (every wave leaves the sum of
-      // its slice, one block adds the slices): no pass over p and q -- 0.388 -> 0.377 ms per inner iteration at 1 M DOF.  At 5 M
-      // DOF the product is 5 us slower for it, one block needs 77 loads per thread for the 78 k slice sums, and the pass it
-      // replaces ran out of the Infinity Cache anyway: no gain (1.4445 vs 1.4474 ms per iteration), so larger operators keep
-      // the panel dot.  HX_COCG_PQ_IN_PRODUCT=0 / 2: never / at every size.
-      const bool pq_in_product = !sharded && Ksell && (pq_env == 2 || (pq_env == 1 && n <= 2000000));
+      // single GPU with a SELL-64 operator: p^T q comes out of the product itself (every wave leaves the sum of its slice, one
+      // block adds the slices): no pass over p and q -- 0.388 -> 0.377 ms per inner iteration at 1 M DOF.  At 5 M DOF the
+      // product is 1.5 us slower for it and the pass it replaces (36 us) ran out of the Infinity Cache; rounds 4-5 kept the panel
+      // dot above 2 M rows (1.4445 vs 1.4474 ms per iteration, inside the noise of one run each); three alternating same-box
+      // pairs in round 6: 2246 / 2246 / 2229 ms per call with the panel dot, 2221 / 2225 / 2213 ms with the fused sum -- every
+      // size now.  HX_COCG_PQ_IN_PRODUCT=0: never (2: the former "at every size", same as the default now).
+      const bool pq_in_product = !sharded && Ksell && pq_env != 0;
       // operators on the CSR kernels (small problems, every launch counts): the product leaves the per-block partials of p^T q,
       // the update sums them like those of the panel dot it replaces (one launch fewer per inner iteration)
       const bool pq_in_csr_product = !sharded && !Ksell && fuse && pq_env != 0;

@@ -51,7 +51,7 @@ enum hx_status {
  *                                                             in the split's model (128) / granularity of the body widths it may choose (8)
  *   HX_SELL_XCD=0|3, HX_SELL_XCD_CHUNK, HX_SELL_ABLATE         XCD-contiguous slice schedule never / always (default: by footprint) / in chunks of that many workgroups;
  *                                                             timing-only ablations
- *   HX_COCG_PQ_IN_PRODUCT=0|2                                 hx_cocg: p^T K p from the product itself (SELL-64: default up to 2 M rows; CSR operators: always) never / at every size
+ *   HX_COCG_PQ_IN_PRODUCT=0                                   hx_cocg: p^T K p from a panel dot instead of from the product itself
  *   HX_AMG_FOLD_DIAG=0                                        the first smoothing step of a level (x1 = a0 D^-1 b) as a launch of its own again (default: written by the
  *                                                             restriction that produced b, on the fine level by hx_cocg's update kernel)
  *   HX_AMG_DEEP_HALO=0                                        row-sharded levels in deep-halo mode run the classic schedule (one exchange per smoothing step) anyway

@@ -71,9 +71,10 @@ __global__ void k_sell_stencil_union(int32_t n, int32_t n_slices, const int32_t*
   }
   if (lane == 0) wu[slice] = ok ? cnt : 0;
 }
-__global__ void k_sell_stencil_sizes(int32_t n_slices, const int32_t* __restrict__ wu, int64_t* __restrict__ slice_sz) {
+// (wu[n_slices], zero on entry and ignored by the exclusive scan that follows, collects the NUMBER of stencil slices)
+__global__ void k_sell_stencil_sizes(int32_t n_slices, int32_t* __restrict__ wu, int64_t* __restrict__ slice_sz) {
   for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_slices; s += gridDim.x * blockDim.x)
-    if (wu[s] > 0) slice_sz[s] = (int64_t)wu[s] * SELL_C;
+    if (wu[s] > 0) { slice_sz[s] = (int64_t)wu[s] * SELL_C; atomicAdd(wu + n_slices, 1); }
 }
 __global__ void k_sell_stencil_pack(int32_t n_slices, const int32_t* __restrict__ st_ptr, const int32_t* __restrict__ tmp,
                                     int32_t* __restrict__ st_delta) {
@@ -116,12 +117,8 @@ __global__ void k_sell_tail_plan(int32_t n, int32_t n_slices, const int32_t* __r
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
   trow[(int64_t)slice * SELL_C + lane] = (uint16_t)(((incl - ex) << 6) | ex);
-  if (lane == 63) tail_sz[slice] = incl;
+  if (lane == 63) { tail_sz[slice] = incl; if (incl > 0) atomicAdd(tail_sz + n_slices + 1, 1); }     // (+1: behind the scan's total)
   if (lane == 0 && best_w != M) slice_sz[slice] = (int64_t)best_w * SELL_C;
-}
-__global__ void k_count_positive(int32_t n, const int32_t* __restrict__ v, int32_t* __restrict__ out) {
-  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    if (v[i + 1] > v[i]) atomicAdd(out, 1);
 }
 
 template <typename VOUT>
@@ -296,13 +293,19 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
       k_sell_stencil_sizes<<<hx_grid(h->n_slices, 256), 256, 0, s>>>(h->n_slices, d_wu, h->slice_ptr);
     }
   } else { (void)hx_free(d_wu); (void)hx_free(d_tmpU); d_wu = nullptr; d_tmpU = nullptr; (void)hipGetLastError(); }
-  // overflow tails of the slices that are no stencil slices (HX_SELL_TAIL=0: every slice as wide as its longest row).  An
-  // allocation failure only skips them: the format is complete without.
+  // overflow tails (HX_SELL_TAIL=0: every slice as wide as its longest row): for operators WITHOUT stencil slices only --
+  // unstructured meshes.  (A structured operator has a handful of irregular slices; splitting those would put the tail code
+  // into its kernels for nothing: same-box runs against round 5 showed the smoother step of the 1 M-row annulus 5 % slower.)
+  // An allocation failure only skips the tails: the format is complete without.
   int32_t* d_tsz = nullptr;
-  if (HX_OPT_INT("sell_tail", 1) != 0 && h->n_slices > 0) {
-    if (hx_malloc((void**)&d_tsz, sizeof(int32_t) * np) == hipSuccess &&
+  const size_t tsz_bytes = sizeof(int32_t) * (np + 1) < ((size_t)1 << 20) ? ((size_t)1 << 20) : sizeof(int32_t) * (np + 1);   // (a pooled size)
+  int32_t n_stencil_slices = 0;
+  if (d_wu && (hipMemcpyAsync(&n_stencil_slices, d_wu + h->n_slices, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+               hipStreamSynchronize(s) != hipSuccess)) { (void)hipGetLastError(); n_stencil_slices = 1; }
+  if (HX_OPT_INT("sell_tail", 1) != 0 && h->n_slices > 0 && n_stencil_slices == 0) {
+    if (hx_malloc((void**)&d_tsz, tsz_bytes) == hipSuccess &&
         hx_malloc((void**)&h->trow, sizeof(uint16_t) * SELL_C * (size_t)h->n_slices) == hipSuccess &&
-        hipMemsetAsync(d_tsz, 0, sizeof(int32_t) * np, s) == hipSuccess) {
+        hipMemsetAsync(d_tsz, 0, sizeof(int32_t) * (np + 1), s) == hipSuccess) {
       k_sell_tail_plan<<<grid, 256, 0, s>>>(n, h->n_slices, rowptr, d_wu, h->slice_ptr, d_tsz, h->trow,
                                            (int)HX_OPT_INT("sell_tail_step", 128), (int)(HX_OPT_INT("sell_tail_gran", 8) > 0 ? HX_OPT_INT("sell_tail_gran", 8) : 8));
     } else { (void)hx_free(d_tsz); (void)hx_free(h->trow); d_tsz = nullptr; h->trow = nullptr; (void)hipGetLastError(); }
@@ -348,20 +351,16 @@ extern "C" int hx_sell_create(hx_sell** out, int32_t n, const int32_t* rowptr, c
     e = hipcub::DeviceScan::ExclusiveSum(nullptr, b3, d_tsz, d_tsz, (int)np, s);
     if (e == hipSuccess) e = hx_malloc(&t3, b3 ? b3 : 16);
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(t3, b3, d_tsz, d_tsz, (int)np, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(&n_tl, d_tsz + h->n_slices, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    int32_t two[2] = {0, 0};              // total tail entries (the scan's last output), slices with a tail (the plan's counter)
+    if (e == hipSuccess) e = hipMemcpyAsync(two, d_tsz + h->n_slices, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hx_free(t3);
+    n_tl = two[0];
     if (e == hipSuccess && n_tl > 0) {
       h->tptr = d_tsz;
       d_tsz = nullptr;
       h->n_tail = n_tl;
-      int32_t* d_ns = nullptr;
-      if (hx_malloc((void**)&d_ns, sizeof(int32_t)) == hipSuccess && hipMemsetAsync(d_ns, 0, sizeof(int32_t), s) == hipSuccess) {
-        k_count_positive<<<hx_grid(h->n_slices, 256), 256, 0, s>>>(h->n_slices, h->tptr, d_ns);
-        (void)hipMemcpyAsync(&h->n_split, d_ns, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-        e = hipStreamSynchronize(s);
-      }
-      (void)hx_free(d_ns);
+      h->n_split = two[1];
     } else { (void)hx_free(h->trow); h->trow = nullptr; }
     (void)hx_free(d_tsz);
     d_tsz = nullptr;
@@ -758,7 +757,7 @@ struct SellOp {            // the scalars of the update
   int ablate;              // timing-only experiment hook (HX_SELL_ABLATE; results are WRONG): bit 0 no D^-1 stream, bit 1 one entry fewer per row, bits 2..5 = q: only (16 - q) / 16 of each slice's width
 };
 
-template <typename V, int MODE, typename MV, int G, bool LDSX>
+template <typename V, int MODE, typename MV, int G, bool LDSX, bool TAILS>
 __global__ void __launch_bounds__(256)
 k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
        const int16_t* __restrict__ dcol, const uint8_t* __restrict__ wide, const int32_t* __restrict__ st_ptr,
@@ -772,9 +771,10 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
   // g-th group of four slices of the k-th EIGHTH of the operator: neighbouring slices (which share their x windows: the
   // plane below, the own plane, the plane above) then meet in ONE L2 instead of being fetched through every XCD's
   int64_t blk = blockIdx.x;
-  if (xcd_chunk > 0) {           // (super-chunks of 8 * xcd_chunk workgroups; one super-chunk = the whole launch by default)
-    const int32_t super = 8 * xcd_chunk, sb = blockIdx.x / super, r = blockIdx.x - sb * super;
-    blk = (int64_t)sb * super + (int64_t)(r & 7) * xcd_chunk + (r >> 3);
+  if (xcd_chunk > 0) blk = (int64_t)(blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3);
+  else if (xcd_chunk < 0) {      // experiment knob HX_SELL_XCD_CHUNK: super-chunks of 8 * |xcd_chunk| workgroups
+    const int32_t c = -xcd_chunk, super = 8 * c, sb = blockIdx.x / super, r = blockIdx.x - sb * super;
+    blk = (int64_t)sb * super + (int64_t)(r & 7) * c + (r >> 3);
   }
   const int32_t wv = __builtin_amdgcn_readfirstlane((int32_t)((blk * (int64_t)blockDim.x + threadIdx.x) >> 6));
   if (wv >= n_slices) return;
@@ -800,15 +800,14 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     }
   }
   const MV* vb = val + base;
-  // overflow tail of a split slice (wave-uniform).  The kernels of operators WITH stencil slices (LDSX: structured meshes, where
-  // a handful of slices may still be split) start their tails after the body: the early loads would cost them a wave of occupancy.
+  // overflow tail of a split slice (wave-uniform; TAILS: the operator has tails at all -- operators without stencil slices only,
+  // see hx_sell_create, so the LDS variant never carries this code)
   bool has_tail = false;
-  int32_t t0 = 0;
   SellTailRow<MV> tr;
-  if (tl.tptr && stw == 0) {
-    t0 = tl.tptr[slice];
+  if constexpr (TAILS) {
+    const int32_t t0 = tl.tptr[slice];
     has_tail = tl.tptr[slice + 1] > t0;
-    if constexpr (!LDSX) { if (has_tail) tr = sell_tail_begin<MV>(tl, t0, row); }
+    if (has_tail) tr = sell_tail_begin<MV>(tl, t0, row);
   }
   V acc;
   bool staged = false;
@@ -821,10 +820,7 @@ k_sell(int32_t n, int32_t n_slices, const int64_t* __restrict__ slice_ptr, const
     acc = stw > 0 ? sell_row_dot_stencil<V, MV, G>(u, vb, lane, x, width, row, n_cols)
           : (dcol && !wide[slice]) ? sell_row_dot<V, MV, int16_t, G>(dcol + base, vb, lane, x, width, row)
                                    : sell_row_dot<V, MV, int32_t, G>(col + base, vb, lane, x, width, row);
-  if (has_tail) {
-    if constexpr (LDSX) tr = sell_tail_begin<MV>(tl, t0, row);
-    acc = zadd(acc, sell_tail_end<V, MV>(tr, x));
-  }
+  if constexpr (TAILS) { if (has_tail) acc = zadd(acc, sell_tail_end<V, MV>(tr, x)); }
   if constexpr (sizeof(MV) != sizeof(V)) acc = zscale(a.vscale, acc);
   if (MODE == 0) {
     V r = zmul(a.alpha, acc);
@@ -857,7 +853,8 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
   // x windows of the stencil slices through LDS (HX_SELL_LDS=0: gathers everywhere; =2: also for complex128 values)
   const int lds_mode = (int)HX_OPT_INT("sell_lds", 1);
   const bool use_lds = h->st_ptr && (lds_mode == 2 || (lds_mode == 1 && sizeof(MV) == 4));
-  auto kern = use_lds ? k_sell<V, MODE, MV, 8, true> : k_sell<V, MODE, MV, 8, false>;
+  const SellTail<MV> tl = sell_tail_of<MV>(h);
+  auto kern = use_lds ? k_sell<V, MODE, MV, 8, true, false> : tl.tptr ? k_sell<V, MODE, MV, 8, false, true> : k_sell<V, MODE, MV, 8, false, false>;
   // part 0: every slice; 1 / 2: the interior / boundary slices of a row-sharded local operator (hx_sell::list_*)
   const int32_t* list = part == 1 ? h->list_interior : part == 2 ? h->list_boundary : nullptr;
   const int32_t nw = part == 1 ? h->n_interior : part == 2 ? h->n_boundary : h->n_slices;
@@ -876,11 +873,11 @@ static void launch_sell(const hx_sell* h, const MV* val, const V* x, V* y, V alp
   // (profiles/r06_xcd_chunks_annulus5M.txt): interleaved 0.649 of the HBM peak, c = 4 and 16 0.648, eighths 0.614 - 0.621 -- small
   // chunks ARE the interleaved schedule as far as the memory system can tell; nothing to adopt beyond the cache-resident size.
   const int32_t want = (int32_t)HX_OPT_INT("sell_xcd_chunk", 0);
-  const int32_t chunk = xcd ? (want > 0 && want < (sell_grid(nw) + 7) / 8 ? want : (sell_grid(nw) + 7) / 8) : 0;
+  const bool chunked = xcd && want > 0 && want < (sell_grid(nw) + 7) / 8;
+  const int32_t chunk = xcd ? (chunked ? want : (sell_grid(nw) + 7) / 8) : 0;
   const int32_t xgrid = xcd ? (int32_t)(((int64_t)sell_grid(nw) + 8 * chunk - 1) / (8 * chunk)) * 8 * chunk : 0;
   kern<<<xcd ? xgrid : sell_grid(nw), 256, 0, hx_s(s)>>>(h->n, nw, h->slice_ptr, h->col, h->dcol, h->wide, h->st_ptr,
-                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list, chunk, dot_out,
-                                           sell_tail_of<MV>(h));
+                                           h->st_delta, h->n_cols, val, x, y, yin ? yin : y, dinv, b, xprev, op, list, chunked ? -chunk : chunk, dot_out, tl);
 }
 
 

@@ -1187,12 +1187,17 @@ def _bloch_sharded_worker(rank, world, port, out, shape=(12, 12, 48), transport=
             D_l.assemble_submatrices('direct')
             D_l.blochify('direct')
             hist_l = []
-            E_l = fixed_point_iteration(bloch_l, D_l, Micca.target, i=0, nev=2, tol=1e-3, history=hist_l, shard=bloch_l.shard)
+            E_l = fixed_point_iteration(bloch_l, D_l, Micca.target, i=0, nev=2, tol=1e-3, history=hist_l, shard=bloch_l.shard,
+                                        st_type="amg")          # (auto would take the replicated direct factor at this size)
             w2, p2 = normalize_eigenvector(local, E_l, 0, BlochRemapper=bloch_l.remapper, print_eigs=False)
+            if transport == "gloo":                              # (the small sector: also through the replicated direct factor)
+                E_lu = fixed_point_iteration(bloch_l, D_l, Micca.target, i=0, nev=2, tol=1e-3, shard=bloch_l.shard, st_type="lu")
+                inner_lu = [v for v in E_lu.inner_cache.values() if hasattr(v, "stats")][0]
+                res["lu"] = dict(eig=E_lu.getEigenvalue(0), stats=inner_lu.stats())
             D_l.assemble_submatrices('adjoint')
             D_l.blochify('adjoint')
             E_a = fixed_point_iteration(bloch_l, D_l, Micca.target.conjugate(), i=0, nev=2, tol=1e-3, problem_type='adjoint',
-                                        shard=bloch_l.shard)
+                                        shard=bloch_l.shard, st_type="amg")
             inner = [v for v in E_l.inner_cache.values() if hasattr(v, "stats")][0]
             l2g = local.part["local_to_global"]
             n_own = local.part["n_own"]

@@ -379,6 +379,17 @@ def test_device_sparse_lu_edge_cases(hx, case):
     hx.check(hx.lib.hx_splu_destroy(h))
 
 
+def test_device_sparse_lu_random_stress():
+    """150 random matrices through hx_splu_* (tools/r6/splu_fuzz.py: sizes 1 ... 7000, grid / band / random / dense patterns,
+    symmetric or not in pattern and values, coordinates or not, leaf sizes, the symmetric-mode flag, A x = b and A^T x = b): every
+    matrix with diagonally dominant rows is solved to a backward error below 1e-12 without a replaced pivot."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "r6", "splu_fuzz.py"), "150", "1000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "failures []" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("n,density", [(1, 1.0), (999, 0.02), (30000, 0.0006)])
 def test_complex64_spmv_and_jacobi(hx, n, density):
     """Single-precision copies used by the AMG V-cycle: ragged rows, an empty row."""

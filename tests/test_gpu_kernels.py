@@ -1,5 +1,6 @@
 """GPU parity of the libhx kernels against NumPy/SciPy and the CPU oracle (called through the C-ABI)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest

@@ -531,6 +531,17 @@ def test_sell64_overflow_tails_of_ragged_slices(hx, want, tails):
     hx.check(hx.lib.hx_sell_destroy(h))
 
 
+def test_sell64_random_stress():
+    """120 random operators through hx_sell_* (tools/r6/sell_fuzz.py: six row-length distributions incl. rows far beyond any body, banded
+    and far columns, rectangular operators, the three value types, random parameters of the body / tail split): operator product, block
+    product, residual and smoother step agree with SciPy."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "r6", "sell_fuzz.py"), "120", "5000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "failures []" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_device_buffer_pool_reuses_released_blocks(hx):
     """csrc/pool.hip: the large buffers a destroyed SELL-64 operator releases are handed to the next operator of the same shape
     without a driver call (every fixed-point call of a driver builds the same objects again); the product computed in reused

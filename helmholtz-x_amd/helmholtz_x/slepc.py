@@ -54,6 +54,7 @@ ROTATE_SLABS = 8                 # DeviceBasis.rotate: the panel is rotated in t
 # final solve 40 -> 35 applications at 5 M DOF (2.37 -> 2.25 s per call), 40 -> 34 at 1 M (0.60 -> 0.56 s), 25 -> 24 on the refined
 # real mesh; same eigenvalues (fourth pair to 2e-10).  profiles/r05_final_solve_start_vector.txt
 WIDE_START = "richest"
+ONE_READBACK = __import__("os").environ.get("HX_CGS_ONE_READBACK", "1") != "0"
 RELAX_CAP = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP", "1e4"))     # 1 switches the relaxation off
 RELAX_CAP_MULTI = float(__import__("os").environ.get("HX_KRYLOV_RELAX_CAP_MULTI", "30"))  # cap for nev > 1 (see set_inner_accuracy)
 
@@ -638,7 +639,8 @@ class DeviceBasis:
         self.V = self._panel[:m]
         self.apply_op = apply_op
         self.seed = seed
-        self.h_dev = torch.empty(m + 1, dtype=torch.complex128, device=dev)
+        self._h2 = torch.empty(2 * (m + 1), dtype=torch.complex128, device=dev)       # both passes' coefficients side by side
+        self.h_dev = self._h2[:m + 1]
         self.ws = torch.empty(_hx.lib.hx_panel_dot_ws(m), dtype=torch.complex128, device=dev)
         self.n_ops = 0
         self.relax = 1.0             # factor on the inner solver's tolerance for the NEXT operator applications
@@ -654,14 +656,16 @@ class DeviceBasis:
         at the 1e-10 level (cap 300: 5e-10) for 4 % fewer inner iterations."""
         self.relax = float(min(max(0.1 / max(lead_residual, 1e-300), 1.0), RELAX_CAP if nev == 1 else RELAX_CAP_MULTI))
 
-    def _dots(self, k, w):
-        _hx.check(_hx.lib.hx_zpanel_dot(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(w), _hx.ptr(self.h_dev),
+    def _dots(self, k, w, out=None):
+        out = self.h_dev if out is None else out
+        _hx.check(_hx.lib.hx_zpanel_dot(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(w), _hx.ptr(out),
                                         _hx.ptr(self.ws), _hx.stream()))
         if self.shard is not None:
-            self.shard.all_reduce_(self.h_dev[:k + 1])
+            self.shard.all_reduce_(out[:k + 1])
 
-    def _sub(self, k, w):
-        _hx.check(_hx.lib.hx_zpanel_sub(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(self.h_dev), _hx.ptr(w),
+    def _sub(self, k, w, coef=None):
+        coef = self.h_dev if coef is None else coef
+        _hx.check(_hx.lib.hx_zpanel_sub(self.n, k, _hx.ptr(self.V), self.V.stride(0), _hx.ptr(coef), _hx.ptr(w),
                                         _hx.stream()))
 
     def set_start(self, j):
@@ -687,12 +691,20 @@ class DeviceBasis:
         self.apply_op(self.V[j], w)
         self.n_ops += 1
         k = j + 1
+        second = self._h2[self.m + 1:]               # the second pass writes beside the first: ONE read-back (one host wait) per vector
         self._dots(k, w)
         self._sub(k, w)
-        h1 = self.h_dev[:k].cpu().numpy().copy()
-        self._dots(k, w)
-        self._sub(k, w)
-        out = self.h_dev[:k + 1].cpu().numpy()
+        if ONE_READBACK:
+            self._dots(k, w, second)
+            self._sub(k, w, second)
+            both = self._h2.cpu().numpy()
+            h1 = both[:k].copy()
+            out = both[self.m + 1:self.m + 2 + k]
+        else:                                        # (HX_CGS_ONE_READBACK=0: a read-back after either pass, the form of rounds 1-5)
+            h1 = self.h_dev[:k].cpu().numpy().copy()
+            self._dots(k, w)
+            self._sub(k, w)
+            out = self.h_dev[:k + 1].cpu().numpy()
         h2, ww = out[:k], out[k].real
         beta2 = ww - float(np.sum(np.abs(h2) ** 2))
         if beta2 <= 1e-8 * ww:                       # cancellation: measure the norm directly

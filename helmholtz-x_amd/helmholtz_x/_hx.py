@@ -195,7 +195,15 @@ def require_gpu():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """The caller's current stream as the C-ABI's hx_stream.  (torch.cuda.current_stream() builds a Stream object per call --
+    8.6 us, 1850 calls in a fixed-point call of the reference's mesh = 11 % of it; the raw query is what torch's own compiled
+    code uses.)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -30,9 +30,9 @@ from .petsc import combine_csr, to_device
 from .solver_utils import info
 
 # st_type "auto": the direct factorisation (device multifrontal LU) up to lu_max_dofs unknowns, AMG-preconditioned Krylov beyond.
-# Measured on one MI355X (round 6, profiles/r06_lu_amg_crossover.txt; one fixed-point call, ms, LU / AMG): 2 k DOF 84 / 93, 16 k 110 /
-# 131, the reference's MICCA mesh (34,787) 177 / 265, 66 k 163 / 177, MICCA refined once (249 k) 370 / 412 (455 with the analysis
-# redone in the call), structured 255 k annulus 324 / 245: the direct route wins up to ~1e5 unknowns on every mesh tried and ties
+# Measured on one MI355X (round 6, profiles/r06_lu_amg_crossover.txt; one fixed-point call, ms, LU / AMG): 2 k DOF 85 / 92, 16 k 93 /
+# 114, the reference's MICCA mesh (34,787) 137 / 264, 66 k 129 / 167, MICCA refined once (249 k) 344 / 406 (431 with the analysis
+# redone in the call), structured 255 k annulus 274 / 259: the direct route wins up to ~1e5 unknowns on every mesh tried and ties
 # around 2.5e5; beyond, its factor (4.6 GiB at 249 k, growing like n^(4/3)) and flops (n^2) lose to the O(n) hierarchy.
 DEFAULTS = {"st_type": "auto", "lu_max_dofs": 100_000}
 # Tolerance factor of the Woodbury columns W = K^-1 U (inner tolerance 1e-11 -> 3e-10).  Larger factors were measured: at

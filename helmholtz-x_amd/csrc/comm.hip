@@ -368,6 +368,29 @@ extern "C" int hx_comm_halo_end(void* ctx, int level, hx_stream s) {
   return HX_OK;
 }
 
+// Every rank's `bytes`-long block into everybody's recv buffer (world x bytes, rank order): one group of point-to-point messages on
+// the caller's stream, like an exchange -- the right-hand sides of the replicated direct solve (slepc.ReplicatedLUSolver).
+extern "C" int hx_comm_allgather(void* ctx, const void* send, void* recv, int64_t bytes, hx_stream s) {
+  hx_comm* c = (hx_comm*)ctx;
+  HX_REQUIRE(c && send && recv && bytes >= 0, "bad argument");
+  { const int rs = same_stream(c, s); if (rs) return rs; }
+  ++c->n_exchange;
+  if (bytes == 0) return HX_OK;
+  char* out = (char*)recv;
+  HX_HIP(hipMemcpyAsync(out + (size_t)c->rank * (size_t)bytes, send, (size_t)bytes, hipMemcpyDeviceToDevice, hx_s(s)));
+  if (c->world == 1) return HX_OK;
+  HX_NCCL(g_rccl.GroupStart());
+  ncclResult_t bad = ncclSuccess;
+  for (int p = 0; p < c->world && bad == ncclSuccess; ++p)
+    if (p != c->rank) bad = g_rccl.Send(send, (size_t)bytes, ncclChar, p, c->comm, hx_s(s));
+  for (int p = 0; p < c->world && bad == ncclSuccess; ++p)
+    if (p != c->rank) bad = g_rccl.Recv(out + (size_t)p * (size_t)bytes, (size_t)bytes, ncclChar, p, c->comm, hx_s(s));
+  const ncclResult_t ge = g_rccl.GroupEnd();
+  if (bad != ncclSuccess) return hx_fail(HX_ERR_COMM, "ncclSend/ncclRecv (all-gather)", g_rccl.GetErrorString(bad));
+  HX_NCCL(ge);
+  return HX_OK;
+}
+
 // hx_allreduce_fn: in-place reduction of `count` reals (dtype 0: float32, 1: float64; op 0: sum, 1: max)
 extern "C" int hx_comm_allreduce(void* ctx, void* buf, int64_t count, int dtype, int op, hx_stream s) {
   hx_comm* c = (hx_comm*)ctx;

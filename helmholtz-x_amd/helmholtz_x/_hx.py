@@ -149,6 +149,7 @@ SIGNATURES = {
     "hx_comm_exchange": (C.c_int, [_vp, _int, _vp, _vp, _int, _vp]),
     "hx_comm_halo": (C.c_int, [_vp, _int, _vp, _int, _vp]),
     "hx_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _int, _int, _vp]),
+    "hx_comm_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "hx_comm_counters": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _int]),
     "hx_shape_derivative_facets": (C.c_int, [_int, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _vp]),
     "hx_sa_strength_diag": (C.c_int, [_i32, _vp, _vp, _vp, C.c_double, _vp, _vp]),

@@ -380,15 +380,18 @@ class ReplicatedLUSolver:
     def _gather(self, b):
         """Global right-hand side from the ranks' owned blocks (equal-sized slots, then compacted)."""
         self._send[:self.n].copy_(b)
-        if self._stage:                                      # gloo with device tensors: through the host (tests, rehearsals)
+        if self.shard.comm is not None and self._send.is_cuda:          # issued by the library, on the compute stream (hx_comm)
+            from .distributed import assert_no_outstanding_work
+            assert_no_outstanding_work("ReplicatedLUSolver (hx_comm_allgather)")
+            _hx.check(_hx.lib.hx_comm_allgather(self.shard.comm, _hx.ptr(self._send), _hx.ptr(self._recv), 16 * self._send.numel(),
+                                                _hx.stream()))
+        elif self._stage:                                      # gloo with device tensors: through the host (tests, rehearsals)
             src = torch.view_as_real(self._send).cpu()
             outs = [torch.empty_like(src) for _ in range(self.shard.world)]
             self._dist.all_gather(outs, src, group=self.shard.group)
             self._recv.copy_(torch.view_as_complex(torch.cat(outs).contiguous()).to(self._recv.device))
         else:
             self._dist.all_gather_into_tensor(torch.view_as_real(self._recv), torch.view_as_real(self._send), group=self.shard.group)
-            if self.shard.comm is not None:                  # the library's own communicator is in use beside torch's: NCCL does
-                torch.cuda.current_stream().synchronize()    # not order two communicators -- this one is finished before the next
         torch.index_select(self._recv, 0, self._pick, out=self.bg)
         self.n_gathers += 1
 

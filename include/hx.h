@@ -563,6 +563,10 @@ int hx_comm_halo_end(void* ctx, int level, hx_stream s);                        
 int64_t hx_comm_overlapped(const hx_comm* c);   /* exchanges that ran split since the last counter reset */
 int64_t hx_comm_stream_switches(const hx_comm* c); /* operations that arrived on another stream than their predecessor (product path: 0) */
 int hx_comm_allreduce(void* ctx, void* buf, int64_t count, int dtype, int op, hx_stream s); /* an hx_allreduce_fn */
+/* recv[p * bytes ... (p + 1) * bytes) <- rank p's `send` block of `bytes` bytes, on every rank (one group of ncclSend / ncclRecv on
+ * the caller's stream): the right-hand sides of the replicated direct solve on the row-sharded path (slepc.ReplicatedLUSolver;
+ * the reference: MUMPS' centralised right-hand side under mpirun, eigensolvers.py:49-50). */
+int hx_comm_allgather(void* ctx, const void* send, void* recv, int64_t bytes, hx_stream s);
 int hx_comm_counters(const hx_comm* c, int64_t* n_exchange, int64_t* n_allreduce, int reset);
 /* hx_gmres on the row-sharded operator: K = local rows over [owned | ghost] columns, b / x / ws sized by n_own;
  * xe (n_ext complex128: staging vector for the K products) and hbuf (restart + 2 + k_max complex128: inner products, all-reduced)

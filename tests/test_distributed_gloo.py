@@ -1467,6 +1467,36 @@ def test_bench_ranks_generate_their_own_slabs_three_ranks():
     assert sum(q["rows"] for q in out[0]["generated"]["partition"]["per_rank"]) == 64896
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_three_ranks_replicated_direct_factor_library_issued_all_gathers():
+    """`bench.py --gpus 3 --st-type lu` (64,896 DOF) with the exchanges issued by the library (hx_comm through the asynchronous librccl
+    stand-in): the direct inner solve of the row-sharded path is the REPLICATED device factor, its right-hand sides travel by
+    hx_comm_allgather (one group of point-to-point messages on the compute stream, counted with the exchanges); the eigenvalue equals
+    the single-GPU direct run's to 1e-9 and no exchange leaves the compute stream."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tests", "fake_rccl", "libfakerccl.so")):
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "fake_rccl")])
+    env = dict(os.environ, HX_DIST_BACKEND="gloo", HX_NATIVE_COMM="1", HX_RCCL_LIB=os.path.join(root, "tests", "fake_rccl", "libfakerccl.so"))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "annulus-66k", "--st-type", "lu", "--no-cpu-baseline", "--steps", "1", "--warmup", "0"]
+    r3 = subprocess.run(cmd + ["--gpus", "3"], capture_output=True, text=True, timeout=500, env=env)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    d3 = json.loads(r3.stdout.strip().splitlines()[-1])
+    r1 = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=dict(os.environ))
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert d3.get("error") is None and d3["n_gpus"] == 3 and "libhx" in d3["exchanges_issued_by"], d3
+    st = d3["config"]["inner_stats"]
+    assert st["replicated_over"] == 3 and st["rhs_all_gathers"] == st["solves"] > 0, st
+    ex = d3["config"]["exchanges_per_step"]
+    assert ex["communicator_stream_switches"] == 0 and ex["halo_exchanges"] >= st["rhs_all_gathers"], ex
+    for a, b in zip(d3["config"]["omega"], d1["config"]["omega"]):
+        assert abs(complex(*a) - complex(*b)) <= 1e-9 * abs(complex(*b)), (a, b)
+
+
 def _rcb_worker(rank, world, port, out, golden_dir):
     """RCB partition of the reference's real (unstructured) MICCA mesh over `world` ranks: distribute, exchange, check."""
     import sys

@@ -1270,7 +1270,9 @@ extern "C" int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int trans
   HX_REQUIRE(h->factored, "hx_splu_factor has not run");
   hipStream_t st = hx_s(stream);
   const SpluSymbolic& S = h->sym;
-  const int tr = transposed ? 1 : 0;
+  // (a factorisation in symmetric mode represents a symmetric matrix exactly -- its U panels are copies of its L panels --: the
+  // transposed system is the system itself, and takes the fast sweeps)
+  const int tr = transposed && !h->dev.sym ? 1 : 0;
   k_splu_permute<<<hx_grid(S.n, 256), 256, 0, st>>>(S.n, h->d_perm, (const zc*)b, h->pb, 0);
   // The two sweeps are ~100 small launches on fixed internal buffers: captured once into a hipGraph and replayed (option
   // splu_graph=0: plain launches).  Only the two permutation kernels around them see the caller's vectors.

@@ -357,7 +357,8 @@ int hx_splu_symbolic(const hx_splu* h, const char* name, void* h_out, int64_t ca
  * 1e-13 relative: the complex symmetric K = A + sigma B + sigma^2 C) is factorised in symmetric mode: the U panels are transposed
  * copies of the unscaled L panels, half the products (option splu_symmetric=0: never).  SYNC (reads back the pivot counter). */
 int hx_splu_factor(hx_splu* h, const hx_c128* val, hx_stream s);
-/* x = A^-1 b (transposed != 0: A^-T b); b, x device vectors of length n, may alias. */
+/* x = A^-1 b (transposed != 0: A^-T b; after a factorisation in symmetric mode that is the same system and takes the same fast
+ * sweeps); b, x device vectors of length n, may alias. */
 int hx_splu_solve(hx_splu* h, const hx_c128* b, hx_c128* x, int transposed, hx_stream s);
 int hx_splu_destroy(hx_splu* h);
 
